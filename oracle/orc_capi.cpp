@@ -1,0 +1,276 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  PARITY UNPINNED.
+// Plain-C entry points so tests/ and bench.py's cpu_baseline leg can drive the oracle via ctypes.
+#include <cstring>
+#include "orc_loam.h"
+
+using namespace orc;
+
+namespace {
+int copy_cloud(const Cloud& c, float* buf, int cap) {
+  int n = (int)c.size();
+  if (buf) {
+    int m = n < cap ? n : cap;
+    std::memcpy(buf, c.data(), sizeof(PointXYZI) * (size_t)m);
+  }
+  return n;
+}
+template <class T>
+int copy_vec(const std::vector<T>& v, T* buf, int cap) {
+  int n = (int)v.size();
+  if (buf) {
+    int m = n < cap ? n : cap;
+    if (m > 0) std::memcpy(buf, v.data(), sizeof(T) * (size_t)m);
+  }
+  return n;
+}
+void pack_summary(const SolveSummary& s, double* trace, int cap_iters, int* n_iters, double* H0, double* g0, int* term,
+                  double* costs2) {
+  int n = (int)s.iterations.size();
+  if (n_iters) *n_iters = n;
+  if (trace) {
+    for (int i = 0; i < n && i < cap_iters; i++) {
+      const IterationSummary& it = s.iterations[i];
+      double* r = trace + 8 * i;
+      r[0] = it.cost; r[1] = it.cost_change; r[2] = it.gradient_max_norm; r[3] = it.step_norm;
+      r[4] = it.relative_decrease; r[5] = it.trust_region_radius; r[6] = it.step_is_valid; r[7] = it.step_is_successful;
+    }
+  }
+  if (H0) std::memcpy(H0, s.H0, sizeof(double) * 36);
+  if (g0) std::memcpy(g0, s.g0, sizeof(double) * 6);
+  if (term) *term = s.termination;
+  if (costs2) { costs2[0] = s.initial_cost; costs2[1] = s.final_cost; }
+}
+struct HelloFunctor {
+  double c;
+  template <class T> bool operator()(const T* x, const T* /*t*/, T* r) const { r[0] = T(c) - x[0]; return true; }
+};
+}  // namespace
+
+extern "C" {
+
+struct orc_handle {
+  Pipeline* p;
+};
+
+orc_handle* orc_create(int scan_line, double minimum_range, float line_res, float plane_res, int mapping_skip_frame,
+                       int detach_vo_lo, int with_mapping) {
+  Config c;
+  c.scan_line = scan_line; c.minimum_range = minimum_range;
+  c.mapping_line_resolution = line_res; c.mapping_plane_resolution = plane_res;
+  c.mapping_skip_frame = mapping_skip_frame; c.detach_VO_LO = detach_vo_lo != 0;
+  orc_handle* h = new orc_handle;
+  h->p = new Pipeline(c, with_mapping != 0);
+  return h;
+}
+void orc_destroy(orc_handle* h) { if (h) { delete h->p; delete h; } }
+
+int orc_process(orc_handle* h, const float* xyz_pad4, int n) { return h->p->process(xyz_pad4, n) ? 0 : -1; }
+int orc_scan_registration(orc_handle* h, const float* xyz_pad4, int n) {
+  return scan_registration(xyz_pad4, n, h->p->cfg, &h->p->sr) ? 0 : -1;
+}
+void orc_set_vo_prior(orc_handle* h, const double* q, const double* t) { h->p->lo.set_vo_prior(q, t); }
+void orc_stage_ms(orc_handle* h, double* ms3) { for (int i = 0; i < 3; i++) ms3[i] = h->p->stage_ms[i]; }
+
+// which: 0 full, 1 sharp, 2 lessSharp, 3 flat, 4 lessFlat, 5 cornerLast, 6 surfLast,
+//        7 map corner stack, 8 map surf stack, 9 cornerFromMap, 10 surfFromMap, 11 registered full-res
+int orc_get_cloud(orc_handle* h, int which, float* buf, int cap) {
+  Pipeline& p = *h->p;
+  switch (which) {
+    case 0: return copy_cloud(p.sr.laserCloud, buf, cap);
+    case 1: return copy_cloud(p.sr.cornerPointsSharp, buf, cap);
+    case 2: return copy_cloud(p.sr.cornerPointsLessSharp, buf, cap);
+    case 3: return copy_cloud(p.sr.surfPointsFlat, buf, cap);
+    case 4: return copy_cloud(p.sr.surfPointsLessFlat, buf, cap);
+    case 5: return copy_cloud(p.lo.laserCloudCornerLast, buf, cap);
+    case 6: return copy_cloud(p.lo.laserCloudSurfLast, buf, cap);
+    case 7: return copy_cloud(p.lm.laserCloudCornerStack, buf, cap);
+    case 8: return copy_cloud(p.lm.laserCloudSurfStack, buf, cap);
+    case 9: return copy_cloud(p.lm.laserCloudCornerFromMap, buf, cap);
+    case 10: return copy_cloud(p.lm.laserCloudSurfFromMap, buf, cap);
+    case 11: { Cloud c; p.lm.registered_cloud(&c); return copy_cloud(c, buf, cap); }
+  }
+  return -1;
+}
+// which: 0 sortInd, 1 picked, 2 label, 3 scanStartInd, 4 scanEndInd, 5 sharpInd, 6 lessSharpInd, 7 flatInd
+int orc_get_sr_ints(orc_handle* h, int which, int* buf, int cap) {
+  ScanRegistrationResult& s = h->p->sr;
+  switch (which) {
+    case 0: return copy_vec(s.cloudSortInd, buf, cap);
+    case 1: return copy_vec(s.cloudNeighborPicked, buf, cap);
+    case 2: return copy_vec(s.cloudLabel, buf, cap);
+    case 3: return copy_vec(s.scanStartInd, buf, cap);
+    case 4: return copy_vec(s.scanEndInd, buf, cap);
+    case 5: return copy_vec(s.sharpInd, buf, cap);
+    case 6: return copy_vec(s.lessSharpInd, buf, cap);
+    case 7: return copy_vec(s.flatInd, buf, cap);
+  }
+  return -1;
+}
+int orc_get_sr_curvature(orc_handle* h, float* buf, int cap) { return copy_vec(h->p->sr.cloudCurvature, buf, cap); }
+void orc_get_sr_scalars(orc_handle* h, float* start_end_ori2, int* half_passed_at, int* n_after_s1) {
+  start_end_ori2[0] = h->p->sr.startOri; start_end_ori2[1] = h->p->sr.endOri;
+  *half_passed_at = h->p->sr.halfPassedAt; *n_after_s1 = h->p->sr.n_after_s1;
+}
+
+void orc_get_lo_pose(orc_handle* h, double* q_w, double* t_w, double* q_lc, double* t_lc) {
+  LaserOdometry& lo = h->p->lo;
+  q_w[0] = lo.q_w_curr.x; q_w[1] = lo.q_w_curr.y; q_w[2] = lo.q_w_curr.z; q_w[3] = lo.q_w_curr.w;
+  t_w[0] = lo.t_w_curr.x; t_w[1] = lo.t_w_curr.y; t_w[2] = lo.t_w_curr.z;
+  for (int i = 0; i < 4; i++) q_lc[i] = lo.para_q[i];
+  for (int i = 0; i < 3; i++) t_lc[i] = lo.para_t[i];
+}
+int orc_lo_num_outer(orc_handle* h) { return (int)h->p->lo.debug.size(); }
+// corner: n x 3 ints (i,a,b); plane: n x 4 ints (i,a,b,c)
+int orc_get_lo_corr(orc_handle* h, int outer, int* corner, int cap_c, int* n_corner, int* plane, int cap_p, int* n_plane) {
+  if (outer < 0 || outer >= (int)h->p->lo.debug.size()) return -1;
+  const LOIterationDebug& d = h->p->lo.debug[outer];
+  *n_corner = (int)d.corner.size();
+  *n_plane = (int)d.plane.size();
+  if (corner) for (int i = 0; i < *n_corner && i < cap_c; i++) { corner[3 * i] = d.corner[i].i; corner[3 * i + 1] = d.corner[i].a; corner[3 * i + 2] = d.corner[i].b; }
+  if (plane) for (int i = 0; i < *n_plane && i < cap_p; i++) { plane[4 * i] = d.plane[i].i; plane[4 * i + 1] = d.plane[i].a; plane[4 * i + 2] = d.plane[i].b; plane[4 * i + 3] = d.plane[i].c; }
+  return 0;
+}
+// trace rows: cost, cost_change, gradient_max_norm, step_norm, relative_decrease, radius, valid, successful
+int orc_get_lo_solve(orc_handle* h, int outer, double* qt_in7, double* qt_out7, double* trace, int cap_iters, int* n_iters,
+                     double* H0, double* g0, int* termination, double* costs2, double* residuals0, int cap_res, int* n_res) {
+  if (outer < 0 || outer >= (int)h->p->lo.debug.size()) return -1;
+  const LOIterationDebug& d = h->p->lo.debug[outer];
+  for (int i = 0; i < 4; i++) { qt_in7[i] = d.q_in[i]; qt_out7[i] = d.q_out[i]; }
+  for (int i = 0; i < 3; i++) { qt_in7[4 + i] = d.t_in[i]; qt_out7[4 + i] = d.t_out[i]; }
+  pack_summary(d.summary, trace, cap_iters, n_iters, H0, g0, termination, costs2);
+  if (n_res) *n_res = (int)d.summary.raw_residuals0.size();
+  if (residuals0) copy_vec(d.summary.raw_residuals0, residuals0, cap_res);
+  return 0;
+}
+
+void orc_get_map_pose(orc_handle* h, double* q_w, double* t_w, double* q_wmap_wodom, double* t_wmap_wodom) {
+  LaserMapping& lm = h->p->lm;
+  for (int i = 0; i < 4; i++) q_w[i] = lm.parameters[i];
+  for (int i = 0; i < 3; i++) t_w[i] = lm.parameters[4 + i];
+  q_wmap_wodom[0] = lm.q_wmap_wodom.x; q_wmap_wodom[1] = lm.q_wmap_wodom.y; q_wmap_wodom[2] = lm.q_wmap_wodom.z; q_wmap_wodom[3] = lm.q_wmap_wodom.w;
+  t_wmap_wodom[0] = lm.t_wmap_wodom.x; t_wmap_wodom[1] = lm.t_wmap_wodom.y; t_wmap_wodom[2] = lm.t_wmap_wodom.z;
+}
+int orc_map_num_outer(orc_handle* h) { return (int)h->p->lm.debug.size(); }
+int orc_get_map_solve(orc_handle* h, int outer, double* qt_in7, double* qt_out7, double* trace, int cap_iters, int* n_iters,
+                      double* H0, double* g0, int* termination, double* costs2, int* corner_surf_num2, double* residuals0,
+                      int cap_res, int* n_res) {
+  if (outer < 0 || outer >= (int)h->p->lm.debug.size()) return -1;
+  const MapIterationDebug& d = h->p->lm.debug[outer];
+  for (int i = 0; i < 4; i++) { qt_in7[i] = d.q_in[i]; qt_out7[i] = d.q_out[i]; }
+  for (int i = 0; i < 3; i++) { qt_in7[4 + i] = d.t_in[i]; qt_out7[4 + i] = d.t_out[i]; }
+  pack_summary(d.summary, trace, cap_iters, n_iters, H0, g0, termination, costs2);
+  corner_surf_num2[0] = d.corner_num; corner_surf_num2[1] = d.surf_num;
+  if (n_res) *n_res = (int)d.summary.raw_residuals0.size();
+  if (residuals0) copy_vec(d.summary.raw_residuals0, residuals0, cap_res);
+  return 0;
+}
+// accepted map factors of outer round `outer`: stack indices + geometry (corner: a,b = 6 doubles; surf: n,d = 4)
+int orc_get_map_factors(orc_handle* h, int outer, int* corner_idx, double* corner_ab, int cap_c, int* surf_idx, double* surf_plane, int cap_s) {
+  if (outer < 0 || outer >= (int)h->p->lm.debug.size()) return -1;
+  const MapIterationDebug& d = h->p->lm.debug[outer];
+  for (int i = 0; i < (int)d.corner_idx.size() && i < cap_c; i++) {
+    if (corner_idx) corner_idx[i] = d.corner_idx[i];
+    if (corner_ab) for (int k = 0; k < 6; k++) corner_ab[6 * i + k] = d.corner_ab[i][k];
+  }
+  for (int i = 0; i < (int)d.surf_idx.size() && i < cap_s; i++) {
+    if (surf_idx) surf_idx[i] = d.surf_idx[i];
+    if (surf_plane) for (int k = 0; k < 4; k++) surf_plane[4 * i + k] = d.surf_plane[i][k];
+  }
+  return 0;
+}
+// map bookkeeping: centre offsets, total points, valid cube list, per-cube sizes
+void orc_get_map_info(orc_handle* h, int* cen3, long long* total2, int* valid_ind, int cap_valid, int* n_valid) {
+  LaserMapping& lm = h->p->lm;
+  cen3[0] = lm.cenW(); cen3[1] = lm.cenH(); cen3[2] = lm.cenD();
+  total2[0] = (long long)lm.map_points_corner(); total2[1] = (long long)lm.map_points_surf();
+  *n_valid = (int)lm.validInd.size();
+  for (int i = 0; i < *n_valid && i < cap_valid; i++) valid_ind[i] = lm.validInd[i];
+}
+int orc_get_map_cube(orc_handle* h, int which /*0 corner,1 surf*/, int cube, float* buf, int cap) {
+  if (cube < 0 || cube >= LaserMapping::laserCloudNum) return -1;
+  return copy_cloud(which == 0 ? h->p->lm.cube_corner(cube) : h->p->lm.cube_surf(cube), buf, cap);
+}
+
+// ---------------------------------------------------------------- standalone pieces
+int orc_voxel_grid(const float* xyzi, int n, float leaf, float* out, int cap) {
+  Cloud in((size_t)n);
+  if (n > 0) std::memcpy(in.data(), xyzi, sizeof(PointXYZI) * (size_t)n);
+  Cloud o = voxel_grid(in, leaf);
+  return copy_cloud(o, out, cap);
+}
+void orc_knn(const float* xyzi, int n, const float* queries_xyz, int nq, int k, int* idx, float* d2, int use_tree) {
+  Cloud pts((size_t)n);
+  if (n > 0) std::memcpy(pts.data(), xyzi, sizeof(PointXYZI) * (size_t)n);
+  KdTree tree;
+  if (use_tree) tree.build(pts);
+  for (int i = 0; i < nq; i++) {
+    for (int j = 0; j < k; j++) { idx[i * k + j] = -1; d2[i * k + j] = -1.0f; }
+    if (use_tree) tree.knn(queries_xyz + 3 * i, k, idx + i * k, d2 + i * k);
+    else knn_brute(pts, queries_xyz + 3 * i, k, idx + i * k, d2 + i * k);
+  }
+}
+
+// type: 0 LidarEdgeFactor (geom = a[3], b[3]), 1 LidarPlaneFactor (geom = j,l,m [9]), 2 LidarPlaneNormFactor (geom = n[3], d).
+// Returns nres; residual[nres]; jac_local = nres x 6 row-major in the tangent space of (q ⊞ δ, t + δt)
+// exactly as Ceres assembles it (autodiff global Jacobian x EigenQuaternionParameterization Jacobian); no loss applied.
+int orc_eval_lidar_factor(int type, const double* curr3, const double* geom, const double* q4, const double* t3, double* residual,
+                          double* jac_local) {
+  std::unique_ptr<CostFunction> f;
+  Vec3d c(curr3[0], curr3[1], curr3[2]);
+  if (type == 0) f.reset(new AutoDiffCost<LidarEdgeFactor, 3, 4>(LidarEdgeFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), 1.0)));
+  else if (type == 1) f.reset(new AutoDiffCost<LidarPlaneFactor, 1, 4>(LidarPlaneFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), Vec3d(geom[6], geom[7], geom[8]), 1.0)));
+  else if (type == 2) f.reset(new AutoDiffCost<LidarPlaneNormFactor, 1, 4>(LidarPlaneNormFactor(c, Vec3d(geom[0], geom[1], geom[2]), geom[3])));
+  else return -1;
+  double j0[12], j1[9];
+  f->Evaluate(q4, t3, residual, j0, j1);
+  const double* x = q4;
+  const double P[12] = {x[3], x[2], -x[1], -x[2], x[3], x[0], x[1], -x[0], x[3], -x[0], -x[1], -x[2]};
+  for (int k = 0; k < f->nres; k++) {
+    for (int a = 0; a < 3; a++) {
+      double s = 0; for (int b = 0; b < 4; b++) s += j0[k * 4 + b] * P[b * 3 + a];
+      jac_local[k * 6 + a] = s;
+      jac_local[k * 6 + 3 + a] = j1[k * 3 + a];
+    }
+  }
+  return f->nres;
+}
+
+// Generic driver for the LM restatement.  Factors: rows of 16 doubles {type, payload...}:
+//   type 0 edge      : curr[3], a[3], b[3]
+//   type 1 plane     : curr[3], j[3], l[3], m[3]
+//   type 2 planenorm : curr[3], n[3], d
+//   type 3 CostFunctor32 : x0,y0,z0,x1_bar,y1_bar
+//   type 4 CostFunctor22 : x0_bar,y0_bar,x1_bar,y1_bar
+//   type 5 scalar test   : r = payload[0] - p0[0]     (Ceres "hello world", VO/README.md:40-50)
+// p0 has 4 entries (quaternion xyzw) when quaternion != 0, else 3.
+int orc_solve(const double* factors, int nf, int quaternion, double huber_a, int max_iters, double* p0, double* p1, double* trace,
+              int cap_iters, int* n_iters, double* H0, double* g0, int* termination, double* costs2) {
+  Problem prob;
+  for (int i = 0; i < nf; i++) {
+    const double* f = factors + 16 * i;
+    const int type = (int)f[0];
+    const double* p = f + 1;
+    Vec3d c(p[0], p[1], p[2]);
+    if (quaternion) {
+      if (type == 0) prob.Add(new AutoDiffCost<LidarEdgeFactor, 3, 4>(LidarEdgeFactor(c, Vec3d(p[3], p[4], p[5]), Vec3d(p[6], p[7], p[8]), 1.0)));
+      else if (type == 1) prob.Add(new AutoDiffCost<LidarPlaneFactor, 1, 4>(LidarPlaneFactor(c, Vec3d(p[3], p[4], p[5]), Vec3d(p[6], p[7], p[8]), Vec3d(p[9], p[10], p[11]), 1.0)));
+      else if (type == 2) prob.Add(new AutoDiffCost<LidarPlaneNormFactor, 1, 4>(LidarPlaneNormFactor(c, Vec3d(p[3], p[4], p[5]), p[6])));
+      else return -1;
+    } else {
+      if (type == 3) prob.Add(new AutoDiffCost<CostFunctor32, 2, 3>(CostFunctor32(p[0], p[1], p[2], p[3], p[4])));
+      else if (type == 4) prob.Add(new AutoDiffCost<CostFunctor22, 1, 3>(CostFunctor22(p[0], p[1], p[2], p[3])));
+      else if (type == 5) prob.Add(new AutoDiffCost<HelloFunctor, 1, 3>(HelloFunctor{p[0]}));
+      else return -1;
+    }
+  }
+  SolveOptions opt;
+  opt.max_num_iterations = max_iters;
+  opt.huber_a = huber_a;
+  opt.quaternion_block0 = quaternion != 0;
+  SolveSummary s;
+  prob.Solve(opt, p0, p1, &s);
+  pack_summary(s, trace, cap_iters, n_iters, H0, g0, termination, costs2);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  PARITY UNPINNED.
+// Trust-region Levenberg–Marquardt as Ceres 2.0.0 runs it for the reference's problems.
+#include "orc_ceres.h"
+
+namespace orc {
+namespace {
+
+// EigenQuaternionParameterization::Plus (local_parameterization.cc): x_plus = delta_q * x,
+// delta_q = (sin|d|/|d| * d, cos|d|), coefficient order x,y,z,w.
+void QuatPlus(const double* x, const double* d, double* out) {
+  const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n > 0.0) {
+    const double s = std::sin(n) / n;
+    Quat<double> dq(s * d[0], s * d[1], s * d[2], std::cos(n));
+    Quat<double> q(x[0], x[1], x[2], x[3]);
+    Quat<double> r = qmul(dq, q);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+  } else {
+    for (int i = 0; i < 4; i++) out[i] = x[i];
+  }
+}
+// EigenQuaternionParameterization::ComputeJacobian, 4x3 row-major.
+void QuatPlusJacobian(const double* x, double* J) {
+  J[0] = x[3];  J[1] = x[2];   J[2] = -x[1];
+  J[3] = -x[2]; J[4] = x[3];   J[5] = x[0];
+  J[6] = x[1];  J[7] = -x[0];  J[8] = x[3];
+  J[9] = -x[0]; J[10] = -x[1]; J[11] = -x[2];
+}
+
+struct Eval {
+  const SolveOptions& opt;
+  const std::vector<std::unique_ptr<CostFunction>>& blocks;
+  int n0;      // ambient size of block 0
+  int nrows;   // total residuals
+  Eval(const SolveOptions& o, const std::vector<std::unique_ptr<CostFunction>>& b) : opt(o), blocks(b) {
+    n0 = o.quaternion_block0 ? 4 : 3;
+    nrows = 0;
+    for (auto& c : b) nrows += c->nres;
+  }
+  void Plus(const double* x, const double* delta, double* out) const {
+    if (opt.quaternion_block0) {
+      QuatPlus(x, delta, out);
+      for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + delta[3 + i];
+    } else {
+      for (int i = 0; i < 6; i++) out[i] = x[i] + delta[i];
+    }
+  }
+  // HuberLoss::Evaluate (loss_function.cc)
+  void Huber(double s, double rho[3]) const {
+    const double a = opt.huber_a, b = a * a;
+    if (a <= 0) { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return; }
+    if (s > b) {
+      const double r = std::sqrt(s);
+      rho[0] = 2.0 * a * r - b;
+      rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else {
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+  }
+  // ProgramEvaluator + ResidualBlock::Evaluate: cost = 1/2 sum rho(s); residuals and tangent-space
+  // Jacobian are corrected (corrector.cc).  For Huber rho'' <= 0 always, so the corrector is the
+  // plain sqrt(rho') scaling of both.  J is nrows x 6 row-major.  raw (optional) gets uncorrected r.
+  void Evaluate(const double* x, double* cost, double* r, double* J, double* raw = nullptr) const {
+    double P[12];
+    if (opt.quaternion_block0 && J) QuatPlusJacobian(x, P);
+    double c = 0.0;
+    int row = 0;
+    for (auto& blk : blocks) {
+      const int nr = blk->nres;
+      double res[3], j0[12], j1[9];
+      blk->Evaluate(x, x + n0, res, J ? j0 : nullptr, J ? j1 : nullptr);
+      double sq = 0.0;
+      for (int k = 0; k < nr; k++) sq += res[k] * res[k];
+      double rho[3];
+      Huber(sq, rho);
+      c += 0.5 * rho[0];
+      if (raw) for (int k = 0; k < nr; k++) raw[row + k] = res[k];
+      // Corrector: sq_norm == 0 or rho'' <= 0  ->  residual_scaling = sqrt(rho'), alpha = 0.
+      double scale = std::sqrt(rho[1]);
+      if (!(sq == 0.0 || rho[2] <= 0.0)) {
+        // Full Triggs correction (never reached with Huber/trivial loss; kept for completeness).
+        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - std::sqrt(D);
+        scale = std::sqrt(rho[1]) / (1 - alpha);
+      }
+      if (r) for (int k = 0; k < nr; k++) r[row + k] = res[k] * scale;
+      if (J) {
+        for (int k = 0; k < nr; k++) {
+          double* Jr = J + (size_t)(row + k) * 6;
+          if (opt.quaternion_block0) {
+            for (int a = 0; a < 3; a++) {
+              double s = 0.0;
+              for (int b = 0; b < 4; b++) s += j0[k * 4 + b] * P[b * 3 + a];
+              Jr[a] = s * scale;
+            }
+          } else {
+            for (int a = 0; a < 3; a++) Jr[a] = j0[k * 3 + a] * scale;
+          }
+          for (int a = 0; a < 3; a++) Jr[3 + a] = j1[k * 3 + a] * scale;
+        }
+      }
+      row += nr;
+    }
+    *cost = c;
+  }
+};
+
+}  // namespace
+
+void Problem::Solve(const SolveOptions& opt, double* p0, double* p1, SolveSummary* summary) {
+  Eval ev(opt, blocks);
+  const int n0 = ev.n0, na = n0 + 3, m = ev.nrows;
+  SolveSummary local;
+  SolveSummary& S = summary ? *summary : local;
+  S.iterations.clear();
+  S.num_residual_blocks = (int)blocks.size();
+  S.num_residuals = m;
+
+  std::vector<double> x(na), cand(na), best(na);
+  for (int i = 0; i < n0; i++) x[i] = p0[i];
+  for (int i = 0; i < 3; i++) x[n0 + i] = p1[i];
+  best = x;
+  auto norm_na = [&](const std::vector<double>& a) { double s = 0; for (int i = 0; i < na; i++) s += a[i] * a[i]; return std::sqrt(s); };
+  double x_norm = norm_na(x);
+
+  std::vector<double> r(m), J((size_t)m * 6), Js((size_t)m * 6);
+  double g[6], scale[6];
+  double x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
+  double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  double diagonal[6];
+  int num_consecutive_invalid = 0;
+  IterationSummary it;
+
+  // EvaluateGradientAndJacobian
+  auto eval_grad_jac = [&](int iteration, double* gmax) {
+    ev.Evaluate(x.data(), &x_cost, r.data(), J.data(), iteration == 0 ? (S.raw_residuals0.resize(m), S.raw_residuals0.data()) : nullptr);
+    for (int a = 0; a < 6; a++) { double s = 0; for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + a] * r[i]; g[a] = s; }
+    if (iteration == 0) {
+      S.residuals0 = r;
+      for (int a = 0; a < 6; a++) {
+        S.g0[a] = g[a];
+        for (int b = 0; b < 6; b++) { double s = 0; for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + a] * J[(size_t)i * 6 + b]; S.H0[a * 6 + b] = s; }
+      }
+      for (int a = 0; a < 6; a++) {
+        double s = 0; for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + a] * J[(size_t)i * 6 + a];
+        scale[a] = opt.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(s)) : 1.0;
+      }
+    }
+    for (int i = 0; i < m; i++) for (int a = 0; a < 6; a++) Js[(size_t)i * 6 + a] = J[(size_t)i * 6 + a] * scale[a];
+    // gradient_max_norm = |x - Plus(x, -g)|_inf in the ambient space
+    double ng[6]; for (int a = 0; a < 6; a++) ng[a] = -g[a];
+    std::vector<double> pg(na);
+    ev.Plus(x.data(), ng, pg.data());
+    double mx = 0; for (int i = 0; i < na; i++) mx = std::max(mx, std::fabs(x[i] - pg[i]));
+    *gmax = mx;
+  };
+
+  // ---- IterationZero
+  it = IterationSummary();
+  it.iteration = 0;
+  eval_grad_jac(0, &it.gradient_max_norm);
+  it.cost = x_cost; it.cost_change = 0; it.step_norm = 0; it.relative_decrease = 0;
+  it.step_is_valid = true; it.step_is_successful = true;
+  S.initial_cost = x_cost;
+  double current_cost = x_cost;  // TrustRegionStepEvaluator (monotonic: reference == current)
+  S.termination = 0;
+
+  for (;;) {
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (it.step_is_successful) {
+      if (x_cost < minimum_cost) { minimum_cost = x_cost; best = x; }
+    }
+    it.trust_region_radius = radius;
+    S.iterations.push_back(it);
+    if (it.iteration >= opt.max_num_iterations) { S.termination = 0; break; }
+    if (it.gradient_max_norm <= opt.gradient_tolerance) { S.termination = 1; break; }
+    if (radius <= opt.min_trust_region_radius) { S.termination = 1; break; }
+
+    const int iteration = it.iteration + 1;
+    it = IterationSummary();
+    it.iteration = iteration;
+
+    // ---- ComputeTrustRegionStep : LevenbergMarquardtStrategy::ComputeStep
+    if (!reuse_diagonal) {
+      for (int a = 0; a < 6; a++) {
+        double s = 0; for (int i = 0; i < m; i++) s += Js[(size_t)i * 6 + a] * Js[(size_t)i * 6 + a];
+        diagonal[a] = std::min(std::max(s, opt.min_lm_diagonal), opt.max_lm_diagonal);
+      }
+    }
+    double lm_diag[6];
+    for (int a = 0; a < 6; a++) lm_diag[a] = std::sqrt(diagonal[a] / radius);
+    // DenseQRSolver: min || [Js; diag(lm_diag)] y - [r; 0] ||, step = -y
+    std::vector<double> A((size_t)(m + 6) * 6, 0.0), rhs(m + 6, 0.0);
+    std::memcpy(A.data(), Js.data(), sizeof(double) * (size_t)m * 6);
+    for (int a = 0; a < 6; a++) A[(size_t)(m + a) * 6 + a] = lm_diag[a];
+    for (int i = 0; i < m; i++) rhs[i] = r[i];
+    double step[6];
+    bool ok = householder_ls(A.data(), rhs.data(), m + 6, 6, step);
+    for (int a = 0; a < 6; a++) if (!std::isfinite(step[a])) ok = false;
+    reuse_diagonal = true;
+    it.step_is_valid = false;
+    double model_cost_change = 0;
+    double delta[6];
+    if (ok) {
+      for (int a = 0; a < 6; a++) step[a] = -step[a];
+      // model_cost_change = -(Js s)^T (r + Js s / 2)
+      double acc = 0;
+      for (int i = 0; i < m; i++) {
+        double mr = 0; for (int a = 0; a < 6; a++) mr += Js[(size_t)i * 6 + a] * step[a];
+        acc += mr * (r[i] + mr / 2.0);
+      }
+      model_cost_change = -acc;
+      it.step_is_valid = model_cost_change > 0.0;
+      if (it.step_is_valid) {
+        for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
+        num_consecutive_invalid = 0;
+      }
+    }
+    if (!it.step_is_valid) {
+      // ---- HandleInvalidStep
+      if (++num_consecutive_invalid >= opt.max_num_consecutive_invalid_steps) { S.termination = 2; break; }
+      radius *= 0.5;  // LevenbergMarquardtStrategy::StepInvalid
+      reuse_diagonal = true;
+      it.cost = x_cost; it.cost_change = 0; it.gradient_max_norm = S.iterations.back().gradient_max_norm;
+      it.step_norm = 0; it.relative_decrease = 0; it.step_is_successful = false;
+      continue;
+    }
+
+    // ---- ComputeCandidatePointAndEvaluateCost
+    double candidate_cost;
+    ev.Plus(x.data(), delta, cand.data());
+    ev.Evaluate(cand.data(), &candidate_cost, nullptr, nullptr);
+    if (!std::isfinite(candidate_cost)) candidate_cost = std::numeric_limits<double>::max();
+
+    // ---- ParameterToleranceReached
+    { double s = 0; for (int i = 0; i < na; i++) s += (x[i] - cand[i]) * (x[i] - cand[i]); it.step_norm = std::sqrt(s); }
+    if (it.step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { S.termination = 1; break; }
+    // ---- FunctionToleranceReached
+    it.cost_change = x_cost - candidate_cost;
+    if (std::fabs(it.cost_change) <= opt.function_tolerance * x_cost) { S.termination = 1; break; }
+
+    // ---- IsStepSuccessful : TrustRegionStepEvaluator::StepQuality (monotonic)
+    if (candidate_cost >= std::numeric_limits<double>::max()) it.relative_decrease = std::numeric_limits<double>::lowest();
+    else it.relative_decrease = (current_cost - candidate_cost) / model_cost_change;
+
+    if (it.relative_decrease > opt.min_relative_decrease) {
+      // ---- HandleSuccessfulStep
+      x = cand;
+      x_norm = norm_na(x);
+      eval_grad_jac(iteration, &it.gradient_max_norm);
+      it.cost = x_cost;
+      it.step_is_successful = true;
+      // LevenbergMarquardtStrategy::StepAccepted
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(opt.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+      current_cost = candidate_cost;
+    } else {
+      // ---- HandleUnsuccessfulStep
+      it.step_is_successful = false;
+      radius = radius / decrease_factor;  // StepRejected
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+      it.cost = candidate_cost;
+      it.gradient_max_norm = S.iterations.back().gradient_max_norm;
+    }
+  }
+
+  S.final_cost = minimum_cost;
+  for (int i = 0; i < n0; i++) p0[i] = best[i];
+  for (int i = 0; i < 3; i++) p1[i] = best[n0 + i];
+}
+
+}  // namespace orc

@@ -1,0 +1,201 @@
+"""Seeded synthetic HDL-64E / VLP-16 sweep generator.
+
+Test / bench input only: analytic ray casting of a ground plane, axis-aligned boxes and vertical
+cylinders placed along a smooth SE3 trajectory.  Emits ring-major ``[n_rings * n_azimuth, 4]``
+float32 clouds (x, y, z, 0) in the sensor frame; misses are NaN (exercises the reference's
+``removeNaNFromPointCloud``, scan_registration.cpp:157), returns closer than ``minimum_range`` are
+kept (exercises ``removeClosedPointCloud``, scan_registration.cpp:100-129).
+
+Beam table: ring r -> elevation 1.9 - r/3 deg (r <= 31), -8.93 - (r-32)/2 deg (r >= 32), i.e. the
+HDL-64E table shifted 0.1 deg down so the reference's ``int((2-angle)*3+0.5)`` /
+``32+int((-8.83-angle)*2+0.5)`` mapping (scan_registration.cpp:213-226) lands mid-bin.
+"""
+import numpy as np
+
+GROUND_Z = -1.73
+MAX_RANGE = 80.0
+
+
+def beam_elevations_deg(n_rings):
+    r = np.arange(n_rings, dtype=np.float64)
+    if n_rings == 64:
+        return np.where(r <= 31, 1.9 - r / 3.0, -8.93 - (r - 32) / 2.0)
+    if n_rings == 16:  # VLP-16: scanID = int((angle + 15) / 2 + 0.5)  (scan_registration.cpp:195-203)
+        return -15.0 + 2.0 * r
+    if n_rings == 32:  # HDL-32: scanID = int((angle + 92/3) * 3/4)      (scan_registration.cpp:204-212)
+        return -92.0 / 3.0 + (r + 0.5) * 4.0 / 3.0
+    raise ValueError("n_rings must be 16, 32 or 64")
+
+
+def _rot_zyx(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+    Ry = np.array([[cp, 0, sp], [0, 1.0, 0], [-sp, 0, cp]])
+    Rx = np.array([[1.0, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+def rot_to_quat_xyzw(R):
+    """Rotation matrix -> unit quaternion (x, y, z, w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def quat_to_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class SynthSequence:
+    def __init__(self, n_rings=64, n_azimuth=2048, n_sweeps=200, seed_scene=1234, seed_traj=42, seed_noise=5678,
+                 noise_sigma=0.02, speed=10.0, dt=0.1):
+        self.n_rings, self.n_azimuth, self.n_sweeps = n_rings, n_azimuth, n_sweeps
+        self.seed_noise, self.noise_sigma = seed_noise, noise_sigma
+        el = np.deg2rad(beam_elevations_deg(n_rings))
+        az = -2.0 * np.pi * np.arange(n_azimuth) / n_azimuth  # clockwise so ori = -atan2(y, x) increases
+        ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+        d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (n_rings, n_azimuth))], -1)
+        self.dirs = d.reshape(-1, 3)  # ring-major
+        # ---- trajectory: smooth speed / yaw-rate / small roll, pitch, heave
+        rt = np.random.default_rng(seed_traj)
+        ph = rt.uniform(0, 2 * np.pi, 6)
+        k = np.arange(n_sweeps)
+        t = k * dt
+        v = speed * (1.0 + 0.1 * np.sin(2 * np.pi * t / 7.3 + ph[0]))
+        yaw_rate = 0.2 * np.sin(2 * np.pi * t / 11.0 + ph[1])
+        yaw = np.concatenate([[0.0], np.cumsum(yaw_rate[:-1] * dt)])
+        x = np.concatenate([[0.0], np.cumsum(v[:-1] * np.cos(yaw[:-1]) * dt)])
+        y = np.concatenate([[0.0], np.cumsum(v[:-1] * np.sin(yaw[:-1]) * dt)])
+        z = 0.05 * np.sin(2 * np.pi * t / 5.0 + ph[2])
+        pitch = 0.01 * np.sin(2 * np.pi * t / 3.7 + ph[3])
+        roll = 0.01 * np.sin(2 * np.pi * t / 4.3 + ph[4])
+        self.R = [_rot_zyx(yaw[i], pitch[i], roll[i]) for i in range(n_sweeps)]
+        self.t = np.stack([x, y, z], -1)
+        # ---- scene placed along the path corridor
+        rs = np.random.default_rng(seed_scene)
+        path_len = float(np.sum(v) * dt) + 160.0
+        boxes, cyls = [], []
+        yaw0, yawN = yaw[0], yaw[-1]
+
+        def path_point(s):  # arc length -> (pos, left normal); extrapolates straight before/after the run
+            s0 = s - 80.0
+            arc = np.concatenate([[0.0], np.cumsum(v[:-1] * dt)])
+            if s0 <= 0:
+                p = np.array([x[0], y[0]]) + s0 * np.array([np.cos(yaw0), np.sin(yaw0)])
+                h = yaw0
+            elif s0 >= arc[-1]:
+                p = np.array([x[-1], y[-1]]) + (s0 - arc[-1]) * np.array([np.cos(yawN), np.sin(yawN)])
+                h = yawN
+            else:
+                i = int(np.searchsorted(arc, s0)) - 1
+                f = (s0 - arc[i]) / max(arc[i + 1] - arc[i], 1e-9)
+                p = np.array([x[i] + f * (x[i + 1] - x[i]), y[i] + f * (y[i + 1] - y[i])])
+                h = yaw[i]
+            return p, np.array([-np.sin(h), np.cos(h)])
+
+        s = 0.0
+        side = 1.0
+        while s < path_len:
+            p, nrm = path_point(s)
+            sx, sy, sz = rs.uniform(2, 10), rs.uniform(2, 10), rs.uniform(2.5, 8)
+            off = rs.uniform(7.0, 22.0) + 0.5 * max(sx, sy)
+            c = p + side * off * nrm
+            boxes.append([c[0] - sx / 2, c[1] - sy / 2, GROUND_Z, c[0] + sx / 2, c[1] + sy / 2, GROUND_Z + sz])
+            side = -side
+            s += rs.uniform(6.0, 10.0)
+        s = 2.0
+        side = -1.0
+        while s < path_len:
+            p, nrm = path_point(s)
+            off = rs.uniform(4.0, 15.0)
+            c = p + side * off * nrm
+            cyls.append([c[0], c[1], 0.15, GROUND_Z, GROUND_Z + rs.uniform(3.0, 6.0)])
+            side = -side
+            s += rs.uniform(3.0, 5.0)
+        self.boxes = np.array(boxes)
+        self.cyls = np.array(cyls)
+
+    # ------------------------------------------------------------------ poses
+    def pose(self, k):
+        return self.R[k], self.t[k]
+
+    def gt_relative(self, k):
+        """(q_xyzw, t) of T_{k-1}^{-1} T_k, i.e. p_last = q * p_curr + t — what LaserOdometry estimates."""
+        R0, t0 = self.pose(k - 1)
+        R1, t1 = self.pose(k)
+        R = R0.T @ R1
+        return rot_to_quat_xyzw(R), R0.T @ (t1 - t0)
+
+    def gt_world(self, k):
+        """Pose of sweep k in sweep 0's frame."""
+        R0, t0 = self.pose(0)
+        R1, t1 = self.pose(k)
+        return rot_to_quat_xyzw(R0.T @ R1), R0.T @ (t1 - t0)
+
+    # ------------------------------------------------------------------ ray casting
+    def ranges(self, k):
+        R, o = self.pose(k)
+        d = self.dirs @ R.T  # world directions
+        n = d.shape[0]
+        best = np.full(n, np.inf)
+        # ground
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (GROUND_Z - o[2]) / d[:, 2]
+        tg = np.where((d[:, 2] < 0) & (tg > 0), tg, np.inf)
+        best = np.minimum(best, tg)
+        # boxes (slab), culled to those within reach
+        bx = self.boxes
+        cen = 0.5 * (bx[:, :2] + bx[:, 3:5])
+        near = np.linalg.norm(cen - o[None, :2], axis=1) < MAX_RANGE + 10.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / d
+        for b in bx[near]:
+            t1 = (b[None, 0:3] - o[None, :]) * inv
+            t2 = (b[None, 3:6] - o[None, :]) * inv
+            tmin = np.nanmax(np.minimum(t1, t2), axis=1)
+            tmax = np.nanmin(np.maximum(t1, t2), axis=1)
+            hit = (tmax >= tmin) & (tmin > 0)
+            best = np.where(hit & (tmin < best), tmin, best)
+        # vertical cylinders
+        cy = self.cyls
+        near = np.linalg.norm(cy[:, :2] - o[None, :2], axis=1) < MAX_RANGE + 2.0
+        a = d[:, 0] ** 2 + d[:, 1] ** 2
+        for c in cy[near]:
+            ox, oy = o[0] - c[0], o[1] - c[1]
+            bq = 2 * (ox * d[:, 0] + oy * d[:, 1])
+            cq = ox * ox + oy * oy - c[2] ** 2
+            disc = bq * bq - 4 * a * cq
+            with np.errstate(invalid="ignore", divide="ignore"):
+                tc = (-bq - np.sqrt(disc)) / (2 * a)
+            zc = o[2] + tc * d[:, 2]
+            hit = (disc > 0) & (tc > 0) & (zc >= c[3]) & (zc <= c[4])
+            best = np.where(hit & (tc < best), tc, best)
+        return best
+
+    def sweep(self, k):
+        """float32 [n_rings*n_azimuth, 4] ring-major cloud of sweep k in the sensor frame."""
+        rng = np.random.default_rng(self.seed_noise + k)
+        r = self.ranges(k)
+        r = r + rng.normal(0.0, self.noise_sigma, r.shape[0]) if self.noise_sigma > 0 else r
+        miss = ~np.isfinite(r) | (r > MAX_RANGE) | (r <= 0.05)
+        pts = self.dirs * r[:, None]
+        out = np.zeros((pts.shape[0], 4), dtype=np.float32)
+        out[:, :3] = pts.astype(np.float32)
+        out[miss, :3] = np.nan
+        return out
