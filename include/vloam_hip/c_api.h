@@ -1,0 +1,142 @@
+/* libvloam_hip.so — C ABI of the MI355X-native (gfx950, HIP) VLOAM per-scan odometry hot path.
+ *
+ * The reference (YukunXia/VLOAM-CMU-16833) has no FFI layer; the seam this ABI replaces is the C++
+ * class surface its façade drives plus the Ceres cost-functor surface:
+ *   vloam::ScanRegistration   src/lidar_odometry_mapping/include/lidar_odometry_mapping/scan_registration.h:71-77
+ *   vloam::LaserOdometry      src/lidar_odometry_mapping/include/lidar_odometry_mapping/laser_odometry.h:70-84
+ *   vloam::LaserMapping       src/lidar_odometry_mapping/include/lidar_odometry_mapping/laser_mapping.h:85-94
+ *   façade call order         src/lidar_odometry_mapping/src/lidar_odometry_mapping.cpp:65-154
+ *   VO residual stack         src/visual_odometry/src/visual_odometry.cpp:157-186,254-450
+ * include/vloam_hip/compat.hpp presents those classes on top of this ABI; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions: plain C, opaque handle, caller-owned buffers, int status (0 = OK, < 0 = error), no
+ * exceptions across the boundary.  One handle = one sequence (one HIP device + one stream).  A handle
+ * is not thread-safe; distinct handles are independent.  Quaternions are (x, y, z, w) — the layout of
+ * the reference's para_q / parameters arrays (laser_odometry.h:126-130, laser_mapping.h:141-143).
+ * Clouds are packed float4: (x, y, z, pad) on input == pcl::PointXYZ, (x, y, z, intensity) on
+ * output == the payload of pcl::PointXYZI (common.h:42).
+ */
+#ifndef VLOAM_HIP_C_API_H
+#define VLOAM_HIP_C_API_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vloam_handle vloam_handle;
+typedef int vloam_status;
+
+enum {
+  VLOAM_OK = 0,
+  VLOAM_ERR_INVALID = -1,     /* bad argument / unsupported scan_line (the reference ROS_BREAK()s) */
+  VLOAM_ERR_HIP = -2,         /* a HIP runtime call failed; vloam_last_error() has the text */
+  VLOAM_ERR_CAPACITY = -3,    /* more points / ring length / map entries than the handle was sized for */
+  VLOAM_ERR_EMPTY = -4,       /* no point survived NaN / minimum_range removal (reference: UB, scan_registration.cpp:166) */
+  VLOAM_ERR_NO_DEVICE = -5,   /* no usable gfx950 device: there is NO CPU fallback */
+  VLOAM_ERR_ORDER = -6        /* stage called out of the façade's order */
+};
+
+/* Tunables = the ROS parameters the reference reads in its init() functions:
+ * LOM/launch/loam_velodyne_HDL_64_kitti.launch:3-16, MAIN/launch/vloam_main.launch:4-10. */
+typedef struct vloam_config {
+  int scan_line;                   /* 16 | 32 | 64                                   (64)   */
+  double minimum_range;            /* removeClosedPointCloud threshold [m]           (5.0)  */
+  int mapping_skip_frame;          /*                                                (1)    */
+  float mapping_line_resolution;   /* corner VoxelGrid leaf [m]                      (0.4)  */
+  float mapping_plane_resolution;  /* surf VoxelGrid leaf [m]                        (0.8)  */
+  int detach_VO_LO;                /* 1: LO warm-starts from its own last estimate   (1)    */
+  int reset_VO_to_identity;        /*                                                (0)    */
+  int remove_VO_outlier;           /* pixel gate on matches                          (100)  */
+  int with_mapping;                /* run laserMapping inside vloam_process_scan     (1)    */
+  int max_points;                  /* capacity of one sweep                          (262144) */
+  int max_frames;                  /* capacity of the on-device trajectory log       (8192) */
+  int map_capacity_log2;           /* voxel-hash slots = 2^n per feature kind        (22)   */
+  int debug;                       /* 1: keep parity-hook arrays (curvature, sort order, …) */
+  int timing;                      /* 1: HIP-event per-stage timing (synchronises every sweep)   */
+} vloam_config;
+
+typedef struct vloam_calib {  /* row-major f32, as PointCloudUtil holds them (point_cloud_util.h:43-46) */
+  float cam_T_velo[16];
+  float rect0_T_cam[16];
+  float P_rect0[12];
+} vloam_calib;
+
+void vloam_default_config(vloam_config* cfg);
+const char* vloam_last_error(void);
+const char* vloam_version(void);
+
+vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** out);
+vloam_status vloam_destroy(vloam_handle* h);
+
+/* == LidarOdometryMapping::reset (lidar_odometry_mapping.cpp:65-71) */
+vloam_status vloam_reset_frame(vloam_handle* h);
+
+/* == ScanRegistration::input (scan_registration.cpp:131-449).  xyz_pad4: n packed float4 in HOST memory. */
+vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int n);
+/* same, input already resident in this device's HBM */
+vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n);
+
+/* == ScanRegistration::output (scan_registration.cpp:501-512).
+ * which: 0 laserCloud, 1 cornerPointsSharp, 2 cornerPointsLessSharp, 3 surfPointsFlat, 4 surfPointsLessFlat,
+ *        5 laserCloudCornerLast, 6 laserCloudSurfLast (LaserOdometry::output, laser_odometry.cpp:610-629),
+ *        7 laserCloudCornerStack, 8 laserCloudSurfStack (down-sampled scan features inside mapping),
+ *        11 full-resolution cloud registered in the map frame (LaserMapping::publish, laser_mapping.cpp:795-799).
+ * Copies min(n, cap) points to the HOST buffer xyzi4 and returns the true count in *n. Synchronises the stream. */
+vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int cap, int* n);
+
+/* == vloam_tf->velo_last_VOT_velo_curr, read by solveLO when detach_VO_LO == 0 (laser_odometry.cpp:223-236) */
+vloam_status vloam_set_lo_prior(vloam_handle* h, const double q_xyzw[4], const double t[3]);
+
+/* == LaserOdometry::input + solveLO + output (laser_odometry.cpp:135-146,187-536,610-629).
+ * Outputs (any may be NULL): world pose q_w_curr/t_w_curr and the frame-to-frame q_last_curr/t_last_curr. */
+vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]);
+
+/* == LaserMapping::input + solveMapping (laser_mapping.cpp:167-196,198-708).  Outputs the map-frame pose. */
+vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[3]);
+
+/* Whole façade for one sweep, enqueued with NO host synchronisation:
+ * reset -> scanRegistrationIO -> laserOdometryIO -> laserMappingIO (MAIN/src/vloam_main_node.cpp:134,166-168).
+ * d_xyz_pad4 is DEVICE memory and must stay valid until vloam_sync().  Poses go to the on-device trajectory log. */
+vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n);
+/* same with a HOST buffer (staged through pinned memory; returns after the copy is enqueued) */
+vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n);
+vloam_status vloam_sync(vloam_handle* h);
+
+/* Trajectory log: per processed frame 14 doubles {q_w_curr[4], t_w_curr[3]} (laser odometry, world_LOT_base_last)
+ * followed by {q_map[4], t_map[3]} (mapping, world_MOT_base_last).  first..first+count-1 -> HOST buffer. */
+vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double* poses14);
+vloam_status vloam_frame_count(vloam_handle* h, int* frames);
+/* device address + byte size of the trajectory log (for an RCCL gather across GPUs) */
+vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long long* bytes);
+
+/* == VisualOdometry::processPointCloud + solveNlsAll (visual_odometry.cpp:157-186,254-450).
+ * prev_uv/curr_uv: n_match integer pixel pairs (the reference truncates keypoints to int, :283-294).
+ * angle_axis/t: in = initial guess (cam0_curr_LOT_cam0_prev) unless reset_VO_to_identity, out = estimate. */
+vloam_status vloam_vo_set_calib(vloam_handle* h, const vloam_calib* calib);
+vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4, int n);
+vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr_uv, int n_match, double angle_axis[3],
+                            double t[3], int counters32_22[2]);
+
+/* Parity hooks (tests only; need cfg.debug = 1 for the per-point arrays).  Copies up to cap elements of
+ * the named array into buf (element type given per item) and returns the element count in *n.
+ *   stage 0 (scan registration): item 0 curvature f32[N2], 1 sort order i32[N2], 2 picked i32[N2],
+ *       3 label i32[N2], 4 scanStartInd i32[64], 5 scanEndInd i32[64], 6 sharp idx i32, 7 lessSharp idx i32,
+ *       8 flat idx i32, 9 scalars f32{startOri,endOri,halfPassedAt,n_after_s1,N2}
+ *   stage 1 (laser odometry, item = outer*16 + k): k=0 corner corr i32[n][3] (i,a,b; -1 = none),
+ *       1 plane corr i32[n][4], 2 LM record f64 (see vloam_device.h LMRecord), 3 per-factor residuals f64
+ *   stage 2 (laser mapping, same k layout; corr rows are f64 geometry: corner a,b[6] / plane n,d[4] / flag)
+ *   stage 3 (VO): 0 buckets, 1 per-match rows, 2 LM record */
+vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, long long cap_bytes, long long* n_bytes);
+
+/* Timing of the last vloam_sync()ed scans: HIP-event milliseconds accumulated per stage
+ * {scanRegistration, laserOdometry, laserMapping, vo} and number of scans covered. */
+vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans);
+/* Measured per-run counts that DESIGN.md's algorithmic-byte formulas need:
+ * {N_in, N2, n_sharp, n_lessSharp, n_flat, n_lessFlat, C, S, F_o_corner, F_o_plane, E_o, n_c, n_s, K_m, E_m, M} of the last scan. */
+vloam_status vloam_get_counts(vloam_handle* h, long long counts16[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""-m gpu: scanRegistration through the C ABI vs the CPU oracle (bit-exact integer / xyz work).
+
+Reference: src/lidar_odometry_mapping/src/scan_registration.cpp:131-449.  Intensity carries
+relTime = f(atan2f) whose libm/OCML implementations differ in the last ulp, so the fractional part
+of intensity is compared with a tolerance (1e-5 absolute on values <= 51); everything else —
+ring ids, compaction order, curvature, per-sector sort order, picks, labels, voxel centroids' xyz —
+must match bit for bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_TOL = 1e-5
+
+
+def run_both(vl, orc, cloud, scan_line=64, minimum_range=5.0):
+    h = vl.Handle(0, scan_line=scan_line, minimum_range=minimum_range, debug=1, with_mapping=0)
+    h.reset_frame()
+    h.scan_registration(cloud)
+    o = orc.Oracle(scan_line=scan_line, minimum_range=minimum_range, with_mapping=False)
+    assert o.scan_registration(cloud) == 0
+    return h, o
+
+
+def check_cloud(dev, ref, what, ori_bounds=None, max_flips=0):
+    """xyz and ring id bit-exact; relTime fraction within INT_TOL except at the reference's unwrap boundaries.
+
+    relTime goes through atan2f and the +-2*pi unwrap tests of scan_registration.cpp:237-261: one ulp of
+    libm-vs-OCML difference right at such a boundary moves relTime by a full turn (0.1 in intensity).
+    Nothing downstream reads the fraction (DISTORTION == false).  Returns the number of flipped points.
+    """
+    assert dev.shape == ref.shape, "%s: %s vs %s" % (what, dev.shape, ref.shape)
+    assert np.array_equal(dev[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)), "%s xyz not bit-identical" % what
+    assert np.array_equal(dev[:, 3].astype(np.int32), ref[:, 3].astype(np.int32)), "%s ring id differs" % what
+    dlt = np.abs(dev[:, 3] - ref[:, 3])
+    assert np.max(dlt, initial=0) <= 0.11, "%s intensity" % what
+    bad = dlt > INT_TOL
+    if ori_bounds is not None:  # full-resolution cloud: every flip must sit on an unwrap boundary
+        ori = -np.arctan2(ref[:, 1].astype(np.float64), ref[:, 0].astype(np.float64))
+        dmin = np.full(ori.shape, np.inf)
+        for b in ori_bounds:
+            w = np.abs((ori - b + np.pi) % (2 * np.pi) - np.pi)
+            dmin = np.minimum(dmin, w)
+        assert np.all(dmin[bad] < 5e-6), "%s: relTime differs away from an unwrap boundary" % what
+    else:                       # voxel means / picks: at most as many as the full cloud had
+        assert np.count_nonzero(bad) <= max_flips, "%s intensity fraction" % what
+    return int(np.count_nonzero(bad))
+
+
+def unwrap_bounds(startOri, endOri):
+    s, e = float(startOri), float(endOri)
+    return [s - np.pi / 2, s + 1.5 * np.pi, s + np.pi, e - 1.5 * np.pi, e + np.pi / 2]
+
+
+@pytest.mark.parametrize("shape,k", [((64, 512), 0), ((64, 512), 3), ((64, 2048), 0), ((64, 2048), 5), ((16, 1024), 1)])
+def test_scan_registration_parity(vl, orc, sweeps, shape, k):
+    cloud = sweeps(shape[0], shape[1], k)
+    h, o = run_both(vl, orc, cloud, scan_line=shape[0])
+    d = h.sr_debug()
+    sc = o.sr_scalars()
+    assert d["n_after_s1"] == sc["n_after_s1"]
+    full_d, full_o = h.features(0), o.cloud(0)
+    flips = check_cloud(full_d, full_o, "laserCloud", unwrap_bounds(sc["startOri"], sc["endOri"]))
+    # startOri / endOri come straight out of atan2f (OCML vs glibc: <= 1-2 ulp apart)
+    assert abs(float(d["startOri"]) - float(sc["startOri"])) < 1e-6 and abs(float(d["endOri"]) - float(sc["endOri"])) < 1e-6
+    assert d["N2"] == full_o.shape[0]
+    assert np.array_equal(d["scanStartInd"][:shape[0]], o.sr_ints(3))
+    assert np.array_equal(d["scanEndInd"][:shape[0]], o.sr_ints(4))
+    # inside the sectors everything the reference reads is defined: compare there
+    start, end = o.sr_ints(3), o.sr_ints(4)
+    cur_o, sort_o, lab_o, pick_o = o.sr_curvature(), o.sr_ints(0), o.sr_ints(2), o.sr_ints(1)
+    for r in range(shape[0]):
+        if end[r] - start[r] < 6:
+            continue
+        s, e = start[r], end[r]  # sectors cover [s, e-1]
+        assert np.array_equal(d["curvature"][s:e].view(np.uint32), cur_o[s:e].view(np.uint32)), "curvature ring %d" % r
+        assert np.array_equal(d["sort"][s:e], sort_o[s:e]), "sort order ring %d" % r
+        assert np.array_equal(d["label"][s:e], lab_o[s:e]), "labels ring %d" % r
+        assert np.array_equal(d["picked"][s - 5:e + 6], pick_o[s - 5:e + 6]), "picked ring %d" % r
+    assert np.array_equal(d["sharpInd"], o.sr_ints(5))
+    assert np.array_equal(d["lessSharpInd"], o.sr_ints(6))
+    assert np.array_equal(d["flatInd"], o.sr_ints(7))
+    for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+        check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
+
+
+def test_scan_registration_edge_cases(vl, orc, sweeps):
+    base = sweeps(64, 512, 2).copy()
+    # leading / trailing NaN runs and close returns move the first / last surviving point
+    c = base.copy()
+    c[:700, :3] = np.nan
+    c[-300:, :3] = np.nan
+    c[1000:1100, :3] *= 0.01
+    h, o = run_both(vl, orc, c)
+    sc = o.sr_scalars()
+    flips = check_cloud(h.features(0), o.cloud(0), "laserCloud", unwrap_bounds(sc["startOri"], sc["endOri"]))
+    for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+        check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
+    # shuffled (non ring-major) input exercises the stable per-ring compaction
+    rng = np.random.default_rng(0)
+    c = base[rng.permutation(base.shape[0])]
+    h, o = run_both(vl, orc, c)
+    sc = o.sr_scalars()
+    check_cloud(h.features(0), o.cloud(0), "laserCloud shuffled", unwrap_bounds(sc["startOri"], sc["endOri"]))
+    # all-NaN cloud: the reference would index an empty cloud; the ABI reports VLOAM_ERR_EMPTY
+    c = np.full((4096, 4), np.nan, dtype=np.float32)
+    hd = vl.Handle(0, with_mapping=0)
+    hd.scan_registration(c)
+    with pytest.raises(vl.VloamError) as ei:
+        hd.laser_odometry()
+    assert ei.value.status == vl.ERR_EMPTY
+    with pytest.raises(vl.VloamError) as ei:
+        vl.Handle(0, max_points=1024).scan_registration(np.zeros((2048, 4), dtype=np.float32))
+    assert ei.value.status == vl.ERR_CAPACITY
+    with pytest.raises(vl.VloamError) as ei:
+        vl.Handle(0, scan_line=48)
+    assert ei.value.status == vl.ERR_INVALID

@@ -1,0 +1,326 @@
+"""vloam-cmu-16833_amd — MI355X-native (gfx950) per-scan LiDAR(-visual) odometry hot path of VLOAM.
+
+Thin ctypes binding over ``libvloam_hip.so`` (hand-written HIP kernels + C ABI, see
+``include/vloam_hip/c_api.h``) plus a Python mirror of the reference's pull-style class surface
+(``ScanRegistration`` / ``LaserOdometry`` / ``LaserMapping`` / ``LidarOdometryMapping``;
+reference: src/lidar_odometry_mapping/include/lidar_odometry_mapping/*.h) used by the tests and the bench.
+
+There is no CPU path in this package: importing it requires the built shared library and creating a
+handle requires a HIP device.  (The CPU oracle lives in ``oracle/`` and is test infrastructure only.)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libvloam_hip.so")
+
+VLOAM_OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY, ERR_NO_DEVICE, ERR_ORDER = 0, -1, -2, -3, -4, -5, -6
+
+K_MAX_RINGS, K_SECTORS = 64, 6
+K_MAX_SHARP, K_MAX_LESS_SHARP, K_MAX_FLAT = 768, 7680, 1536
+K_MAX_LO_FACTORS = K_MAX_SHARP + K_MAX_FLAT
+K_LM_MAX_TRACE = 104
+
+
+class VloamError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("vloam status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("scan_line", C.c_int), ("minimum_range", C.c_double), ("mapping_skip_frame", C.c_int),
+                ("mapping_line_resolution", C.c_float), ("mapping_plane_resolution", C.c_float), ("detach_VO_LO", C.c_int),
+                ("reset_VO_to_identity", C.c_int), ("remove_VO_outlier", C.c_int), ("with_mapping", C.c_int),
+                ("max_points", C.c_int), ("max_frames", C.c_int), ("map_capacity_log2", C.c_int), ("debug", C.c_int),
+                ("timing", C.c_int)]
+
+
+class Calib(C.Structure):
+    _fields_ = [("cam_T_velo", C.c_float * 16), ("rect0_T_cam", C.c_float * 16), ("P_rect0", C.c_float * 12)]
+
+
+class LMRecord(C.Structure):
+    _fields_ = [("x_in", C.c_double * 7), ("x_out", C.c_double * 7), ("H0", C.c_double * 36), ("g0", C.c_double * 6),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("n_iterations", C.c_double),
+                ("termination", C.c_double), ("n_factors", C.c_double), ("n_evals", C.c_double),
+                ("trace", (C.c_double * 8) * K_LM_MAX_TRACE)]
+
+    def to_dict(self):
+        n = int(self.n_iterations)
+        tr = np.ctypeslib.as_array(self.trace).reshape(K_LM_MAX_TRACE, 8)[:n].copy()
+        return dict(x_in=np.array(self.x_in), x_out=np.array(self.x_out), H0=np.array(self.H0).reshape(6, 6),
+                    g0=np.array(self.g0), initial_cost=self.initial_cost, final_cost=self.final_cost, trace=tr,
+                    termination=int(self.termination), n_factors=int(self.n_factors), n_evals=int(self.n_evals))
+
+
+_lib = None
+
+
+def lib():
+    """Load libvloam_hip.so.  Raises (loudly) if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libvloam_hip.so is not built (%s). Run __graft_entry__.build() or "
+                              "`make -C vloam-cmu-16833_amd/csrc`. This package has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.vloam_last_error.restype = C.c_char_p
+        L.vloam_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    c = Config()
+    lib().vloam_default_config(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError("vloam_config has no field %r" % k)
+        setattr(c, k, v)
+    return c
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """One sequence on one GPU (``vloam_handle``)."""
+
+    def __init__(self, device=0, **cfg):
+        self.L = lib()
+        self.cfg = default_config(**cfg)
+        self.h = C.c_void_p()
+        self._chk(self.L.vloam_create(C.byref(self.cfg), int(device), C.byref(self.h)))
+
+    def _chk(self, st):
+        if st != VLOAM_OK:
+            raise VloamError(st, self.L.vloam_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.vloam_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- façade stages (LidarOdometryMapping::reset / scanRegistrationIO / laserOdometryIO / laserMappingIO)
+    def reset_frame(self):
+        self._chk(self.L.vloam_reset_frame(self.h))
+
+    def scan_registration(self, cloud):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        assert cloud.ndim == 2 and cloud.shape[1] == 4
+        self._chk(self.L.vloam_scan_registration(self.h, _fp(cloud), cloud.shape[0]))
+
+    def scan_registration_device(self, dptr, n):
+        self._chk(self.L.vloam_scan_registration_device(self.h, C.c_void_p(dptr), int(n)))
+
+    def features(self, which):
+        n = C.c_int(0)
+        self._chk(self.L.vloam_get_features(self.h, which, None, 0, C.byref(n)))
+        buf = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+        self._chk(self.L.vloam_get_features(self.h, which, _fp(buf), n.value, C.byref(n)))
+        return buf[:n.value]
+
+    def set_lo_prior(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        self._chk(self.L.vloam_set_lo_prior(self.h, _fp(q), _fp(t)))
+
+    def laser_odometry(self):
+        qw, tw, ql, tl = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        self._chk(self.L.vloam_laser_odometry(self.h, _fp(qw), _fp(tw), _fp(ql), _fp(tl)))
+        return qw, tw, ql, tl
+
+    def laser_mapping(self):
+        q, t = np.zeros(4), np.zeros(3)
+        self._chk(self.L.vloam_laser_mapping(self.h, _fp(q), _fp(t)))
+        return q, t
+
+    # ---- asynchronous whole-sweep path
+    def process_scan(self, cloud):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        self._chk(self.L.vloam_process_scan(self.h, _fp(cloud), cloud.shape[0]))
+
+    def process_scan_device(self, dptr, n):
+        self._chk(self.L.vloam_process_scan_device(self.h, C.c_void_p(dptr), int(n)))
+
+    def sync(self):
+        self._chk(self.L.vloam_sync(self.h))
+
+    def frame_count(self):
+        n = C.c_int(0)
+        self._chk(self.L.vloam_frame_count(self.h, C.byref(n)))
+        return n.value
+
+    def trajectory(self, first=0, count=None):
+        if count is None:
+            count = self.frame_count() - first
+        out = np.zeros((max(count, 1), 14))
+        self._chk(self.L.vloam_get_trajectory(self.h, first, count, _fp(out)))
+        return out[:count]
+
+    def trajectory_device_ptr(self):
+        p, b = C.c_void_p(), C.c_longlong(0)
+        self._chk(self.L.vloam_trajectory_device_ptr(self.h, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def stage_ms(self):
+        ms = np.zeros(4)
+        n = C.c_int(0)
+        self._chk(self.L.vloam_get_stage_ms(self.h, _fp(ms), C.byref(n)))
+        return ms, n.value
+
+    def counts(self):
+        c = np.zeros(16, dtype=np.int64)
+        self._chk(self.L.vloam_get_counts(self.h, _fp(c)))
+        names = ["N_in", "N2", "n_sharp", "n_lessSharp", "n_flat", "n_lessFlat", "C", "S", "F_corner", "F_plane", "E_o", "n_c",
+                 "n_s", "K_m", "E_m", "M"]
+        return dict(zip(names, [int(v) for v in c]))
+
+    # ---- VO
+    def vo_set_calib(self, cam_T_velo, rect0_T_cam, P_rect0):
+        c = Calib()
+        c.cam_T_velo[:] = [float(v) for v in np.asarray(cam_T_velo, dtype=np.float32).ravel()]
+        c.rect0_T_cam[:] = [float(v) for v in np.asarray(rect0_T_cam, dtype=np.float32).ravel()]
+        c.P_rect0[:] = [float(v) for v in np.asarray(P_rect0, dtype=np.float32).ravel()]
+        self._chk(self.L.vloam_vo_set_calib(self.h, C.byref(c)))
+
+    def vo_process_point_cloud(self, cloud):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        self._chk(self.L.vloam_vo_process_point_cloud(self.h, _fp(cloud), cloud.shape[0]))
+
+    def vo_solve(self, prev_uv, curr_uv, angle_axis, t):
+        pu = np.ascontiguousarray(prev_uv, dtype=np.int32)
+        cu = np.ascontiguousarray(curr_uv, dtype=np.int32)
+        aa = np.array(angle_axis, dtype=np.float64)
+        tt = np.array(t, dtype=np.float64)
+        cnt = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.vloam_vo_solve(self.h, _fp(pu), _fp(cu), pu.shape[0], _fp(aa), _fp(tt), _fp(cnt)))
+        return aa, tt, int(cnt[0]), int(cnt[1])
+
+    # ---- parity hooks
+    def debug_raw(self, stage, item, dtype, max_bytes=1 << 26):
+        n = C.c_longlong(0)
+        self._chk(self.L.vloam_debug_get(self.h, stage, item, None, C.c_longlong(0), C.byref(n)))
+        nb = min(n.value, max_bytes)
+        buf = np.zeros(max(nb, 8), dtype=np.uint8)
+        self._chk(self.L.vloam_debug_get(self.h, stage, item, _fp(buf), C.c_longlong(nb), C.byref(n)))
+        return buf[:nb].view(dtype)
+
+    def debug_lm_record(self, stage, item):
+        raw = self.debug_raw(stage, item, np.uint8)
+        rec = LMRecord.from_buffer_copy(raw.tobytes())
+        return rec.to_dict()
+
+    def sr_debug(self):
+        sc = self.debug_raw(0, 9, np.float32)
+        return dict(curvature=self.debug_raw(0, 0, np.float32), sort=self.debug_raw(0, 1, np.int32),
+                    picked=self.debug_raw(0, 2, np.int32), label=self.debug_raw(0, 3, np.int32),
+                    scanStartInd=self.debug_raw(0, 4, np.int32), scanEndInd=self.debug_raw(0, 5, np.int32),
+                    sharpInd=self.debug_raw(0, 6, np.int32), lessSharpInd=self.debug_raw(0, 7, np.int32),
+                    flatInd=self.debug_raw(0, 8, np.int32), startOri=sc[0], endOri=sc[1], istar=int(sc[2]),
+                    n_after_s1=int(sc[3]), N2=int(sc[4]))
+
+    def lo_debug(self, outer):
+        c = self.debug_raw(1, outer * 16 + 0, np.int32).reshape(-1, 4)
+        p = self.debug_raw(1, outer * 16 + 1, np.int32).reshape(-1, 4)
+        rec = self.debug_lm_record(1, outer * 16 + 2)
+        resid = self.debug_raw(1, outer * 16 + 3, np.float64).reshape(3, K_MAX_LO_FACTORS)
+        return dict(corner=c[c[:, 0] >= 0][:, :3], plane=p[p[:, 0] >= 0], corner_slots=np.nonzero(c[:, 0] >= 0)[0],
+                    plane_slots=np.nonzero(p[:, 0] >= 0)[0] + K_MAX_SHARP, rec=rec, resid=resid)
+
+
+# ------------------------------------------------------------------------------------------------
+# Python mirror of the reference's class surface (same method names / call order / error behaviour).
+class ScanRegistration:
+    """vloam::ScanRegistration (scan_registration.h:71-77): init / reset / input / output."""
+
+    def __init__(self, handle):
+        self.hd = handle
+
+    def init(self):
+        pass  # parameters were bound at vloam_create (the reference reads them from the ROS parameter server here)
+
+    def reset(self):
+        self.hd.reset_frame()
+
+    def input(self, laserCloudIn):
+        self.hd.scan_registration(laserCloudIn)
+
+    def output(self):
+        return tuple(self.hd.features(k) for k in range(5))
+
+
+class LaserOdometry:
+    """vloam::LaserOdometry (laser_odometry.h:70-84): init / input / solveLO / output."""
+
+    def __init__(self, handle):
+        self.hd = handle
+        self._pose = None
+
+    def init(self):
+        pass
+
+    def input(self, *clouds):
+        pass  # clouds stay resident in HBM; the reference deep-copies them here (laser_odometry.cpp:141-145)
+
+    def solveLO(self):
+        self._pose = self.hd.laser_odometry()
+
+    def output(self):
+        qw, tw, _, _ = self._pose
+        skip = (self.hd.frame_count() + (0 if self.hd.cfg.with_mapping else 0)) % self.hd.cfg.mapping_skip_frame != 0
+        return qw, tw, self.hd.features(5), self.hd.features(6), self.hd.features(0), skip
+
+
+class LaserMapping:
+    """vloam::LaserMapping (laser_mapping.h:85-94): init / reset / input / solveMapping."""
+
+    def __init__(self, handle):
+        self.hd = handle
+        self.pose = None
+
+    def init(self):
+        pass
+
+    def reset(self):
+        pass
+
+    def input(self, *args):
+        pass
+
+    def solveMapping(self):
+        self.pose = self.hd.laser_mapping()
+
+
+class LidarOdometryMapping:
+    """vloam::LidarOdometryMapping façade (lidar_odometry_mapping.cpp:65-154)."""
+
+    def __init__(self, device=0, **cfg):
+        self.hd = Handle(device, **cfg)
+        self.scan_registration = ScanRegistration(self.hd)
+        self.laser_odometry = LaserOdometry(self.hd)
+        self.laser_mapping = LaserMapping(self.hd)
+
+    def reset(self):
+        self.scan_registration.reset()
+        self.laser_mapping.reset()
+
+    def scanRegistrationIO(self, laserCloudIn):
+        self.scan_registration.input(laserCloudIn)
+
+    def laserOdometryIO(self):
+        self.laser_odometry.solveLO()
+        return self.laser_odometry._pose
+
+    def laserMappingIO(self):
+        self.laser_mapping.solveMapping()
+        return self.laser_mapping.pose

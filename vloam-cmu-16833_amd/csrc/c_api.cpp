@@ -1,0 +1,525 @@
+// Host side of libvloam_hip.so: the C ABI declared in include/vloam_hip/c_api.h.
+// One handle = one sequence = one HIP device + one stream; every per-frame count stays in HBM, so a
+// sweep is a fixed chain of kernel launches with no host synchronisation until the caller asks for
+// results.  There is NO CPU fallback: without a usable HIP device vloam_create fails.
+#include "../../include/vloam_hip/c_api.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "lm_solve.h"
+#include "lo_kernels.h"
+#include "map_kernels.h"
+#include "sr_kernels.h"
+#include "vloam_device.h"
+#include "vo_kernels.h"
+
+using namespace vloam;
+
+static thread_local std::string g_err;
+static void set_err(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+      return VLOAM_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+struct vloam_handle {
+  vloam_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  int frame = 0;        // sweeps fully enqueued
+  int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
+  int nblk_max = 0;
+  // scan registration
+  float4* d_in = nullptr;
+  SRBuffers sr[2];      // ping-pong halves: only S / less_sharp / less_flat differ
+  // laser odometry
+  LOState* lo = nullptr;
+  FactorTable lo_F{};
+  int* lo_corr[2] = {nullptr, nullptr};
+  LMRecord* lo_rec = nullptr;  // [2]
+  double* lo_resid[2] = {nullptr, nullptr};
+  double* traj = nullptr;      // [max_frames][14]
+  // mapping + vo
+  MapContext map;
+  VOContext vo;
+  // timing
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double stage_ms[4] = {0, 0, 0, 0};
+  int timed_scans = 0;
+  int last_n_in = 0;
+};
+
+template <class T>
+static vloam_status dalloc(vloam_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, count * sizeof(T) + 256));
+  HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T) + 256, h->stream));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return VLOAM_OK;
+}
+#define ALLOC(p, n)                              \
+  do {                                           \
+    vloam_status s_ = dalloc(h, &(p), (n));      \
+    if (s_ != VLOAM_OK) return s_;               \
+  } while (0)
+
+static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap) {
+  F->cap = cap;
+  ALLOC(F->type, cap);
+  ALLOC(F->p, 3 * (size_t)cap);
+  ALLOC(F->A, 3 * (size_t)cap);
+  ALLOC(F->B, 3 * (size_t)cap);
+  ALLOC(F->resid, 3 * (size_t)cap);
+  return VLOAM_OK;
+}
+
+extern "C" {
+
+void vloam_default_config(vloam_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->scan_line = 64;
+  c->minimum_range = 5.0;
+  c->mapping_skip_frame = 1;
+  c->mapping_line_resolution = 0.4f;
+  c->mapping_plane_resolution = 0.8f;
+  c->detach_VO_LO = 1;
+  c->reset_VO_to_identity = 0;
+  c->remove_VO_outlier = 100;
+  c->with_mapping = 1;
+  c->max_points = 262144;
+  c->max_frames = 8192;
+  c->map_capacity_log2 = 22;
+  c->debug = 0;
+  c->timing = 0;
+}
+
+const char* vloam_last_error(void) { return g_err.c_str(); }
+const char* vloam_version(void) { return "vloam_hip 0.1 (gfx950)"; }
+
+vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** out) {
+  if (!cfg || !out) { set_err("null argument"); return VLOAM_ERR_INVALID; }
+  if (cfg->scan_line != 16 && cfg->scan_line != 32 && cfg->scan_line != 64) {
+    set_err("only support velodyne with 16, 32 or 64 scan line!");  // scan_registration.cpp:54-58
+    return VLOAM_ERR_INVALID;
+  }
+  if (cfg->max_points < 64 || cfg->max_frames < 1 || cfg->mapping_skip_frame < 1) { set_err("bad capacity"); return VLOAM_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err("no HIP device visible: libvloam_hip has no CPU fallback");
+    return VLOAM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_err("device %d out of range (%d visible)", device, ndev); return VLOAM_ERR_NO_DEVICE; }
+  HIPCHK(hipSetDevice(device));
+  vloam_handle* h = new vloam_handle;
+  h->cfg = *cfg;
+  h->device = device;
+  *out = nullptr;
+  vloam_status st = VLOAM_OK;
+  do {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
+    if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
+    const int P = cfg->max_points;
+    h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
+    auto body = [&]() -> vloam_status {
+      ALLOC(h->d_in, (size_t)P);
+      SRBuffers& a = h->sr[0];
+      ALLOC(a.sid, (size_t)P);
+      ALLOC(a.ori, (size_t)P);
+      ALLOC(a.blockhist, (size_t)h->nblk_max * kMaxRings);
+      ALLOC(a.blockoff, (size_t)h->nblk_max * kMaxRings);
+      ALLOC(a.cloud, (size_t)P);
+      ALLOC(a.sharp_idx, kMaxSharp);
+      ALLOC(a.less_sharp_idx, kMaxLessSharp);
+      ALLOC(a.flat_idx, kMaxFlat);
+      ALLOC(a.ring_ds, (size_t)kMaxRings * kMaxRingLen);
+      ALLOC(a.sharp, kMaxSharp);
+      ALLOC(a.flat, kMaxFlat);
+      ALLOC(a.dbg_curv, (size_t)P);
+      ALLOC(a.dbg_sort, (size_t)P);
+      ALLOC(a.dbg_picked, (size_t)P);
+      ALLOC(a.dbg_label, (size_t)P);
+      ALLOC(a.dbg_feat_idx, 3 * kMaxLessSharp);
+      h->sr[1] = a;
+      for (int k = 0; k < 2; k++) {
+        ALLOC(h->sr[k].S, 1);
+        ALLOC(h->sr[k].less_sharp, kMaxLessSharp);
+        ALLOC(h->sr[k].less_flat, (size_t)P);
+      }
+      ALLOC(h->lo, 1);
+      vloam_status s = alloc_factor_table(h, &h->lo_F, kMaxLoFactors);
+      if (s != VLOAM_OK) return s;
+      for (int k = 0; k < 2; k++) { ALLOC(h->lo_corr[k], kMaxLoFactors * 4); ALLOC(h->lo_resid[k], 3 * kMaxLoFactors); }
+      ALLOC(h->lo_rec, 2);
+      ALLOC(h->traj, (size_t)cfg->max_frames * 14);
+      LOState init;
+      memset(&init, 0, sizeof(init));
+      init.para_q[3] = 1.0; init.q_w_curr[3] = 1.0; init.prior_q[3] = 1.0;  // laser_odometry.cpp:80-90
+      HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+      s = map_create(&h->map, h->cfg, h->stream, h->allocs);
+      if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
+      s = vo_create(&h->vo, h->cfg, h->stream, h->allocs);
+      if (s != VLOAM_OK) { set_err("vo_create failed"); return VLOAM_ERR_HIP; }
+      for (int k = 0; k < 5; k++) HIPCHK(hipEventCreate(&h->ev[k]));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      return VLOAM_OK;
+    };
+    st = body();
+  } while (0);
+  if (st != VLOAM_OK) { vloam_destroy(h); return st; }
+  *out = h;
+  return VLOAM_OK;
+}
+
+vloam_status vloam_destroy(vloam_handle* h) {
+  if (!h) return VLOAM_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  for (int k = 0; k < 5; k++) if (h->ev[k]) hipEventDestroy(h->ev[k]);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return VLOAM_OK;
+}
+
+vloam_status vloam_reset_frame(vloam_handle* h) {
+  if (!h) return VLOAM_ERR_INVALID;
+  h->stage = 0;  // scan_registration.reset() clears the per-frame clouds; laser_mapping.reset() zeroes the valid-cube counters
+  return VLOAM_OK;
+}
+
+// ------------------------------------------------------------------ stage enqueue helpers
+static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
+  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+  if (h->frame >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
+  const int cur = h->frame & 1;
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0));
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+  h->last_n_in = n;
+  h->stage = 1;
+  return VLOAM_OK;
+}
+
+static vloam_status enqueue_lo(vloam_handle* h) {
+  if (h->stage != 1) { set_err("laser odometry called before scan registration"); return VLOAM_ERR_ORDER; }
+  const int cur = h->frame & 1, prev = cur ^ 1;
+  if (h->frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
+    for (int outer = 0; outer < 2; outer++) {  // laser_odometry.cpp:211
+      if (!h->cfg.detach_VO_LO) lo_set_prior_launch(h->stream, h->lo);
+      FactorTable F = h->lo_F;
+      F.resid = h->lo_resid[outer];
+      lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
+                      h->sr[prev].S, h->lo, F, h->lo_corr[outer]);
+      lm_launch(h->stream, F, nullptr, kMaxLoFactors, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr);
+    }
+  }
+  lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0);
+  HIPCHK(hipGetLastError());
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  h->stage = 2;
+  return VLOAM_OK;
+}
+
+static vloam_status enqueue_map(vloam_handle* h) {
+  if (h->stage != 2) { set_err("laser mapping called before laser odometry"); return VLOAM_ERR_ORDER; }
+  const int cur = h->frame & 1;
+  // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
+  const bool skip = ((h->frame + 1) % h->cfg.mapping_skip_frame) != 0;
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->stream, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip);
+  if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+  return VLOAM_OK;
+}
+
+static vloam_status finish_frame(vloam_handle* h) {
+  if (h->cfg.timing) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stage_ms[0] += ms;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->stage_ms[1] += ms;
+    if (h->cfg.with_mapping) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stage_ms[2] += ms; }
+    h->timed_scans++;
+  }
+  h->frame++;
+  h->stage = 0;
+  return VLOAM_OK;
+}
+
+// ------------------------------------------------------------------ stage-wise API (façade order)
+vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
+  if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->stage == 2) { vloam_status s = finish_frame(h); if (s != VLOAM_OK) return s; }  // previous sweep ended after LO (no mapping call)
+  return enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+}
+
+vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int n) {
+  if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
+  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  return vloam_scan_registration_device(h, h->d_in, n);
+}
+
+static vloam_status read_sr_error(vloam_handle* h, int cur) {
+  int err = 0;
+  HIPCHK(hipMemcpyAsync(&err, &h->sr[cur].S->error, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
+  if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int cap, int* n) {
+  if (!h || !n) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  // after finish_frame() the sweep just processed is frame-1
+  const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
+  const int cur = f & 1;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  FrameScalars S;
+  HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
+  const float4* src = nullptr;
+  int cnt = 0;
+  switch (which) {
+    case 0: src = h->sr[cur].cloud; cnt = S.N2; break;
+    case 1: src = h->sr[cur].sharp; cnt = S.n_sharp; break;
+    case 2: case 5: src = h->sr[cur].less_sharp; cnt = S.n_less_sharp; break;
+    case 3: src = h->sr[cur].flat; cnt = S.n_flat; break;
+    case 4: case 6: src = h->sr[cur].less_flat; cnt = S.n_less_flat; break;
+    default: return map_get_cloud(&h->map, h->stream, which, h->sr[cur], xyzi4, cap, n);
+  }
+  *n = cnt;
+  const int m = cnt < cap ? cnt : cap;
+  if (xyzi4 && m > 0) HIPCHK(hipMemcpy(xyzi4, src, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost));
+  return VLOAM_OK;
+}
+
+vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double t[3]) {
+  if (!h || !q || !t) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  double buf[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+  HIPCHK(hipMemcpyAsync(h->lo->prior_q, buf, sizeof(buf), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VLOAM_OK;
+}
+
+vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  vloam_status s = enqueue_lo(h);
+  if (s != VLOAM_OK) return s;
+  s = read_sr_error(h, h->frame & 1);
+  if (s != VLOAM_OK) return s;
+  LOState lo;
+  HIPCHK(hipMemcpy(&lo, h->lo, sizeof(lo), hipMemcpyDeviceToHost));
+  if (q_w) memcpy(q_w, lo.q_w_curr, sizeof(double) * 4);
+  if (t_w) memcpy(t_w, lo.t_w_curr, sizeof(double) * 3);
+  if (q_lc) memcpy(q_lc, lo.para_q, sizeof(double) * 4);
+  if (t_lc) memcpy(t_lc, lo.para_t, sizeof(double) * 3);
+  if (!h->cfg.with_mapping) return finish_frame(h);
+  return VLOAM_OK;
+}
+
+vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[3]) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  vloam_status s = enqueue_map(h);
+  if (s != VLOAM_OK) return s;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  MapState ms;
+  HIPCHK(hipMemcpy(&ms, h->map.state, sizeof(ms), hipMemcpyDeviceToHost));
+  if (q_map) memcpy(q_map, ms.parameters, sizeof(double) * 4);
+  if (t_map) memcpy(t_map, ms.parameters + 4, sizeof(double) * 3);
+  return finish_frame(h);
+}
+
+// ------------------------------------------------------------------ whole façade, asynchronous
+vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
+  if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
+  vloam_status s = enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+  if (s != VLOAM_OK) return s;
+  s = enqueue_lo(h);
+  if (s != VLOAM_OK) return s;
+  if (h->cfg.with_mapping) { s = enqueue_map(h); if (s != VLOAM_OK) return s; }
+  return finish_frame(h);
+}
+
+vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
+  if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
+  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  return vloam_process_scan_device(h, h->d_in, n);
+}
+
+vloam_status vloam_sync(vloam_handle* h) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->frame > 0) {
+    // surface sticky device-side errors of the last sweep
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, &h->sr[(h->frame - 1) & 1].S->error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
+    if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
+    int merr = 0;
+    vloam_status s = map_error(&h->map, &merr);
+    if (s != VLOAM_OK) return s;
+    if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
+    if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
+  }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double* poses14) {
+  if (!h || !poses14 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (count) HIPCHK(hipMemcpy(poses14, h->traj + (size_t)first * 14, sizeof(double) * 14 * (size_t)count, hipMemcpyDeviceToHost));
+  return VLOAM_OK;
+}
+vloam_status vloam_frame_count(vloam_handle* h, int* frames) {
+  if (!h || !frames) return VLOAM_ERR_INVALID;
+  *frames = h->frame;
+  return VLOAM_OK;
+}
+vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long long* bytes) {
+  if (!h || !d_ptr || !bytes) return VLOAM_ERR_INVALID;
+  *d_ptr = h->traj;
+  *bytes = (long long)h->cfg.max_frames * 14 * (long long)sizeof(double);
+  return VLOAM_OK;
+}
+
+// ------------------------------------------------------------------ VO
+vloam_status vloam_vo_set_calib(vloam_handle* h, const vloam_calib* c) {
+  if (!h || !c) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  return vo_set_calib(&h->vo, h->stream, c) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4, int n) {
+  if (!h || !xyz_pad4 || n <= 0) return VLOAM_ERR_INVALID;
+  if (n > h->cfg.max_points) return VLOAM_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  return vo_process_point_cloud(&h->vo, h->stream, h->d_in, n) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr_uv, int n_match, double aa[3], double t[3], int counters[2]) {
+  if (!h || !prev_uv || !curr_uv || !aa || !t || n_match < 0) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  vloam_status s = vo_solve(&h->vo, h->cfg, h->stream, prev_uv, curr_uv, n_match, aa, t, counters);
+  if (s != VLOAM_OK) set_err("vo_solve failed: %s", hipGetErrorString(hipGetLastError()));
+  return s;
+}
+
+// ------------------------------------------------------------------ parity hooks
+static vloam_status copy_out(const void* d_src, size_t bytes, void* buf, long long cap, long long* n) {
+  if (n) *n = (long long)bytes;
+  size_t m = bytes < (size_t)cap ? bytes : (size_t)cap;
+  if (buf && m) HIPCHK(hipMemcpy(buf, d_src, m, hipMemcpyDeviceToHost));
+  return VLOAM_OK;
+}
+
+vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, long long cap, long long* n) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
+  const int cur = f & 1;
+  if (stage == 0) {
+    FrameScalars S;
+    HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
+    const SRBuffers& b = h->sr[cur];
+    switch (item) {
+      case 0: return copy_out(b.dbg_curv, sizeof(float) * S.N2, buf, cap, n);
+      case 1: return copy_out(b.dbg_sort, sizeof(int) * S.N2, buf, cap, n);
+      case 2: return copy_out(b.dbg_picked, sizeof(int) * S.N2, buf, cap, n);
+      case 3: return copy_out(b.dbg_label, sizeof(int) * S.N2, buf, cap, n);
+      case 4: return copy_out(&b.S->scanStartInd[0], sizeof(int) * kMaxRings, buf, cap, n);
+      case 5: return copy_out(&b.S->scanEndInd[0], sizeof(int) * kMaxRings, buf, cap, n);
+      case 6: return copy_out(b.dbg_feat_idx, sizeof(int) * S.n_sharp, buf, cap, n);
+      case 7: return copy_out(b.dbg_feat_idx + kMaxLessSharp, sizeof(int) * S.n_less_sharp, buf, cap, n);
+      case 8: return copy_out(b.dbg_feat_idx + 2 * kMaxLessSharp, sizeof(int) * S.n_flat, buf, cap, n);
+      case 9: {
+        float sc[5] = {S.startOri, S.endOri, (float)S.istar, (float)S.n_after_s1, (float)S.N2};
+        if (n) *n = sizeof(sc);
+        if (buf) memcpy(buf, sc, (size_t)cap < sizeof(sc) ? (size_t)cap : sizeof(sc));
+        return VLOAM_OK;
+      }
+      case 10: return copy_out(b.S, sizeof(FrameScalars), buf, cap, n);
+    }
+    return VLOAM_ERR_INVALID;
+  }
+  if (stage == 1) {
+    const int outer = item / 16, k = item % 16;
+    if (outer < 0 || outer > 1) return VLOAM_ERR_INVALID;
+    switch (k) {
+      case 0: return copy_out(h->lo_corr[outer], sizeof(int) * 4 * kMaxSharp, buf, cap, n);
+      case 1: return copy_out(h->lo_corr[outer] + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
+      case 2: return copy_out(h->lo_rec + outer, sizeof(LMRecord), buf, cap, n);
+      case 3: return copy_out(h->lo_resid[outer], sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
+    }
+    return VLOAM_ERR_INVALID;
+  }
+  if (stage == 2) return map_debug_get(&h->map, item, buf, cap, n);
+  if (stage == 3) return vo_debug_get(&h->vo, item, buf, cap, n);
+  return VLOAM_ERR_INVALID;
+}
+
+vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans) {
+  if (!h || !ms4) return VLOAM_ERR_INVALID;
+  for (int k = 0; k < 4; k++) ms4[k] = h->stage_ms[k];
+  if (scans) *scans = h->timed_scans;
+  return VLOAM_OK;
+}
+
+vloam_status vloam_get_counts(vloam_handle* h, long long c[16]) {
+  if (!h || !c) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  memset(c, 0, sizeof(long long) * 16);
+  if (h->frame == 0) return VLOAM_OK;
+  const int f = (h->stage == 0) ? h->frame - 1 : h->frame;
+  const int cur = f & 1, prev = cur ^ 1;
+  FrameScalars S, Sp;
+  HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&Sp, h->sr[prev].S, sizeof(Sp), hipMemcpyDeviceToHost));
+  LMRecord rec[2];
+  HIPCHK(hipMemcpy(rec, h->lo_rec, sizeof(rec), hipMemcpyDeviceToHost));
+  c[0] = h->last_n_in; c[1] = S.N2; c[2] = S.n_sharp; c[3] = S.n_less_sharp; c[4] = S.n_flat; c[5] = S.n_less_flat;
+  c[6] = Sp.n_less_sharp; c[7] = Sp.n_less_flat;
+  if (f > 0) {
+    // factor counts of the 2nd outer round; evaluations summed over both rounds
+    int corr[4 * kMaxLoFactors];
+    HIPCHK(hipMemcpy(corr, h->lo_corr[1], sizeof(corr), hipMemcpyDeviceToHost));
+    for (int k = 0; k < kMaxLoFactors; k++) if (corr[4 * k] >= 0) c[k < kMaxSharp ? 8 : 9]++;
+    c[10] = (long long)(rec[0].n_evals + rec[1].n_evals);
+  }
+  return map_counts(&h->map, c);
+}
+
+}  // extern "C"

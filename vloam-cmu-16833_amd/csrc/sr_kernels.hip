@@ -1,0 +1,601 @@
+// scanRegistration on gfx950: NaN / min-range removal, ring + relTime labelling, stable per-ring
+// compaction, 11-tap curvature, per-sector sort, greedy sharp / flat pick, per-ring VoxelGrid(0.2).
+// Restates ScanRegistration::input, /root/reference/src/lidar_odometry_mapping/src/scan_registration.cpp:131-449
+// (cited per step as "SR:<line>").  Integer / index results are bit-identical to the CPU oracle; f32
+// arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
+//
+// Kernels (one sweep = 6 launches, no host synchronisation):
+//   k_sr_first_last  1 WG        first / last surviving point -> startOri / endOri            SR:157-176
+//   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
+//   k_sr_scan        1 WG        ring offsets, per-WG ring bases, scanStart/EndInd            SR:276-281
+//   k_sr_scatter     n/1024 WGs  relTime / intensity, stable scatter into ring-major cloud     SR:264-266
+//   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, 6 sector sorts (one wavefront each,
+//                                bitonic in LDS), greedy picks, lessFlat + VoxelGrid(0.2)        SR:288-439
+//   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include "sr_kernels.h"
+
+namespace vloam {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void lds_fence_wave() {
+  // LDS ops of one wavefront retire in order; this only has to stop the compiler from caching or
+  // reordering LDS accesses across the point where lanes exchange data.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// SR:157 removeNaNFromPointCloud + SR:100-129 removeClosedPointCloud
+__device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float thres) {
+  if (!isfinite(x) || !isfinite(y) || !isfinite(z)) return false;
+  if (x * x + y * y + z * z < thres * thres) return false;
+  return true;
+}
+
+// SR:192-226.  Returns the ring id or -1 when the point is dropped.
+__device__ __forceinline__ int sr_scan_id(float x, float y, float z, int N_SCANS) {
+  float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
+  int scanID = 0;
+  if (N_SCANS == 16) {
+    scanID = int((double)((angle + 15) / 2) + 0.5);
+    if (scanID > (N_SCANS - 1) || scanID < 0) return -1;
+  } else if (N_SCANS == 32) {
+    scanID = int(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);
+    if (scanID > (N_SCANS - 1) || scanID < 0) return -1;
+  } else {
+    if ((double)angle >= -8.83) scanID = int((double)(2 - angle) * 3.0 + 0.5);
+    else scanID = N_SCANS / 2 + int((-8.83 - (double)angle) * 2.0 + 0.5);
+    if (angle > 2 || (double)angle < -24.33 || scanID > 50 || scanID < 0) return -1;
+  }
+  return scanID;
+}
+
+// SR:237-244, the !halfPassed branch
+__device__ __forceinline__ float sr_ori_first_half(float ori, float startOri) {
+  if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
+  else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
+  return ori;
+}
+// SR:253-261, the halfPassed branch
+__device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
+  ori = (float)((double)ori + 2 * M_PI);
+  if ((double)ori < (double)endOri - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
+  else if ((double)ori > (double)endOri + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
+  return ori;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, FrameScalars* S) {
+  __shared__ int s_first, s_last;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_first = INT_MAX; s_last = -1; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    if (i < n) {
+      float4 p = in[i];
+      if (sr_survives_s1(p.x, p.y, p.z, thres)) atomicMin(&s_first, i);
+    }
+    __syncthreads();
+    if (s_first != INT_MAX) break;
+  }
+  for (int base = n - 1; base >= 0; base -= 1024) {
+    int i = base - tid;
+    if (i >= 0) {
+      float4 p = in[i];
+      if (sr_survives_s1(p.x, p.y, p.z, thres)) atomicMax(&s_last, i);
+    }
+    __syncthreads();
+    if (s_last >= 0) break;
+  }
+  if (tid == 0) {
+    S->first_valid = s_first == INT_MAX ? -1 : s_first;
+    S->last_valid = s_last;
+    S->istar = INT_MAX;
+    S->n_after_s1 = 0;
+    S->error = 0;
+    if (s_last < 0) {
+      S->error = kErrEmpty;
+      S->startOri = 0.f; S->endOri = 0.f;
+    } else {
+      float4 a = in[s_first], b = in[s_last];
+      float startOri = -atan2f(a.y, a.x);                                      // SR:166
+      float endOri = (float)((double)(-atan2f(b.y, b.x)) + 2 * M_PI);          // SR:167
+      if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
+      else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
+      S->startOri = startOri; S->endOri = endOri;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restrict__ in, int n, float thres, int N_SCANS,
+                                                          FrameScalars* S, signed char* __restrict__ sid,
+                                                          float* __restrict__ ori_raw, int* __restrict__ blockhist) {
+  __shared__ int hist[kMaxRings];
+  __shared__ int s_istar, s_cnt;
+  const int tid = threadIdx.x;
+  if (tid < kMaxRings) hist[tid] = 0;
+  if (tid == 0) { s_istar = INT_MAX; s_cnt = 0; }
+  __syncthreads();
+  const int i = blockIdx.x * kLabelBlock + tid;
+  const float startOri = S->startOri;
+  int id = -1;
+  bool v1 = false;
+  if (i < n) {
+    float4 p = in[i];
+    v1 = sr_survives_s1(p.x, p.y, p.z, thres);
+    if (v1) {
+      id = sr_scan_id(p.x, p.y, p.z, N_SCANS);
+      float ori = -atan2f(p.y, p.x);  // SR:234
+      ori_raw[i] = ori;
+      if (id >= 0) {
+        atomicAdd(&hist[id], 1);
+        float o = sr_ori_first_half(ori, startOri);
+        if ((double)(o - startOri) > M_PI) atomicMin(&s_istar, i);  // SR:246-249 candidate pivot
+      }
+    }
+    sid[i] = (signed char)id;
+  }
+  unsigned long long mv = __ballot(v1);
+  if ((tid & 63) == 0 && mv) atomicAdd(&s_cnt, __popcll(mv));
+  __syncthreads();
+  if (tid < kMaxRings) blockhist[blockIdx.x * kMaxRings + tid] = hist[tid];
+  if (tid == 0) {
+    if (s_istar != INT_MAX) atomicMin(&S->istar, s_istar);
+    if (s_cnt) atomicAdd(&S->n_after_s1, s_cnt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sr_scan(int nblk, int N_SCANS, FrameScalars* S, const int* __restrict__ blockhist,
+                                                int* __restrict__ blockoff) {
+  __shared__ int tot[kMaxRings];
+  __shared__ int off[kMaxRings + 1];
+  const int r = threadIdx.x;
+  int t = 0;
+  for (int b = 0; b < nblk; b++) t += blockhist[b * kMaxRings + r];
+  tot[r] = t;
+  __syncthreads();
+  if (r == 0) {
+    int acc = 0;
+    for (int k = 0; k < kMaxRings; k++) { off[k] = acc; acc += tot[k]; }
+    off[kMaxRings] = acc;
+    S->N2 = acc;
+    S->ring_off[kMaxRings] = acc;
+  }
+  __syncthreads();
+  int run = off[r];
+  for (int b = 0; b < nblk; b++) { blockoff[b * kMaxRings + r] = run; run += blockhist[b * kMaxRings + r]; }
+  S->ring_count[r] = tot[r];
+  S->ring_off[r] = off[r];
+  // SR:276-281: rings >= N_SCANS are empty, so start/end equal those of an empty append
+  S->scanStartInd[r] = off[r] + 5;
+  S->scanEndInd[r] = off[r] + tot[r] - 6;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __restrict__ in, int n, const FrameScalars* __restrict__ S,
+                                                            const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
+                                                            const int* __restrict__ blockoff, float4* __restrict__ cloud) {
+  __shared__ int wcnt[kLabelBlock / 64][kMaxRings];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < (kLabelBlock / 64) * kMaxRings; k += kLabelBlock) (&wcnt[0][0])[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * kLabelBlock + tid;
+  int id = (i < n) ? (int)sid[i] : -1;
+  // stable rank of this point among same-ring points of its wavefront
+  int rank = 0;
+  bool pending = id >= 0;
+  while (true) {
+    u64 act = __ballot(pending);
+    if (act == 0) break;
+    int leader = __ffsll((long long)act) - 1;
+    int lid = __shfl(id, leader);
+    u64 same = __ballot(pending && id == lid);
+    if (pending && id == lid) {
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      pending = false;
+    }
+    if (lane == leader) wcnt[wave][lid] = __popcll(same);
+  }
+  __syncthreads();
+  if (id >= 0) {
+    int base = blockoff[blockIdx.x * kMaxRings + id];
+    for (int w = 0; w < wave; w++) base += wcnt[w][id];
+    const float startOri = S->startOri, endOri = S->endOri;
+    float ori = ori_raw[i];
+    if (i <= S->istar) ori = sr_ori_first_half(ori, startOri);
+    else ori = sr_ori_second_half(ori, endOri);
+    float relTime = (ori - startOri) / (endOri - startOri);  // SR:264
+    float4 p = in[i];
+    float4 o;
+    o.x = p.x; o.y = p.y; o.z = p.z;
+    o.w = (float)((double)id + 0.1 * (double)relTime);  // SR:265, scanPeriod = 0.1 (scan_registration.h:84)
+    cloud[base + rank] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide helpers for k_sr_ring (512 threads = 8 wavefronts).
+constexpr int kRingThreads = 512;
+
+// In-place exclusive scan of an LDS int array (n <= 16 * kRingThreads); returns the total.
+__device__ int block_exclusive_scan(int* a, int n, int* scratch /* kRingThreads ints */) {
+  const int tid = threadIdx.x;
+  const int per = (n + kRingThreads - 1) / kRingThreads;
+  const int lo = tid * per, hi = min(lo + per, n);
+  int s = 0;
+  for (int k = lo; k < hi; k++) s += a[k];
+  scratch[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < kRingThreads; d <<= 1) {  // Hillis–Steele inclusive scan of the per-thread sums
+    int v = tid >= d ? scratch[tid - d] : 0;
+    __syncthreads();
+    scratch[tid] += v;
+    __syncthreads();
+  }
+  const int total = scratch[kRingThreads - 1];
+  int run = tid ? scratch[tid - 1] : 0;
+  __syncthreads();
+  for (int k = lo; k < hi; k++) { int v = a[k]; a[k] = run; run += v; }
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ void bitonic_step(u64* a, int t, int j, int k) {
+  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  const int l = i | j;
+  const bool up = (i & k) == 0;
+  const u64 x = a[i], y = a[l];
+  if ((x > y) == up) { a[i] = y; a[l] = x; }
+}
+
+// SR:353-376 == SR:397-420.  Serial neighbour suppression around local index ind (one lane).
+__device__ void sr_spread(int ind, const float* px, const float* py, const float* pz, unsigned char* picked) {
+  for (int l = 1; l <= 5; l++) {
+    float dx = px[ind + l] - px[ind + l - 1];
+    float dy = py[ind + l] - py[ind + l - 1];
+    float dz = pz[ind + l] - pz[ind + l - 1];
+    if ((double)(dx * dx + dy * dy + dz * dz) > 0.05) break;
+    picked[ind + l] = 1;
+  }
+  for (int l = -1; l >= -5; l--) {
+    float dx = px[ind + l] - px[ind + l + 1];
+    float dy = py[ind + l] - py[ind + l + 1];
+    float dz = pz[ind + l] - pz[ind + l + 1];
+    if ((double)(dx * dx + dy * dy + dz * dz) > 0.05) break;
+    picked[ind + l] = 1;
+  }
+}
+
+__global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restrict__ cloud, FrameScalars* S, int* __restrict__ sharp_idx,
+                                                          int* __restrict__ less_sharp_idx, int* __restrict__ flat_idx,
+                                                          float4* __restrict__ ring_ds, float* __restrict__ dbg_curv,
+                                                          int* __restrict__ dbg_sort, int* __restrict__ dbg_picked,
+                                                          int* __restrict__ dbg_label) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* px = (float*)smem;                          // [kMaxRingLen]
+  float* py = px + kMaxRingLen;
+  float* pz = py + kMaxRingLen;
+  float* pi = pz + kMaxRingLen;                      // intensity
+  u64* keys = (u64*)(pi + kMaxRingLen);              // [kSectors * kSectCap]
+  int* iscratch = (int*)(keys + kSectors * kSectCap);  // [kMaxRingLen] heads / ranks
+  int* scan_tmp = iscratch + kMaxRingLen;            // [kRingThreads]
+  unsigned char* picked = (unsigned char*)(scan_tmp + kRingThreads);  // [kMaxRingLen]
+  signed char* label = (signed char*)(picked + kMaxRingLen);         // [kMaxRingLen]
+  int* s_sp = (int*)(label + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
+  int* s_ep = s_sp + 8;                                              // [kSectors]    region so its base stays 16-B aligned)
+  float* s_red = (float*)(s_ep + 8);                                 // [6]
+  int* s_ncand_p = (int*)(s_red + 8);
+
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = S->ring_count[r], off = S->ring_off[r];
+  const int start = off + 5, end = off + len - 6;  // SR:278-280
+  if (tid < kSectors * 3) (&S->sect_cnt[r][0][0])[tid] = 0;
+  if (tid == 0) S->ring_ds_cnt[r] = 0;
+  if (len > kMaxRingLen) { if (tid == 0) atomicOr(&S->error, kErrRingTooLong); return; }
+  if (end - start < 6) return;  // SR:314
+
+  for (int l = tid; l < len; l += kRingThreads) {
+    float4 p = cloud[off + l];
+    px[l] = p.x; py[l] = p.y; pz[l] = p.z; pi[l] = p.w;
+    picked[l] = 0; label[l] = 0;  // SR:305-306
+  }
+  if (tid < kSectors) {
+    s_sp[tid] = start + (end - start) * tid / 6;            // SR:319
+    s_ep[tid] = start + (end - start) * (tid + 1) / 6 - 1;  // SR:320
+  }
+  __syncthreads();
+
+  // ---- curvature (SR:288-303) + sort keys, one wavefront per sector
+  if (wave < kSectors) {
+    const int sp = s_sp[wave] - off, ep = s_ep[wave] - off;  // local indices
+    const int seclen = ep - sp + 1;
+    int P = 2;
+    while (P < seclen) P <<= 1;
+    u64* K = keys + wave * kSectCap;
+    for (int t = lane; t < P; t += 64) {
+      u64 key = ~0ull;
+      if (t < seclen) {
+        const int i = sp + t;
+        float dX = px[i - 5] + px[i - 4] + px[i - 3] + px[i - 2] + px[i - 1] - 10 * px[i] + px[i + 1] + px[i + 2] + px[i + 3] + px[i + 4] + px[i + 5];
+        float dY = py[i - 5] + py[i - 4] + py[i - 3] + py[i - 2] + py[i - 1] - 10 * py[i] + py[i + 1] + py[i + 2] + py[i + 3] + py[i + 4] + py[i + 5];
+        float dZ = pz[i - 5] + pz[i - 4] + pz[i - 3] + pz[i - 2] + pz[i - 1] - 10 * pz[i] + pz[i + 1] + pz[i + 2] + pz[i + 3] + pz[i + 4] + pz[i + 5];
+        float c = dX * dX + dY * dY + dZ * dZ;
+        if (dbg_curv) dbg_curv[off + i] = c;
+        key = ((u64)__float_as_uint(c) << 32) | (unsigned)i;  // c >= 0: the bit pattern orders like the value; ties -> lower index first
+      }
+      K[t] = key;
+    }
+    lds_fence_wave();
+    // SR:323 std::sort by curvature (canonical tie order: index ascending) — wavefront-local bitonic network in LDS
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < P / 2; t += 64) bitonic_step(K, t, j, k);
+        lds_fence_wave();
+      }
+    if (dbg_sort) for (int t = lane; t < seclen; t += 64) dbg_sort[off + sp + t] = off + (int)(K[t] & 0xffffffffu);
+  }
+  __syncthreads();
+
+  // ---- greedy picks, sector after sector (neighbour suppression leaks into the next sector)
+  for (int s = 0; s < kSectors; s++) {
+    if (wave == s) {
+      const int seclen = s_ep[s] - s_sp[s] + 1;
+      const u64* K = keys + s * kSectCap;
+      int* o_sharp = sharp_idx + (r * kSectors + s) * kMaxSharpPerSect;
+      int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
+      int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
+      int n_sharp = 0, n_less = 0, n_flat = 0;
+      // SR:327-378, descending curvature
+      int largestPickedNum = 0;
+      bool done = false;
+      for (int top = seclen - 1; top >= 0 && !done; top -= 64) {
+        const int pos = top - lane;
+        const bool in = pos >= 0;
+        const u64 key = in ? K[pos] : 0ull;
+        const float c = __uint_as_float((unsigned)(key >> 32));
+        const int l = (int)(key & 0xffffffffu);
+        bool cand = in && ((double)c > 0.1);
+        const u64 m = __ballot(cand);
+        if (m == 0) break;
+        while (true) {
+          const bool elig = cand && picked[l] == 0;
+          const u64 e = __ballot(elig);
+          if (e == 0) break;
+          const int f = __ffsll((long long)e) - 1;
+          const int lf = __shfl(l, f);
+          largestPickedNum++;
+          if (largestPickedNum <= 2) {
+            if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; }
+            n_sharp++; n_less++;
+          } else if (largestPickedNum <= 20) {
+            if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; }
+            n_less++;
+          } else {
+            done = true;
+            break;
+          }
+          if (lane == 0) { picked[lf] = 1; sr_spread(lf, px, py, pz, picked); }
+          lds_fence_wave();
+          cand = cand && lane > f;
+        }
+        if (m != __ballot(in)) done = true;  // sorted: everything further down is <= 0.1
+      }
+      // SR:380-422, ascending curvature
+      int smallestPickedNum = 0;
+      done = false;
+      for (int base = 0; base < seclen && !done; base += 64) {
+        const int pos = base + lane;
+        const bool in = pos < seclen;
+        const u64 key = in ? K[pos] : 0ull;
+        const float c = __uint_as_float((unsigned)(key >> 32));
+        const int l = (int)(key & 0xffffffffu);
+        bool cand = in && ((double)c < 0.1);
+        const u64 m = __ballot(cand);
+        if (m == 0) break;
+        while (true) {
+          const bool elig = cand && picked[l] == 0;
+          const u64 e = __ballot(elig);
+          if (e == 0) break;
+          const int f = __ffsll((long long)e) - 1;
+          const int lf = __shfl(l, f);
+          if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; }
+          n_flat++;
+          smallestPickedNum++;
+          if (smallestPickedNum >= 4) { done = true; break; }  // the 4th flat point is emitted but not suppressed (SR:390-394)
+          if (lane == 0) { picked[lf] = 1; sr_spread(lf, px, py, pz, picked); }
+          lds_fence_wave();
+          cand = cand && lane > f;
+        }
+        if (m != __ballot(in)) done = true;
+      }
+      if (lane == 0) { S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat; }
+    }
+    __syncthreads();
+  }
+  if (dbg_picked) for (int l = tid; l < len; l += kRingThreads) { dbg_picked[off + l] = picked[l]; dbg_label[off + l] = label[l]; }
+
+  // ---- lessFlat (SR:424-430) + per-ring pcl::VoxelGrid leaf 0.2 (SR:433-437)
+  const int c_lo = 5, c_hi = len - 7;  // local range covered by the six sectors: [start, end-1]
+  const int ncov = c_hi - c_lo + 1;
+  // bounding box of the candidates (getMinMax3D)
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  int mycnt = 0;
+  for (int l = c_lo + tid; l <= c_hi; l += kRingThreads)
+    if (label[l] <= 0) {
+      mn[0] = fminf(mn[0], px[l]); mx[0] = fmaxf(mx[0], px[l]);
+      mn[1] = fminf(mn[1], py[l]); mx[1] = fmaxf(mx[1], py[l]);
+      mn[2] = fminf(mn[2], pz[l]); mx[2] = fmaxf(mx[2], pz[l]);
+      mycnt++;
+    }
+  for (int a = 0; a < 3; a++)
+    for (int d = 32; d > 0; d >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], d)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d)); }
+  for (int d = 32; d > 0; d >>= 1) mycnt += __shfl_xor(mycnt, d);
+  float* wred = (float*)scan_tmp;  // [8 waves][6] + counts
+  if (lane == 0) {
+    for (int a = 0; a < 3; a++) { wred[wave * 8 + a] = mn[a]; wred[wave * 8 + 3 + a] = mx[a]; }
+    ((int*)wred)[wave * 8 + 6] = mycnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int a = 0; a < 3; a++) { mn[a] = wred[a]; mx[a] = wred[3 + a]; }
+    for (int w = 0; w < kRingThreads / 64; w++) {
+      for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], wred[w * 8 + a]); mx[a] = fmaxf(mx[a], wred[w * 8 + 3 + a]); }
+      tot += ((int*)wred)[w * 8 + 6];
+    }
+    for (int a = 0; a < 3; a++) { s_red[a] = mn[a]; s_red[3 + a] = mx[a]; }
+    *s_ncand_p = tot;
+  }
+  __syncthreads();
+  const int ncand = *s_ncand_p;
+  if (ncand == 0) return;
+  const float inv = 1.0f / 0.2f;  // inverse_leaf_size_
+  for (int a = 0; a < 3; a++) { mn[a] = s_red[a]; mx[a] = s_red[3 + a]; }
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  float4* out = ring_ds + (size_t)r * kMaxRingLen;
+  if (dx * dy * dz > (long long)INT_MAX) {
+    // PCL: "Leaf size is too small for the input dataset" -> output = input.  Keep input order.
+    for (int l = tid; l < len; l += kRingThreads) iscratch[l] = (l >= c_lo && l <= c_hi && label[l] <= 0) ? 1 : 0;
+    __syncthreads();
+    block_exclusive_scan(iscratch, len, scan_tmp);
+    for (int l = c_lo + tid; l <= c_hi; l += kRingThreads)
+      if (label[l] <= 0) out[iscratch[l]] = make_float4(px[l], py[l], pz[l], pi[l]);
+    if (tid == 0) S->ring_ds_cnt[r] = ncand;
+    return;
+  }
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; a++) {
+    min_b[a] = (int)floorf(mn[a] * inv);
+    div_b[a] = (int)floorf(mx[a] * inv) - min_b[a] + 1;
+  }
+  int P2 = 2;
+  while (P2 < ncov) P2 <<= 1;
+  u64* K2 = keys;  // P2 <= kMaxRingLen <= kSectors * kSectCap
+  for (int t = tid; t < P2; t += kRingThreads) {
+    u64 key = ~0ull;
+    const int l = c_lo + t;
+    if (t < ncov && label[l] <= 0) {
+      int ijk0 = (int)(floorf(px[l] * inv) - (float)min_b[0]);
+      int ijk1 = (int)(floorf(py[l] * inv) - (float)min_b[1]);
+      int ijk2 = (int)(floorf(pz[l] * inv) - (float)min_b[2]);
+      int idx = ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1];
+      key = ((u64)(unsigned)idx << 12) | (unsigned)l;  // stable: input order inside a voxel
+    }
+    K2[t] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P2 / 2; t += kRingThreads) bitonic_step(K2, t, j, k);
+      __syncthreads();
+    }
+  // voxel heads -> output rank
+  for (int t = tid; t < ncand; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 12) != (K2[t - 1] >> 12)) ? 1 : 0;
+  __syncthreads();
+  const int nvox = block_exclusive_scan(iscratch, ncand, scan_tmp);
+  for (int t = tid; t < ncand; t += kRingThreads) {
+    const u64 vid = K2[t] >> 12;
+    if (t == 0 || vid != (K2[t - 1] >> 12)) {
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in sorted order
+      int u = t;
+      for (; u < ncand && (K2[u] >> 12) == vid; u++) {
+        const int l = (int)(K2[u] & 0xfffu);
+        sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l];
+      }
+      const float cnt = (float)(u - t);
+      out[iscratch[t]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    }
+  }
+  if (tid == 0) S->ring_ds_cnt[r] = nvox;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ cloud, FrameScalars* S, const int* __restrict__ sharp_idx,
+                                                    const int* __restrict__ less_sharp_idx, const int* __restrict__ flat_idx,
+                                                    const float4* __restrict__ ring_ds, float4* __restrict__ sharp,
+                                                    float4* __restrict__ less_sharp, float4* __restrict__ flat,
+                                                    float4* __restrict__ less_flat, int* __restrict__ dbg_feat_idx /* [3][kMaxLessSharp] */) {
+  __shared__ int base[4];
+  __shared__ int soff[kSectors][3];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  {
+    // 4 wavefronts: kinds 0..2 = sharp / lessSharp / flat picks per ring, kind 3 = per-ring VoxelGrid output size
+    const int kind = tid >> 6, q = tid & 63;
+    int v = 0;
+    if (kind < 3) { for (int s = 0; s < kSectors; s++) v += S->sect_cnt[q][s][kind]; }
+    else v = S->ring_ds_cnt[q];
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d); if (q >= d) inc += t; }
+    if (q == r) base[kind] = inc - v;
+    if (q == 63 && r == kMaxRings - 1) {
+      if (kind == 0) S->n_sharp = inc; else if (kind == 1) S->n_less_sharp = inc; else if (kind == 2) S->n_flat = inc; else S->n_less_flat = inc;
+    }
+  }
+  __syncthreads();
+  if (tid < 3) {
+    int run = base[tid];
+    for (int s = 0; s < kSectors; s++) { soff[s][tid] = run; run += S->sect_cnt[r][s][tid]; }
+  }
+  __syncthreads();
+  // sector lists: tiny — one thread per (sector, kind, slot)
+  for (int k = tid; k < kSectors * (kMaxSharpPerSect + kMaxLessSharpPerSect + kMaxFlatPerSect); k += 256) {
+    const int per = kMaxSharpPerSect + kMaxLessSharpPerSect + kMaxFlatPerSect;
+    const int s = k / per, q = k % per;
+    if (q < kMaxSharpPerSect) {
+      if (q < S->sect_cnt[r][s][0]) {
+        int src = sharp_idx[(r * kSectors + s) * kMaxSharpPerSect + q];
+        sharp[soff[s][0] + q] = cloud[src];
+        if (dbg_feat_idx) dbg_feat_idx[soff[s][0] + q] = src;
+      }
+    } else if (q < kMaxSharpPerSect + kMaxLessSharpPerSect) {
+      const int qq = q - kMaxSharpPerSect;
+      if (qq < S->sect_cnt[r][s][1]) {
+        int src = less_sharp_idx[(r * kSectors + s) * kMaxLessSharpPerSect + qq];
+        less_sharp[soff[s][1] + qq] = cloud[src];
+        if (dbg_feat_idx) dbg_feat_idx[kMaxLessSharp + soff[s][1] + qq] = src;
+      }
+    } else {
+      const int qq = q - kMaxSharpPerSect - kMaxLessSharpPerSect;
+      if (qq < S->sect_cnt[r][s][2]) {
+        int src = flat_idx[(r * kSectors + s) * kMaxFlatPerSect + qq];
+        flat[soff[s][2] + qq] = cloud[src];
+        if (dbg_feat_idx) dbg_feat_idx[2 * kMaxLessSharp + soff[s][2] + qq] = src;
+      }
+    }
+  }
+  const int nds = S->ring_ds_cnt[r];
+  const float4* src = ring_ds + (size_t)r * kMaxRingLen;
+  for (int k = tid; k < nds; k += 256) less_flat[base[3] + k] = src[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t sr_ring_smem_bytes() {
+  return sizeof(float) * 4 * kMaxRingLen + sizeof(u64) * kSectors * kSectCap + sizeof(int) * (kMaxRingLen + kRingThreads) +
+         2 * kMaxRingLen + 32 * sizeof(int);
+}
+
+hipError_t sr_init() {
+  return hipFuncSetAttribute((const void*)k_sr_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_ring_smem_bytes());
+}
+
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug) {
+  const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
+  hipLaunchKernelGGL(k_sr_first_last, dim3(1), dim3(1024), 0, st, d_in, n, min_range, b.S);
+  hipLaunchKernelGGL(k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
+  hipLaunchKernelGGL(k_sr_scan, dim3(1), dim3(64), 0, st, nblk, N_SCANS, b.S, b.blockhist, b.blockoff);
+  hipLaunchKernelGGL(k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockoff, b.cloud);
+  hipLaunchKernelGGL(k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
+                     b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
+                     debug ? b.dbg_label : nullptr);
+  hipLaunchKernelGGL(k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
+                     b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr);
+  return hipGetLastError();
+}
+
+}  // namespace vloam

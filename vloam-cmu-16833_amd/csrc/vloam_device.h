@@ -1,0 +1,93 @@
+// Device-side data layout shared by the HIP kernels and the host side of libvloam_hip.so.
+// gfx950 / CDNA4 only.  All per-frame counts live in HBM (FrameScalars) so that a whole sweep is
+// enqueued without a single host round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vloam {
+
+constexpr int kMaxRings = 64;        // N_SCANS upper bound (scan_registration.cpp:195-226)
+constexpr int kSectors = 6;          // scan_registration.cpp:317
+constexpr int kMaxRingLen = 4096;    // points of one ring kept in LDS by k_sr_ring (HDL-64E: <= ~2100)
+constexpr int kSectCap = 1024;       // padded sector length for the LDS bitonic sort
+constexpr int kLabelBlock = 1024;    // points per workgroup in the label / scatter kernels
+constexpr int kMaxSharpPerSect = 2, kMaxLessSharpPerSect = 20, kMaxFlatPerSect = 4;  // scan_registration.cpp:335-345,391
+constexpr int kMaxSharp = kMaxRings * kSectors * kMaxSharpPerSect;          // 768
+constexpr int kMaxLessSharp = kMaxRings * kSectors * kMaxLessSharpPerSect;  // 7680
+constexpr int kMaxFlat = kMaxRings * kSectors * kMaxFlatPerSect;            // 1536
+constexpr int kMaxLoFactors = kMaxSharp + kMaxFlat;                         // 2304
+
+enum ErrorBits : int {
+  kErrEmpty = 1,       // no point survived S1
+  kErrRingTooLong = 2, // a ring exceeded kMaxRingLen
+  kErrMapFull = 4,     // voxel hash out of slots
+  kErrMapDeferred = 8, // a scan point landed in a cube outside the valid 5x5x3 block
+  kErrStackFull = 16,
+};
+
+// Per-frame scalars of scan registration (one per sequence).
+struct FrameScalars {
+  int first_valid, last_valid;  // raw input indices of the first / last point surviving S1
+  int istar;                    // raw index of the kept point that flips halfPassed (INT_MAX: none)
+  int n_after_s1;               // debug
+  int N2;                       // points kept (== laserCloud->size())
+  float startOri, endOri;
+  int error;
+  int ring_count[kMaxRings];
+  int ring_off[kMaxRings + 1];
+  int scanStartInd[kMaxRings], scanEndInd[kMaxRings];
+  int sect_cnt[kMaxRings][kSectors][3];  // sharp, lessSharp, flat picks per sector
+  int ring_ds_cnt[kMaxRings];            // per-ring VoxelGrid(0.2) output size
+  int n_sharp, n_less_sharp, n_flat, n_less_flat;
+};
+
+// ---------------------------------------------------------------- Levenberg–Marquardt
+// One record per solve, written by k_lm_solve.  Plain doubles so tests can read it verbatim.
+constexpr int kLmMaxTrace = 104;
+struct LMRecord {
+  double x_in[7], x_out[7];
+  double H0[36], g0[6];          // J^T J and J^T r at the initial point (tangent space, after the loss corrector)
+  double initial_cost, final_cost;
+  double n_iterations;           // rows of trace that are valid
+  double termination;            // 0 iteration cap, 1 convergence, 2 failure
+  double n_factors;              // residual blocks in the problem
+  double n_evals;                // residual/Jacobian evaluations performed (E_o / E_m of SURVEY §8d)
+  double trace[kLmMaxTrace][8];  // cost, cost_change, gradient_max_norm, step_norm, relative_decrease, radius, valid, successful
+};
+
+// Factor table consumed by k_lm_solve (structure of arrays, one slot per candidate feature).
+//   type 0: none
+//   type 1: LidarEdgeFactor       p = curr, A = last_point_a, B = last_point_b     (lidarFactor.hpp:14-56)
+//   type 2: LidarPlaneFactor      p = curr, A = last_point_j, B = ljm_norm         (lidarFactor.hpp:58-106)
+//   type 3: LidarPlaneNormFactor  p = curr, A = plane_unit_norm, B.x = negative_OA_dot_norm (lidarFactor.hpp:108-139)
+//   type 4: CostFunctor32         p = X0, A.x,A.y = x1_bar,y1_bar                  (ceres_cost_function.h:54-96)
+//   type 5: CostFunctor22         p.x,p.y = x0_bar,y0_bar, A.x,A.y = x1_bar,y1_bar (ceres_cost_function.h:147-185)
+struct FactorTable {
+  int* type;      // [cap]
+  double* p;      // [3][cap]
+  double* A;      // [3][cap]
+  double* B;      // [3][cap]
+  double* resid;  // [3][cap] raw residuals at the initial point (parity hook)
+  int cap;
+};
+
+struct LOState {           // laser odometry state carried across frames (laser_odometry.h:106-146)
+  double para_q[4], para_t[3];  // q_last_curr (x,y,z,w), t_last_curr
+  double q_w_curr[4], t_w_curr[3];
+  double prior_q[4], prior_t[3];  // vloam_tf->velo_last_VOT_velo_curr
+};
+
+struct MapState {          // laser mapping state (laser_mapping.h:141-155)
+  double parameters[7];    // q_w_curr (x,y,z,w), t_w_curr
+  double q_wmap_wodom[4], t_wmap_wodom[3];
+  double q_wodom_curr[4], t_wodom_curr[3];
+  int cenW, cenH, cenD;    // laserCloudCen{Width,Height,Depth}
+  int centerCube[3];
+  int n_corner_stack, n_surf_stack;
+  int do_optimize;         // laserCloudCornerFromMapNum > 10 && laserCloudSurfFromMapNum > 50
+  int n_map_corner, n_map_surf;  // points in the valid 5x5x3 block at gather time
+  int deferred;            // inserts outside the valid block
+};
+
+}  // namespace vloam
