@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — scans/s of the MI355X-native VLOAM per-scan odometry hot path on synthetic HDL-64E sweeps.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched through
+``python -m torch.distributed.run --nproc-per-node N …`` (one rank per GPU, RCCL).  A *step* is one
+sweep (64 rings x 2048 azimuth steps = 131 072 points) through the façade
+reset -> scanRegistration -> laserOdometry [-> laserMapping] on inputs already resident in HBM.
+Rank r drives its own independent sequence (different scene / trajectory / noise seeds): the path
+shards one-sequence-per-GPU with no data-path collective; the only collective is an
+all-gather of the trajectories after the timed region.  Rank 0 prints ONE JSON line.
+
+PyTorch is plumbing only here (device buffers for the inputs, torch.distributed barrier / gather).
+The CPU oracle (oracle/) is used only for the ``cpu_baseline`` leg and the parity numbers — never
+inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+WORKLOADS = {
+    "lo": "configs[1]: scanRegistration + scan-to-scan laserOdometry ICP, synthetic HDL-64E 64x2048",
+    "map": "configs[2]: scanRegistration + laserOdometry + laserMapping scan-to-map ICP (voxel-hash local map), synthetic HDL-64E 64x2048",
+}
+
+
+def algorithmic_bytes(kernel, c):
+    """ALGORITHMIC (compulsory) bytes one launch of `kernel` moves, from the measured counts of the run."""
+    n_feat = c["n_sharp"] + c["n_flat"]
+    F = c["F_corner"] + c["F_plane"]
+    if kernel == "k_lo_assoc":  # features + both candidate clouds read once, one 76-byte factor record written per factor
+        return 16 * n_feat + 16 * (c["C"] + c["S"]) + 76 * F
+    if kernel == "k_lm_solve":  # every evaluation re-reads the 76-byte factor records
+        return 76 * F * max(c["E_o"], 2) / 2.0
+    if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
+        return 16 * c["N2"] + 16 * c["n_lessFlat"] + 4 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"])
+    if kernel in ("k_sr_label",):
+        return 16 * c["N_in"] + 5 * c["N_in"]
+    if kernel in ("k_sr_scatter",):
+        return 16 * c["N_in"] + 5 * c["N_in"] + 16 * c["N2"]
+    if kernel == "k_sr_compact":
+        return 32 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"] + c["n_lessFlat"])
+    if kernel == "k_map_assoc":
+        return (c["n_c"] + c["n_s"]) * (16 + 5 * 16) + 76 * c["K_m"]
+    return 0
+
+
+def sweep_bytes(c, with_mapping):
+    """B_SR + B_LO (+ B_MAP) per sweep from measured counts."""
+    n_feat_all = c["n_sharp"] + c["n_lessSharp"] + c["n_flat"] + c["n_lessFlat"]
+    b_sr = 16 * c["N_in"] + 16 * c["N2"] + 16 * n_feat_all
+    F_o = c["F_corner"] + c["F_plane"]
+    b_lo = 2 * (16 * (c["n_sharp"] + c["n_flat"]) + 16 * (c["C"] + c["S"])) + c["E_o"] * F_o * 64 + 16 * (c["n_lessSharp"] + c["n_lessFlat"])
+    b_map = 0
+    if with_mapping:
+        nn = c["n_c"] + c["n_s"]
+        b_map = 16 * (c["C"] + c["S"]) + 16 * c["M"] + 2 * nn * (16 + 5 * 16) + c["E_m"] * c["K_m"] * 64 + 16 * nn + 2 * 16 * c["M"]
+    return b_sr, b_lo, b_map
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("VLOAM_BENCH_WORKLOAD", "lo"))
+    ap.add_argument("--kernel", default=os.environ.get("VLOAM_BENCH_KERNEL", ""), help="kernel to bracket with HIP events (default: the dominant one)")
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--azimuth", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=48, help="sweeps of the same sequence timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    K, W = args.steps, args.warmup
+    with_mapping = args.workload == "map"
+
+    import torch
+    import conftest
+    vl = conftest.load_pkg()
+    synth = conftest.load_synth()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic input, one independent sequence per rank, resident in HBM before the timed region
+    seq = synth.SynthSequence(n_rings=args.rings, n_azimuth=args.azimuth, n_sweeps=W + K, seed_scene=1234 + 17 * rank,
+                              seed_traj=42 + rank, seed_noise=5678 + 100003 * rank)
+    host = np.stack([seq.sweep(k) for k in range(W + K)])
+    n_pts = host.shape[1]
+    d_clouds = torch.from_numpy(host).to(torch.device("cuda", local_rank))
+    base_ptr, stride = d_clouds.data_ptr(), n_pts * 16
+
+    h = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
+    kernel = args.kernel or ("k_map_assoc" if with_mapping else "k_lo_assoc")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(W):
+        h.process_scan_device(base_ptr + k * stride, n_pts)
+    h.sync()
+    h.profile_kernel(kernel, 8 * K + 16)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        h.process_scan_device(base_ptr + k * stride, n_pts)
+    h.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    k_ms, k_launches = h.profile_read()
+    counts = h.counts()
+    traj = h.trajectory()
+
+    # the one collective of the path: gather the per-sequence trajectories
+    if dist is not None:
+        t_dev = torch.from_numpy(traj).to("cuda")
+        gathered = [torch.empty_like(t_dev) for _ in range(world)]
+        dist.all_gather(gathered, t_dev)
+
+    out = None
+    if rank == 0:
+        value = K * world / elapsed
+        b_sr, b_lo, b_map = sweep_bytes(counts, with_mapping)
+        kb = algorithmic_bytes(kernel, counts)
+        avg_ms = k_ms / max(k_launches, 1)
+        achieved = kb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "scans/sec end-to-end odometry on 64x2048 cloud", "value": value, "unit": "scans/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 points / f64 poses+residuals", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload], "points_per_sweep": int(n_pts), "sequences": world,
+                       "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run"},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": kb,
+                         "avg_launch_us": 1e3 * avg_ms, "launches_timed": k_launches,
+                         "sweep_algorithmic_bytes": {"B_SR": b_sr, "B_LO": b_lo, "B_MAP": b_map},
+                         "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
+            "counts_last_sweep": counts,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import orc
+            ns = min(args.cpu_sample, W + K)
+            o = orc.Oracle(scan_line=args.rings, with_mapping=with_mapping)
+            c0 = time.perf_counter()
+            for k in range(ns):
+                o.process(host[k])
+            c1 = time.perf_counter()
+            out["cpu_baseline"] = {"value": ns / (c1 - c0), "unit": "scans/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d sweeps of the same synthetic sequence through the CPU oracle "
+                                             "(restated reference path, single thread like the reference)" % ns}
+            # parity of the sample: re-run the same sweeps on a fresh handle and compare poses frame by frame
+            hp = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024))
+            dt_max = dq_max = 0.0
+            np_ = min(ns, 12)
+            for k in range(np_):
+                hp.process_scan(host[k])
+            hp.sync()
+            tj = hp.trajectory()
+            o3 = orc.Oracle(scan_line=args.rings, with_mapping=with_mapping)
+            for k in range(np_):
+                o3.process(host[k])
+                qw, tw, _, _ = o3.lo_pose()
+                dt_max = max(dt_max, float(np.linalg.norm(tj[k, 4:7] - tw)))
+                dq_max = max(dq_max, float(min(np.linalg.norm(tj[k, 0:4] - qw), np.linalg.norm(tj[k, 0:4] + qw))))
+                if with_mapping:
+                    qm, tm, _, _ = o3.map_pose()
+                    dt_max = max(dt_max, float(np.linalg.norm(tj[k, 11:14] - tm)))
+                    dq_max = max(dq_max, float(min(np.linalg.norm(tj[k, 7:11] - qm), np.linalg.norm(tj[k, 7:11] + qm))))
+            out["parity_vs_oracle"] = {"frames": np_, "max_abs_dt_m": dt_max, "max_abs_dq": dq_max, "bar": 1e-4}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,12 @@ vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr
  *   stage 3 (VO): 0 buckets, 1 per-match rows, 2 LM record */
 vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, long long cap_bytes, long long* n_bytes);
 
+/* Per-kernel HIP-event timer for bench.py's roofline line: brackets every launch of the kernel whose __global__
+ * symbol is `name` (e.g. "k_lo_assoc") with an event pair on the handle's own stream.  "" disables.
+ * vloam_profile_read returns the summed milliseconds and launch count since the last read. */
+vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_launches);
+vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches);
+
 /* Timing of the last vloam_sync()ed scans: HIP-event milliseconds accumulated per stage
  * {scanRegistration, laserOdometry, laserMapping, vo} and number of scans covered. */
 vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans);

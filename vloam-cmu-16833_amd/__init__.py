@@ -172,6 +172,15 @@ class Handle:
         self._chk(self.L.vloam_trajectory_device_ptr(self.h, C.byref(p), C.byref(b)))
         return p.value, b.value
 
+    def profile_kernel(self, name, max_launches=4096):
+        """HIP-event pair around every launch of the kernel named `name` (its __global__ symbol) on the handle's stream."""
+        self._chk(self.L.vloam_profile_kernel(self.h, name.encode(), int(max_launches)))
+
+    def profile_read(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.L.vloam_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def stage_ms(self):
         ms = np.zeros(4)
         n = C.c_int(0)

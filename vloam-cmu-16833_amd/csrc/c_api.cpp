@@ -65,6 +65,8 @@ struct vloam_handle {
   double stage_ms[4] = {0, 0, 0, 0};
   int timed_scans = 0;
   int last_n_in = 0;
+  ProfHook prof;
+  std::vector<hipEvent_t> prof_events;
 };
 
 template <class T>
@@ -191,11 +193,12 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
 
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  for (void* p : h->allocs) hipFree(p);
-  for (int k = 0; k < 5; k++) if (h->ev[k]) hipEventDestroy(h->ev[k]);
-  if (h->stream) hipStreamDestroy(h->stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (int k = 0; k < 5; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return VLOAM_OK;
 }
@@ -213,7 +216,7 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   if (h->frame >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
   const int cur = h->frame & 1;
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0));
+  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   h->last_n_in = n;
   h->stage = 1;
@@ -229,11 +232,11 @@ static vloam_status enqueue_lo(vloam_handle* h) {
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
-                      h->sr[prev].S, h->lo, F, h->lo_corr[outer]);
-      lm_launch(h->stream, F, nullptr, kMaxLoFactors, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr);
+                      h->sr[prev].S, h->lo, F, h->lo_corr[outer], &h->prof);
+      lm_launch(h->stream, F, nullptr, kMaxLoFactors, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
     }
   }
-  lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0);
+  lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   h->stage = 2;
@@ -488,6 +491,42 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
   if (stage == 2) return map_debug_get(&h->map, item, buf, cap, n);
   if (stage == 3) return vo_debug_get(&h->vo, item, buf, cap, n);
   return VLOAM_ERR_INVALID;
+}
+
+// Per-kernel HIP-event timer: every launch of the named kernel (its __global__ symbol, e.g. "k_lo_assoc") is
+// bracketed by an event pair on the handle's stream; max_launches bounds the event pool.  name == "" disables.
+vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_launches) {
+  if (!h || !name) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int id = kKNone;
+  for (int k = 1; k < kKCount; k++) if (strcmp(name, kKernelNames[k]) == 0) id = k;
+  if (id == kKNone && name[0] != 0) { set_err("unknown kernel %s", name); return VLOAM_ERR_INVALID; }
+  while ((int)h->prof_events.size() < 2 * max_launches) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    h->prof_events.push_back(e);
+  }
+  h->prof.id = id;
+  h->prof.ev = h->prof_events.data();
+  h->prof.cap = max_launches;
+  h->prof.used = 0;
+  return VLOAM_OK;
+}
+vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches) {
+  if (!h || !total_ms || !launches) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double tot = 0;
+  for (int k = 0; k < h->prof.used; k++) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof.ev[2 * k], h->prof.ev[2 * k + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = h->prof.used;
+  h->prof.used = 0;
+  return VLOAM_OK;
 }
 
 vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans) {

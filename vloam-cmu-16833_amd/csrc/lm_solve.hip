@@ -399,8 +399,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
 }
 
 void lm_launch(hipStream_t st, const FactorTable& F, const int* d_n_slots, int n_slots_fixed, double* d_x, LMRecord* d_rec, int max_iters,
-               double huber_a, bool quat, const int* d_enable) {
-  hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kLmThreads), 0, st, F, d_n_slots, n_slots_fixed, d_x, d_rec, max_iters, huber_a, quat ? 1 : 0,
+               double huber_a, bool quat, const int* d_enable, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve, dim3(1), dim3(kLmThreads), 0, st, F, d_n_slots, n_slots_fixed, d_x, d_rec, max_iters, huber_a, quat ? 1 : 0,
                      d_enable);
 }
 

@@ -195,12 +195,12 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
 }
 
 void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
-                     const FrameScalars* Sp, const LOState* lo, const FactorTable& F, int* corr) {
-  hipLaunchKernelGGL(k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, lo, F, corr);
+                     const FrameScalars* Sp, const LOState* lo, const FactorTable& F, int* corr, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, lo, F, corr);
 }
 void lo_set_prior_launch(hipStream_t st, LOState* lo) { hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo); }
-void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate) {
-  hipLaunchKernelGGL(k_lo_finish, dim3(1), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0);
+void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoFinish, st, k_lo_finish, dim3(1), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0);
 }
 
 }  // namespace vloam

@@ -3,7 +3,7 @@ namespace vloam {
 vloam_status map_create(MapContext* m, const vloam_config&, hipStream_t, std::vector<void*>& allocs) {
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(MapState) + 256) != hipSuccess) return VLOAM_ERR_HIP;
-  hipMemset(p, 0, sizeof(MapState) + 256);
+  (void)hipMemset(p, 0, sizeof(MapState) + 256);
   allocs.push_back(p);
   m->state = (MapState*)p;
   return VLOAM_OK;

@@ -27,6 +27,6 @@ struct SRBuffers {
 };
 
 hipError_t sr_init();
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug);
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph = nullptr);
 
 }  // namespace vloam

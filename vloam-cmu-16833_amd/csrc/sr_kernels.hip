@@ -584,16 +584,16 @@ hipError_t sr_init() {
   return hipFuncSetAttribute((const void*)k_sr_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_ring_smem_bytes());
 }
 
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug) {
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph) {
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  hipLaunchKernelGGL(k_sr_first_last, dim3(1), dim3(1024), 0, st, d_in, n, min_range, b.S);
-  hipLaunchKernelGGL(k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
-  hipLaunchKernelGGL(k_sr_scan, dim3(1), dim3(64), 0, st, nblk, N_SCANS, b.S, b.blockhist, b.blockoff);
-  hipLaunchKernelGGL(k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockoff, b.cloud);
-  hipLaunchKernelGGL(k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
+  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(1), dim3(1024), 0, st, d_in, n, min_range, b.S);
+  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
+  VLOAM_LAUNCH(ph, kKSrScan, st, k_sr_scan, dim3(1), dim3(64), 0, st, nblk, N_SCANS, b.S, b.blockhist, b.blockoff);
+  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockoff, b.cloud);
+  VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                      debug ? b.dbg_label : nullptr);
-  hipLaunchKernelGGL(k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
+  VLOAM_LAUNCH(ph, kKSrCompact, st, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
                      b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr);
   return hipGetLastError();
 }

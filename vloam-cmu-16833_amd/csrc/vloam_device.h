@@ -18,6 +18,34 @@ constexpr int kMaxLessSharp = kMaxRings * kSectors * kMaxLessSharpPerSect;  // 7
 constexpr int kMaxFlat = kMaxRings * kSectors * kMaxFlatPerSect;            // 1536
 constexpr int kMaxLoFactors = kMaxSharp + kMaxFlat;                         // 2304
 
+// Kernel ids for the per-kernel HIP-event timer (vloam_profile_kernel); names = the __global__ symbols.
+enum KernelId : int {
+  kKNone = 0, kKSrFirstLast, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
+  kKMapPrepare, kKMapStack, kKMapAssoc, kKMapInsert, kKMapFinalize, kKVoProject, kKVoMatch, kKCount
+};
+static const char* const kKernelNames[kKCount] = {"", "k_sr_first_last", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
+  "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_stack", "k_map_assoc", "k_map_insert",
+  "k_map_finalize", "k_vo_project", "k_vo_match"};
+
+// Records a HIP-event pair around every launch of one selected kernel, on the stream it is launched on.
+struct ProfHook {
+  int id = kKNone;
+  hipEvent_t* ev = nullptr;  // [2 * cap] start/stop pairs
+  int cap = 0, used = 0;
+  inline bool begin(int kid, hipStream_t st) {
+    if (kid != id || used >= cap) return false;
+    (void)hipEventRecord(ev[2 * used], st);
+    return true;
+  }
+  inline void end(hipStream_t st) { (void)hipEventRecord(ev[2 * used + 1], st); used++; }
+};
+#define VLOAM_LAUNCH(ph, kid, st, ...)                     \
+  do {                                                     \
+    bool prof_ = (ph) && (ph)->begin((kid), (st));         \
+    hipLaunchKernelGGL(__VA_ARGS__);                       \
+    if (prof_) (ph)->end((st));                            \
+  } while (0)
+
 enum ErrorBits : int {
   kErrEmpty = 1,       // no point survived S1
   kErrRingTooLong = 2, // a ring exceeded kMaxRingLen

@@ -149,44 +149,77 @@ class SynthSequence:
         return rot_to_quat_xyzw(R0.T @ R1), R0.T @ (t1 - t0)
 
     # ------------------------------------------------------------------ ray casting
+    def _az_window(self, pts_world, R, o, margin_cols=3):
+        """Column range [j0, j1) (mod n_azimuth) whose rays can reach the object with the given world corner points."""
+        n_az = self.n_azimuth
+        ps = (pts_world - o[None, :]) @ R  # sensor frame
+        if np.min(np.hypot(ps[:, 0], ps[:, 1])) < 1.0:
+            return 0, n_az
+        az = np.arctan2(ps[:, 1], ps[:, 0])
+        ref = az[0]
+        d = (az - ref + np.pi) % (2 * np.pi) - np.pi  # spread around the first corner, wrap-safe for spans < pi
+        lo, hi = ref + d.min(), ref + d.max()
+        if hi - lo > np.pi * 0.9:
+            return 0, n_az
+        # column j has azimuth -2*pi*j/n_az (roll/pitch <= 0.01 rad shift it by < 1 column at these elevations)
+        j_hi = int(np.ceil(-lo / (2 * np.pi) * n_az)) + margin_cols
+        j_lo = int(np.floor(-hi / (2 * np.pi) * n_az)) - margin_cols
+        return j_lo, j_hi + 1
+
     def ranges(self, k):
         R, o = self.pose(k)
-        d = self.dirs @ R.T  # world directions
-        n = d.shape[0]
-        best = np.full(n, np.inf)
+        nr, na = self.n_rings, self.n_azimuth
+        d = (self.dirs @ R.T).reshape(nr, na, 3)  # world directions, [ring][column]
+        best = np.full((nr, na), np.inf)
         # ground
         with np.errstate(divide="ignore", invalid="ignore"):
-            tg = (GROUND_Z - o[2]) / d[:, 2]
-        tg = np.where((d[:, 2] < 0) & (tg > 0), tg, np.inf)
+            tg = (GROUND_Z - o[2]) / d[:, :, 2]
+        tg = np.where((d[:, :, 2] < 0) & (tg > 0), tg, np.inf)
         best = np.minimum(best, tg)
-        # boxes (slab), culled to those within reach
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / d
+
+        def cols(j0, j1):
+            if j1 - j0 >= na:
+                return [slice(0, na)]
+            a, b = j0 % na, j1 % na
+            return [slice(a, b)] if a < b else [slice(a, na), slice(0, b)]
+
+        # boxes (slab test) — only the columns that can see the box
         bx = self.boxes
         cen = 0.5 * (bx[:, :2] + bx[:, 3:5])
         near = np.linalg.norm(cen - o[None, :2], axis=1) < MAX_RANGE + 10.0
-        with np.errstate(divide="ignore", invalid="ignore"):
-            inv = 1.0 / d
         for b in bx[near]:
-            t1 = (b[None, 0:3] - o[None, :]) * inv
-            t2 = (b[None, 3:6] - o[None, :]) * inv
-            tmin = np.nanmax(np.minimum(t1, t2), axis=1)
-            tmax = np.nanmin(np.maximum(t1, t2), axis=1)
-            hit = (tmax >= tmin) & (tmin > 0)
-            best = np.where(hit & (tmin < best), tmin, best)
+            corners = np.array([[b[i], b[j], b[kk]] for i in (0, 3) for j in (1, 4) for kk in (2, 5)])
+            j0, j1 = self._az_window(corners, R, o)
+            for sl in cols(j0, j1):
+                t1 = (b[None, None, 0:3] - o[None, None, :]) * inv[:, sl]
+                t2 = (b[None, None, 3:6] - o[None, None, :]) * inv[:, sl]
+                tmin = np.nanmax(np.minimum(t1, t2), axis=2)
+                tmax = np.nanmin(np.maximum(t1, t2), axis=2)
+                hit = (tmax >= tmin) & (tmin > 0)
+                bs = best[:, sl]
+                best[:, sl] = np.where(hit & (tmin < bs), tmin, bs)
         # vertical cylinders
         cy = self.cyls
         near = np.linalg.norm(cy[:, :2] - o[None, :2], axis=1) < MAX_RANGE + 2.0
-        a = d[:, 0] ** 2 + d[:, 1] ** 2
         for c in cy[near]:
+            corners = np.array([[c[0] + sx * c[2], c[1] + sy * c[2], z] for sx in (-1, 1) for sy in (-1, 1) for z in (c[3], c[4])])
+            j0, j1 = self._az_window(corners, R, o)
             ox, oy = o[0] - c[0], o[1] - c[1]
-            bq = 2 * (ox * d[:, 0] + oy * d[:, 1])
-            cq = ox * ox + oy * oy - c[2] ** 2
-            disc = bq * bq - 4 * a * cq
-            with np.errstate(invalid="ignore", divide="ignore"):
-                tc = (-bq - np.sqrt(disc)) / (2 * a)
-            zc = o[2] + tc * d[:, 2]
-            hit = (disc > 0) & (tc > 0) & (zc >= c[3]) & (zc <= c[4])
-            best = np.where(hit & (tc < best), tc, best)
-        return best
+            for sl in cols(j0, j1):
+                dd = d[:, sl]
+                a = dd[:, :, 0] ** 2 + dd[:, :, 1] ** 2
+                bq = 2 * (ox * dd[:, :, 0] + oy * dd[:, :, 1])
+                cq = ox * ox + oy * oy - c[2] ** 2
+                disc = bq * bq - 4 * a * cq
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    tc = (-bq - np.sqrt(disc)) / (2 * a)
+                zc = o[2] + tc * dd[:, :, 2]
+                hit = (disc > 0) & (tc > 0) & (zc >= c[3]) & (zc <= c[4])
+                bs = best[:, sl]
+                best[:, sl] = np.where(hit & (tc < bs), tc, bs)
+        return best.reshape(-1)
 
     def sweep(self, k):
         """float32 [n_rings*n_azimuth, 4] ring-major cloud of sweep k in the sensor frame."""
@@ -194,7 +227,8 @@ class SynthSequence:
         r = self.ranges(k)
         r = r + rng.normal(0.0, self.noise_sigma, r.shape[0]) if self.noise_sigma > 0 else r
         miss = ~np.isfinite(r) | (r > MAX_RANGE) | (r <= 0.05)
-        pts = self.dirs * r[:, None]
+        with np.errstate(invalid="ignore"):
+            pts = self.dirs * r[:, None]
         out = np.zeros((pts.shape[0], 4), dtype=np.float32)
         out[:, :3] = pts.astype(np.float32)
         out[miss, :3] = np.nan
