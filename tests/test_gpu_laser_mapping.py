@@ -1,0 +1,119 @@
+"""-m gpu: laserMapping (scan-to-map ICP on the persistent voxel hash) through the C ABI vs the CPU oracle.
+
+Reference: src/lidar_odometry_mapping/src/laser_mapping.cpp:167-708.  The oracle keeps the reference's
+21x21x11 cube clouds, gathers the valid block, builds kd-trees and re-runs VoxelGrid per cube; the
+device keeps one hash slot per (cube, voxel).  They must agree on: the down-sampled scan features
+(bit-exact), which stack points produce factors and the line / plane geometry fitted from the 5 nearest
+map points, the Levenberg–Marquardt trace, the map pose (north_star bar 1e-4; asserted 1e-8) and the
+map itself after every sweep (same voxel centroids, bit-exact xyz).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-8
+
+
+def qdist(a, b):
+    return min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+
+
+def lexsort_rows(a):
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def oracle_map_points(o, kind):
+    info = o.map_info()
+    total = info["total_corner"] if kind == 0 else info["total_surf"]
+    pts = [o.map_cube(kind, c) for c in range(21 * 21 * 11)] if total else []
+    pts = [p for p in pts if p.shape[0]]
+    return np.concatenate(pts) if pts else np.zeros((0, 4), np.float32)
+
+
+def compare_map_round(h, o, outer):
+    d = h.map_debug(outer)
+    ci, cab, si, spl = o.map_factors(outer)
+    assert np.array_equal(d["corner_idx"], ci), "corner factor set differs (outer %d)" % outer
+    assert np.array_equal(d["surf_idx"], si), "surf factor set differs (outer %d)" % outer
+    # line through the 5-NN: (a, b) up to the eigenvector sign
+    da, db = d["corner_ab"][:, :3], d["corner_ab"][:, 3:]
+    oa, ob = cab[:, :3], cab[:, 3:]
+    e1 = np.maximum(np.abs(da - oa).max(axis=1), np.abs(db - ob).max(axis=1))
+    e2 = np.maximum(np.abs(da - ob).max(axis=1), np.abs(db - oa).max(axis=1))
+    assert np.max(np.minimum(e1, e2), initial=0) < 1e-9
+    assert np.max(np.abs(d["surf_plane"] - spl), initial=0) < 1e-9
+    s = o.map_solve(outer)
+    rec = d["rec"]
+    assert rec["n_factors"] == ci.size + si.size
+    assert qdist(rec["x_in"][:4], s["q_in"]) < 1e-12 and np.linalg.norm(rec["x_in"][4:] - s["t_in"]) < 1e-11
+    scale = np.sqrt(np.outer(np.diag(s["H0"]), np.diag(s["H0"]))) + 1e-30
+    assert np.max(np.abs(rec["H0"] - s["H0"]) / scale) < 1e-9
+    assert np.max(np.abs(rec["g0"] - s["g0"])) < 1e-9 * (1 + np.max(np.abs(s["g0"])))
+    assert rec["trace"].shape == s["trace"].shape
+    assert np.array_equal(rec["trace"][:, 6:8], s["trace"][:, 6:8])
+    assert np.allclose(rec["trace"][:, 0], s["trace"][:, 0], rtol=1e-8, atol=1e-12)
+    assert rec["termination"] == s["termination"]
+    assert qdist(rec["x_out"][:4], s["q_out"]) < POSE_TOL and np.linalg.norm(rec["x_out"][4:] - s["t_out"]) < POSE_TOL
+
+
+@pytest.mark.parametrize("shape,nframes", [((64, 512), 6), ((64, 2048), 4)])
+def test_laser_mapping_parity(vl, orc, sweeps, shape, nframes):
+    h = vl.Handle(0, scan_line=shape[0], debug=1, with_mapping=1)
+    o = orc.Oracle(scan_line=shape[0], with_mapping=True)
+    for k in range(nframes):
+        cloud = sweeps(shape[0], shape[1], k)
+        h.reset_frame()
+        h.scan_registration(cloud)
+        h.laser_odometry()
+        qm, tm = h.laser_mapping()
+        assert o.process(cloud) == 0
+        # laserCloudCornerStack / laserCloudSurfStack: VoxelGrid(0.4 / 0.8) of the scan features, bit-exact incl. order
+        for which in (7, 8):
+            dv, rf = h.features(which), o.cloud(which)
+            assert dv.shape == rf.shape, (which, dv.shape, rf.shape)
+            assert np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d" % which
+        st = h.map_state()
+        assert st["deferred"] == 0
+        if k == 0:
+            assert o.map_num_outer() == 0 and st["do_optimize"] == 0  # empty map: no optimisation (laser_mapping.cpp:448)
+        else:
+            assert o.map_num_outer() == 2 and st["do_optimize"] == 1
+            assert st["n_map_corner"] == o.cloud(9).shape[0] and st["n_map_surf"] == o.cloud(10).shape[0]
+            for outer in range(2):
+                compare_map_round(h, o, outer)
+        oq, ot, oqm, otm = o.map_pose()
+        assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, "frame %d map pose" % k
+        assert qdist(st["q_wmap_wodom"], oqm) < POSE_TOL and np.linalg.norm(st["t_wmap_wodom"] - otm) < POSE_TOL
+        assert np.array_equal(st["cen"], o.map_info()["cen"])
+        # the map after this sweep: same voxel centroids
+        for kind in (0, 1):
+            cnt, pts = h.map_dump(kind)
+            ref = oracle_map_points(o, kind)
+            assert np.all(cnt == 1)
+            assert pts.shape == ref.shape, "map kind %d: %s vs %s" % (kind, pts.shape, ref.shape)
+            a, b = lexsort_rows(pts), lexsort_rows(ref)
+            assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+    # full-resolution cloud registered in the map frame (LaserMapping::publish, laser_mapping.cpp:795-799)
+    reg_d, reg_o = h.features(11), o.cloud(11)
+    assert reg_d.shape == reg_o.shape and np.max(np.abs(reg_d[:, :3] - reg_o[:, :3])) < 1e-5
+
+
+def test_mapping_async_trajectory(vl, orc, sweeps):
+    """vloam_process_scan with mapping, 10 sweeps, vs the oracle's per-frame LO and map poses."""
+    h = vl.Handle(0, with_mapping=1)
+    o = orc.Oracle(with_mapping=True)
+    ref = []
+    for k in range(10):
+        c = sweeps(64, 512, k)
+        h.process_scan(c)
+        o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm, _, _ = o.map_pose()
+        ref.append(np.concatenate([qw, tw, qm, tm]))
+    h.sync()
+    tj = h.trajectory()
+    ref = np.array(ref)
+    for k in range(10):
+        assert qdist(tj[k, 0:4], ref[k, 0:4]) < 1e-7 and np.linalg.norm(tj[k, 4:7] - ref[k, 4:7]) < 1e-7
+        assert qdist(tj[k, 7:11], ref[k, 7:11]) < 1e-7 and np.linalg.norm(tj[k, 11:14] - ref[k, 11:14]) < 1e-7

@@ -21,6 +21,8 @@ K_MAX_RINGS, K_SECTORS = 64, 6
 K_MAX_SHARP, K_MAX_LESS_SHARP, K_MAX_FLAT = 768, 7680, 1536
 K_MAX_LO_FACTORS = K_MAX_SHARP + K_MAX_FLAT
 K_LM_MAX_TRACE = 104
+K_STACK_CAP_CORNER, K_STACK_CAP_SURF = 8192, 16384
+K_MAP_FACTOR_CAP = K_STACK_CAP_CORNER + K_STACK_CAP_SURF
 
 
 class VloamError(RuntimeError):
@@ -245,6 +247,33 @@ class Handle:
         resid = self.debug_raw(1, outer * 16 + 3, np.float64).reshape(3, K_MAX_LO_FACTORS)
         return dict(corner=c[c[:, 0] >= 0][:, :3], plane=p[p[:, 0] >= 0], corner_slots=np.nonzero(c[:, 0] >= 0)[0],
                     plane_slots=np.nonzero(p[:, 0] >= 0)[0] + K_MAX_SHARP, rec=rec, resid=resid)
+
+
+    def map_debug(self, outer):
+        cap = K_MAP_FACTOR_CAP
+        types = self.debug_raw(2, outer * 16 + 0, np.int32)
+        A = self.debug_raw(2, outer * 16 + 1, np.float64).reshape(3, cap).T
+        B = self.debug_raw(2, outer * 16 + 2, np.float64).reshape(3, cap).T
+        resid = self.debug_raw(2, outer * 16 + 4, np.float64).reshape(3, cap)
+        rec = self.debug_lm_record(2, outer * 16 + 3)
+        cs = np.nonzero(types[:K_STACK_CAP_CORNER] == 1)[0]
+        ss = np.nonzero(types[K_STACK_CAP_CORNER:] == 3)[0]
+        return dict(corner_idx=cs, corner_ab=np.hstack([A[cs], B[cs]]), surf_idx=ss,
+                    surf_plane=np.hstack([A[ss + K_STACK_CAP_CORNER], B[ss + K_STACK_CAP_CORNER, :1]]), rec=rec, resid=resid,
+                    corner_slots=cs, surf_slots=ss + K_STACK_CAP_CORNER)
+
+    def map_state(self):
+        raw = self.debug_raw(2, 64, np.uint8)
+        d = raw[:21 * 8].view(np.float64)
+        i = raw[21 * 8:21 * 8 + 13 * 4].view(np.int32)
+        return dict(parameters=d[:7].copy(), q_wmap_wodom=d[7:11].copy(), t_wmap_wodom=d[11:14].copy(), cen=i[0:3].copy(),
+                    centerCube=i[3:6].copy(), n_corner_stack=int(i[6]), n_surf_stack=int(i[7]), do_optimize=int(i[8]),
+                    n_map_corner=int(i[9]), n_map_surf=int(i[10]), deferred=int(i[11]))
+
+    def map_dump(self, kind):
+        """Live voxels of the corner (0) / surf (1) map as (count int32[n], xyzi float32[n, 4])."""
+        rows = self.debug_raw(2, 67 + kind, np.uint32, max_bytes=1 << 30).reshape(-1, 7)
+        return rows[:, 2].astype(np.int32), rows[:, 3:7].copy().view(np.float32)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -248,7 +248,7 @@ static vloam_status enqueue_map(vloam_handle* h) {
   const int cur = h->frame & 1;
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
   const bool skip = ((h->frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->stream, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip);
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->stream, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, &h->prof);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
   return VLOAM_OK;

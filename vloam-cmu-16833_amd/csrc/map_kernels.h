@@ -1,4 +1,11 @@
 // laserMapping on gfx950 — host-visible interface (map_kernels.hip).
+//
+// The reference keeps 21x21x11 cubes of pcl clouds, gathers the 5x5x3 block around the sensor, builds
+// two kd-trees per sweep and re-voxelises every valid cube (laser_mapping.cpp:198-708).  Here the map
+// is a PERSISTENT voxel hash in HBM keyed by (absolute cube, voxel inside the cube), one slot per
+// per-cube VoxelGrid cell, holding the cell's f32 running sum + count — which reproduces the
+// reference's "centroid of (old centroid, new points...)" update exactly (SURVEY.md §8a map notes)
+// with no per-sweep gather / tree build / re-sort.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -8,13 +15,61 @@
 
 namespace vloam {
 
+constexpr int kCubeW = 21, kCubeH = 21, kCubeD = 11, kCubeNum = kCubeW * kCubeH * kCubeD;  // laser_mapping.h:110-117
+constexpr int kStackCapCorner = 8192;   // >= kMaxLessSharp
+constexpr int kStackCapSurf = 16384;    // voxels of one sweep's lessFlat cloud at the plane resolution
+constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
+constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
+constexpr int kDsBucketCorner = 64, kDsBucketSurf = 128;  // sweep points per stack voxel
+constexpr int kDsHashCorner = 1 << 15, kDsHashSurf = 1 << 16;
+
+struct VoxelTable {       // structure of arrays, open addressing, linear probing
+  unsigned long long* keys;  // 0 = empty
+  float4* sum;               // f32 running sum (x, y, z, intensity) in arrival order
+  int* count;                // points in the sum (1 after a valid-cube finalize; 0 = purged)
+  int* pend_cnt;             // stack points queued this sweep
+  int* pend;                 // [slots][kPendCap] stack indices
+  unsigned mask;             // slots - 1
+};
+
+struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
+  unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
+  int* cnt;                  // [hash]
+  int* bucket;               // [hash][bucket_cap] point indices
+  unsigned long long* uniq;  // [stack_cap] keys of occupied voxels (unordered)
+  int hash_mask, bucket_cap, stack_cap;
+};
+
+struct MapFrame {         // per-sweep device counters
+  int n_uniq[2];
+  int n_stack[2];
+  int n_touched[2];
+  int n_deferred[2];
+  int rolled;
+  int error;
+  int n_factors[2][2];    // [outer][corner, surf] accepted factors
+};
+
 struct MapContext {
   MapState* state = nullptr;
-  int* error = nullptr;
+  MapFrame* frame = nullptr;
+  VoxelTable tab[2];       // 0 corner, 1 surf
+  int* cube_cnt = nullptr; // [2][kCubeNum] points per cube, window-relative index (== the reference's array index)
+  DsScratch ds[2];
+  float4* stack[2] = {nullptr, nullptr};      // laserCloudCornerStack / laserCloudSurfStack (sensor frame)
+  float4* stack_map[2] = {nullptr, nullptr};  // the same points in the map frame (at insert time)
+  int* touched[2] = {nullptr, nullptr};       // table slots that received points this sweep
+  int* deferred[2] = {nullptr, nullptr};      // slots holding raw points outside the valid block
+  FactorTable F[2];        // one per outer round (kept for the parity hooks)
+  LMRecord* rec = nullptr; // [2]
+  float4* registered = nullptr;  // full-resolution cloud in the map frame, on request
+  int max_points = 0;
+  float inv_leaf[2] = {0, 0};
 };
 
 vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs);
-vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14, bool skip_frame);
+vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
+                         bool skip_frame, ProfHook* ph);
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n);
 vloam_status map_error(MapContext* m, int* err_bits);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);

@@ -1,16 +1,774 @@
+// laserMapping on gfx950: scan-to-map ICP against a persistent voxel hash.
+// Restates LaserMapping::input / solveMapping, /root/reference/src/lidar_odometry_mapping/src/laser_mapping.cpp:167-708
+// ("LM:<line>").  One sweep = 8 launches + 2 Levenberg–Marquardt launches, no host synchronisation:
+//   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448)
+//   k_map_purge     grid      only does work after a roll: drops voxels whose cube left the 21x21x11 window
+//   k_map_ds_bucket grid      pcl::VoxelGrid of the scan features, pass 1: hash sweep points into voxel buckets (LM:432-440)
+//   k_map_ds_emit   2 WGs     pass 2: LDS bitonic sort of the occupied voxel keys, in-order f32 centroid per voxel
+//   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN by probing the voxel hash in a +-1 m box, 3x3 eigen /
+//                             5x3 least squares, emission of LidarEdgeFactor / LidarPlaneNormFactor (LM:472-581)   x2
+//   (k_lm_solve)                                                                                                x2
+//   k_map_update    1 WG      transformUpdate (LM:140-144,636) + trajectory row
+//   k_map_insert    grid      scan voxels -> map frame -> cube -> hash find-or-insert, queue on the voxel (LM:639-683)
+//   k_map_finalize  grid      per touched voxel: stack-ordered f32 accumulation == per-cube VoxelGrid re-filter (LM:689-702)
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <string.h>
+#include "lm_solve.h"
 #include "map_kernels.h"
+
 namespace vloam {
-vloam_status map_create(MapContext* m, const vloam_config&, hipStream_t, std::vector<void*>& allocs) {
-  void* p = nullptr;
-  if (hipMalloc(&p, sizeof(MapState) + 256) != hipSuccess) return VLOAM_ERR_HIP;
-  (void)hipMemset(p, 0, sizeof(MapState) + 256);
-  allocs.push_back(p);
-  m->state = (MapState*)p;
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ u64 mix64(u64 x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+// LM:207-216 / LM:643-652: C int() truncation plus the "< 0" correction; absolute cube coordinate (no centre offset)
+__device__ __forceinline__ int cube_abs(double v) {
+  int c = int((v + 25.0) / 50.0);
+  if (v + 25.0 < 0) c--;
+  return c;
+}
+__device__ __forceinline__ int cube_lo(double v) { return (int)floor((v - 1e-3 + 25.0) * 0.02); }
+__device__ __forceinline__ int cube_hi(double v) { return (int)floor((v + 1e-3 + 25.0) * 0.02); }
+// first global voxel index that can belong to cube A (minus one cell of slack so the local index is never negative)
+__device__ __forceinline__ int cube_voxel_base(int A, float inv) { return (int)floor((50.0 * (double)A - 25.0) * (double)inv) - 1; }
+
+__device__ __forceinline__ u64 pack_key(int Ai, int Aj, int Ak, int lx, int ly, int lz) {
+  return ((u64)(unsigned)(Ai + 8192) << 50) | ((u64)(unsigned)(Aj + 8192) << 36) | ((u64)(unsigned)(Ak + 2048) << 24) |
+         ((u64)(unsigned)lx << 16) | ((u64)(unsigned)ly << 8) | (u64)(unsigned)lz;
+}
+__device__ __forceinline__ void unpack_cube(u64 k, int* Ai, int* Aj, int* Ak) {
+  *Ai = (int)((k >> 50) & 0x3fff) - 8192; *Aj = (int)((k >> 36) & 0x3fff) - 8192; *Ak = (int)((k >> 24) & 0xfff) - 2048;
+}
+
+// Eigen q * v (see lm_solve.hip / lo_kernels.hip) followed by + t, rounded to f32: pointAssociateToMap, LM:146-155
+__device__ __forceinline__ float4 associate_to_map(float4 pi, const double* q, const double* t) {
+  const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  const double vx = pi.x, vy = pi.y, vz = pi.z;
+  double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+  cx = cx + cx; cy = cy + cy; cz = cz + cz;
+  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  float4 o;
+  o.x = (float)(((vx + w * cx) + dx) + t[0]);
+  o.y = (float)(((vy + w * cy) + dy) + t[1]);
+  o.z = (float)(((vz + w * cz) + dz) + t[2]);
+  o.w = pi.w;
+  return o;
+}
+
+__device__ __forceinline__ void dquat_mul(const double* a, const double* b, double* r) {
+  r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__device__ __forceinline__ void dquat_rot(const double* q, const double* v, double* o) {
+  const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  cx = cx + cx; cy = cy + cy; cz = cz + cz;
+  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  o[0] = (v[0] + w * cx) + dx; o[1] = (v[1] + w * cy) + dy; o[2] = (v[2] + w * cz) + dz;
+}
+
+// ---------------------------------------------------------------------------------------------- prepare
+__global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr, const LOState* lo, int* cube_cnt, int skip_frame,
+                                                     double* traj_row14) {
+  __shared__ int shift[3];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    // LaserMapping::input LM:182-195: q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom
+    for (int k = 0; k < 4; k++) ms->q_wodom_curr[k] = lo->q_w_curr[k];
+    for (int k = 0; k < 3; k++) ms->t_wodom_curr[k] = lo->t_w_curr[k];
+    double q[4], t[3];
+    dquat_mul(ms->q_wmap_wodom, ms->q_wodom_curr, q);
+    dquat_rot(ms->q_wmap_wodom, ms->t_wodom_curr, t);
+    for (int k = 0; k < 3; k++) t[k] = t[k] + ms->t_wmap_wodom[k];
+    shift[0] = shift[1] = shift[2] = 0;
+    fr->rolled = 0;
+    if (skip_frame) {  // only the high-frequency pose is produced (LM:186-190)
+      if (traj_row14) { for (int k = 0; k < 4; k++) traj_row14[7 + k] = q[k]; for (int k = 0; k < 3; k++) traj_row14[11 + k] = t[k]; }
+    } else {
+      for (int k = 0; k < 4; k++) ms->parameters[k] = q[k];
+      for (int k = 0; k < 3; k++) ms->parameters[4 + k] = t[k];
+      // LM:207-216
+      int cI = cube_abs(t[0]) + ms->cenW, cJ = cube_abs(t[1]) + ms->cenH, cK = cube_abs(t[2]) + ms->cenD;
+      // LM:218-402: the six while loops only move cube pointers and the centre offsets
+      while (cI < 3) { cI++; ms->cenW++; shift[0]++; }
+      while (cI >= kCubeW - 3) { cI--; ms->cenW--; shift[0]--; }
+      while (cJ < 3) { cJ++; ms->cenH++; shift[1]++; }
+      while (cJ >= kCubeH - 3) { cJ--; ms->cenH--; shift[1]--; }
+      while (cK < 3) { cK++; ms->cenD++; shift[2]++; }
+      while (cK >= kCubeD - 3) { cK--; ms->cenD--; shift[2]--; }
+      ms->centerCube[0] = cI; ms->centerCube[1] = cJ; ms->centerCube[2] = cK;
+      if (shift[0] | shift[1] | shift[2]) fr->rolled = 1;
+      for (int k = 0; k < 2; k++) { fr->n_uniq[k] = 0; fr->n_stack[k] = 0; fr->n_touched[k] = 0; }
+      for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
+    }
+  }
+  __syncthreads();
+  if (skip_frame) return;
+  // shift the per-cube point counters exactly like the reference shifts its cube arrays (cleared slabs -> 0)
+  if (shift[0] | shift[1] | shift[2]) {
+    for (int kind = 0; kind < 2; kind++) {
+      int* cnt = cube_cnt + kind * kCubeNum;
+      // gather-with-offset through registers: new[i][j][k] = old[i - sx][j - sy][k - sz] or 0
+      int vals[(kCubeNum + 255) / 256];
+      int n = 0;
+      for (int c = tid; c < kCubeNum; c += 256, n++) {
+        const int i = c % kCubeW, j = (c / kCubeW) % kCubeH, k = c / (kCubeW * kCubeH);
+        const int si = i - shift[0], sj = j - shift[1], sk = k - shift[2];
+        vals[n] = (si >= 0 && si < kCubeW && sj >= 0 && sj < kCubeH && sk >= 0 && sk < kCubeD) ? cnt[si + kCubeW * sj + kCubeW * kCubeH * sk] : 0;
+      }
+      __syncthreads();
+      n = 0;
+      for (int c = tid; c < kCubeNum; c += 256, n++) cnt[c] = vals[n];
+      __syncthreads();
+    }
+  }
+  // LM:404-430,448: points in the valid 5x5x3 block decide whether the optimisation runs
+  if (tid < 64) {
+    int s0 = 0, s1 = 0;
+    for (int c = tid; c < 75; c += 64) {
+      const int i = ms->centerCube[0] - 2 + c / 15, j = ms->centerCube[1] - 2 + (c / 3) % 5, k = ms->centerCube[2] - 1 + c % 3;
+      if (i >= 0 && i < kCubeW && j >= 0 && j < kCubeH && k >= 0 && k < kCubeD) {
+        const int ci = i + kCubeW * j + kCubeW * kCubeH * k;
+        s0 += cube_cnt[ci]; s1 += cube_cnt[kCubeNum + ci];
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) { s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d); }
+    if (tid == 0) {
+      ms->n_map_corner = s0; ms->n_map_surf = s1;
+      ms->do_optimize = (s0 > 10 && s1 > 50) ? 1 : 0;
+    }
+  }
+}
+
+// Drop voxels whose cube left the window (the reference clears the slab that wraps, LM:240-241 etc.).
+__global__ __launch_bounds__(256) void k_map_purge(VoxelTable T0, VoxelTable T1, const MapState* ms, const MapFrame* fr) {
+  if (!fr->rolled) return;
+  const VoxelTable T = blockIdx.y ? T1 : T0;
+  const int cW = ms->cenW, cH = ms->cenH, cD = ms->cenD;
+  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
+    const u64 k = T.keys[s];
+    if (k == 0 || T.count[s] == 0) continue;
+    int Ai, Aj, Ak;
+    unpack_cube(k, &Ai, &Aj, &Ak);
+    const int i = Ai + cW, j = Aj + cH, kk = Ak + cD;
+    if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || kk < 0 || kk >= kCubeD) { T.count[s] = 0; T.sum[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- scan VoxelGrid
+// pcl::VoxelGrid<PointXYZI> (voxel_grid.hpp applyFilter): cell = floor(p * inverse_leaf) on the global lattice, output sorted
+// by the linearised cell index (x fastest) == lexicographic (iz, iy, ix), centroid = f32 sum in input order / n.
+__device__ __forceinline__ u64 ds_key(float4 p, float inv) {
+  const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv), iz = (int)floorf(p.z * inv);
+  return ((u64)(unsigned)(iz + (1 << 20)) << 42) | ((u64)(unsigned)(iy + (1 << 20)) << 21) | (u64)(unsigned)(ix + (1 << 20));
+}
+
+__global__ __launch_bounds__(256) void k_map_ds_bucket(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
+                                                       const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
+                                                       float inv1, MapFrame* fr) {
+  const int kind = blockIdx.y;
+  const DsScratch D = kind ? D1 : D0;
+  const float inv = kind ? inv1 : inv0;
+  const float4* pts = kind ? surf_last : corner_last;
+  const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u64 key = ds_key(pts[i], inv);
+    unsigned s = (unsigned)mix64(key) & D.hash_mask;
+    for (int probe = 0; probe <= D.hash_mask; probe++, s = (s + 1) & D.hash_mask) {
+      const u64 old = atomicCAS(&D.keys[s], 0ull, key);
+      if (old == 0ull) {  // new voxel
+        const int u = atomicAdd(&fr->n_uniq[kind], 1);
+        if (u < D.stack_cap) D.uniq[u] = key; else atomicOr(&fr->error, kErrStackFull);
+      }
+      if (old == 0ull || old == key) {
+        const int pos = atomicAdd(&D.cnt[s], 1);
+        if (pos < D.bucket_cap) D.bucket[(size_t)s * D.bucket_cap + pos] = i; else atomicOr(&fr->error, kErrStackFull);
+        break;
+      }
+    }
+  }
+}
+
+constexpr int kEmitThreads = 1024;
+__global__ __launch_bounds__(kEmitThreads) void k_map_ds_emit(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
+                                                              DsScratch D0, DsScratch D1, float4* __restrict__ stack0,
+                                                              float4* __restrict__ stack1, MapFrame* fr, MapState* ms) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* K = (u64*)smem;
+  const int kind = blockIdx.x, tid = threadIdx.x;
+  const DsScratch D = kind ? D1 : D0;
+  const float4* pts = kind ? surf_last : corner_last;
+  float4* stack = kind ? stack1 : stack0;
+  const int u = min(fr->n_uniq[kind], D.stack_cap);
+  int P = 2;
+  while (P < u) P <<= 1;
+  for (int t = tid; t < P; t += kEmitThreads) K[t] = t < u ? D.uniq[t] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P / 2; t += kEmitThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const bool up = (i & k) == 0;
+        const u64 x = K[i], y = K[l];
+        if ((x > y) == up) { K[i] = y; K[l] = x; }
+      }
+      __syncthreads();
+    }
+  for (int t = tid; t < u; t += kEmitThreads) {
+    const u64 key = K[t];
+    unsigned s = (unsigned)mix64(key) & D.hash_mask;
+    while (D.keys[s] != key) s = (s + 1) & D.hash_mask;
+    const int cnt = min(D.cnt[s], D.bucket_cap);
+    int* b = D.bucket + (size_t)s * D.bucket_cap;
+    for (int a = 1; a < cnt; a++) {  // restore input order inside the voxel (the atomics appended in arbitrary order)
+      const int v = b[a];
+      int c = a - 1;
+      while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; }
+      b[c + 1] = v;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (int a = 0; a < cnt; a++) { const float4 p = pts[b[a]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
+    const float nn = (float)cnt;
+    stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
+    D.keys[s] = 0ull; D.cnt[s] = 0;  // leave the scratch hash clean for the next sweep
+  }
+  if (tid == 0) {
+    fr->n_stack[kind] = u;
+    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- data association
+struct Top5 {
+  float d[5];
+  unsigned id[5];
+  __device__ __forceinline__ void init() { for (int k = 0; k < 5; k++) { d[k] = 3.0e38f; id[k] = 0xffffffffu; } }
+  __device__ __forceinline__ void push(float dd, unsigned ii) {
+    if (!(dd < d[4] || (dd == d[4] && ii < id[4]))) return;
+    d[4] = dd; id[4] = ii;
+#pragma unroll
+    for (int k = 4; k > 0; k--) {
+      const bool sw = d[k] < d[k - 1] || (d[k] == d[k - 1] && id[k] < id[k - 1]);
+      const float td = sw ? d[k - 1] : d[k]; const unsigned ti = sw ? id[k - 1] : id[k];
+      d[k - 1] = sw ? d[k] : d[k - 1]; id[k - 1] = sw ? id[k] : id[k - 1];
+      d[k] = td; id[k] = ti;
+    }
+  }
+  __device__ __forceinline__ void pop() {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { d[k] = d[k + 1]; id[k] = id[k + 1]; }
+    d[4] = 3.0e38f; id[4] = 0xffffffffu;
+  }
+};
+
+// cyclic Jacobi, identical operation order to oracle/orc_math.h sym_eig3 (Eigen::SelfAdjointEigenSolver stand-in, LM:500)
+__device__ void sym_eig3(const double A_[3][3], double evals[3], double evecs[3][3]) {
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = A_[i][j];
+  for (int sweep = 0; sweep < 64; sweep++) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-40 * diag || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int q = p + 1; q < 3; q++) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+      }
+  }
+  int i0 = 0, i1 = 1, i2 = 2;
+  const double d[3] = {A[0][0], A[1][1], A[2][2]};
+  // stable 3-element sort by eigenvalue (std::sort in the oracle; distinct values in practice)
+  if (d[i1] < d[i0]) { int t = i0; i0 = i1; i1 = t; }
+  if (d[i2] < d[i1]) { int t = i1; i1 = i2; i2 = t; }
+  if (d[i1] < d[i0]) { int t = i0; i0 = i1; i1 = t; }
+  const int idx[3] = {i0, i1, i2};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    evals[k] = d[idx[k]];
+    for (int r = 0; r < 3; r++) evecs[r][k] = V[r][idx[k]];
+  }
+}
+
+// Householder least squares, identical operation order to oracle/orc_math.h householder_ls (m = 5, n = 3; LM:557)
+__device__ bool householder_ls_5x3(double* A, double* b, double* x) {
+  const int m = 5, n = 3;
+  for (int k = 0; k < n; k++) {
+    double nrm = 0;
+    for (int i = k; i < m; i++) nrm += A[i * n + k] * A[i * n + k];
+    nrm = sqrt(nrm);
+    if (nrm == 0.0) return false;
+    const double alpha = (A[k * n + k] > 0) ? -nrm : nrm;
+    const double v0 = A[k * n + k] - alpha;
+    double vtv = v0 * v0;
+    for (int i = k + 1; i < m; i++) vtv += A[i * n + k] * A[i * n + k];
+    if (vtv != 0.0) {
+      for (int j = k + 1; j < n; j++) {
+        double s = v0 * A[k * n + j];
+        for (int i = k + 1; i < m; i++) s += A[i * n + k] * A[i * n + j];
+        s = 2.0 * s / vtv;
+        A[k * n + j] -= s * v0;
+        for (int i = k + 1; i < m; i++) A[i * n + j] -= s * A[i * n + k];
+      }
+      double s = v0 * b[k];
+      for (int i = k + 1; i < m; i++) s += A[i * n + k] * b[i];
+      s = 2.0 * s / vtv;
+      b[k] -= s * v0;
+      for (int i = k + 1; i < m; i++) b[i] -= s * A[i * n + k];
+    }
+    A[k * n + k] = alpha;
+    for (int i = k + 1; i < m; i++) A[i * n + k] = 0.0;
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    double s = b[k];
+    for (int j = k + 1; j < n; j++) s -= A[k * n + j] * x[j];
+    if (A[k * n + k] == 0.0) return false;
+    x[k] = s / A[k * n + k];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
+                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
+                                                   FactorTable F, int outer) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= kMapFactorCap) return;
+  const int kind = slot < kStackCapCorner ? 0 : 1;
+  const int i = kind ? slot - kStackCapCorner : slot;
+  const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
+  int type = 0;
+  if (ms->do_optimize && i < nst) {
+    const VoxelTable T = kind ? T1 : T0;
+    const float inv = kind ? inv1 : inv0;
+    const float4 pointOri = kind ? stack1[i] : stack0[i];
+    const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
+    const float q3[3] = {sel.x, sel.y, sel.z};
+    // cells of the global lattice that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547)
+    int lo[3], cnt[3];
+    for (int a = 0; a < 3; a++) {
+      lo[a] = (int)floorf((q3[a] - 1.001f) * inv);
+      cnt[a] = (int)floorf((q3[a] + 1.001f) * inv) - lo[a] + 1;
+    }
+    const int cI = ms->centerCube[0] - ms->cenW, cJ = ms->centerCube[1] - ms->cenH, cK = ms->centerCube[2] - ms->cenD;  // absolute centre cube
+    const double leaf = 1.0 / (double)inv;
+    Top5 top;
+    top.init();
+    // every cell is probed once per cube it can straddle (25 m is not a multiple of the leaf)
+    const int ncell = cnt[0] * cnt[1] * cnt[2];
+    for (int cc = lane; cc < ncell; cc += 64) {
+      const int ix = lo[0] + cc % cnt[0], iy = lo[1] + (cc / cnt[0]) % cnt[1], iz = lo[2] + cc / (cnt[0] * cnt[1]);
+      // conservative cube range of the cell (1 mm margin; the exact rule is applied where points are inserted)
+      const int ax0 = cube_lo((double)ix * leaf), ax1 = cube_hi((double)(ix + 1) * leaf);
+      const int ay0 = cube_lo((double)iy * leaf), ay1 = cube_hi((double)(iy + 1) * leaf);
+      const int az0 = cube_lo((double)iz * leaf), az1 = cube_hi((double)(iz + 1) * leaf);
+      for (int Ak = az0; Ak <= az1; Ak++)
+        for (int Aj = ay0; Aj <= ay1; Aj++)
+          for (int Ai = ax0; Ai <= ax1; Ai++) {
+            // only cubes of the valid 5 x 5 x 3 block inside the window are gathered (LM:404-420)
+            if (abs(Ai - cI) > 2 || abs(Aj - cJ) > 2 || abs(Ak - cK) > 1) continue;
+            const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
+            if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) continue;
+            const int lx = ix - cube_voxel_base(Ai, inv), ly = iy - cube_voxel_base(Aj, inv), lz = iz - cube_voxel_base(Ak, inv);
+            if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u) continue;
+            const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
+            unsigned s = (unsigned)mix64(key) & T.mask;
+            for (;;) {
+              const u64 k = T.keys[s];
+              if (k == 0ull) break;
+              if (k == key) {
+                const int n = T.count[s];
+                if (n > 0) {
+                  float4 p = T.sum[s];
+                  if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+                  const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
+                  top.push(d0 * d0 + d1 * d1 + d2 * d2, s);
+                }
+                break;
+              }
+              s = (s + 1) & T.mask;
+            }
+          }
+    }
+    // merge the per-lane lists: five rounds of wavefront-min extraction
+    float nd[5];
+    unsigned ns[5];
+    for (int r = 0; r < 5; r++) {
+      u64 key = ((u64)__float_as_uint(top.d[0]) << 32) | top.id[0];
+      u64 m = key;
+      for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_xor(m, d); m = o < m ? o : m; }
+      nd[r] = __uint_as_float((unsigned)(m >> 32));
+      ns[r] = (unsigned)(m & 0xffffffffu);
+      if (key == m && top.id[0] != 0xffffffffu) top.pop();
+    }
+    if (ns[4] != 0xffffffffu && nd[4] < 1.0f) {
+      double P[5][3];
+      for (int j = 0; j < 5; j++) {
+        const int n = T.count[ns[j]];
+        float4 p = T.sum[ns[j]];
+        if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+        P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
+      }
+      double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
+      if (kind == 0) {  // LM:481-517
+        double center[3] = {0, 0, 0};
+        for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) center[a] = center[a] + P[j][a];
+        for (int a = 0; a < 3; a++) center[a] = center[a] / 5.0;
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int j = 0; j < 5; j++) {
+          const double z[3] = {P[j][0] - center[0], P[j][1] - center[1], P[j][2] - center[2]};
+          for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a][b] = cov[a][b] + z[a] * z[b];
+        }
+        double ev[3], evec[3][3];
+        sym_eig3(cov, ev, evec);
+        if (ev[2] > 3 * ev[1]) {
+          for (int a = 0; a < 3; a++) { A3[a] = 0.1 * evec[a][2] + center[a]; B3[a] = -0.1 * evec[a][2] + center[a]; }
+          type = 1;
+        }
+      } else {          // LM:545-581
+        double matA0[15], matB0[5], nrm[3];
+        for (int j = 0; j < 5; j++) { matA0[j * 3] = P[j][0]; matA0[j * 3 + 1] = P[j][1]; matA0[j * 3 + 2] = P[j][2]; matB0[j] = -1.0; }
+        if (householder_ls_5x3(matA0, matB0, nrm)) {
+          const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+          const double negative_OA_dot_norm = 1 / nn;
+          nrm[0] = nrm[0] / nn; nrm[1] = nrm[1] / nn; nrm[2] = nrm[2] / nn;
+          bool planeValid = true;
+          for (int j = 0; j < 5; j++)
+            if (fabs(nrm[0] * P[j][0] + nrm[1] * P[j][1] + nrm[2] * P[j][2] + negative_OA_dot_norm) > 0.2) { planeValid = false; break; }
+          if (planeValid) { A3[0] = nrm[0]; A3[1] = nrm[1]; A3[2] = nrm[2]; B3[0] = negative_OA_dot_norm; type = 3; }
+        }
+      }
+      if (type && lane == 0) {
+        const int cap = F.cap;
+        F.p[slot] = pointOri.x; F.p[cap + slot] = pointOri.y; F.p[2 * cap + slot] = pointOri.z;
+        F.A[slot] = A3[0]; F.A[cap + slot] = A3[1]; F.A[2 * cap + slot] = A3[2];
+        F.B[slot] = B3[0]; F.B[cap + slot] = B3[1]; F.B[2 * cap + slot] = B3[2];
+      }
+    }
+  }
+  if (lane == 0) {
+    F.type[slot] = type;
+    if (type) atomicAdd(&fr->n_factors[outer][kind], 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- update / insert / finalize
+__global__ void k_map_update(MapState* ms, double* traj_row14) {
+  if (threadIdx.x != 0) return;
+  // transformUpdate LM:140-144: q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
+  const double* q = ms->q_wodom_curr;
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  double qi[4] = {0, 0, 0, 0};
+  if (n2 > 0.0) { qi[0] = -q[0] / n2; qi[1] = -q[1] / n2; qi[2] = -q[2] / n2; qi[3] = q[3] / n2; }
+  double r[4], t[3];
+  dquat_mul(ms->parameters, qi, r);
+  for (int k = 0; k < 4; k++) ms->q_wmap_wodom[k] = r[k];
+  dquat_rot(ms->q_wmap_wodom, ms->t_wodom_curr, t);
+  for (int k = 0; k < 3; k++) ms->t_wmap_wodom[k] = ms->parameters[4 + k] - t[k];
+  if (traj_row14) for (int k = 0; k < 7; k++) traj_row14[7 + k] = ms->parameters[k];
+}
+
+__global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ stack0, const float4* __restrict__ stack1,
+                                                    float4* __restrict__ smap0, float4* __restrict__ smap1, VoxelTable T0, VoxelTable T1,
+                                                    float inv0, float inv1, MapState* ms, MapFrame* fr, int* __restrict__ touched0,
+                                                    int* __restrict__ touched1, int* __restrict__ deferred0, int* __restrict__ deferred1) {
+  const int kind = blockIdx.y;
+  const VoxelTable T = kind ? T1 : T0;
+  const float inv = kind ? inv1 : inv0;
+  const float4* stack = kind ? stack1 : stack0;
+  float4* smap = kind ? smap1 : smap0;
+  int* touched = kind ? touched1 : touched0;
+  int* deferred = kind ? deferred1 : deferred0;
+  const int n = kind ? ms->n_surf_stack : ms->n_corner_stack;
+  const int cap = kind ? kStackCapSurf : kStackCapCorner;
+  const int cI = ms->centerCube[0], cJ = ms->centerCube[1], cK = ms->centerCube[2];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = associate_to_map(stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
+    smap[i] = p;
+    const int Ai = cube_abs((double)p.x), Aj = cube_abs((double)p.y), Ak = cube_abs((double)p.z);
+    const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;  // == cubeI, cubeJ, cubeK of LM:643-652
+    if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) continue;  // LM:654-655: outside the grid -> dropped
+    const int lx = (int)floorf(p.x * inv) - cube_voxel_base(Ai, inv), ly = (int)floorf(p.y * inv) - cube_voxel_base(Aj, inv),
+              lz = (int)floorf(p.z * inv) - cube_voxel_base(Ak, inv);
+    if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u) { atomicOr(&fr->error, kErrMapFull); continue; }
+    const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
+    unsigned s = (unsigned)mix64(key) & T.mask;
+    bool done = false;
+    for (unsigned probe = 0; probe <= T.mask && !done; probe++, s = (s + 1) & T.mask) {
+      const u64 old = atomicCAS(&T.keys[s], 0ull, key);
+      if (old == 0ull || old == key) {
+        const int pos = atomicAdd(&T.pend_cnt[s], 1);
+        if (pos < kPendCap) T.pend[(size_t)s * kPendCap + pos] = i; else atomicOr(&fr->error, kErrMapFull);
+        if (pos == 0) {
+          const int tpos = atomicAdd(&fr->n_touched[kind], 1);
+          if (tpos < cap) touched[tpos] = (int)s; else atomicOr(&fr->error, kErrMapFull);
+        }
+        const bool valid = abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1;
+        if (!valid && pos == 0) {  // raw accumulation until the cube next enters the valid block (LM:689 runs over valid cubes only)
+          atomicOr(&fr->error, kErrMapDeferred);
+          atomicAdd(&ms->deferred, 1);
+          const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
+          if (dpos < cap) deferred[dpos] = (int)s;
+        }
+        done = true;
+      }
+    }
+    if (!done) atomicOr(&fr->error, kErrMapFull);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__ smap0, const float4* __restrict__ smap1, VoxelTable T0,
+                                                      VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr,
+                                                      const int* __restrict__ touched0, const int* __restrict__ touched1,
+                                                      int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ cube_cnt) {
+  const int kind = blockIdx.y;
+  const VoxelTable T = kind ? T1 : T0;
+  const float4* smap = kind ? smap1 : smap0;
+  const int* touched = kind ? touched1 : touched0;
+  const int cap = kind ? kStackCapSurf : kStackCapCorner;
+  const int nt = min(fr->n_touched[kind], cap);
+  const int cI = ms->centerCube[0], cJ = ms->centerCube[1], cK = ms->centerCube[2];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nt) {
+    const int s = touched[t];
+    int idx[kPendCap];
+    const int np = min(T.pend_cnt[s], kPendCap);
+    for (int a = 0; a < np; a++) idx[a] = T.pend[(size_t)s * kPendCap + a];
+    for (int a = 1; a < np; a++) {  // stack order == the order the reference push_back()s into the cube cloud
+      const int v = idx[a];
+      int c = a - 1;
+      while (c >= 0 && idx[c] > v) { idx[c + 1] = idx[c]; c--; }
+      idx[c + 1] = v;
+    }
+    int n = T.count[s];
+    float4 acc = n > 0 ? T.sum[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int Ai, Aj, Ak;
+    unpack_cube(T.keys[s], &Ai, &Aj, &Ak);
+    const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
+    if (n == 0) atomicAdd(&cube_cnt[kind * kCubeNum + wi + kCubeW * wj + kCubeW * kCubeH * wk], 1);
+    for (int a = 0; a < np; a++) { const float4 p = smap[idx[a]]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+    n += np;
+    const bool valid = abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1;
+    if (valid) {  // VoxelGrid re-filter of a valid cube: centroid of (old centroid, new points...), LM:689-702
+      const float nn = (float)n;
+      acc.x = acc.x / nn; acc.y = acc.y / nn; acc.z = acc.z / nn; acc.w = acc.w / nn;
+      n = 1;
+    }
+    T.sum[s] = acc; T.count[s] = n; T.pend_cnt[s] = 0;
+  }
+  // raw voxels of earlier sweeps whose cube is valid now (rare; only with ranges beyond the 5x5x3 block)
+  if (blockIdx.x == 0) {
+    int* deferred = kind ? deferred1 : deferred0;
+    const int nd = min(fr->n_deferred[kind], cap);
+    for (int d = threadIdx.x; d < nd; d += 256) {
+      const int s = deferred[d];
+      if (s < 0) continue;
+      int Ai, Aj, Ak;
+      unpack_cube(T.keys[s], &Ai, &Aj, &Ak);
+      const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
+      if (abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1) {
+        const int n = T.count[s];
+        if (n > 1) { float4 a = T.sum[s]; const float nn = (float)n; a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn; T.sum[s] = a; T.count[s] = 1; }
+        deferred[d] = -1;
+      }
+    }
+  }
+}
+
+__global__ void k_map_register(const float4* __restrict__ cloud, const FrameScalars* __restrict__ S, const MapState* __restrict__ ms,
+                               float4* __restrict__ out) {
+  const int n = S->N2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = associate_to_map(cloud[i], ms->parameters, ms->parameters + 4);  // LM:795-799
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <class T>
+static bool dmalloc(std::vector<void*>& allocs, hipStream_t st, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, count * sizeof(T) + 256) != hipSuccess) return false;
+  if (hipMemsetAsync(q, 0, count * sizeof(T) + 256, st) != hipSuccess) return false;
+  allocs.push_back(q);
+  *p = (T*)q;
+  return true;
+}
+
+vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs) {
+  bool ok = true;
+  ok = ok && dmalloc(allocs, st, &m->state, 1);
+  ok = ok && dmalloc(allocs, st, &m->frame, 1);
+  ok = ok && dmalloc(allocs, st, &m->cube_cnt, 2 * (size_t)kCubeNum);
+  const int lg = cfg.map_capacity_log2 < 10 ? 10 : (cfg.map_capacity_log2 > 28 ? 28 : cfg.map_capacity_log2);
+  const size_t slots = (size_t)1 << lg;
+  for (int k = 0; k < 2 && ok; k++) {
+    VoxelTable& T = m->tab[k];
+    ok = ok && dmalloc(allocs, st, &T.keys, slots) && dmalloc(allocs, st, &T.sum, slots) && dmalloc(allocs, st, &T.count, slots) &&
+         dmalloc(allocs, st, &T.pend_cnt, slots) && dmalloc(allocs, st, &T.pend, slots * kPendCap);
+    T.mask = (unsigned)(slots - 1);
+    DsScratch& D = m->ds[k];
+    D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
+    D.bucket_cap = k ? kDsBucketSurf : kDsBucketCorner;
+    D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
+    const size_t hs = (size_t)D.hash_mask + 1;
+    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.bucket, hs * D.bucket_cap) &&
+         dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap);
+    ok = ok && dmalloc(allocs, st, &m->stack[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->stack_map[k], (size_t)D.stack_cap) &&
+         dmalloc(allocs, st, &m->touched[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->deferred[k], (size_t)D.stack_cap);
+    FactorTable& F = m->F[k];
+    F.cap = kMapFactorCap;
+    ok = ok && dmalloc(allocs, st, &F.type, (size_t)F.cap) && dmalloc(allocs, st, &F.p, 3 * (size_t)F.cap) &&
+         dmalloc(allocs, st, &F.A, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.B, 3 * (size_t)F.cap) &&
+         dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap);
+  }
+  ok = ok && dmalloc(allocs, st, &m->rec, 2);
+  ok = ok && dmalloc(allocs, st, &m->registered, (size_t)cfg.max_points);
+  if (!ok) return VLOAM_ERR_HIP;
+  m->max_points = cfg.max_points;
+  m->inv_leaf[0] = 1.0f / cfg.mapping_line_resolution;   // inverse_leaf_size_ of downSizeFilterCorner (LM:100)
+  m->inv_leaf[1] = 1.0f / cfg.mapping_plane_resolution;  // downSizeFilterSurf (LM:101)
+  MapState init;
+  memset(&init, 0, sizeof(init));
+  init.parameters[3] = 1.0; init.q_wmap_wodom[3] = 1.0; init.q_wodom_curr[3] = 1.0;  // LM:74-91
+  init.cenW = 10; init.cenH = 10; init.cenD = 5;                                      // laser_mapping.h:76-78
+  if (hipMemcpyAsync(m->state, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipFuncSetAttribute((const void*)k_map_ds_emit, hipFuncAttributeMaxDynamicSharedMemorySize, kStackCapSurf * (int)sizeof(u64)) != hipSuccess)
+    return VLOAM_ERR_HIP;
+  return hipStreamSynchronize(st) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
+                         bool skip_frame, ProfHook* ph) {
+  (void)cfg;
+  MapState* ms = m->state;
+  MapFrame* fr = m->frame;
+  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14);
+  if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+  hipLaunchKernelGGL(k_map_purge, dim3(256, 2), dim3(256), 0, st, m->tab[0], m->tab[1], ms, fr);
+  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_bucket, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+               m->inv_leaf[0], m->inv_leaf[1], fr);
+  hipLaunchKernelGGL(k_map_ds_emit, dim3(2), dim3(kEmitThreads), kStackCapSurf * sizeof(u64), st, cur.less_sharp, cur.less_flat, m->ds[0],
+                     m->ds[1], m->stack[0], m->stack[1], fr, ms);
+  for (int outer = 0; outer < 2; outer++) {  // LM:458
+    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
+                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->F[outer], outer);
+    lm_launch(st, m->F[outer], nullptr, kMapFactorCap, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
+  }
+  hipLaunchKernelGGL(k_map_update, dim3(1), dim3(64), 0, st, ms, traj_row14);
+  VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
+               m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1]);
+  VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
+               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt);
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n) {
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  MapState ms;
+  if (hipMemcpy(&ms, m->state, sizeof(ms), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  const float4* src = nullptr;
+  int cnt = 0;
+  if (which == 7) { src = m->stack[0]; cnt = ms.n_corner_stack; }
+  else if (which == 8) { src = m->stack[1]; cnt = ms.n_surf_stack; }
+  else if (which == 11) {
+    FrameScalars S;
+    if (hipMemcpy(&S, cur.S, sizeof(S), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    hipLaunchKernelGGL(k_map_register, dim3(256), dim3(256), 0, st, cur.cloud, cur.S, m->state, m->registered);
+    if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+    src = m->registered; cnt = S.N2;
+  } else return VLOAM_ERR_INVALID;
+  *n = cnt;
+  const int c = cnt < cap ? cnt : cap;
+  if (xyzi4 && c > 0 && hipMemcpy(xyzi4, src, (size_t)c * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
   return VLOAM_OK;
 }
-vloam_status map_enqueue(MapContext*, const vloam_config&, hipStream_t, const SRBuffers&, LOState*, double*, bool) { return VLOAM_OK; }
-vloam_status map_get_cloud(MapContext*, hipStream_t, int, const SRBuffers&, float*, int, int*) { return VLOAM_ERR_INVALID; }
-vloam_status map_error(MapContext*, int* e) { *e = 0; return VLOAM_OK; }
-vloam_status map_debug_get(MapContext*, int, void*, long long, long long*) { return VLOAM_ERR_INVALID; }
-vloam_status map_counts(MapContext*, long long*) { return VLOAM_OK; }
+
+vloam_status map_error(MapContext* m, int* e) {
+  MapFrame fr;
+  if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  *e = fr.error;
+  return VLOAM_OK;
 }
+
+static vloam_status copy_dev(const void* src, size_t bytes, void* buf, long long cap, long long* n) {
+  if (n) *n = (long long)bytes;
+  const size_t c = bytes < (size_t)cap ? bytes : (size_t)cap;
+  if (buf && c && hipMemcpy(buf, src, c, hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  return VLOAM_OK;
+}
+
+// item = outer * 16 + k:  k = 0 factor types i32[kMapFactorCap], 1 A f64[3][cap], 2 B f64[3][cap], 3 LM record, 4 residuals f64[3][cap],
+//                         5 p f64[3][cap].  item 64: MapState.  item 65: MapFrame.  item 66: cube_cnt i32[2][4851].
+//                         item 67/68: dump of the corner / surf table as rows {key lo, key hi, count, x, y, z, w} (7 x 4 bytes) for live slots.
+vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n) {
+  if (item == 64) return copy_dev(m->state, sizeof(MapState), buf, cap, n);
+  if (item == 65) return copy_dev(m->frame, sizeof(MapFrame), buf, cap, n);
+  if (item == 66) return copy_dev(m->cube_cnt, sizeof(int) * 2 * kCubeNum, buf, cap, n);
+  if (item == 67 || item == 68) {
+    const VoxelTable& T = m->tab[item - 67];
+    const size_t slots = (size_t)T.mask + 1;
+    std::vector<u64> keys(slots);
+    std::vector<int> cnt(slots);
+    std::vector<float4> sum(slots);
+    if (hipMemcpy(keys.data(), T.keys, slots * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    if (hipMemcpy(cnt.data(), T.count, slots * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    if (hipMemcpy(sum.data(), T.sum, slots * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    std::vector<unsigned> rows;
+    for (size_t s = 0; s < slots; s++) {
+      if (keys[s] == 0 || cnt[s] == 0) continue;
+      unsigned r[7];
+      r[0] = (unsigned)(keys[s] & 0xffffffffu); r[1] = (unsigned)(keys[s] >> 32); r[2] = (unsigned)cnt[s];
+      memcpy(r + 3, &sum[s], 16);
+      rows.insert(rows.end(), r, r + 7);
+    }
+    if (n) *n = (long long)(rows.size() * 4);
+    const size_t c = rows.size() * 4 < (size_t)cap ? rows.size() * 4 : (size_t)cap;
+    if (buf && c) memcpy(buf, rows.data(), c);
+    return VLOAM_OK;
+  }
+  const int outer = item / 16, k = item % 16;
+  if (outer < 0 || outer > 1) return VLOAM_ERR_INVALID;
+  const FactorTable& F = m->F[outer];
+  switch (k) {
+    case 0: return copy_dev(F.type, sizeof(int) * F.cap, buf, cap, n);
+    case 1: return copy_dev(F.A, sizeof(double) * 3 * F.cap, buf, cap, n);
+    case 2: return copy_dev(F.B, sizeof(double) * 3 * F.cap, buf, cap, n);
+    case 3: return copy_dev(m->rec + outer, sizeof(LMRecord), buf, cap, n);
+    case 4: return copy_dev(F.resid, sizeof(double) * 3 * F.cap, buf, cap, n);
+    case 5: return copy_dev(F.p, sizeof(double) * 3 * F.cap, buf, cap, n);
+  }
+  return VLOAM_ERR_INVALID;
+}
+
+vloam_status map_counts(MapContext* m, long long c[16]) {
+  MapState ms;
+  MapFrame fr;
+  LMRecord rec[2];
+  if (hipMemcpy(&ms, m->state, sizeof(ms), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemcpy(rec, m->rec, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  c[11] = ms.n_corner_stack; c[12] = ms.n_surf_stack;
+  c[13] = fr.n_factors[1][0] + fr.n_factors[1][1];
+  c[14] = ms.do_optimize ? (long long)(rec[0].n_evals + rec[1].n_evals) : 0;
+  c[15] = ms.n_map_corner + ms.n_map_surf;
+  return VLOAM_OK;
+}
+
+}  // namespace vloam
