@@ -20,7 +20,6 @@ constexpr int kStackCapCorner = 8192;   // >= kMaxLessSharp
 constexpr int kStackCapSurf = 16384;    // voxels of one sweep's lessFlat cloud at the plane resolution
 constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
 constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
-constexpr int kDsBucketCorner = 64, kDsBucketSurf = 128;  // sweep points per stack voxel
 constexpr int kDsHashCorner = 1 << 15, kDsHashSurf = 1 << 16;
 
 struct VoxelTable {       // structure of arrays, open addressing, linear probing
@@ -34,10 +33,14 @@ struct VoxelTable {       // structure of arrays, open addressing, linear probin
 
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
   unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
-  int* cnt;                  // [hash]
-  int* bucket;               // [hash][bucket_cap] point indices
+  int* cnt;                  // [hash] points per voxel (pass 1), then fill cursor (pass 3)
+  int* slot_off;             // [hash] start of the voxel's segment in seg
   unsigned long long* uniq;  // [stack_cap] keys of occupied voxels (unordered)
-  int hash_mask, bucket_cap, stack_cap;
+  int* point_slot;           // [max_points] hash slot of every sweep point
+  int* seg;                  // [max_points] point indices grouped by voxel
+  int* rank_slot;            // [stack_cap] hash slot of the t-th voxel in VoxelGrid output order
+  int* rank_off;             // [stack_cap + 1] segment bounds in output order
+  int hash_mask, stack_cap;
 };
 
 struct MapFrame {         // per-sweep device counters

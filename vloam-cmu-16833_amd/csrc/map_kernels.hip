@@ -1,10 +1,12 @@
 // laserMapping on gfx950: scan-to-map ICP against a persistent voxel hash.
 // Restates LaserMapping::input / solveMapping, /root/reference/src/lidar_odometry_mapping/src/laser_mapping.cpp:167-708
-// ("LM:<line>").  One sweep = 8 launches + 2 Levenberg–Marquardt launches, no host synchronisation:
+// ("LM:<line>").  One sweep = 12 launches + 2 Levenberg–Marquardt launches, no host synchronisation:
 //   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448)
 //   k_map_purge     grid      only does work after a roll: drops voxels whose cube left the 21x21x11 window
-//   k_map_ds_bucket grid      pcl::VoxelGrid of the scan features, pass 1: hash sweep points into voxel buckets (LM:432-440)
-//   k_map_ds_emit   2 WGs     pass 2: LDS bitonic sort of the occupied voxel keys, in-order f32 centroid per voxel
+//   k_map_ds_count  grid      pcl::VoxelGrid of the scan features (LM:432-440), pass 1: hash sweep points to voxels, count
+//   k_map_ds_sort   2 WGs     pass 2: LDS bitonic sort of the occupied voxel keys (= output order), segment offsets
+//   k_map_ds_scatter grid     pass 3: group point indices by voxel
+//   k_map_ds_reduce grid      pass 4: per voxel, input-ordered f32 centroid
 //   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN by probing the voxel hash in a +-1 m box, 3x3 eigen /
 //                             5x3 least squares, emission of LidarEdgeFactor / LidarPlaneNormFactor (LM:472-581)   x2
 //   (k_lm_solve)                                                                                                x2
@@ -172,9 +174,10 @@ __device__ __forceinline__ u64 ds_key(float4 p, float inv) {
   return ((u64)(unsigned)(iz + (1 << 20)) << 42) | ((u64)(unsigned)(iy + (1 << 20)) << 21) | (u64)(unsigned)(ix + (1 << 20));
 }
 
-__global__ __launch_bounds__(256) void k_map_ds_bucket(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
-                                                       const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
-                                                       float inv1, MapFrame* fr) {
+// pass 1: voxel membership + per-voxel counts
+__global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
+                                                      const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
+                                                      float inv1, MapFrame* fr) {
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const float inv = kind ? inv1 : inv0;
@@ -183,31 +186,27 @@ __global__ __launch_bounds__(256) void k_map_ds_bucket(const float4* __restrict_
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u64 key = ds_key(pts[i], inv);
     unsigned s = (unsigned)mix64(key) & D.hash_mask;
+    int found = -1;
     for (int probe = 0; probe <= D.hash_mask; probe++, s = (s + 1) & D.hash_mask) {
       const u64 old = atomicCAS(&D.keys[s], 0ull, key);
       if (old == 0ull) {  // new voxel
         const int u = atomicAdd(&fr->n_uniq[kind], 1);
         if (u < D.stack_cap) D.uniq[u] = key; else atomicOr(&fr->error, kErrStackFull);
       }
-      if (old == 0ull || old == key) {
-        const int pos = atomicAdd(&D.cnt[s], 1);
-        if (pos < D.bucket_cap) D.bucket[(size_t)s * D.bucket_cap + pos] = i; else atomicOr(&fr->error, kErrStackFull);
-        break;
-      }
+      if (old == 0ull || old == key) { atomicAdd(&D.cnt[s], 1); found = (int)s; break; }
     }
+    D.point_slot[i] = found;
+    if (found < 0) atomicOr(&fr->error, kErrStackFull);
   }
 }
 
+// pass 2: output order (LDS bitonic sort of the occupied voxel keys) + segment offsets (block scan)
 constexpr int kEmitThreads = 1024;
-__global__ __launch_bounds__(kEmitThreads) void k_map_ds_emit(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
-                                                              DsScratch D0, DsScratch D1, float4* __restrict__ stack0,
-                                                              float4* __restrict__ stack1, MapFrame* fr, MapState* ms) {
+__global__ __launch_bounds__(kEmitThreads) void k_map_ds_sort(DsScratch D0, DsScratch D1, MapFrame* fr, MapState* ms) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* K = (u64*)smem;
   const int kind = blockIdx.x, tid = threadIdx.x;
   const DsScratch D = kind ? D1 : D0;
-  const float4* pts = kind ? surf_last : corner_last;
-  float4* stack = kind ? stack1 : stack0;
   const int u = min(fr->n_uniq[kind], D.stack_cap);
   int P = 2;
   while (P < u) P <<= 1;
@@ -223,13 +222,68 @@ __global__ __launch_bounds__(kEmitThreads) void k_map_ds_emit(const float4* __re
       }
       __syncthreads();
     }
-  for (int t = tid; t < u; t += kEmitThreads) {
+  // per-thread contiguous chunk of ranks: slot lookup, local count sum, block scan of the sums, offsets
+  const int per = (u + kEmitThreads - 1) / kEmitThreads;
+  const int lo = tid * per, hi = min(lo + per, u);
+  int local = 0;
+  for (int t = lo; t < hi; t++) {
     const u64 key = K[t];
     unsigned s = (unsigned)mix64(key) & D.hash_mask;
     while (D.keys[s] != key) s = (s + 1) & D.hash_mask;
-    const int cnt = min(D.cnt[s], D.bucket_cap);
-    int* b = D.bucket + (size_t)s * D.bucket_cap;
-    for (int a = 1; a < cnt; a++) {  // restore input order inside the voxel (the atomics appended in arbitrary order)
+    D.rank_slot[t] = (int)s;
+    local += D.cnt[s];
+  }
+  __syncthreads();
+  int* sums = (int*)smem;  // keys are no longer needed
+  sums[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < kEmitThreads; d <<= 1) {
+    const int v = tid >= d ? sums[tid - d] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? sums[tid - 1] : 0;
+  for (int t = lo; t < hi; t++) {
+    const int s = D.rank_slot[t];
+    D.rank_off[t] = run;
+    D.slot_off[s] = run;
+    run += D.cnt[s];
+    D.cnt[s] = 0;  // becomes the fill cursor of pass 3
+  }
+  if (tid == kEmitThreads - 1) D.rank_off[u] = sums[kEmitThreads - 1];
+  if (tid == 0) {
+    fr->n_stack[kind] = u;
+    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
+  }
+}
+
+// pass 3: group the point indices by voxel
+__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1) {
+  const int kind = blockIdx.y;
+  const DsScratch D = kind ? D1 : D0;
+  const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int s = D.point_slot[i];
+    if (s < 0) continue;
+    const int pos = D.slot_off[s] + atomicAdd(&D.cnt[s], 1);
+    D.seg[pos] = i;
+  }
+}
+
+// pass 4: one thread per output voxel: restore input order, f32 centroid, release the hash slot
+__global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
+                                                       DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
+                                                       const MapFrame* __restrict__ fr) {
+  const int kind = blockIdx.y;
+  const DsScratch D = kind ? D1 : D0;
+  const float4* pts = kind ? surf_last : corner_last;
+  float4* stack = kind ? stack1 : stack0;
+  const int u = min(fr->n_stack[kind], D.stack_cap);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < u; t += gridDim.x * 256) {
+    const int b0 = D.rank_off[t], cnt = D.rank_off[t + 1] - b0;
+    int* b = D.seg + b0;
+    for (int a = 1; a < cnt; a++) {  // the atomics appended in arbitrary order; VoxelGrid sums in input order
       const int v = b[a];
       int c = a - 1;
       while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; }
@@ -239,11 +293,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_map_ds_emit(const float4* __re
     for (int a = 0; a < cnt; a++) { const float4 p = pts[b[a]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
     const float nn = (float)cnt;
     stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
+    const int s = D.rank_slot[t];
     D.keys[s] = 0ull; D.cnt[s] = 0;  // leave the scratch hash clean for the next sweep
-  }
-  if (tid == 0) {
-    fr->n_stack[kind] = u;
-    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
   }
 }
 
@@ -625,11 +676,12 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     T.mask = (unsigned)(slots - 1);
     DsScratch& D = m->ds[k];
     D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
-    D.bucket_cap = k ? kDsBucketSurf : kDsBucketCorner;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
     const size_t hs = (size_t)D.hash_mask + 1;
-    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.bucket, hs * D.bucket_cap) &&
-         dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap);
+    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.slot_off, hs) &&
+         dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.point_slot, (size_t)cfg.max_points) &&
+         dmalloc(allocs, st, &D.seg, (size_t)cfg.max_points) && dmalloc(allocs, st, &D.rank_slot, (size_t)D.stack_cap) &&
+         dmalloc(allocs, st, &D.rank_off, (size_t)D.stack_cap + 1);
     ok = ok && dmalloc(allocs, st, &m->stack[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->stack_map[k], (size_t)D.stack_cap) &&
          dmalloc(allocs, st, &m->touched[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->deferred[k], (size_t)D.stack_cap);
     FactorTable& F = m->F[k];
@@ -649,7 +701,7 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
   init.parameters[3] = 1.0; init.q_wmap_wodom[3] = 1.0; init.q_wodom_curr[3] = 1.0;  // LM:74-91
   init.cenW = 10; init.cenH = 10; init.cenD = 5;                                      // laser_mapping.h:76-78
   if (hipMemcpyAsync(m->state, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
-  if (hipFuncSetAttribute((const void*)k_map_ds_emit, hipFuncAttributeMaxDynamicSharedMemorySize, kStackCapSurf * (int)sizeof(u64)) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)k_map_ds_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kStackCapSurf * (int)sizeof(u64)) != hipSuccess)
     return VLOAM_ERR_HIP;
   return hipStreamSynchronize(st) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
@@ -662,10 +714,12 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   hipLaunchKernelGGL(k_map_purge, dim3(256, 2), dim3(256), 0, st, m->tab[0], m->tab[1], ms, fr);
-  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_bucket, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
                m->inv_leaf[0], m->inv_leaf[1], fr);
-  hipLaunchKernelGGL(k_map_ds_emit, dim3(2), dim3(kEmitThreads), kStackCapSurf * sizeof(u64), st, cur.less_sharp, cur.less_flat, m->ds[0],
-                     m->ds[1], m->stack[0], m->stack[1], fr, ms);
+  hipLaunchKernelGGL(k_map_ds_sort, dim3(2), dim3(kEmitThreads), kStackCapSurf * sizeof(u64), st, m->ds[0], m->ds[1], fr, ms);
+  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1]);
+  hipLaunchKernelGGL(k_map_ds_reduce, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+                     m->stack[0], m->stack[1], fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
                  m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->F[outer], outer);
