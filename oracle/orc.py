@@ -265,8 +265,10 @@ class VOOracle:
         trace = np.zeros((128, 8))
         ni, term = I(0), I(0)
         H0, g0, costs = np.zeros((6, 6)), np.zeros(6), np.zeros(2)
-        ia = _p(np.ascontiguousarray(init_angles, dtype=np.float64), D) if init_angles is not None else None
-        it = _p(np.ascontiguousarray(init_t, dtype=np.float64), D) if init_t is not None else None
+        ia_arr = np.ascontiguousarray(init_angles, dtype=np.float64) if init_angles is not None else None
+        it_arr = np.ascontiguousarray(init_t, dtype=np.float64) if init_t is not None else None
+        ia = _p(ia_arr, D) if ia_arr is not None else None
+        it = _p(it_arr, D) if it_arr is not None else None
         self.L.orc_vo_solve(self.h, _p(pu, I), _p(cu, I), pu.shape[0], ia, it, _p(ang, D), _p(t, D), _p(cnt, I), _p(trace, D), 128,
                             C.byref(ni), _p(H0, D), _p(g0, D), C.byref(term), _p(costs, D))
         rows = np.zeros((pu.shape[0], 7))

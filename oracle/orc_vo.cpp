@@ -18,7 +18,7 @@ void DepthMap::projectPointCloud(const float* xyz, int n, const VOCalib& c) {
     for (int r = 0; r < 4; r++) a[r] = ((t[0] * c.cam_T_velo[r * 4 + 0] + t[1] * c.cam_T_velo[r * 4 + 1]) + t[2] * c.cam_T_velo[r * 4 + 2]) + t[3] * c.cam_T_velo[r * 4 + 3];
     for (int r = 0; r < 4; r++) b[r] = ((a[0] * c.rect0_T_cam[r * 4 + 0] + a[1] * c.rect0_T_cam[r * 4 + 1]) + a[2] * c.rect0_T_cam[r * 4 + 2]) + a[3] * c.rect0_T_cam[r * 4 + 3];
     for (int r = 0; r < 3; r++) p[r] = ((b[0] * c.P_rect0[r * 4 + 0] + b[1] * c.P_rect0[r * 4 + 1]) + b[2] * c.P_rect0[r * 4 + 2]) + b[3] * c.P_rect0[r * 4 + 3];
-    if (!(p[2] > 0.1)) continue;  // :156-158 (f32 vs double 0.1; NaN fails the test and is dropped)
+    if (!(p[2] > 0.1f)) continue;  // :156-158 (Eigen compares the f32 array with Scalar(0.1); NaN fails the test and is dropped)
     const float inv = 1.0f / p[2];  // Eigen::inverse(col(2).array()) then a product, :171-173
     point_cloud_2d.push_back(p[0] * inv);
     point_cloud_2d.push_back(p[1] * inv);

@@ -262,6 +262,13 @@ class Handle:
                     surf_plane=np.hstack([A[ss + K_STACK_CAP_CORNER], B[ss + K_STACK_CAP_CORNER, :1]]), rec=rec, resid=resid,
                     corner_slots=cs, surf_slots=ss + K_STACK_CAP_CORNER)
 
+    def vo_debug(self, n_match):
+        nb = 249 * 75
+        cur = [self.debug_raw(3, k, np.float32 if k < 3 else np.int32)[:nb] for k in range(4)]
+        prev = [self.debug_raw(3, 4 + k, np.float32 if k < 3 else np.int32)[:nb] for k in range(4)]
+        rows = self.debug_raw(3, 8, np.float64).reshape(-1, 7)[:n_match]
+        return dict(cur=cur, prev=prev, match_rows=rows, rec=self.debug_lm_record(3, 9))
+
     def map_state(self):
         raw = self.debug_raw(2, 64, np.uint8)
         d = raw[:21 * 8].view(np.float64)

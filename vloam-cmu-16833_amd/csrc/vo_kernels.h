@@ -1,4 +1,6 @@
 // Depth-enhanced VO residual stack on gfx950 — host-visible interface (vo_kernels.hip).
+// Restates PointCloudUtil::{projectPointCloud, downsamplePointCloud, queryDepth} and VisualOdometry::solveNlsAll
+// (/root/reference/src/visual_odometry/src/point_cloud_util.cpp:148-174,205-260,302-387; visual_odometry.cpp:254-450).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -7,8 +9,32 @@
 
 namespace vloam {
 
+constexpr int kImgW = 1242, kImgH = 375, kGrid = 5;          // point_cloud_util.h:41-42, visual_odometry.cpp:56
+constexpr int kBW = 249, kBH = 75, kBuckets = kBW * kBH;     // ceil(1242/5) x ceil(375/5)
+constexpr int kVoMaxMatches = 8192;
+
+struct DepthMapDev {
+  float *bx, *by, *bd;  // [kBuckets]  bucket_x / bucket_y / bucket_depth
+  int* bc;              // [kBuckets]  bucket_count
+};
+
 struct VOContext {
-  int dummy = 0;
+  vloam_calib* d_calib = nullptr;
+  bool have_calib = false;
+  DepthMapDev maps[2];
+  int count = -1, i = 0;     // VisualOdometry::reset(): ++count; i = count % 2
+  float4* uvd = nullptr;     // [max_points] (u, v, depth, bucket id as int bits; -1 = not in a bucket)
+  int* bcount = nullptr;     // [kBuckets + 1] scratch counts -> offsets
+  int* bfill = nullptr;      // [kBuckets]
+  int* seg = nullptr;        // [max_points]
+  int* d_prev = nullptr;     // [kVoMaxMatches][2]
+  int* d_curr = nullptr;
+  FactorTable F{};
+  LMRecord* rec = nullptr;
+  double* x = nullptr;       // [6] angle-axis, t
+  double* match_dbg = nullptr;  // [kVoMaxMatches][7] kind, depth0, obs[5]
+  int* counters = nullptr;   // [2] counter32, counter22
+  int max_points = 0;
 };
 
 vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs);

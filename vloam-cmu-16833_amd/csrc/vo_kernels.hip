@@ -1,8 +1,307 @@
+// Depth-enhanced visual-odometry residual stack on gfx950 (config 4).
+//   k_vo_project  grid   N x 4 f32 homogeneous points through cam_T_velo^T, rect0_T_cam^T, P_rect0^T (PCU:148-174), bucket id
+//   k_vo_scan     1 WG   bucket counts -> segment offsets
+//   k_vo_scatter  grid   group point indices by 5-px bucket
+//   k_vo_fold     grid   per bucket: input-ordered "incremental average" of (u, v, depth) exactly as written (PCU:205-260)
+//   k_vo_match    grid   per match: outlier gate, queryDepth 3-NN inverse-distance lookup (PCU:302-387), K^-1 by f32
+//                        column-pivoted QR, CostFunctor32 / CostFunctor22 factor (VO:283-416)
+//   (k_lm_solve)         Huber(0.1), DENSE_QR-equivalent LM, <= 100 iterations on (angle-axis, t) (VO:67-68,423)
+// "PCU" = /root/reference/src/visual_odometry/src/point_cloud_util.cpp, "VO" = .../visual_odometry.cpp.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "lm_solve.h"
 #include "vo_kernels.h"
+
 namespace vloam {
-vloam_status vo_create(VOContext*, const vloam_config&, hipStream_t, std::vector<void*>&) { return VLOAM_OK; }
-vloam_status vo_set_calib(VOContext*, hipStream_t, const vloam_calib*) { return VLOAM_ERR_INVALID; }
-vloam_status vo_process_point_cloud(VOContext*, hipStream_t, const float4*, int) { return VLOAM_ERR_INVALID; }
-vloam_status vo_solve(VOContext*, const vloam_config&, hipStream_t, const int*, const int*, int, double*, double*, int*) { return VLOAM_ERR_INVALID; }
-vloam_status vo_debug_get(VOContext*, int, void*, long long, long long*) { return VLOAM_ERR_INVALID; }
+
+__global__ __launch_bounds__(256) void k_vo_project(const float4* __restrict__ in, int n, const vloam_calib* __restrict__ c,
+                                                    float4* __restrict__ uvd, int* __restrict__ bcount) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 q = in[i];
+    const float t[4] = {q.x, q.y, q.z, 1.0f};
+    float a[4], b[4], p[3];
+    // three f32 GEMMs evaluated left to right, K = 4 inner products accumulated in k order
+    for (int r = 0; r < 4; r++) a[r] = ((t[0] * c->cam_T_velo[r * 4 + 0] + t[1] * c->cam_T_velo[r * 4 + 1]) + t[2] * c->cam_T_velo[r * 4 + 2]) + t[3] * c->cam_T_velo[r * 4 + 3];
+    for (int r = 0; r < 4; r++) b[r] = ((a[0] * c->rect0_T_cam[r * 4 + 0] + a[1] * c->rect0_T_cam[r * 4 + 1]) + a[2] * c->rect0_T_cam[r * 4 + 2]) + a[3] * c->rect0_T_cam[r * 4 + 3];
+    for (int r = 0; r < 3; r++) p[r] = ((b[0] * c->P_rect0[r * 4 + 0] + b[1] * c->P_rect0[r * 4 + 1]) + b[2] * c->P_rect0[r * 4 + 2]) + b[3] * c->P_rect0[r * 4 + 3];
+    int bucket = -1;
+    float u = 0.f, v = 0.f;
+    if (p[2] > 0.1f) {                  // PCU:156-158 (Eigen: f32 array > Scalar(0.1))
+      const float inv = 1.0f / p[2];    // PCU:171-173
+      u = p[0] * inv; v = p[1] * inv;
+      const int ix = (int)(u / kGrid), iy = (int)(v / kGrid);  // PCU:218-219 (truncation toward zero)
+      if (ix >= 0 && ix < kBW && iy >= 0 && iy < kBH) { bucket = ix * kBH + iy; atomicAdd(&bcount[bucket], 1); }
+    }
+    uvd[i] = make_float4(u, v, p[2], __int_as_float(bucket));
+  }
 }
+
+__global__ __launch_bounds__(1024) void k_vo_scan(int* bcount, int* bfill) {
+  __shared__ int sums[1024];
+  const int tid = threadIdx.x;
+  const int per = (kBuckets + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, kBuckets);
+  int s = 0;
+  for (int k = lo; k < hi; k++) s += bcount[k];
+  sums[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? sums[tid - d] : 0; __syncthreads(); sums[tid] += v; __syncthreads(); }
+  int run = tid ? sums[tid - 1] : 0;
+  for (int k = lo; k < hi; k++) { const int c = bcount[k]; bcount[k] = run; bfill[k] = 0; run += c; }
+  if (tid == 1023) bcount[kBuckets] = sums[1023];
+}
+
+__global__ __launch_bounds__(256) void k_vo_scatter(const float4* __restrict__ uvd, int n, const int* __restrict__ boff, int* bfill,
+                                                    int* __restrict__ seg) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int b = __float_as_int(uvd[i].w);
+    if (b < 0) continue;
+    seg[boff[b] + atomicAdd(&bfill[b], 1)] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vo_fold(const float4* __restrict__ uvd, int* __restrict__ boff, int* __restrict__ seg, DepthMapDev M) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= kBuckets) return;
+  const int b0 = boff[b], cnt = boff[b + 1] - b0;
+  int* s = seg + b0;
+  for (int a = 1; a < cnt; a++) {  // input order
+    const int v = s[a];
+    int c = a - 1;
+    while (c >= 0 && s[c] > v) { s[c + 1] = s[c]; c--; }
+    s[c + 1] = v;
+  }
+  float x = 0.f, y = 0.f, d = 0.f;
+  int count = 0;
+  for (int a = 0; a < cnt; a++) {
+    const float4 p = uvd[s[a]];
+    if (count == 0) { x = p.x; y = p.y; d = p.z; }
+    else {  // "incremental averaging" with the count BEFORE the increment, verbatim (PCU:230-235)
+      x += (p.x - x) / count; y += (p.y - y) / count; d += (p.z - d) / count;
+    }
+    ++count;
+  }
+  M.bx[b] = x; M.by[b] = y; M.bd[b] = d; M.bc[b] = count;
+}
+
+// PCU:302-387
+__device__ float query_depth(const DepthMapDev& M, float x, float y) {
+  const int searching_radius = 2;
+  const int index_x = (int)(x / kGrid), index_y = (int)(y / kGrid);
+  float nx[25], ny[25], nd[25], ndist[25];
+  int cnt = 0;
+  for (int ix = index_x - searching_radius; ix <= index_x + searching_radius; ++ix)
+    for (int iy = index_y - searching_radius; iy <= index_y + searching_radius; ++iy)
+      if (ix >= 0 && ix < kBW && iy >= 0 && iy < kBH && M.bc[ix * kBH + iy] > 0) {
+        const int b = ix * kBH + iy;
+        const float bx = M.bx[b], by = M.by[b];
+        const double dx = (double)(x - bx), dy = (double)(y - by);
+        const float dist = (float)sqrt(dx * dx + dy * dy);  // std::sqrt(std::pow(float, 2) + std::pow(float, 2)) in double
+        int pos = cnt;  // stable insertion by distance (std::sort in the reference; canonical tie order = scan order)
+        while (pos > 0 && dist < ndist[pos - 1]) { nx[pos] = nx[pos - 1]; ny[pos] = ny[pos - 1]; nd[pos] = nd[pos - 1]; ndist[pos] = ndist[pos - 1]; pos--; }
+        nx[pos] = bx; ny[pos] = by; nd[pos] = M.bd[b]; ndist[pos] = dist;
+        cnt++;
+      }
+  if (cnt < 10) return -1.0f;
+  return (nd[0] * ndist[1] * ndist[2] + nd[1] * ndist[0] * ndist[2] + nd[2] * ndist[0] * ndist[1]) /
+         (0.0001f + ndist[1] * ndist[2] + ndist[0] * ndist[2] + ndist[0] * ndist[1]);
+}
+
+// op-for-op twin of oracle/orc_vo.cpp solve3x3_colpiv_qr_f32 (P_rect0.leftCols(3).colPivHouseholderQr().solve, VO:350-355)
+__device__ void solve3x3_colpiv_qr_f32(const float* A_, const float* b_, float* x) {
+  float A[3][3], b[3] = {b_[0], b_[1], b_[2]};
+  int perm[3] = {0, 1, 2};
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = A_[r * 3 + c];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int best = k; float bestn = -1.0f;
+    for (int c = k; c < 3; c++) {
+      float s = 0.0f;
+      for (int r = k; r < 3; r++) s += A[r][c] * A[r][c];
+      if (s > bestn) { bestn = s; best = c; }
+    }
+    if (best != k) {
+      for (int r = 0; r < 3; r++) { const float t = A[r][k]; A[r][k] = A[r][best]; A[r][best] = t; }
+      const int t = perm[k]; perm[k] = perm[best]; perm[best] = t;
+    }
+    const float nrm = sqrtf(bestn);
+    if (nrm == 0.0f) continue;
+    const float alpha = A[k][k] > 0.0f ? -nrm : nrm;
+    float v[3] = {0, 0, 0};
+    v[k] = A[k][k] - alpha;
+    float vtv = v[k] * v[k];
+    for (int r = k + 1; r < 3; r++) { v[r] = A[r][k]; vtv += v[r] * v[r]; }
+    if (vtv != 0.0f) {
+      for (int c = k + 1; c < 3; c++) {
+        float s = 0.0f;
+        for (int r = k; r < 3; r++) s += v[r] * A[r][c];
+        s = 2.0f * s / vtv;
+        for (int r = k; r < 3; r++) A[r][c] -= s * v[r];
+      }
+      float s = 0.0f;
+      for (int r = k; r < 3; r++) s += v[r] * b[r];
+      s = 2.0f * s / vtv;
+      for (int r = k; r < 3; r++) b[r] -= s * v[r];
+    }
+    A[k][k] = alpha;
+    for (int r = k + 1; r < 3; r++) A[r][k] = 0.0f;
+  }
+  float y[3];
+  for (int k = 2; k >= 0; k--) {
+    float s = b[k];
+    for (int c = k + 1; c < 3; c++) s -= A[k][c] * y[c];
+    y[k] = s / A[k][k];
+  }
+  for (int k = 0; k < 3; k++) x[perm[k]] = y[k];
+}
+
+__global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_uv, const int* __restrict__ curr_uv, int n_match,
+                                                  const vloam_calib* __restrict__ c, DepthMapDev Mprev, int remove_outlier, FactorTable F,
+                                                  double* __restrict__ dbg, int* counters) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= F.cap) return;
+  int type = 0;
+  double obs[5] = {0, 0, 0, 0, 0};
+  float depth0 = 0.f;
+  if (j < n_match) {
+    const int px = prev_uv[2 * j], py = prev_uv[2 * j + 1], cx = curr_uv[2 * j], cy = curr_uv[2 * j + 1];
+    const long long d2 = (long long)(px - cx) * (px - cx) + (long long)(py - cy) * (py - cy);
+    if (!(remove_outlier > 0 && d2 > (long long)remove_outlier * remove_outlier)) {  // VO:309-314
+      float K[9];
+      for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) K[r * 3 + q] = c->P_rect0[r * 4 + q];
+      depth0 = query_depth(Mprev, (float)px, (float)py);  // VO:316 (depth1 is computed but unused in the reference)
+      float p0[3], p1[3], r0[3], r1[3];
+      if (depth0 > 0) {  // VO:345-368
+        p0[0] = px * depth0; p0[1] = py * depth0; p0[2] = depth0;
+        p1[0] = (float)cx; p1[1] = (float)cy; p1[2] = 1.0f;
+        solve3x3_colpiv_qr_f32(K, p0, r0);
+        solve3x3_colpiv_qr_f32(K, p1, r1);
+        type = 4;
+        obs[0] = r0[0]; obs[1] = r0[1]; obs[2] = r0[2];
+        obs[3] = (double)r1[0] / (double)r1[2]; obs[4] = (double)r1[1] / (double)r1[2];
+        atomicAdd(&counters[0], 1);
+      } else {           // VO:393-415
+        p0[0] = (float)px; p0[1] = (float)py; p0[2] = 1.0f;
+        p1[0] = (float)cx; p1[1] = (float)cy; p1[2] = 1.0f;
+        solve3x3_colpiv_qr_f32(K, p0, r0);
+        solve3x3_colpiv_qr_f32(K, p1, r1);
+        type = 5;
+        obs[0] = (double)r0[0] / (double)r0[2]; obs[1] = (double)r0[1] / (double)r0[2];
+        obs[2] = (double)r1[0] / (double)r1[2]; obs[3] = (double)r1[1] / (double)r1[2];
+        atomicAdd(&counters[1], 1);
+      }
+    }
+  }
+  const int cap = F.cap;
+  F.type[j] = type;
+  if (type == 4) {
+    F.p[j] = obs[0]; F.p[cap + j] = obs[1]; F.p[2 * cap + j] = obs[2];
+    F.A[j] = obs[3]; F.A[cap + j] = obs[4]; F.A[2 * cap + j] = 0;
+  } else if (type == 5) {
+    F.p[j] = obs[0]; F.p[cap + j] = obs[1]; F.p[2 * cap + j] = 0;
+    F.A[j] = obs[2]; F.A[cap + j] = obs[3]; F.A[2 * cap + j] = 0;
+  }
+  if (j < n_match) {
+    dbg[7 * j] = type == 4 ? 32 : (type == 5 ? 22 : 0);
+    dbg[7 * j + 1] = depth0;
+    for (int k = 0; k < 5; k++) dbg[7 * j + 2 + k] = obs[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <class T>
+static bool dmalloc(std::vector<void*>& allocs, hipStream_t st, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, count * sizeof(T) + 256) != hipSuccess) return false;
+  if (hipMemsetAsync(q, 0, count * sizeof(T) + 256, st) != hipSuccess) return false;
+  allocs.push_back(q);
+  *p = (T*)q;
+  return true;
+}
+
+vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs) {
+  bool ok = dmalloc(allocs, st, &v->d_calib, 1);
+  for (int k = 0; k < 2 && ok; k++)
+    ok = dmalloc(allocs, st, &v->maps[k].bx, kBuckets) && dmalloc(allocs, st, &v->maps[k].by, kBuckets) &&
+         dmalloc(allocs, st, &v->maps[k].bd, kBuckets) && dmalloc(allocs, st, &v->maps[k].bc, kBuckets);
+  ok = ok && dmalloc(allocs, st, &v->uvd, (size_t)cfg.max_points) && dmalloc(allocs, st, &v->bcount, kBuckets + 1) &&
+       dmalloc(allocs, st, &v->bfill, kBuckets) && dmalloc(allocs, st, &v->seg, (size_t)cfg.max_points) &&
+       dmalloc(allocs, st, &v->d_prev, 2 * kVoMaxMatches) && dmalloc(allocs, st, &v->d_curr, 2 * kVoMaxMatches);
+  v->F.cap = kVoMaxMatches;
+  ok = ok && dmalloc(allocs, st, &v->F.type, kVoMaxMatches) && dmalloc(allocs, st, &v->F.p, 3 * kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->F.A, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.B, 3 * kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches);
+  ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->counters, 2);
+  v->max_points = cfg.max_points;
+  return ok ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+vloam_status vo_set_calib(VOContext* v, hipStream_t st, const vloam_calib* c) {
+  if (hipMemcpyAsync(v->d_calib, c, sizeof(*c), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  v->have_calib = true;
+  return VLOAM_OK;
+}
+
+vloam_status vo_process_point_cloud(VOContext* v, hipStream_t st, const float4* d_in, int n) {
+  if (!v->have_calib) return VLOAM_ERR_ORDER;
+  ++v->count;                // VisualOdometry::reset(), VO:86-90
+  v->i = v->count % 2;
+  if (hipMemsetAsync(v->bcount, 0, sizeof(int) * (kBuckets + 1), st) != hipSuccess) return VLOAM_ERR_HIP;
+  hipLaunchKernelGGL(k_vo_project, dim3(256), dim3(256), 0, st, d_in, n, v->d_calib, v->uvd, v->bcount);
+  hipLaunchKernelGGL(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
+  hipLaunchKernelGGL(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
+  hipLaunchKernelGGL(k_vo_fold, dim3((kBuckets + 255) / 256), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[v->i]);
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, const int* prev_uv, const int* curr_uv, int n_match,
+                      double aa[3], double t[3], int counters[2]) {
+  if (!v->have_calib || v->count < 1) return VLOAM_ERR_ORDER;  // needs the previous frame's depth map
+  if (n_match > kVoMaxMatches) return VLOAM_ERR_CAPACITY;
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  if (!cfg.reset_VO_to_identity) { for (int k = 0; k < 3; k++) { x[k] = aa[k]; x[3 + k] = t[k]; } }  // VO:260-281
+  if (hipMemcpyAsync(v->d_prev, prev_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemcpyAsync(v->d_curr, curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemcpyAsync(v->x, x, sizeof(x), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
+  hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib, v->maps[1 - v->i],
+                     cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters);
+  lm_launch(st, v->F, nullptr, kVoMaxMatches, v->x, v->rec, 100, 0.1, false, nullptr);
+  if (hipMemcpyAsync(x, v->x, sizeof(x), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
+  int cnt[2];
+  if (hipMemcpyAsync(cnt, v->counters, sizeof(cnt), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  for (int k = 0; k < 3; k++) { aa[k] = x[k]; t[k] = x[3 + k]; }
+  if (counters) { counters[0] = cnt[0]; counters[1] = cnt[1]; }
+  return VLOAM_OK;
+}
+
+static vloam_status copy_dev(const void* src, size_t bytes, void* buf, long long cap, long long* n) {
+  if (n) *n = (long long)bytes;
+  const size_t c = bytes < (size_t)cap ? bytes : (size_t)cap;
+  if (buf && c && hipMemcpy(buf, src, c, hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  return VLOAM_OK;
+}
+
+// item 0..3: bucket_x / bucket_y / bucket_depth / bucket_count of the CURRENT map; 4..7 the same of the PREVIOUS map;
+// 8: per-match rows f64[n][7]; 9: LM record; 10: projected points f32[n][4] (u, v, depth, bucket id bits)
+vloam_status vo_debug_get(VOContext* v, int item, void* buf, long long cap, long long* n) {
+  if (item >= 0 && item < 8) {
+    const DepthMapDev& M = v->maps[item < 4 ? v->i : 1 - v->i];
+    switch (item & 3) {
+      case 0: return copy_dev(M.bx, sizeof(float) * kBuckets, buf, cap, n);
+      case 1: return copy_dev(M.by, sizeof(float) * kBuckets, buf, cap, n);
+      case 2: return copy_dev(M.bd, sizeof(float) * kBuckets, buf, cap, n);
+      case 3: return copy_dev(M.bc, sizeof(int) * kBuckets, buf, cap, n);
+    }
+  }
+  if (item == 8) return copy_dev(v->match_dbg, sizeof(double) * 7 * kVoMaxMatches, buf, cap, n);
+  if (item == 9) return copy_dev(v->rec, sizeof(LMRecord), buf, cap, n);
+  if (item == 10) return copy_dev(v->uvd, sizeof(float4) * (size_t)v->max_points, buf, cap, n);
+  return VLOAM_ERR_INVALID;
+}
+
+}  // namespace vloam

@@ -233,3 +233,41 @@ class SynthSequence:
         out[:, :3] = pts.astype(np.float32)
         out[miss, :3] = np.nan
         return out
+
+
+# ---------------------------------------------------------------------------------------------------- camera (config 4)
+def kitti_like_calib():
+    """(cam_T_velo 4x4, rect0_T_cam 4x4 with only the 3x3 block filled — the ROS path leaves (3,3) = 0,
+    visual_odometry.cpp:140-144 — and P_rect0 3x4), f32, KITTI-like pinhole 1242 x 375."""
+    cam_T_velo = np.array([[0, -1, 0, -0.004], [0, 0, -1, -0.076], [1, 0, 0, -0.272], [0, 0, 0, 1]], dtype=np.float32)
+    rect0_T_cam = np.zeros((4, 4), dtype=np.float32)
+    rect0_T_cam[:3, :3] = np.eye(3, dtype=np.float32)
+    P = np.array([[718.856, 0, 607.1928, 0], [0, 718.856, 185.2157, 0], [0, 0, 1, 0]], dtype=np.float32)
+    return cam_T_velo, rect0_T_cam, P
+
+
+def synth_matches(seq, k, n_match=1400, pixel_noise=0.5, seed=99):
+    """Pixel pairs (prev frame k-1 -> current frame k) of scene points visible in both images, standing in for the
+    OpenCV front-end (out of scope): integer (truncated) pixel coordinates like visual_odometry.cpp:283-294."""
+    cam_T_velo, _, P = kitti_like_calib()
+    K = P[:, :3].astype(np.float64)
+    Tcv = cam_T_velo.astype(np.float64)
+    rng = np.random.default_rng(seed + k)
+    prev = seq.sweep(k - 1)[:, :3].astype(np.float64)
+    prev = prev[np.isfinite(prev[:, 0])]
+    q, t = seq.gt_relative(k)          # p_prev = R p_curr + t
+    R = quat_to_rot(q)
+    curr = (prev - t[None, :]) @ R      # R^T (p_prev - t)
+    def proj(pts):
+        pc = pts @ Tcv[:3, :3].T + Tcv[:3, 3]
+        uv = pc @ K.T
+        return uv[:, :2] / uv[:, 2:3], pc[:, 2]
+    uv0, z0 = proj(prev)
+    uv1, z1 = proj(curr)
+    ok = (z0 > 1.0) & (z1 > 1.0) & (uv0[:, 0] > 2) & (uv0[:, 0] < 1239) & (uv0[:, 1] > 2) & (uv0[:, 1] < 372) & \
+         (uv1[:, 0] > 2) & (uv1[:, 0] < 1239) & (uv1[:, 1] > 2) & (uv1[:, 1] < 372)
+    idx = np.nonzero(ok)[0]
+    idx = rng.choice(idx, size=min(n_match, idx.size), replace=False)
+    a = uv0[idx] + rng.normal(0, pixel_noise, (idx.size, 2))
+    b = uv1[idx] + rng.normal(0, pixel_noise, (idx.size, 2))
+    return a.astype(np.float32).astype(np.int32), b.astype(np.float32).astype(np.int32)
