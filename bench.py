@@ -90,6 +90,8 @@ def main():
     import conftest
     vl = conftest.load_pkg()
     synth = conftest.load_synth()
+    import importlib
+    multi = importlib.import_module("vloam_amd.multi")
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -101,8 +103,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic input, one independent sequence per rank, resident in HBM before the timed region
-    seq = synth.SynthSequence(n_rings=args.rings, n_azimuth=args.azimuth, n_sweeps=W + K, seed_scene=1234 + 17 * rank,
-                              seed_traj=42 + rank, seed_noise=5678 + 100003 * rank)
+    seq = synth.SynthSequence(n_rings=args.rings, n_azimuth=args.azimuth, n_sweeps=W + K, **multi.rank_sequence_seeds(rank))
     host = np.stack([seq.sweep(k) for k in range(W + K)])
     n_pts = host.shape[1]
     d_clouds = torch.from_numpy(host).to(torch.device("cuda", local_rank))
@@ -132,22 +133,20 @@ def main():
 
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = multi.max_over_ranks(dist, elapsed, device="cuda")
     k_ms, k_launches = h.profile_read()
     counts = h.counts()
     traj = h.trajectory()
 
     # the one collective of the path: gather the per-sequence trajectories
+    trajectories = [traj]
     if dist is not None:
-        t_dev = torch.from_numpy(traj).to("cuda")
-        gathered = [torch.empty_like(t_dev) for _ in range(world)]
-        dist.all_gather(gathered, t_dev)
+        trajectories = multi.gather_trajectories(dist, traj, W + K + 8, device="cuda")
 
     out = None
     if rank == 0:
-        value = K * world / elapsed
+        value = multi.aggregate_throughput(K, world, elapsed)
+        assert len(trajectories) == world and all(t.shape == (W + K, 14) for t in trajectories)
         b_sr, b_lo, b_map = sweep_bytes(counts, with_mapping)
         kb = algorithmic_bytes(kernel, counts)
         avg_ms = k_ms / max(k_launches, 1)
