@@ -1,0 +1,119 @@
+// vloam_hip/factors.hpp — the reference's Ceres cost-functor surface, without a Ceres include.
+//
+// Same structs, constructors and `template <typename T> bool operator()(const T* q, const T* t, T* residual) const`
+// as /root/reference/src/lidar_odometry_mapping/include/lidar_odometry_mapping/lidarFactor.hpp:14-139 and
+// src/visual_odometry/include/visual_odometry/ceres_cost_function.h:54-96,147-185, written against a tiny
+// self-contained vector algebra (no Eigen), so a user who HAS Ceres can still do
+//   new ceres::AutoDiffCostFunction<vloam::factors::LidarEdgeFactor, 3, 4, 3>(new vloam::factors::LidarEdgeFactor(...))
+// while the GPU path evaluates the same residuals with closed-form Jacobians (csrc/lm_solve.hip).
+// T must support + - * / < >, sqrt, sin, cos (found by ADL, as for ceres::Jet).  s == 1 (DISTORTION == false,
+// laser_odometry.h:90): Identity.slerp(1, q) == q, so the slerp of the reference is the identity here.
+#pragma once
+#include <cmath>
+#include <limits>
+
+namespace vloam {
+namespace factors {
+
+template <class T> struct V3 { T x, y, z; };
+template <class T> inline V3<T> sub(const V3<T>& a, const V3<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> inline V3<T> cross(const V3<T>& a, const V3<T>& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+template <class T> inline T dot(const V3<T>& a, const V3<T>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// q = (x, y, z, w); v + w (2 u x v) + u x (2 u x v)   (Eigen's QuaternionBase::_transformVector)
+template <class T> inline V3<T> rotate(const T* q, const V3<T>& v) {
+  V3<T> u{q[0], q[1], q[2]};
+  V3<T> uv = cross(u, v);
+  uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+  V3<T> c = cross(u, uv);
+  return {v.x + q[3] * uv.x + c.x, v.y + q[3] * uv.y + c.y, v.z + q[3] * uv.z + c.z};
+}
+
+struct LidarEdgeFactor {
+  LidarEdgeFactor(const double c[3], const double a[3], const double b[3], double s_) : s(s_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; lpa[i] = a[i]; lpb[i] = b[i]; } }
+  template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
+    using std::sqrt;
+    V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, a{T(lpa[0]), T(lpa[1]), T(lpa[2])}, b{T(lpb[0]), T(lpb[1]), T(lpb[2])};
+    V3<T> r = rotate(q, p);
+    V3<T> lp{r.x + T(s) * t[0], r.y + T(s) * t[1], r.z + T(s) * t[2]};
+    V3<T> nu = cross(sub(lp, a), sub(lp, b));
+    V3<T> de = sub(a, b);
+    T n = sqrt(dot(de, de));
+    residual[0] = nu.x / n; residual[1] = nu.y / n; residual[2] = nu.z / n;
+    return true;
+  }
+  double cp[3], lpa[3], lpb[3], s;
+};
+
+struct LidarPlaneFactor {
+  LidarPlaneFactor(const double c[3], const double j[3], const double l[3], const double m[3], double s_) : s(s_) {
+    for (int i = 0; i < 3; i++) { cp[i] = c[i]; lpj[i] = j[i]; }
+    V3<double> a{j[0] - l[0], j[1] - l[1], j[2] - l[2]}, b{j[0] - m[0], j[1] - m[1], j[2] - m[2]};
+    V3<double> n = cross(a, b);
+    double nn = std::sqrt(dot(n, n));
+    ljm[0] = n.x / nn; ljm[1] = n.y / nn; ljm[2] = n.z / nn;
+  }
+  template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
+    V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, j{T(lpj[0]), T(lpj[1]), T(lpj[2])}, n{T(ljm[0]), T(ljm[1]), T(ljm[2])};
+    V3<T> r = rotate(q, p);
+    V3<T> lp{r.x + T(s) * t[0], r.y + T(s) * t[1], r.z + T(s) * t[2]};
+    residual[0] = dot(sub(lp, j), n);
+    return true;
+  }
+  double cp[3], lpj[3], ljm[3], s;
+};
+
+struct LidarPlaneNormFactor {
+  LidarPlaneNormFactor(const double c[3], const double n[3], double d_) : d(d_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; nrm[i] = n[i]; } }
+  template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
+    V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, n{T(nrm[0]), T(nrm[1]), T(nrm[2])};
+    V3<T> r = rotate(q, p);
+    V3<T> w{r.x + t[0], r.y + t[1], r.z + t[2]};
+    residual[0] = dot(n, w) + T(d);
+    return true;
+  }
+  double cp[3], nrm[3], d;
+};
+
+// ceres::AngleAxisRotatePoint
+template <class T> inline void angle_axis_rotate(const T* w_, const T* pt, T* out) {
+  using std::sqrt; using std::sin; using std::cos;
+  const T th2 = w_[0] * w_[0] + w_[1] * w_[1] + w_[2] * w_[2];
+  if (th2 > T(std::numeric_limits<double>::epsilon())) {
+    const T th = sqrt(th2), c = cos(th), s = sin(th), ti = T(1.0) / th;
+    const T w[3] = {w_[0] * ti, w_[1] * ti, w_[2] * ti};
+    const T x[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+    const T tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (T(1.0) - c);
+    for (int k = 0; k < 3; k++) out[k] = pt[k] * c + x[k] * s + w[k] * tmp;
+  } else {
+    const T x[3] = {w_[1] * pt[2] - w_[2] * pt[1], w_[2] * pt[0] - w_[0] * pt[2], w_[0] * pt[1] - w_[1] * pt[0]};
+    for (int k = 0; k < 3; k++) out[k] = pt[k] + x[k];
+  }
+}
+
+struct CostFunctor32 {  // 3D - 2D
+  CostFunctor32(double x0_, double y0_, double z0_, double x1_bar_, double y1_bar_) : x0(x0_), y0(y0_), z0(z0_), x1_bar(x1_bar_), y1_bar(y1_bar_) {}
+  template <typename T> bool operator()(const T* const angles, const T* const t, T* residuals) const {
+    T X0[3] = {T(x0), T(y0), T(z0)}, X1[3];
+    angle_axis_rotate(angles, X0, X1);
+    X1[0] = X1[0] + t[0]; X1[1] = X1[1] + t[1]; X1[2] = X1[2] + t[2];
+    residuals[0] = X1[0] - X1[2] * T(x1_bar);
+    residuals[1] = X1[1] - X1[2] * T(y1_bar);
+    return true;
+  }
+  double x0, y0, z0, x1_bar, y1_bar;
+};
+
+struct CostFunctor22 {  // 2D - 2D epipolar
+  CostFunctor22(double x0_bar_, double y0_bar_, double x1_bar_, double y1_bar_) : x0_bar(x0_bar_), y0_bar(y0_bar_), x1_bar(x1_bar_), y1_bar(y1_bar_) {}
+  template <typename T> bool operator()(const T* const angles, const T* const t, T* residuals) const {
+    T X0[3] = {T(x0_bar), T(y0_bar), T(1.0)}, R[3];
+    angle_axis_rotate(angles, X0, R);
+    const T c[3] = {t[1] * R[2] - t[2] * R[1], t[2] * R[0] - t[0] * R[2], t[0] * R[1] - t[1] * R[0]};
+    residuals[0] = T(x1_bar) * c[0] + T(y1_bar) * c[1] + c[2];
+    return true;
+  }
+  double x0_bar, y0_bar, x1_bar, y1_bar;
+};
+
+}  // namespace factors
+}  // namespace vloam

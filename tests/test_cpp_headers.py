@@ -1,0 +1,49 @@
+"""CPU: include/vloam_hip/{c_api.h, compat.hpp, factors.hpp} compile as plain C / C++14 and the functor templates
+agree with the oracle's autodiff restatement of the reference functors."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PROBE = r'''
+#include <cstdio>
+#include "vloam_hip/compat.hpp"
+#include "vloam_hip/factors.hpp"
+int main() {
+  double c[3] = {1.5, -2.0, 0.7}, a[3] = {1.0, 0.5, 0.2}, b[3] = {1.2, 0.1, 1.4}, m[3] = {-0.4, 2.0, 0.3};
+  double q[4] = {0.01, -0.02, 0.03, 0.9993}, t[3] = {0.8, -0.1, 0.05}, r[3];
+  vloam::factors::LidarEdgeFactor e(c, a, b, 1.0); e(q, t, r); std::printf("%.17g %.17g %.17g\n", r[0], r[1], r[2]);
+  vloam::factors::LidarPlaneFactor p(c, a, b, m, 1.0); p(q, t, r); std::printf("%.17g\n", r[0]);
+  double n[3] = {0.0, 0.6, 0.8};
+  vloam::factors::LidarPlaneNormFactor pn(c, n, 0.25); pn(q, t, r); std::printf("%.17g\n", r[0]);
+  vloam_config cfg; vloam_default_config(&cfg);
+  std::printf("%d %s\n", cfg.scan_line, vloam_version());
+  return 0;
+}
+'''
+
+
+def test_headers_compile_and_functors_match_oracle(tmp_path, orc, vl):
+    src = tmp_path / "probe.cpp"
+    src.write_text(PROBE)
+    exe = tmp_path / "probe"
+    libdir = os.path.join(ROOT, "vloam-cmu-16833_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lvloam_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    e = np.array([float(x) for x in out[0].split()])
+    curr, a, b, m = [1.5, -2.0, 0.7], [1.0, 0.5, 0.2], [1.2, 0.1, 1.4], [-0.4, 2.0, 0.3]
+    q, t = [0.01, -0.02, 0.03, 0.9993], [0.8, -0.1, 0.05]
+    r0, _ = orc.eval_lidar_factor(0, curr, a + b, q, t)
+    r1, _ = orc.eval_lidar_factor(1, curr, a + b + m, q, t)
+    r2, _ = orc.eval_lidar_factor(2, curr, [0.0, 0.6, 0.8, 0.25], q, t)
+    assert np.allclose(e, r0, rtol=1e-13, atol=1e-14)
+    assert abs(float(out[1]) - r1[0]) < 1e-13 and abs(float(out[2]) - r2[0]) < 1e-13
+    assert out[3].startswith("64 vloam_hip")
+    # c_api.h is plain C
+    csrc = tmp_path / "c.c"
+    csrc.write_text('#include "vloam_hip/c_api.h"\nint main(void) { vloam_config c; vloam_default_config(&c); return c.scan_line != 64; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(csrc), "-o", str(tmp_path / "c.o")])
