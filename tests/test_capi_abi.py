@@ -55,4 +55,4 @@ def test_struct_layouts_match_the_device_header(vl):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"\b(?:int|double|float)\s+([a-zA-Z_0-9]+);", body)
     assert fields == [f[0] for f in vl.Config._fields_]
-    assert C.sizeof(vl.LMRecord) == 8 * (7 + 7 + 36 + 6 + 6 + 8 * vl.K_LM_MAX_TRACE)
+    assert C.sizeof(vl.LMRecord) == 8 * (7 + 7 + 36 + 6 + 6 + 4 + 8 * vl.K_LM_MAX_TRACE)

@@ -47,14 +47,15 @@ class LMRecord(C.Structure):
     _fields_ = [("x_in", C.c_double * 7), ("x_out", C.c_double * 7), ("H0", C.c_double * 36), ("g0", C.c_double * 6),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("n_iterations", C.c_double),
                 ("termination", C.c_double), ("n_factors", C.c_double), ("n_evals", C.c_double),
-                ("trace", (C.c_double * 8) * K_LM_MAX_TRACE)]
+                ("cyc", C.c_double * 4), ("trace", (C.c_double * 8) * K_LM_MAX_TRACE)]
 
     def to_dict(self):
         n = int(self.n_iterations)
         tr = np.ctypeslib.as_array(self.trace).reshape(K_LM_MAX_TRACE, 8)[:n].copy()
         return dict(x_in=np.array(self.x_in), x_out=np.array(self.x_out), H0=np.array(self.H0).reshape(6, 6),
                     g0=np.array(self.g0), initial_cost=self.initial_cost, final_cost=self.final_cost, trace=tr,
-                    termination=int(self.termination), n_factors=int(self.n_factors), n_evals=int(self.n_evals))
+                    termination=int(self.termination), n_factors=int(self.n_factors), n_evals=int(self.n_evals),
+                    cyc=np.array(self.cyc))
 
 
 _lib = None

@@ -91,6 +91,10 @@ static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap)
   ALLOC(F->A, 3 * (size_t)cap);
   ALLOC(F->B, 3 * (size_t)cap);
   ALLOC(F->resid, 3 * (size_t)cap);
+  ALLOC(F->ctype, cap);
+  ALLOC(F->cslot, cap);
+  ALLOC(F->cpack, 9 * (size_t)cap);
+  ALLOC(F->rowcnt, (size_t)cap / 64 + 1);
   return VLOAM_OK;
 }
 
@@ -233,7 +237,7 @@ static vloam_status enqueue_lo(vloam_handle* h) {
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
                       h->sr[prev].S, h->lo, F, h->lo_corr[outer], &h->prof);
-      lm_launch(h->stream, F, nullptr, kMaxLoFactors, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
+      lm_launch(h->stream, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
     }
   }
   lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);

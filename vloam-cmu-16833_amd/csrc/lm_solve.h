@@ -5,10 +5,12 @@
 
 namespace vloam {
 
-// Solves over slots [0, n) of F where n = *d_n_slots (device) if d_n_slots != nullptr, else n_slots_fixed.
+// Runs the whole ceres::Solve() over the accepted slots of F (type != 0; the association kernels also count them per
+// 64-slot row in F.rowcnt).  Two launches: k_lm_compact (grid) + k_lm_solve (one workgroup).
 // d_x: 7 doubles (q xyzw, t) when quat, else 6 (angle-axis, t); updated in place like ceres::Solve.
 // d_enable (optional): device int; 0 skips the solve entirely (mapping gate, laser_mapping.cpp:448).
-void lm_launch(hipStream_t st, const FactorTable& F, const int* d_n_slots, int n_slots_fixed, double* d_x, LMRecord* d_rec, int max_iters,
-               double huber_a, bool quat, const int* d_enable, ProfHook* ph = nullptr);
+// n_edge_slots: slots [0, n_edge_slots) hold LidarEdgeFactors, the rest plane factors (multiple of 64; ignored when !quat).
+void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
+               const int* d_enable, ProfHook* ph = nullptr);
 
 }  // namespace vloam

@@ -1,6 +1,7 @@
 // Levenberg–Marquardt on one workgroup: the whole ceres::Solve() of the reference
 // (laser_odometry.cpp:457-463, laser_mapping.cpp:609-617, visual_odometry.cpp:423) runs inside ONE
-// kernel launch.  16 wavefronts evaluate the residual blocks (closed-form Jacobians in the tangent
+// kernel launch.  A prologue compacts the accepted factors (slot order, deterministic) so every later
+// evaluation streams dense arrays; 8 wavefronts evaluate the residual blocks (closed-form Jacobians in the tangent
 // space of EigenQuaternionParameterization, Huber corrector), reduce the 6x6 J^T J / J^T r / cost
 // with wavefront shuffles + a fixed-order LDS pass (bit-reproducible), and lane 0 runs the
 // trust-region bookkeeping of Ceres 2.0 (Jacobi scaling, LM diagonal clamp, step acceptance,
@@ -15,7 +16,8 @@
 
 namespace vloam {
 
-constexpr int kLmThreads = 512;
+constexpr int kLmThreads = 256;
+
 constexpr int kAcc = 28;  // cost, g[6], H upper triangle[21]
 
 struct D3 { double x, y, z; };
@@ -93,178 +95,317 @@ __device__ void angle_axis_rotate(const Dual6* w_, const Dual6* pt, Dual6* out) 
   }
 }
 
-// One residual block: residuals r[nres] and tangent-space Jacobian J[nres][6].  Returns nres.
-__device__ int lm_factor(int type, D3 p, D3 A, D3 B, const double* x, double r[3], double J[3][6]) {
-  if (type >= 1 && type <= 3) {
-    D3 rp = quat_rotate(x, p);                       // R(q) p
-    D3 lp = rp + d3(x[4], x[5], x[6]);
-    // d lp / d delta = -2 [R p]x  (EigenQuaternionParameterization: q+ = exp(delta) * q), d lp / d t = I
-    if (type == 1) {                                 // LidarEdgeFactor, lidarFactor.hpp:21-45
-      D3 nu = cross(lp - A, lp - B);
-      D3 de = A - B;
-      double dn = sqrt(dot(de, de));
-      r[0] = nu.x / dn; r[1] = nu.y / dn; r[2] = nu.z / dn;
-      D3 v = d3((B.x - A.x) / dn, (B.y - A.y) / dn, (B.z - A.z) / dn);   // d r / d lp = [v]x
-      const double M[3][3] = {{0, -v.z, v.y}, {v.z, 0, -v.x}, {-v.y, v.x, 0}};
-      const double R2[3][3] = {{0, 2 * rp.z, -2 * rp.y}, {-2 * rp.z, 0, 2 * rp.x}, {2 * rp.y, -2 * rp.x, 0}};  // -2 [rp]x
-      for (int k = 0; k < 3; k++) {
-        for (int a = 0; a < 3; a++) {
-          J[k][a] = M[k][0] * R2[0][a] + M[k][1] * R2[1][a] + M[k][2] * R2[2][a];
-          J[k][3 + a] = M[k][a];
-        }
-      }
-      return 3;
-    }
-    D3 n = (type == 2) ? B : A;
-    if (type == 2) r[0] = dot(lp - A, B);            // LidarPlaneFactor, lidarFactor.hpp:72-93
-    else r[0] = dot(A, lp) + B.x;                    // LidarPlaneNormFactor, lidarFactor.hpp:115-127
-    D3 nr = cross(n, rp);                            // n^T (-2 [rp]x) = -2 (n x rp)^T
-    J[0][0] = -2 * nr.x; J[0][1] = -2 * nr.y; J[0][2] = -2 * nr.z;
-    J[0][3] = n.x; J[0][4] = n.y; J[0][5] = n.z;
-    return 1;
-  }
-  // VO functors on (angle_axis[3], t[3]) — dual numbers == Ceres autodiff
-  Dual6 w[3] = {dvar(x[0], 0), dvar(x[1], 1), dvar(x[2], 2)};
-  Dual6 t[3] = {dvar(x[3], 3), dvar(x[4], 4), dvar(x[5], 5)};
-  if (type == 4) {                                   // CostFunctor32, ceres_cost_function.h:68-85
-    Dual6 X0[3] = {dconst(p.x), dconst(p.y), dconst(p.z)}, X1[3];
-    angle_axis_rotate(w, X0, X1);
-    for (int k = 0; k < 3; k++) X1[k] = X1[k] + t[k];
-    Dual6 r0 = X1[0] - X1[2] * dconst(A.x);
-    Dual6 r1 = X1[1] - X1[2] * dconst(A.y);
-    r[0] = r0.a; r[1] = r1.a;
-    for (int a = 0; a < 6; a++) { J[0][a] = r0.v[a]; J[1][a] = r1.v[a]; }
-    return 2;
-  }
-  {                                                  // CostFunctor22, ceres_cost_function.h:159-174
-    Dual6 X0[3] = {dconst(p.x), dconst(p.y), dconst(1.0)}, RX[3];
-    angle_axis_rotate(w, X0, RX);
-    Dual6 c[3] = {t[1] * RX[2] - t[2] * RX[1], t[2] * RX[0] - t[0] * RX[2], t[0] * RX[1] - t[1] * RX[0]};
-    Dual6 r0 = dconst(A.x) * c[0] + dconst(A.y) * c[1] + c[2];
-    r[0] = r0.a;
-    for (int a = 0; a < 6; a++) J[0][a] = r0.v[a];
-    return 1;
-  }
-}
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
 
-// Evaluate every factor at x: cost, g = J^T r, H = J^T J (upper triangle), after the Huber corrector.
-// Result lands in s_out[kAcc] (LDS).  All kLmThreads threads must call.
-__device__ void lm_evaluate(const FactorTable& F, int n_slots, const double* x, double huber_a, double* s_part /* [16][kAcc] */,
-                            double* s_out, bool store_resid, int* s_count) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double acc[kAcc];
-  for (int i = 0; i < kAcc; i++) acc[i] = 0.0;
-  int cnt = 0;
-  const int cap = F.cap;
-  for (int k = tid; k < n_slots; k += kLmThreads) {
-    const int type = F.type[k];
-    if (type == 0) continue;
-    cnt++;
-    D3 p = d3(F.p[k], F.p[cap + k], F.p[2 * cap + k]);
-    D3 A = d3(F.A[k], F.A[cap + k], F.A[2 * cap + k]);
-    D3 B = d3(F.B[k], F.B[cap + k], F.B[2 * cap + k]);
-    double r[3], J[3][6];
-    const int nr = lm_factor(type, p, A, B, x, r, J);
-    if (store_resid) for (int q = 0; q < 3; q++) F.resid[q * cap + k] = q < nr ? r[q] : 0.0;
-    double sq = 0.0;
-    for (int q = 0; q < nr; q++) sq += r[q] * r[q];
-    // ceres::HuberLoss::Evaluate + Corrector (rho'' <= 0 -> plain sqrt(rho') scaling)
-    double rho0 = sq, sc = 1.0;
-    if (huber_a > 0.0 && sq > huber_a * huber_a) {
-      const double rr = sqrt(sq);
-      rho0 = 2.0 * huber_a * rr - huber_a * huber_a;
-      sc = sqrt(fmax(DBL_MIN, huber_a / rr));
-    }
-    acc[0] += 0.5 * rho0;
-    for (int q = 0; q < nr; q++) {
-      const double rq = r[q] * sc;
-      double Jq[6];
-      for (int a = 0; a < 6; a++) Jq[a] = J[q][a] * sc;
-      int h = 7;
-      for (int a = 0; a < 6; a++) {
-        acc[1 + a] += Jq[a] * rq;
-        for (int b = a; b < 6; b++) acc[h++] += Jq[a] * Jq[b];
-      }
-    }
-  }
-  for (int i = 0; i < kAcc; i++) {
-    double v = wave_sum(acc[i]);
-    if (lane == 0) s_part[wave * kAcc + i] = v;
-  }
-  cnt += __shfl_xor(cnt, 32); cnt += __shfl_xor(cnt, 16); cnt += __shfl_xor(cnt, 8);
-  cnt += __shfl_xor(cnt, 4); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 1);
-  if (lane == 0) ((int*)(s_part + 16 * kAcc))[wave] = cnt;
-  __syncthreads();
-  if (tid < kAcc) {
-    double s = 0.0;
-    for (int w = 0; w < kLmThreads / 64; w++) s += s_part[w * kAcc + tid];  // fixed order: reproducible
-    s_out[tid] = s;
-  }
-  if (tid == 0) {
-    int c = 0;
-    for (int w = 0; w < kLmThreads / 64; w++) c += ((int*)(s_part + 16 * kAcc))[w];
-    *s_count = c;
-  }
-  __syncthreads();
+// acc += (cost, J^T r, upper triangle of J^T J) of one residual row; everything statically indexed (registers)
+__device__ __forceinline__ void accumulate_row(double (&acc)[kAcc], const double (&J)[6], double r) {
+#pragma unroll
+  for (int a = 0; a < 6; a++) acc[1 + a] += J[a] * r;
+  int h = 7;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = a; b < 6; b++) acc[h++] += J[a] * J[b];
 }
 
-__device__ __forceinline__ double Hget(const double* acc, int a, int b) {  // symmetric accessor into the packed triangle
-  if (a > b) { int t = a; a = b; b = t; }
-  // offset of row a in the packed upper triangle: sum_{i<a} (6 - i)
-  const int off = a * 6 - (a * (a - 1)) / 2;
-  return acc[7 + off + (b - a)];
+// ceres::HuberLoss::Evaluate + Corrector: rho'' <= 0 for Huber, so residual and Jacobian rows are scaled by sqrt(rho').
+// Branching form (VO path).
+__device__ __forceinline__ double huber(double sq, double a, double* cost) {
+  if (a > 0.0 && sq > a * a) {
+    const double rr = sqrt(sq);
+    *cost += 0.5 * (2.0 * a * rr - a * a);
+    return sqrt(fmax(DBL_MIN, a / rr));
+  }
+  *cost += 0.5 * sq;
+  return 1.0;
+}
+// Branch-free form given |r| (straight-line code lets the compiler interleave several factors per lane, which is what
+// hides the ~12-cycle dependent f64 latency when only one wavefront sits on each SIMD).
+__device__ __forceinline__ double huber_sel(double sq, double rr, double a, double* cost) {
+  const bool out = sq > a * a;
+  const double sc_out = sqrt(fmax(DBL_MIN, a / fmax(rr, DBL_MIN)));
+  *cost += out ? 0.5 * (2.0 * a * rr - a * a) : 0.5 * sq;
+  return out ? sc_out : 1.0;
 }
 
-// 6x6 SPD solve by Cholesky; returns false on a non-positive pivot.
-__device__ bool chol6_solve(double M[6][6], const double* rhs, double* y) {
-  double L[6][6];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j <= i; j++) {
-      double s = M[i][j];
-      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-      if (i == j) {
-        if (!(s > 0.0)) return false;
-        L[i][i] = sqrt(s);
-      } else {
-        L[i][j] = s / L[j][j];
-      }
-    }
-  double z[6];
-  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i][k] * z[k]; z[i] = s / L[i][i]; }
-  for (int i = 5; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < 6; k++) s -= L[k][i] * y[k]; y[i] = s / L[i][i]; }
-  return true;
+// LidarEdgeFactor (lidarFactor.hpp:21-45) with lp = R p + t:  r = ((lp - a) x (lp - b)) / |a - b| == v x (lp - a),
+// v = (b - a) / |a - b| (precomputed by k_lm_compact into B);  d r / d lp = [v]x;  d lp / d delta = -2 [R p]x
+// (EigenQuaternionParameterization, q+ = exp(delta) * q);  [v]x (-2 [rp]x) = -2 (rp v^T - (v . rp) I).
+__device__ __forceinline__ void eval_edge(D3 p, D3 A, D3 v, const double (&Rm)[9], D3 t, double huber_a, double (&acc)[kAcc], double* r3) {
+  const D3 rp = d3(Rm[0] * p.x + Rm[1] * p.y + Rm[2] * p.z, Rm[3] * p.x + Rm[4] * p.y + Rm[5] * p.z, Rm[6] * p.x + Rm[7] * p.y + Rm[8] * p.z);
+  const D3 lp = rp + t;
+  const D3 r = cross(v, lp - A);
+  r3[0] = r.x; r3[1] = r.y; r3[2] = r.z;
+  const double sq = r.x * r.x + r.y * r.y + r.z * r.z;
+  const double sc = huber_sel(sq, sqrt(sq), huber_a, &acc[0]);
+  const double vr = dot(v, rp);
+  const double s2 = -2.0 * sc;
+  const D3 sv = d3(sc * v.x, sc * v.y, sc * v.z);
+  {
+    const double J[6] = {s2 * (rp.x * v.x - vr), s2 * (rp.x * v.y), s2 * (rp.x * v.z), 0.0, -sv.z, sv.y};
+    accumulate_row(acc, J, r.x * sc);
+  }
+  {
+    const double J[6] = {s2 * (rp.y * v.x), s2 * (rp.y * v.y - vr), s2 * (rp.y * v.z), sv.z, 0.0, -sv.x};
+    accumulate_row(acc, J, r.y * sc);
+  }
+  {
+    const double J[6] = {s2 * (rp.z * v.x), s2 * (rp.z * v.y), s2 * (rp.z * v.z - vr), -sv.y, sv.x, 0.0};
+    accumulate_row(acc, J, r.z * sc);
+  }
+}
+
+// LidarPlaneFactor / LidarPlaneNormFactor (lidarFactor.hpp:72-93, 115-127) in the common form r = n . lp + d
+// (k_lm_compact rewrites the plane factor's (lp - j) . n as n . lp - n . j);  d r / d lp = n^T,  n^T (-2 [rp]x) = -2 (n x rp)^T.
+__device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&Rm)[9], D3 t, double huber_a, double (&acc)[kAcc], double* r3) {
+  const D3 rp = d3(Rm[0] * p.x + Rm[1] * p.y + Rm[2] * p.z, Rm[3] * p.x + Rm[4] * p.y + Rm[5] * p.z, Rm[6] * p.x + Rm[7] * p.y + Rm[8] * p.z);
+  const D3 lp = rp + t;
+  const double r0 = dot(n, lp) + d;
+  r3[0] = r0; r3[1] = 0.0; r3[2] = 0.0;
+  const double sc = huber_sel(r0 * r0, fabs(r0), huber_a, &acc[0]);
+  const D3 nr = cross(n, rp);
+  const double s2 = -2.0 * sc;
+  const double J[6] = {s2 * nr.x, s2 * nr.y, s2 * nr.z, n.x * sc, n.y * sc, n.z * sc};
+  accumulate_row(acc, J, r0 * sc);
+}
+
+// CostFunctor32 / CostFunctor22 on (angle_axis[3], t[3]) — dual numbers == Ceres autodiff
+__device__ __forceinline__ void eval_vo(int type, D3 p, D3 A, const double* x, double huber_a, double (&acc)[kAcc], double* r3) {
+  Dual6 w[3] = {dvar(x[0], 0), dvar(x[1], 1), dvar(x[2], 2)};
+  Dual6 t[3] = {dvar(x[3], 3), dvar(x[4], 4), dvar(x[5], 5)};
+  if (type == 4) {  // ceres_cost_function.h:68-85
+    Dual6 X0[3] = {dconst(p.x), dconst(p.y), dconst(p.z)}, X1[3];
+    angle_axis_rotate(w, X0, X1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) X1[k] = X1[k] + t[k];
+    const Dual6 q0 = X1[0] - X1[2] * dconst(A.x);
+    const Dual6 q1 = X1[1] - X1[2] * dconst(A.y);
+    r3[0] = q0.a; r3[1] = q1.a; r3[2] = 0.0;
+    const double sc = huber(q0.a * q0.a + q1.a * q1.a, huber_a, &acc[0]);
+    double J[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) J[a] = q0.v[a] * sc;
+    accumulate_row(acc, J, q0.a * sc);
+#pragma unroll
+    for (int a = 0; a < 6; a++) J[a] = q1.v[a] * sc;
+    accumulate_row(acc, J, q1.a * sc);
+  } else {          // ceres_cost_function.h:159-174
+    Dual6 X0[3] = {dconst(p.x), dconst(p.y), dconst(1.0)}, RX[3];
+    angle_axis_rotate(w, X0, RX);
+    const Dual6 c0 = t[1] * RX[2] - t[2] * RX[1], c1 = t[2] * RX[0] - t[0] * RX[2], c2 = t[0] * RX[1] - t[1] * RX[0];
+    const Dual6 q0 = dconst(A.x) * c0 + dconst(A.y) * c1 + c2;
+    r3[0] = q0.a; r3[1] = 0.0; r3[2] = 0.0;
+    const double sc = huber(q0.a * q0.a, huber_a, &acc[0]);
+    double J[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) J[a] = q0.v[a] * sc;
+    accumulate_row(acc, J, q0.a * sc);
+  }
 }
 
 struct LmShared {
-  double part[16 * kAcc + 16];
+  double red[kAcc * kLmThreads];  // [value][thread] transpose buffer of the block reduction
+  double part[8 * kAcc];          // [sub-sum][value]
   double cur[kAcc];    // accumulators at x
   double cand[kAcc];   // accumulators at the candidate
-  double x[7], xc[7];
+  double x[8], xc[8];
+  double mcc;          // model_cost_change of the pending candidate
+  double scale[6], diagonal[6], best[8];  // trust-region state that must survive the evaluations (kept out of registers)
+  int scan[kLmThreads], scan2[kLmThreads];
+  int n_edge;
   int go;              // 1: evaluate candidate next, 0: finished
-  int count;
+  int n_valid;
 };
 
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const int* n_slots_ptr, int n_slots_fixed, double* x_io,
-                                                         LMRecord* rec, int max_iters, double huber_a, int quat, const int* enable_flag) {
+// Evaluate the compacted factors at x: cost, g = J^T r, H = J^T J (upper triangle) -> s_out[kAcc] (LDS).
+template <bool QUAT>
+__device__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh, double* s_out,
+                            bool store_resid) {
+  const int tid = threadIdx.x;
+  double acc[kAcc];
+#pragma unroll
+  for (int i = 0; i < kAcc; i++) acc[i] = 0.0;
+  const int cap = F.cap;
+  double xl[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) xl[i] = x[i];
+  // rotation matrix of q = (x, y, z, w) as Eigen's toRotationMatrix() builds it (q is unit up to rounding)
+  double Rm[9];
+  {
+    const double tx = 2 * xl[0], ty = 2 * xl[1], tz = 2 * xl[2];
+    const double twx = tx * xl[3], twy = ty * xl[3], twz = tz * xl[3];
+    const double txx = tx * xl[0], txy = ty * xl[0], txz = tz * xl[0], tyy = ty * xl[1], tyz = tz * xl[1], tzz = tz * xl[2];
+    Rm[0] = 1 - (tyy + tzz); Rm[1] = txy - twz; Rm[2] = txz + twy;
+    Rm[3] = txy + twz; Rm[4] = 1 - (txx + tzz); Rm[5] = tyz - twx;
+    Rm[6] = txz - twy; Rm[7] = tyz + twx; Rm[8] = 1 - (txx + tyy);
+  }
+  const D3 tt = d3(xl[4], xl[5], xl[6]);
+  // kTrip factors per lane and trip, straight-line: their loads are all in flight before the first is consumed and the
+  // independent dependency chains interleave (one workgroup has to hide memory AND f64 latency by itself).
+  constexpr int kTrip = 4;
+  auto run = [&](int lo, int hi, auto&& body) {
+    for (int k0 = lo + tid; k0 < hi; k0 += kTrip * kLmThreads) {
+      double v[kTrip][9];
+      bool live[kTrip];
+#pragma unroll
+      for (int u = 0; u < kTrip; u++) {
+        const int k = k0 + u * kLmThreads;
+        live[u] = k < hi;
+        const int kk = live[u] ? k : k0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) v[u][a] = F.cpack[a * cap + kk];
+      }
+#pragma unroll
+      for (int u = 0; u < kTrip; u++) {
+        double r3[3];
+        body(u, v[u], live[u], r3);
+        if (store_resid && live[u]) {
+          const int slot = F.cslot[k0 + u * kLmThreads];
+          F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
+        }
+      }
+    }
+  };
+  if (QUAT) {
+    // compact order == slot order: the edge factors (corner slots) come first, then the plane factors
+    run(0, n_edge, [&](int, const double (&w)[9], bool live, double* r3) {
+      if (live) eval_edge(d3(w[0], w[1], w[2]), d3(w[3], w[4], w[5]), d3(w[6], w[7], w[8]), Rm, tt, huber_a, acc, r3);
+    });
+    run(n_edge, n_valid, [&](int, const double (&w)[9], bool live, double* r3) {
+      if (live) eval_plane(d3(w[0], w[1], w[2]), d3(w[3], w[4], w[5]), w[6], Rm, tt, huber_a, acc, r3);
+    });
+  } else {
+    for (int k = tid; k < n_valid; k += kLmThreads) {
+      double r3[3];
+      eval_vo(F.ctype[k], d3(F.cpack[k], F.cpack[cap + k], F.cpack[2 * cap + k]), d3(F.cpack[3 * cap + k], F.cpack[4 * cap + k], F.cpack[5 * cap + k]),
+              xl, huber_a, acc, r3);
+      if (store_resid) {
+        const int slot = F.cslot[k];
+        F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
+      }
+    }
+  }
+  // block reduction without cross-lane shuffles (a chain of ds_bpermute round trips is what dominated this kernel):
+  // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
+#pragma unroll
+  for (int i = 0; i < kAcc; i++) sh.red[i * kLmThreads + tid] = acc[i];
+  __syncthreads();
+  if (tid < 8 * kAcc) {
+    const int i = tid >> 3, sub = tid & 7;
+    const double* col = sh.red + i * kLmThreads + sub;
+    double s = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < kLmThreads / 8; j++) s += col[8 * j];
+    sh.part[sub * kAcc + i] = s;
+  }
+  __syncthreads();
+  if (tid < kAcc) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) s += sh.part[w * kAcc + tid];
+    s_out[tid] = s;
+  }
+  __syncthreads();
+}
+
+// packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
+__device__ __forceinline__ double Hget(const double* acc, int a, int b) {
+  const int lo = a < b ? a : b, hi = a < b ? b : a;
+  return acc[7 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+}
+
+// 6x6 SPD solve by Cholesky on the packed lower triangle, in place (fully unrolled: lives in registers).
+#define LIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
+__device__ __forceinline__ bool chol6_solve(double (&L)[21], const double (&rhs)[6], double (&y)[6]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double s = L[LIDX(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[LIDX(i, k)] * L[LIDX(j, k)];
+      if (i == j) { ok = ok && (s > 0.0); L[LIDX(i, i)] = sqrt(s); }
+      else L[LIDX(i, j)] = s / L[LIDX(j, j)];
+    }
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[LIDX(i, k)] * z[k];
+    z[i] = s / L[LIDX(i, i)]; }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) { double s = z[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[LIDX(k, i)] * y[k];
+    y[i] = s / L[LIDX(i, i)]; }
+  return ok;
+}
+
+template <bool QUAT>
+__device__ __forceinline__ void lm_plus_t(const double* x, const double (&delta)[6], double* out) {
+  if (QUAT) {  // EigenQuaternionParameterization::Plus: x_plus = (sin|d|/|d| d, cos|d|) * x
+    const double n = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+    if (n > 0.0) {
+      const double s = sin(n) / n;
+      const double dq[4] = {s * delta[0], s * delta[1], s * delta[2], cos(n)};
+      quat_mul(dq, x, out);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) out[i] = x[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + delta[3 + i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) out[i] = x[i] + delta[i];
+  }
+}
+
+template <bool QUAT>
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
+                                                         double huber_a, const int* enable_flag) {
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
-  if (enable_flag && *enable_flag == 0) return;
-  const int n_slots = n_slots_ptr ? min(*n_slots_ptr, F.cap) : n_slots_fixed;
-  const int na = quat ? 7 : 6;
+  if (enable_flag && *enable_flag == 0) {
+    for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
+    return;
+  }
+  constexpr int na = QUAT ? 7 : 6;
   if (tid < na) sh.x[tid] = x_io[tid];
-  __syncthreads();
+  if (tid == 7) sh.x[7] = 0.0;
 
-  lm_evaluate(F, n_slots, sh.x, huber_a, sh.part, sh.cur, true, &sh.count);
+  // ---- prologue: the factors were compacted by k_lm_compact; count them and release the row counters
+  const long long t_start = clock64();
+  {
+    const int nrows = F.cap >> 6;
+    int c = 0, ce = 0;
+    for (int r = tid; r < nrows; r += kLmThreads) { const int q = F.rowcnt[r]; c += q; if (r < edge_rows) ce += q; }
+    sh.scan[tid] = c;
+    sh.scan2[tid] = ce;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0, te = 0;
+      for (int w = 0; w < kLmThreads; w++) { t += sh.scan[w]; te += sh.scan2[w]; }
+      sh.n_valid = t; sh.n_edge = te;
+    }
+    for (int r = tid; r < nrows; r += kLmThreads) F.rowcnt[r] = 0;
+    __syncthreads();
+  }
+  const long long t_pro = clock64();
+  long long cyc_eval = 0, cyc_serial = 0, t_mark;
+  const int n_valid = sh.n_valid, n_edge = sh.n_edge;
 
-  // ---- trust-region state (registers of thread 0; other threads only follow sh.go)
-  double scale[6], diagonal[6];
+  t_mark = clock64();
+  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true);
+  cyc_eval += clock64() - t_mark;
+
+  // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
-  double best[7];
   bool reuse_diagonal = false;
   int num_invalid = 0, iteration = 0, n_rec = 0, termination = 0, n_evals = 1;
   double it_cost = 0, it_cost_change = 0, it_step_norm = 0, it_rho = 0;
@@ -272,32 +413,45 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
 
   auto grad_max = [&](const double* xx, const double* acc) {
     double ng[6], pg[7];
+#pragma unroll
     for (int a = 0; a < 6; a++) ng[a] = -acc[1 + a];
-    lm_plus(xx, ng, pg, quat);
+    lm_plus_t<QUAT>(xx, ng, pg);
     double m = 0;
+#pragma unroll
     for (int i = 0; i < na; i++) m = fmax(m, fabs(xx[i] - pg[i]));
     return m;
   };
 
   if (tid == 0) {
     x_cost = sh.cur[0];
-    for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + sqrt(Hget(sh.cur, a, a)));  // jacobi_scaling, fixed at iteration 0
+#pragma unroll
+    for (int a = 0; a < 6; a++) sh.scale[a] = 1.0 / (1.0 + sqrt(Hget(sh.cur, a, a)));  // jacobi_scaling, fixed at iteration 0
     gmax = grad_max(sh.x, sh.cur);
-    { double s = 0; for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i]; x_norm = sqrt(s); }
+    { double s = 0;
+#pragma unroll
+      for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i];
+      x_norm = sqrt(s); }
     current_cost = x_cost;
     it_cost = x_cost;
-    for (int i = 0; i < 7; i++) { best[i] = i < na ? sh.x[i] : 0; rec->x_in[i] = best[i]; }
-    for (int a = 0; a < 6; a++) { rec->g0[a] = sh.cur[1 + a]; for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(sh.cur, a, b); }
+#pragma unroll
+    for (int i = 0; i < 7; i++) { sh.best[i] = i < na ? sh.x[i] : 0.0; rec->x_in[i] = sh.best[i]; }
+#pragma unroll
+    for (int a = 0; a < 6; a++) { rec->g0[a] = sh.cur[1 + a];
+#pragma unroll
+      for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(sh.cur, a, b); }
     rec->initial_cost = x_cost;
-    rec->n_factors = sh.count;
+    rec->n_factors = n_valid;
   }
 
   for (;;) {
+    t_mark = clock64();
     if (tid == 0) {
-      int go = -1;  // -1: keep looping inside thread 0 (invalid step), 0: stop, 1: evaluate candidate
+      int go = -1;  // -1: invalid step, loop again inside thread 0; 0: stop; 1: evaluate the candidate
       while (go < 0) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (it_success && x_cost < minimum_cost) { minimum_cost = x_cost; for (int i = 0; i < na; i++) best[i] = sh.x[i]; }
+        if (it_success && x_cost < minimum_cost) { minimum_cost = x_cost;
+#pragma unroll
+          for (int i = 0; i < na; i++) sh.best[i] = sh.x[i]; }
         if (n_rec < kLmMaxTrace) {
           double* row = rec->trace[n_rec];
           row[0] = it_cost; row[1] = it_cost_change; row[2] = gmax; row[3] = it_step_norm; row[4] = it_rho; row[5] = radius;
@@ -308,22 +462,37 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
         if (gmax <= 1e-10) { termination = 1; go = 0; break; }
         if (radius <= 1e-32) { termination = 1; go = 0; break; }
         iteration++;
-        // ---- LevenbergMarquardtStrategy::ComputeStep on the normal equations of the scaled Jacobian
-        double Hs[6][6], gs[6];
-        for (int a = 0; a < 6; a++) { gs[a] = sh.cur[1 + a] * scale[a]; for (int b = 0; b < 6; b++) Hs[a][b] = Hget(sh.cur, a, b) * scale[a] * scale[b]; }
-        if (!reuse_diagonal) for (int a = 0; a < 6; a++) diagonal[a] = fmin(fmax(Hs[a][a], 1e-6), 1e32);
-        double M[6][6];
-        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) M[a][b] = Hs[a][b] + (a == b ? diagonal[a] / radius : 0.0);
-        double y[6], step[6];
-        bool ok = chol6_solve(M, gs, y);
-        for (int a = 0; a < 6; a++) if (!isfinite(y[a])) ok = false;
+        // ---- LevenbergMarquardtStrategy::ComputeStep on the normal equations of the column-scaled Jacobian
+        double gs[6], L[21], y[6], step[6], cur[kAcc], sc6[6];
+#pragma unroll
+        for (int i = 0; i < kAcc; i++) cur[i] = sh.cur[i];  // one batch of independent LDS reads
+#pragma unroll
+        for (int a = 0; a < 6; a++) sc6[a] = sh.scale[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++) gs[a] = cur[1 + a] * sc6[a];
+        if (!reuse_diagonal) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) sh.diagonal[a] = fmin(fmax(Hget(cur, a, a) * sc6[a] * sc6[a], 1e-6), 1e32);
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) L[LIDX(a, b)] = Hget(cur, a, b) * sc6[a] * sc6[b] + (a == b ? sh.diagonal[a] / radius : 0.0);
+        bool ok = chol6_solve(L, gs, y);
+#pragma unroll
+        for (int a = 0; a < 6; a++) ok = ok && isfinite(y[a]);
         reuse_diagonal = true;
         double model_cost_change = 0;
         it_valid = false;
         if (ok) {
           double sg = 0, sHs = 0;
+#pragma unroll
           for (int a = 0; a < 6; a++) step[a] = -y[a];
-          for (int a = 0; a < 6; a++) { sg += step[a] * gs[a]; double t = 0; for (int b = 0; b < 6; b++) t += Hs[a][b] * step[b]; sHs += step[a] * t; }
+#pragma unroll
+          for (int a = 0; a < 6; a++) { sg += step[a] * gs[a]; double t = 0;
+#pragma unroll
+            for (int b = 0; b < 6; b++) t += Hget(cur, a, b) * sc6[a] * sc6[b] * step[b];
+            sHs += step[a] * t; }
           model_cost_change = -sg - 0.5 * sHs;  // == -(Js s)^T (r + Js s / 2)
           it_valid = model_cost_change > 0.0;
         }
@@ -336,24 +505,31 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
         }
         num_invalid = 0;
         double delta[6];
-        for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
-        lm_plus(sh.x, delta, sh.xc, quat);
-        sh.cand[0] = model_cost_change;  // parked; overwritten by the evaluation after being read back below
+#pragma unroll
+        for (int a = 0; a < 6; a++) delta[a] = step[a] * sc6[a];
+        lm_plus_t<QUAT>(sh.x, delta, sh.xc);
+        sh.mcc = model_cost_change;
         go = 1;
       }
       sh.go = go;
     }
     __syncthreads();
+    cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
-    double model_cost_change = sh.cand[0];  // (only thread 0 uses it)
-    __syncthreads();
-    lm_evaluate(F, n_slots, sh.xc, huber_a, sh.part, sh.cand, false, &sh.count);
+    t_mark = clock64();
+    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false);
+    cyc_eval += clock64() - t_mark;
+    t_mark = clock64();
     if (tid == 0) {
       n_evals++;
+      const double model_cost_change = sh.mcc;
       double candidate_cost = sh.cand[0];
       if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
       bool stop = false;
-      { double s = 0; for (int i = 0; i < na; i++) s += (sh.x[i] - sh.xc[i]) * (sh.x[i] - sh.xc[i]); it_step_norm = sqrt(s); }
+      { double s = 0;
+#pragma unroll
+        for (int i = 0; i < na; i++) s += (sh.x[i] - sh.xc[i]) * (sh.x[i] - sh.xc[i]);
+        it_step_norm = sqrt(s); }
       if (it_step_norm <= 1e-8 * (x_norm + 1e-8)) { termination = 1; stop = true; }  // ParameterToleranceReached
       if (!stop) {
         it_cost_change = x_cost - candidate_cost;
@@ -362,13 +538,18 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
       if (!stop) {
         it_rho = candidate_cost >= DBL_MAX ? -DBL_MAX : (current_cost - candidate_cost) / model_cost_change;
         if (it_rho > 1e-3) {  // HandleSuccessfulStep
+#pragma unroll
           for (int i = 0; i < na; i++) sh.x[i] = sh.xc[i];
+#pragma unroll
           for (int i = 0; i < kAcc; i++) sh.cur[i] = sh.cand[i];
-          { double s = 0; for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i]; x_norm = sqrt(s); }
+          { double s = 0;
+#pragma unroll
+            for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i];
+            x_norm = sqrt(s); }
           x_cost = candidate_cost;
           gmax = grad_max(sh.x, sh.cur);
           it_cost = x_cost; it_success = true;
-          radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * it_rho - 1.0, 3.0));
+          { const double c = 2.0 * it_rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - c * c * c); }
           radius = fmin(1e16, radius);
           decrease_factor = 2.0;
           reuse_diagonal = false;
@@ -384,24 +565,66 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, const in
       sh.go = stop ? 0 : 1;
     }
     __syncthreads();
+    cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     __syncthreads();
   }
 
   if (tid == 0) {
-    for (int i = 0; i < na; i++) x_io[i] = best[i];
-    for (int i = 0; i < 7; i++) rec->x_out[i] = i < na ? best[i] : 0;
+#pragma unroll
+    for (int i = 0; i < na; i++) x_io[i] = sh.best[i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) rec->x_out[i] = i < na ? sh.best[i] : 0.0;
     rec->final_cost = minimum_cost;
     rec->n_iterations = n_rec < kLmMaxTrace ? n_rec : kLmMaxTrace;
     rec->termination = termination;
     rec->n_evals = n_evals;
+    rec->cyc[0] = (double)(t_pro - t_start); rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
+    rec->cyc[3] = (double)(clock64() - t_start);
   }
 }
 
-void lm_launch(hipStream_t st, const FactorTable& F, const int* d_n_slots, int n_slots_fixed, double* d_x, LMRecord* d_rec, int max_iters,
-               double huber_a, bool quat, const int* d_enable, ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve, dim3(1), dim3(kLmThreads), 0, st, F, d_n_slots, n_slots_fixed, d_x, d_rec, max_iters, huber_a, quat ? 1 : 0,
-                     d_enable);
+// Deterministic stream compaction of the accepted factors (slot order): one wavefront per 64-slot row, many rows in flight
+// across the chip (a single workgroup would expose the full HBM latency of every row).  Edge factors get
+// v = (b - a) / |a - b| precomputed in place of b (lidarFactor.hpp:37-42 divides by de.norm()).
+__global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, const int* enable_flag) {
+  if (enable_flag && *enable_flag == 0) return;
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (F.rowcnt[r] == 0) return;
+  int off = 0;
+  for (int q = lane; q < r; q += 64) off += F.rowcnt[q];
+  for (int d = 32; d > 0; d >>= 1) off += __shfl_xor(off, d);
+  const int cap = F.cap;
+  const int k = (r << 6) + lane;
+  const int ty = F.type[k];
+  double v[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { v[a] = F.p[a * cap + k]; v[3 + a] = F.A[a * cap + k]; v[6 + a] = F.B[a * cap + k]; }
+  const unsigned long long m = __ballot(ty != 0);
+  if (ty) {
+    const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+    F.ctype[o] = ty; F.cslot[o] = k;
+    if (quat && ty == 1) {
+      const double dx = v[3] - v[6], dy = v[4] - v[7], dz = v[5] - v[8];
+      const double dn = sqrt(dx * dx + dy * dy + dz * dz);
+      v[6] = -dx / dn; v[7] = -dy / dn; v[8] = -dz / dn;
+    } else if (quat && ty == 2) {  // LidarPlaneFactor (lp - j) . n  ->  n . lp + d with d = -(n . j); A := n, B.x := d
+      const double d = -(v[6] * v[3] + v[7] * v[4] + v[8] * v[5]);
+      v[3] = v[6]; v[4] = v[7]; v[5] = v[8]; v[6] = d;
+    }
+#pragma unroll
+    for (int a = 0; a < 9; a++) F.cpack[a * cap + o] = v[a];
+  }
+}
+
+void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
+               const int* d_enable, ProfHook* ph) {
+  const int edge_rows = n_edge_slots >> 6;
+  hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
+  if (quat)
+    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<true>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable);
+  else
+    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<false>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable);
 }
 
 }  // namespace vloam

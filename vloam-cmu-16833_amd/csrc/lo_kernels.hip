@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   }
   if (lane == 0) {
     F.type[slot] = type;
+    if (type) atomicAdd(&F.rowcnt[slot >> 6], 1);
     corr[slot * 4 + 0] = type ? i : -1;
     corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
   }

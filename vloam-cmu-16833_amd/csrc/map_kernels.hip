@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   }
   if (lane == 0) {
     F.type[slot] = type;
-    if (type) atomicAdd(&fr->n_factors[outer][kind], 1);
+    if (type) { atomicAdd(&fr->n_factors[outer][kind], 1); atomicAdd(&F.rowcnt[slot >> 6], 1); }
   }
 }
 
@@ -688,7 +688,9 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     F.cap = kMapFactorCap;
     ok = ok && dmalloc(allocs, st, &F.type, (size_t)F.cap) && dmalloc(allocs, st, &F.p, 3 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.A, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.B, 3 * (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap);
+         dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.ctype, (size_t)F.cap) &&
+         dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 9 * (size_t)F.cap) &&
+         dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1);
   }
   ok = ok && dmalloc(allocs, st, &m->rec, 2);
   ok = ok && dmalloc(allocs, st, &m->registered, (size_t)cfg.max_points);
@@ -723,7 +725,7 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
                  m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->F[outer], outer);
-    lm_launch(st, m->F[outer], nullptr, kMapFactorCap, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
+    lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
   hipLaunchKernelGGL(k_map_update, dim3(1), dim3(64), 0, st, ms, traj_row14);
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],

@@ -81,6 +81,7 @@ struct LMRecord {
   double termination;            // 0 iteration cap, 1 convergence, 2 failure
   double n_factors;              // residual blocks in the problem
   double n_evals;                // residual/Jacobian evaluations performed (E_o / E_m of SURVEY §8d)
+  double cyc[4];                 // shader-clock cycles: prologue (compaction), evaluations, thread-0 LM bookkeeping, whole kernel
   double trace[kLmMaxTrace][8];  // cost, cost_change, gradient_max_norm, step_norm, relative_decrease, radius, valid, successful
 };
 
@@ -97,6 +98,10 @@ struct FactorTable {
   double* A;      // [3][cap]
   double* B;      // [3][cap]
   double* resid;  // [3][cap] raw residuals at the initial point (parity hook)
+  int* ctype;     // [cap]    k_lm_solve's compacted copy (accepted factors only, slot order)
+  int* cslot;     // [cap]    original slot of every compacted factor
+  double* cpack;  // [9][cap] p, A, B of the compacted factors
+  int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
   int cap;
 };
 

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_u
   }
   const int cap = F.cap;
   F.type[j] = type;
+  if (type) atomicAdd(&F.rowcnt[j >> 6], 1);
   if (type == 4) {
     F.p[j] = obs[0]; F.p[cap + j] = obs[1]; F.p[2 * cap + j] = obs[2];
     F.A[j] = obs[3]; F.A[cap + j] = obs[4]; F.A[2 * cap + j] = 0;
@@ -231,7 +232,9 @@ vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, st
   v->F.cap = kVoMaxMatches;
   ok = ok && dmalloc(allocs, st, &v->F.type, kVoMaxMatches) && dmalloc(allocs, st, &v->F.p, 3 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.A, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.B, 3 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches);
+       dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.ctype, kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->F.cslot, kVoMaxMatches) && dmalloc(allocs, st, &v->F.cpack, 9 * kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->F.rowcnt, kVoMaxMatches / 64 + 1);
   ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->counters, 2);
   v->max_points = cfg.max_points;
@@ -269,7 +272,7 @@ vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, con
   if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
   hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib, v->maps[1 - v->i],
                      cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters);
-  lm_launch(st, v->F, nullptr, kVoMaxMatches, v->x, v->rec, 100, 0.1, false, nullptr);
+  lm_launch(st, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
   if (hipMemcpyAsync(x, v->x, sizeof(x), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
   int cnt[2];
   if (hipMemcpyAsync(cnt, v->counters, sizeof(cnt), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
