@@ -57,6 +57,7 @@ struct vloam_handle {
   LMRecord* lo_rec = nullptr;  // [2]
   double* lo_resid[2] = {nullptr, nullptr};
   double* traj = nullptr;      // [max_frames][14]
+  LoGrid grid[2];              // per ping-pong half: NN grid over that sweep's lessSharp / lessFlat
   // mapping + vo
   MapContext map;
   VOContext vo;
@@ -170,6 +171,12 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         ALLOC(h->sr[k].less_sharp, kMaxLessSharp);
         ALLOC(h->sr[k].less_flat, (size_t)P);
       }
+      for (int k = 0; k < 2; k++) {
+        h->grid[k].mask[0] = kGridBucketsCorner - 1; h->grid[k].mask[1] = kGridBucketsSurf - 1;
+        ALLOC(h->grid[k].start[0], kGridBucketsCorner + 2); ALLOC(h->grid[k].start[1], kGridBucketsSurf + 2);
+        ALLOC(h->grid[k].fill[0], kGridBucketsCorner); ALLOC(h->grid[k].fill[1], kGridBucketsSurf);
+        ALLOC(h->grid[k].items[0], kMaxLessSharp); ALLOC(h->grid[k].items[1], (size_t)P);
+      }
       ALLOC(h->lo, 1);
       vloam_status s = alloc_factor_table(h, &h->lo_F, kMaxLoFactors);
       if (s != VLOAM_OK) return s;
@@ -236,11 +243,13 @@ static vloam_status enqueue_lo(vloam_handle* h) {
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
-                      h->sr[prev].S, h->lo, F, h->lo_corr[outer], &h->prof);
+                      h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], &h->prof);
       lm_launch(h->stream, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
     }
   }
   lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);
+  // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
+  lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   h->stage = 2;

@@ -39,11 +39,58 @@ __device__ __forceinline__ float sqdist(float4 c, float3 s) {
   return d0 * d0 + d1 * d1 + d2 * d2;
 }
 
+__device__ __forceinline__ unsigned grid_hash(int ix, int iy, int iz) {
+  unsigned h = (unsigned)ix * 73856093u ^ (unsigned)iy * 19349663u ^ (unsigned)iz * 83492791u;
+  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+  return h;
+}
+__device__ __forceinline__ unsigned grid_bucket(float x, float y, float z, int mask) {
+  return grid_hash((int)floorf(x), (int)floorf(y), (int)floorf(z)) & (unsigned)mask;
+}
+
+__global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
+                                                       const FrameScalars* __restrict__ S, LoGrid G) {
+  const int kind = blockIdx.y;
+  const float4* pts = kind ? less_flat : less_sharp;
+  const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    atomicAdd(&G.start[kind][grid_bucket(p.x, p.y, p.z, G.mask[kind])], 1);
+  }
+}
+__global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
+  __shared__ int sums[1024];
+  const int kind = blockIdx.x, tid = threadIdx.x;
+  const int nb = G.mask[kind] + 1;
+  int* a = G.start[kind];
+  const int per = nb / 1024;
+  const int lo = tid * per;
+  int s = 0;
+  for (int k = 0; k < per; k++) s += a[lo + k];
+  sums[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? sums[tid - d] : 0; __syncthreads(); sums[tid] += v; __syncthreads(); }
+  int run = tid ? sums[tid - 1] : 0;
+  for (int k = 0; k < per; k++) { const int c = a[lo + k]; a[lo + k] = run; G.fill[kind][lo + k] = 0; run += c; }
+  if (tid == 1023) a[nb] = sums[1023];
+}
+__global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
+                                                         const FrameScalars* __restrict__ S, LoGrid G) {
+  const int kind = blockIdx.y;
+  const float4* pts = kind ? less_flat : less_sharp;
+  const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    const unsigned b = grid_bucket(p.x, p.y, p.z, G.mask[kind]);
+    G.items[kind][G.start[kind][b] + atomicAdd(&G.fill[kind][b], 1)] = i;
+  }
+}
+
 constexpr unsigned kBack = 0x40000000u;
 
 __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sharp, const float4* __restrict__ flat,
                                                   const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
-                                                  const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp,
+                                                  const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
                                                   const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,62 +104,100 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     const float3 sel = transform_to_start(pf, lo->para_q, lo->para_t);  // LO:268 / LO:355
     const float4* cand = is_corner ? CL : SL;
     const int n = is_corner ? Sp->n_less_sharp : Sp->n_less_flat;
-    // ---- exact nearest neighbour (pcl::KdTreeFLANN::nearestKSearch k = 1, flann::L2_Simple<float>), LO:269 / LO:356
+    // ---- exact nearest neighbour (pcl::KdTreeFLANN::nearestKSearch k = 1, flann::L2_Simple<float>), LO:269 / LO:356.
+    // Expanding search over the 1 m hash grid: after every cell within Chebyshev radius R of the query's cell has been
+    // scanned, any unseen point is farther than R metres; the search stops as soon as the best distance is inside that
+    // bound (or at R = 5, beyond which DISTANCE_SQ_THRESHOLD = 25 rejects the match anyway).  Key = (f32 d2 bits, index)
+    // so ties resolve to the lowest index irrespective of visiting order.
+    const int kind = is_corner ? 0 : 1;
+    const int* gstart = G.start[kind];
+    const int* gitems = G.items[kind];
+    const int gmask = G.mask[kind];
+    const int cx = (int)floorf(sel.x), cy = (int)floorf(sel.y), cz = (int)floorf(sel.z);
     u64 best = ~0ull;
-    for (int j = lane; j < n; j += 64) {
-      const float4 c = cand[j];
-      const float d0 = sel.x - c.x, d1 = sel.y - c.y, d2 = sel.z - c.z;
-      const float d = d0 * d0 + d1 * d1 + d2 * d2;
-      const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
-      best = key < best ? key : best;
+    for (int R = 1; R <= 5 && n > 0; R++) {
+      const int w = 2 * R + 1, ncell = w * w * w;
+      u64 loc = ~0ull;
+      for (int cc = lane; cc < ncell; cc += 64) {
+        const int ox = cc % w - R, oy = (cc / w) % w - R, oz = cc / (w * w) - R;
+        if (R > 1 && abs(ox) < R && abs(oy) < R && abs(oz) < R) continue;  // interior was scanned at the previous radius
+        const unsigned b = grid_hash(cx + ox, cy + oy, cz + oz) & (unsigned)gmask;
+        const int e = gstart[b + 1];
+        for (int t = gstart[b]; t < e; t++) {
+          const int j = gitems[t];
+          const float4 c = cand[j];
+          const float d0 = sel.x - c.x, d1 = sel.y - c.y, d2 = sel.z - c.z;
+          const float d = d0 * d0 + d1 * d1 + d2 * d2;
+          const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
+          loc = key < loc ? key : loc;
+        }
+      }
+      loc = wave_min_u64(loc);
+      best = loc < best ? loc : best;
+      const float bd = __uint_as_float((unsigned)(best >> 32));
+      const float bound = (float)(R * R) * 0.999999f;
+      if (best != ~0ull && bd <= bound) break;
     }
-    best = wave_min_u64(best);
     const float dmin = __uint_as_float((unsigned)(best >> 32));
     if (best != ~0ull && dmin < 25.0f) {  // DISTANCE_SQ_THRESHOLD, LO:272 / LO:359
       const int idx = (int)(best & 0xffffffffu);
       const int ringA = (int)cand[idx].w;  // closestPointScanID
       u64 b2 = ~0ull, b3 = ~0ull;
+      // Both walks stream the candidate array in trips of kU x 64 points whose loads are all issued before the first is
+      // examined (the stop test is applied afterwards, chunk by chunk, exactly in visiting order; points fetched beyond the
+      // stop are simply ignored) — otherwise every 64-point chunk would cost a full dependent memory round trip.
+      constexpr int kU = 8;
       // ---- increasing scan line, LO:279-300 / LO:368-391
       bool stopped = false;
-      for (int base = idx + 1; base < n && !stopped; base += 64) {
-        const int j = base + lane;
-        const bool in = j < n;
-        const float4 c = in ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int rj = (int)c.w;
-        const bool stop = in && ((double)rj > (double)ringA + 2.5);  // NEARBY_SCAN
-        const u64 sm = __ballot(stop);
-        const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
-        if (in && lane < first_stop) {
-          const float d = sqdist(c, sel);
-          const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)(j - idx);
-          if (d < 25.0f) {
-            if (is_corner) { if (!(rj <= ringA)) b2 = key < b2 ? key : b2; }
-            else if (rj <= ringA) b2 = key < b2 ? key : b2;
-            else b3 = key < b3 ? key : b3;
+      for (int base = idx + 1; base < n && !stopped; base += 64 * kU) {
+        float4 c[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const int j = base + u * 64 + lane; c[u] = j < n ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const int j = base + u * 64 + lane;
+          const bool in = j < n && !stopped;
+          const int rj = (int)c[u].w;
+          const bool stop = in && ((double)rj > (double)ringA + 2.5);  // NEARBY_SCAN
+          const u64 sm = __ballot(stop);
+          const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
+          if (in && lane < first_stop) {
+            const float d = sqdist(c[u], sel);
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)(j - idx);
+            if (d < 25.0f) {
+              if (is_corner) { if (!(rj <= ringA)) b2 = key < b2 ? key : b2; }
+              else if (rj <= ringA) b2 = key < b2 ? key : b2;
+              else b3 = key < b3 ? key : b3;
+            }
           }
+          stopped = stopped || sm != 0;
         }
-        stopped = sm != 0;
       }
       // ---- decreasing scan line, LO:303-324 / LO:394-417
       stopped = false;
-      for (int base = idx - 1; base >= 0 && !stopped; base -= 64) {
-        const int j = base - lane;
-        const bool in = j >= 0;
-        const float4 c = in ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int rj = (int)c.w;
-        const bool stop = in && ((double)rj < (double)ringA - 2.5);
-        const u64 sm = __ballot(stop);
-        const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
-        if (in && lane < first_stop) {
-          const float d = sqdist(c, sel);
-          const u64 key = ((u64)__float_as_uint(d) << 32) | (kBack + (unsigned)(idx - j));
-          if (d < 25.0f) {
-            if (is_corner) { if (!(rj >= ringA)) b2 = key < b2 ? key : b2; }
-            else if (rj >= ringA) b2 = key < b2 ? key : b2;
-            else b3 = key < b3 ? key : b3;
+      for (int base = idx - 1; base >= 0 && !stopped; base -= 64 * kU) {
+        float4 c[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const int j = base - u * 64 - lane; c[u] = j >= 0 ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const int j = base - u * 64 - lane;
+          const bool in = j >= 0 && !stopped;
+          const int rj = (int)c[u].w;
+          const bool stop = in && ((double)rj < (double)ringA - 2.5);
+          const u64 sm = __ballot(stop);
+          const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
+          if (in && lane < first_stop) {
+            const float d = sqdist(c[u], sel);
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (kBack + (unsigned)(idx - j));
+            if (d < 25.0f) {
+              if (is_corner) { if (!(rj >= ringA)) b2 = key < b2 ? key : b2; }
+              else if (rj >= ringA) b2 = key < b2 ? key : b2;
+              else b3 = key < b3 ? key : b3;
+            }
           }
+          stopped = stopped || sm != 0;
         }
-        stopped = sm != 0;
       }
       b2 = wave_min_u64(b2);
       b3 = wave_min_u64(b3);
@@ -196,8 +281,16 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
 }
 
 void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
-                     const FrameScalars* Sp, const LOState* lo, const FactorTable& F, int* corr, ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, lo, F, corr);
+                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr);
+}
+void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
+  (void)ph;
+  (void)hipMemsetAsync(G.start[0], 0, sizeof(int) * (size_t)(G.mask[0] + 2), st);
+  (void)hipMemsetAsync(G.start[1], 0, sizeof(int) * (size_t)(G.mask[1] + 2), st);
+  hipLaunchKernelGGL(k_lo_grid_count, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
+  hipLaunchKernelGGL(k_lo_grid_scan, dim3(2), dim3(1024), 0, st, G);
+  hipLaunchKernelGGL(k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
 }
 void lo_set_prior_launch(hipStream_t st, LOState* lo) { hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo); }
 void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {

@@ -15,6 +15,7 @@
 //   k_map_finalize  grid      per touched voxel: stack-ordered f32 accumulation == per-cube VoxelGrid re-filter (LM:689-702)
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 #include "lm_solve.h"
@@ -271,30 +272,65 @@ __global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __re
   }
 }
 
-// pass 4: one thread per output voxel: restore input order, f32 centroid, release the hash slot
+// pass 4: one wavefront per output voxel.  The atomics of pass 3 appended the members in arbitrary order; VoxelGrid sums in
+// input order, so each lane ranks its member by counting (readlane loop, cnt is ~4 on average), the member points are
+// fetched in parallel and then folded one by one in rank order (f32, exactly like CentroidPoint).
+__device__ __forceinline__ float rl(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
 __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                        DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
                                                        const MapFrame* __restrict__ fr) {
+  __shared__ int s_idx[4][1024];
+  __shared__ int s_sorted[4][1024];
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const float4* pts = kind ? surf_last : corner_last;
   float4* stack = kind ? stack1 : stack0;
   const int u = min(fr->n_stack[kind], D.stack_cap);
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < u; t += gridDim.x * 256) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = blockIdx.x * 4 + wave; t < u; t += gridDim.x * 4) {
     const int b0 = D.rank_off[t], cnt = D.rank_off[t + 1] - b0;
-    int* b = D.seg + b0;
-    for (int a = 1; a < cnt; a++) {  // the atomics appended in arbitrary order; VoxelGrid sums in input order
-      const int v = b[a];
-      int c = a - 1;
-      while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; }
-      b[c + 1] = v;
-    }
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    for (int a = 0; a < cnt; a++) { const float4 p = pts[b[a]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
-    const float nn = (float)cnt;
-    stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
-    const int s = D.rank_slot[t];
-    D.keys[s] = 0ull; D.cnt[s] = 0;  // leave the scratch hash clean for the next sweep
+    if (cnt <= 64) {
+      const int idx = lane < cnt ? D.seg[b0 + lane] : INT_MAX;
+      const float4 p = lane < cnt ? pts[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      int rank = 0;
+      for (int j = 0; j < cnt; j++) rank += __builtin_amdgcn_readlane(idx, j) < idx;
+      for (int r = 0; r < cnt; r++) {
+        const int src = __ffsll((long long)__ballot(rank == r && lane < cnt)) - 1;
+        sx += rl(p.x, src); sy += rl(p.y, src); sz += rl(p.z, src); si += rl(p.w, src);
+      }
+    } else if (cnt <= 1024) {
+      for (int j = lane; j < cnt; j += 64) s_idx[wave][j] = D.seg[b0 + j];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int j = lane; j < cnt; j += 64) {
+        const int mine = s_idx[wave][j];
+        int rank = 0;
+        for (int q = 0; q < cnt; q++) rank += s_idx[wave][q] < mine;
+        s_sorted[wave][rank] = mine;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int m = min(64, cnt - c0);
+        const float4 p = lane < m ? pts[s_sorted[wave][c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
+      }
+    } else {  // > 1024 sweep points in one voxel: serial fallback in global memory
+      int* b = D.seg + b0;
+      if (lane == 0) {
+        for (int a = 1; a < cnt; a++) { const int v = b[a]; int c = a - 1; while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; } b[c + 1] = v; }
+        for (int a = 0; a < cnt; a++) { const float4 p = pts[b[a]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
+      }
+      sx = rl(sx, 0); sy = rl(sy, 0); sz = rl(sz, 0); si = rl(si, 0);
+    }
+    if (lane == 0) {
+      const float nn = (float)cnt;
+      stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
+      const int s = D.rank_slot[t];
+      D.keys[s] = 0ull; D.cnt[s] = 0;  // leave the scratch hash clean for the next sweep
+    }
   }
 }
 
@@ -720,7 +756,7 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
                m->inv_leaf[0], m->inv_leaf[1], fr);
   hipLaunchKernelGGL(k_map_ds_sort, dim3(2), dim3(kEmitThreads), kStackCapSurf * sizeof(u64), st, m->ds[0], m->ds[1], fr, ms);
   hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1]);
-  hipLaunchKernelGGL(k_map_ds_reduce, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+  hipLaunchKernelGGL(k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
                      m->stack[0], m->stack[1], fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],

@@ -4,11 +4,10 @@
 // (cited per step as "SR:<line>").  Integer / index results are bit-identical to the CPU oracle; f32
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
 //
-// Kernels (one sweep = 6 launches, no host synchronisation):
+// Kernels (one sweep = 5 launches, no host synchronisation):
 //   k_sr_first_last  1 WG        first / last surviving point -> startOri / endOri            SR:157-176
 //   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
-//   k_sr_scan        1 WG        ring offsets, per-WG ring bases, scanStart/EndInd            SR:276-281
-//   k_sr_scatter     n/1024 WGs  relTime / intensity, stable scatter into ring-major cloud     SR:264-266
+//   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, 6 sector sorts (one wavefront each,
 //                                bitonic in LDS), greedy picks, lessFlat + VoxelGrid(0.2)        SR:288-439
 //   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
@@ -70,26 +69,28 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, FrameScalars* S) {
   __shared__ int s_first, s_last;
+  __shared__ float s_xy[4];
   const int tid = threadIdx.x;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
+  // both ends are fetched in the same trip; the winning threads hand their point over through LDS (no dependent reload)
   for (int base = 0; base < n; base += 1024) {
-    int i = base + tid;
-    if (i < n) {
-      float4 p = in[i];
-      if (sr_survives_s1(p.x, p.y, p.z, thres)) atomicMin(&s_first, i);
-    }
+    const int i = base + tid, j = n - 1 - base - tid;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+    const bool need_f = s_first == INT_MAX, need_l = s_last < 0;
+    if (need_f && i < n) p = in[i];
+    if (need_l && j >= 0) q = in[j];
+    const bool vf = need_f && i < n && sr_survives_s1(p.x, p.y, p.z, thres);
+    const bool vl = need_l && j >= 0 && sr_survives_s1(q.x, q.y, q.z, thres);
+    // i grows and j shrinks with the lane id: the lowest valid lane of a wavefront holds its min i / max j
+    const unsigned long long mf = __ballot(vf), ml = __ballot(vl);
+    if (vf && (tid & 63) == __ffsll((long long)mf) - 1) atomicMin(&s_first, i);
+    if (vl && (tid & 63) == __ffsll((long long)ml) - 1) atomicMax(&s_last, j);
     __syncthreads();
-    if (s_first != INT_MAX) break;
-  }
-  for (int base = n - 1; base >= 0; base -= 1024) {
-    int i = base - tid;
-    if (i >= 0) {
-      float4 p = in[i];
-      if (sr_survives_s1(p.x, p.y, p.z, thres)) atomicMax(&s_last, i);
-    }
+    if (vf && s_first == i) { s_xy[0] = p.x; s_xy[1] = p.y; }
+    if (vl && s_last == j) { s_xy[2] = q.x; s_xy[3] = q.y; }
     __syncthreads();
-    if (s_last >= 0) break;
+    if (s_first != INT_MAX && s_last >= 0) break;
   }
   if (tid == 0) {
     S->first_valid = s_first == INT_MAX ? -1 : s_first;
@@ -101,9 +102,8 @@ __global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict
       S->error = kErrEmpty;
       S->startOri = 0.f; S->endOri = 0.f;
     } else {
-      float4 a = in[s_first], b = in[s_last];
-      float startOri = -atan2f(a.y, a.x);                                      // SR:166
-      float endOri = (float)((double)(-atan2f(b.y, b.x)) + 2 * M_PI);          // SR:167
+      float startOri = -atan2f(s_xy[1], s_xy[0]);                                    // SR:166
+      float endOri = (float)((double)(-atan2f(s_xy[3], s_xy[2])) + 2 * M_PI);        // SR:167
       if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
       else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
       S->startOri = startOri; S->endOri = endOri;
@@ -151,40 +151,45 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sr_scan(int nblk, int N_SCANS, FrameScalars* S, const int* __restrict__ blockhist,
-                                                int* __restrict__ blockoff) {
-  __shared__ int tot[kMaxRings];
-  __shared__ int off[kMaxRings + 1];
-  const int r = threadIdx.x;
-  int t = 0;
-  for (int b = 0; b < nblk; b++) t += blockhist[b * kMaxRings + r];
-  tot[r] = t;
-  __syncthreads();
-  if (r == 0) {
-    int acc = 0;
-    for (int k = 0; k < kMaxRings; k++) { off[k] = acc; acc += tot[k]; }
-    off[kMaxRings] = acc;
-    S->N2 = acc;
-    S->ring_off[kMaxRings] = acc;
-  }
-  __syncthreads();
-  int run = off[r];
-  for (int b = 0; b < nblk; b++) { blockoff[b * kMaxRings + r] = run; run += blockhist[b * kMaxRings + r]; }
-  S->ring_count[r] = tot[r];
-  S->ring_off[r] = off[r];
-  // SR:276-281: rings >= N_SCANS are empty, so start/end equal those of an empty append
-  S->scanStartInd[r] = off[r] + 5;
-  S->scanEndInd[r] = off[r] + tot[r] - 6;
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __restrict__ in, int n, const FrameScalars* __restrict__ S,
+// Stable scatter into the ring-major cloud.  Every workgroup first derives, from the per-WG ring histograms of k_sr_label,
+// the ring offsets (SR:276-281) and its own base inside every ring — 32 KB of L2 reads per WG instead of a separate
+// single-workgroup scan kernel on the critical path.
+__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __restrict__ in, int n, FrameScalars* S,
                                                             const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
-                                                            const int* __restrict__ blockoff, float4* __restrict__ cloud) {
+                                                            const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud) {
   __shared__ int wcnt[kLabelBlock / 64][kMaxRings];
+  __shared__ int part_before[kLabelBlock / 64][kMaxRings], part_all[kLabelBlock / 64][kMaxRings];
+  __shared__ int ring_base[kMaxRings];   // ring offset + points of this ring in earlier workgroups
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = tid; k < (kLabelBlock / 64) * kMaxRings; k += kLabelBlock) (&wcnt[0][0])[k] = 0;
+  {
+    // wavefront w sums blocks w, w + 16, ... for ring = lane
+    int before = 0, all = 0;
+    for (int b = wave; b < nblk; b += kLabelBlock / 64) {
+      const int h = blockhist[b * kMaxRings + lane];
+      all += h;
+      if (b < (int)blockIdx.x) before += h;
+    }
+    part_before[wave][lane] = before;
+    part_all[wave][lane] = all;
+  }
   __syncthreads();
+  if (tid < kMaxRings) {
+    int before = 0, all = 0;
+    for (int w = 0; w < kLabelBlock / 64; w++) { before += part_before[w][tid]; all += part_all[w][tid]; }
+    // exclusive prefix of the ring totals across the 64 rings of this wavefront
+    int inc = all;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (tid >= d) inc += t; }
+    const int roff = inc - all;
+    ring_base[tid] = roff + before;
+    if (blockIdx.x == 0) {
+      S->ring_count[tid] = all;
+      S->ring_off[tid] = roff;
+      S->scanStartInd[tid] = roff + 5;         // SR:278
+      S->scanEndInd[tid] = roff + all - 6;     // SR:280
+      if (tid == kMaxRings - 1) { S->N2 = inc; S->ring_off[kMaxRings] = inc; }
+    }
+  }
   const int i = blockIdx.x * kLabelBlock + tid;
   int id = (i < n) ? (int)sid[i] : -1;
   // stable rank of this point among same-ring points of its wavefront
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __rest
   }
   __syncthreads();
   if (id >= 0) {
-    int base = blockoff[blockIdx.x * kMaxRings + id];
+    int base = ring_base[id];
     for (int w = 0; w < wave; w++) base += wcnt[w][id];
     const float startOri = S->startOri, endOri = S->endOri;
     float ori = ori_raw[i];
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   int* scan_tmp = iscratch + kMaxRingLen;            // [kRingThreads]
   unsigned char* picked = (unsigned char*)(scan_tmp + kRingThreads);  // [kMaxRingLen]
   signed char* label = (signed char*)(picked + kMaxRingLen);         // [kMaxRingLen]
-  int* s_sp = (int*)(label + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
+  unsigned char* gap = (unsigned char*)(label + kMaxRingLen);        // [kMaxRingLen]
+  int* s_sp = (int*)(gap + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
   int* s_ep = s_sp + 8;                                              // [kSectors]    region so its base stays 16-B aligned)
   float* s_red = (float*)(s_ep + 8);                                 // [6]
   int* s_ncand_p = (int*)(s_red + 8);
@@ -342,7 +348,21 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   }
   __syncthreads();
 
-  // ---- greedy picks, sector after sector (neighbour suppression leaks into the next sector)
+  // ---- neighbour-suppression reach of every point, computed once in parallel (SR:353-376 walks outwards while consecutive
+  // points are closer than sqrt(0.05) m): fwd[l] / bwd[l] = how many of l+1..l+5 / l-1..l-5 a pick at l would mark.
+  // gapf[l] = 1 when dist2(p[l+1], p[l]) > 0.05 (stored in the `label` scratch bytes' sibling array `gap`).
+  for (int l = tid; l < len; l += kRingThreads) {
+    unsigned char g = 1;
+    if (l + 1 < len) {
+      const float dx = px[l + 1] - px[l], dy = py[l + 1] - py[l], dz = pz[l + 1] - pz[l];
+      g = ((double)(dx * dx + dy * dy + dz * dz) > 0.05) ? 1 : 0;
+    }
+    gap[l] = g;
+  }
+  __syncthreads();
+
+  // ---- greedy picks, sector after sector (the suppression leaks into the next sector).  One wavefront per sector; 64 sorted
+  // candidates per trip live in registers, a pick knocks out the lanes inside its reach without re-reading LDS.
   for (int s = 0; s < kSectors; s++) {
     if (wave == s) {
       const int seclen = s_ep[s] - s_sp[s] + 1;
@@ -351,6 +371,12 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
       int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
       int n_sharp = 0, n_less = 0, n_flat = 0;
+      auto reach = [&](int l, int* a, int* b) {  // candidates are >= 5 away from both ring ends, so l +- 5 is in range
+        int f = 0, k = 0;
+        while (f < 5 && gap[l + f] == 0) f++;       // SR:353-364
+        while (k < 5 && gap[l - 1 - k] == 0) k++;   // SR:365-376
+        *a = k; *b = f;
+      };
       // SR:327-378, descending curvature
       int largestPickedNum = 0;
       bool done = false;
@@ -359,16 +385,18 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         const bool in = pos >= 0;
         const u64 key = in ? K[pos] : 0ull;
         const float c = __uint_as_float((unsigned)(key >> 32));
-        const int l = (int)(key & 0xffffffffu);
-        bool cand = in && ((double)c > 0.1);
+        const int l = in ? (int)(key & 0xffffffffu) : 8;
+        const bool cand = in && ((double)c > 0.1);
         const u64 m = __ballot(cand);
         if (m == 0) break;
+        int ra, rb;
+        reach(l, &ra, &rb);
+        bool elig = cand && picked[l] == 0;
         while (true) {
-          const bool elig = cand && picked[l] == 0;
           const u64 e = __ballot(elig);
           if (e == 0) break;
           const int f = __ffsll((long long)e) - 1;
-          const int lf = __shfl(l, f);
+          const int lf = __builtin_amdgcn_readlane(l, f);
           largestPickedNum++;
           if (largestPickedNum <= 2) {
             if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; }
@@ -380,11 +408,12 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
             done = true;
             break;
           }
-          if (lane == 0) { picked[lf] = 1; sr_spread(lf, px, py, pz, picked); }
-          lds_fence_wave();
-          cand = cand && lane > f;
+          const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
+          if (lane <= hi_m - lo_m) picked[lo_m + lane] = 1;   // at most 11 marks
+          elig = elig && (l < lo_m || l > hi_m);
         }
         if (m != __ballot(in)) done = true;  // sorted: everything further down is <= 0.1
+        lds_fence_wave();
       }
       // SR:380-422, ascending curvature
       int smallestPickedNum = 0;
@@ -394,25 +423,28 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         const bool in = pos < seclen;
         const u64 key = in ? K[pos] : 0ull;
         const float c = __uint_as_float((unsigned)(key >> 32));
-        const int l = (int)(key & 0xffffffffu);
-        bool cand = in && ((double)c < 0.1);
+        const int l = in ? (int)(key & 0xffffffffu) : 8;
+        const bool cand = in && ((double)c < 0.1);
         const u64 m = __ballot(cand);
         if (m == 0) break;
+        int ra, rb;
+        reach(l, &ra, &rb);
+        bool elig = cand && picked[l] == 0;
         while (true) {
-          const bool elig = cand && picked[l] == 0;
           const u64 e = __ballot(elig);
           if (e == 0) break;
           const int f = __ffsll((long long)e) - 1;
-          const int lf = __shfl(l, f);
+          const int lf = __builtin_amdgcn_readlane(l, f);
           if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; }
           n_flat++;
           smallestPickedNum++;
           if (smallestPickedNum >= 4) { done = true; break; }  // the 4th flat point is emitted but not suppressed (SR:390-394)
-          if (lane == 0) { picked[lf] = 1; sr_spread(lf, px, py, pz, picked); }
-          lds_fence_wave();
-          cand = cand && lane > f;
+          const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
+          if (lane <= hi_m - lo_m) picked[lo_m + lane] = 1;
+          elig = elig && (l < lo_m || l > hi_m);
         }
         if (m != __ballot(in)) done = true;
+        lds_fence_wave();
       }
       if (lane == 0) { S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat; }
     }
@@ -577,7 +609,7 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
 // ------------------------------------------------------------------------------------------------
 size_t sr_ring_smem_bytes() {
   return sizeof(float) * 4 * kMaxRingLen + sizeof(u64) * kSectors * kSectCap + sizeof(int) * (kMaxRingLen + kRingThreads) +
-         2 * kMaxRingLen + 32 * sizeof(int);
+         3 * kMaxRingLen + 32 * sizeof(int);
 }
 
 hipError_t sr_init() {
@@ -588,8 +620,7 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
   VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(1), dim3(1024), 0, st, d_in, n, min_range, b.S);
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
-  VLOAM_LAUNCH(ph, kKSrScan, st, k_sr_scan, dim3(1), dim3(64), 0, st, nblk, N_SCANS, b.S, b.blockhist, b.blockoff);
-  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockoff, b.cloud);
+  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud);
   VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                      debug ? b.dbg_label : nullptr);
