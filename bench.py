@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--azimuth", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=48, help="sweeps of the same sequence timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
+                    help="extra leg: this many independent sequences driven concurrently on ONE GPU (own handle + stream each); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +145,37 @@ def main():
     if dist is not None:
         trajectories = multi.gather_trajectories(dist, traj, W + K + 8, device="cuda")
 
+    # ---- extra leg (reported separately, never the headline): multi-session throughput of one GPU.  A single sequence is a
+    # chain of dependent launches (latency bound); independent sessions on separate streams overlap those latencies.
+    multi_session = None
+    if args.sessions > 1 and world == 1:
+        import threading
+        B = args.sessions
+        hs = [vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
+              for _ in range(B)]
+
+        def drive(hh, lo, hi):
+            for kk in range(lo, hi):
+                hh.process_scan_device(base_ptr + kk * stride, n_pts)
+            hh.sync()
+
+        ths = [threading.Thread(target=drive, args=(hh, 0, W)) for hh in hs]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        torch.cuda.synchronize()
+        m0 = time.perf_counter()
+        ths = [threading.Thread(target=drive, args=(hh, W, W + K)) for hh in hs]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        torch.cuda.synchronize()
+        m1 = time.perf_counter()
+        same = all(np.array_equal(hh.trajectory(), traj) for hh in hs)
+        multi_session = {"sessions": B, "value": B * K / (m1 - m0), "unit": "scans/s", "ms_per_step_all_sessions": 1e3 * (m1 - m0) / K,
+                         "trajectories_identical_to_single_session": bool(same),
+                         "note": "B independent handles/streams on one GPU replaying the same sweeps; not the headline value"}
+        for hh in hs:
+            hh.close()
+
     out = None
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)
@@ -164,6 +197,8 @@ def main():
                          "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
             "counts_last_sweep": counts,
         }
+        if multi_session:
+            out["multi_session"] = multi_session
         if world == 1 and not args.no_cpu_baseline:
             import orc
             ns = min(args.cpu_sample, W + K)

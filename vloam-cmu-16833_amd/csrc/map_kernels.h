@@ -29,6 +29,10 @@ struct VoxelTable {       // structure of arrays, open addressing, linear probin
   int* pend_cnt;             // stack points queued this sweep
   int* pend;                 // [slots][kPendCap] stack indices
   unsigned mask;             // slots - 1
+  // occupancy index: one entry per 4 x 4 x 4 block of voxels of a cube -> 64-bit mask of the voxels that exist.
+  // The 5-NN search probes ~27 blocks instead of ~343 mostly empty voxels.
+  ulonglong2* blk;           // {key (0 = empty), mask}: one 16-byte load per probe
+  unsigned bslots_mask;      // block slots - 1
 };
 
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
@@ -65,6 +69,7 @@ struct MapContext {
   int* deferred[2] = {nullptr, nullptr};      // slots holding raw points outside the valid block
   FactorTable F[2];        // one per outer round (kept for the parity hooks)
   LMRecord* rec = nullptr; // [2]
+  int* nn = nullptr;       // [kMapFactorCap][5] hash slots of the 5 nearest map voxels of every stack point (-1: rejected)
   float4* registered = nullptr;  // full-resolution cloud in the map frame, on request
   int max_points = 0;
   float inv_leaf[2] = {0, 0};

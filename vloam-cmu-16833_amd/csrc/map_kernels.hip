@@ -335,6 +335,11 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- data association
+__device__ __forceinline__ void lds_sync_wave() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct Top5 {
   float d[5];
   unsigned id[5];
@@ -357,42 +362,37 @@ struct Top5 {
   }
 };
 
-// cyclic Jacobi, identical operation order to oracle/orc_math.h sym_eig3 (Eigen::SelfAdjointEigenSolver stand-in, LM:500)
-__device__ void sym_eig3(const double A_[3][3], double evals[3], double evecs[3][3]) {
-  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = A_[i][j];
-  for (int sweep = 0; sweep < 64; sweep++) {
-    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-    const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
-    if (off <= 1e-40 * diag || off == 0.0) break;
+// Largest two eigenvalues + unit eigenvector of the largest, of a symmetric 3x3 (the only outputs LM:500-506 uses of
+// Eigen::SelfAdjointEigenSolver).  Closed form (trigonometric solution of the characteristic cubic; eigenvector from the
+// best-conditioned cross product of two rows of A - lambda I): ~2 us of dependent f64 latency instead of ~25 us for the
+// iterative sweeps the CPU oracle runs.  Agrees with the oracle's Jacobi iteration to ~1e-13 for the well-separated
+// spectra of line features; the eigenvector's sign is arbitrary in both.
+__device__ void sym_eig3_top(const double A[3][3], double* e_mid, double* e_max, double v[3]) {
+  const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+  const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+  const double d0 = A[0][0] - q, d1 = A[1][1] - q, d2 = A[2][2] - q;
+  const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1;
+  if (!(p2 > 0.0)) { *e_mid = q; *e_max = q; v[0] = 1; v[1] = 0; v[2] = 0; return; }
+  const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
+  const double b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = A[0][1] * ip, b02 = A[0][2] * ip, b12 = A[1][2] * ip;
+  double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+  r = fmin(1.0, fmax(-1.0, r));
+  const double phi = acos(r) / 3.0;
+  const double emax = q + 2.0 * p * cos(phi);
+  const double emin = q + 2.0 * p * cos(phi + 2.0943951023931954923);  // + 2 pi / 3
+  *e_max = emax;
+  *e_mid = 3.0 * q - emax - emin;
+  const double r0[3] = {A[0][0] - emax, A[0][1], A[0][2]}, r1[3] = {A[0][1], A[1][1] - emax, A[1][2]}, r2[3] = {A[0][2], A[1][2], A[2][2] - emax};
+  const double c0[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+  const double c1[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+  const double c2[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  const double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2], n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2],
+               n2 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+  const bool u0 = n0 >= n1 && n0 >= n2, u1 = !u0 && n1 >= n2;
+  const double nn = u0 ? n0 : (u1 ? n1 : n2);
+  const double inv = 1.0 / sqrt(nn);
 #pragma unroll
-    for (int p = 0; p < 2; p++)
-#pragma unroll
-      for (int q = p + 1; q < 3; q++) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
-      }
-  }
-  int i0 = 0, i1 = 1, i2 = 2;
-  const double d[3] = {A[0][0], A[1][1], A[2][2]};
-  // stable 3-element sort by eigenvalue (std::sort in the oracle; distinct values in practice)
-  if (d[i1] < d[i0]) { int t = i0; i0 = i1; i1 = t; }
-  if (d[i2] < d[i1]) { int t = i1; i1 = i2; i2 = t; }
-  if (d[i1] < d[i0]) { int t = i0; i0 = i1; i1 = t; }
-  const int idx[3] = {i0, i1, i2};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    evals[k] = d[idx[k]];
-    for (int r = 0; r < 3; r++) evecs[r][k] = V[r][idx[k]];
-  }
+  for (int k = 0; k < 3; k++) v[k] = (u0 ? c0[k] : (u1 ? c1[k] : c2[k])) * inv;
 }
 
 // Householder least squares, identical operation order to oracle/orc_math.h householder_ls (m = 5, n = 3; LM:557)
@@ -434,126 +434,224 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
 }
 
 __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
-                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
-                                                   FactorTable F, int outer) {
+                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms,
+                                                   int* __restrict__ nn) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (slot >= kMapFactorCap) return;
   const int kind = slot < kStackCapCorner ? 0 : 1;
   const int i = kind ? slot - kStackCapCorner : slot;
   const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
-  int type = 0;
   if (ms->do_optimize && i < nst) {
     const VoxelTable T = kind ? T1 : T0;
     const float inv = kind ? inv1 : inv0;
     const float4 pointOri = kind ? stack1[i] : stack0[i];
     const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
     const float q3[3] = {sel.x, sel.y, sel.z};
-    // cells of the global lattice that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547)
-    int lo[3], cnt[3];
-    for (int a = 0; a < 3; a++) {
-      lo[a] = (int)floorf((q3[a] - 1.001f) * inv);
-      cnt[a] = (int)floorf((q3[a] + 1.001f) * inv) - lo[a] + 1;
-    }
-    const int cI = ms->centerCube[0] - ms->cenW, cJ = ms->centerCube[1] - ms->cenH, cK = ms->centerCube[2] - ms->cenD;  // absolute centre cube
+    // Voxels of the global lattice that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547).
+    // Per axis the voxel index range [lo, hi] is cut into (cube, 4-voxel block) pieces — a voxel that straddles a 50 m cube face
+    // exists once per cube — each with the 4-bit mask of its voxels inside the range.  Phase 1: one lane per candidate block
+    // fetches its occupancy mask.  Phase 2: the existing voxels of all blocks are flattened into an LDS work list so that
+    // phase 3 fetches one voxel per lane (all probes in flight together instead of a per-lane chain).
+    const int cenv[3] = {ms->cenW, ms->cenH, ms->cenD};
+    const int ctr[3] = {ms->centerCube[0] - cenv[0], ms->centerCube[1] - cenv[1], ms->centerCube[2] - cenv[2]};  // absolute centre cube
+    const int halfw[3] = {2, 2, 1};   // valid block: 5 x 5 x 3 cubes (LM:404-420)
+    const int wdim[3] = {kCubeW, kCubeH, kCubeD};
     const double leaf = 1.0 / (double)inv;
-    Top5 top;
-    top.init();
-    // every cell is probed once per cube it can straddle (25 m is not a multiple of the leaf)
-    const int ncell = cnt[0] * cnt[1] * cnt[2];
-    for (int cc = lane; cc < ncell; cc += 64) {
-      const int ix = lo[0] + cc % cnt[0], iy = lo[1] + (cc / cnt[0]) % cnt[1], iz = lo[2] + cc / (cnt[0] * cnt[1]);
-      // conservative cube range of the cell (1 mm margin; the exact rule is applied where points are inserted)
-      const int ax0 = cube_lo((double)ix * leaf), ax1 = cube_hi((double)(ix + 1) * leaf);
-      const int ay0 = cube_lo((double)iy * leaf), ay1 = cube_hi((double)(iy + 1) * leaf);
-      const int az0 = cube_lo((double)iz * leaf), az1 = cube_hi((double)(iz + 1) * leaf);
-      for (int Ak = az0; Ak <= az1; Ak++)
-        for (int Aj = ay0; Aj <= ay1; Aj++)
-          for (int Ai = ax0; Ai <= ax1; Ai++) {
-            // only cubes of the valid 5 x 5 x 3 block inside the window are gathered (LM:404-420)
-            if (abs(Ai - cI) > 2 || abs(Aj - cJ) > 2 || abs(Ak - cK) > 1) continue;
-            const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
-            if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) continue;
-            const int lx = ix - cube_voxel_base(Ai, inv), ly = iy - cube_voxel_base(Aj, inv), lz = iz - cube_voxel_base(Ak, inv);
-            if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u) continue;
-            const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
-            unsigned s = (unsigned)mix64(key) & T.mask;
-            for (;;) {
-              const u64 k = T.keys[s];
-              if (k == 0ull) break;
-              if (k == key) {
-                const int n = T.count[s];
-                if (n > 0) {
-                  float4 p = T.sum[s];
-                  if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
-                  const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
-                  top.push(d0 * d0 + d1 * d1 + d2 * d2, s);
-                }
-                break;
-              }
-              s = (s + 1) & T.mask;
-            }
-          }
+    constexpr int kMaxPieces = 8;
+    int pa[3][kMaxPieces], pb[3][kMaxPieces], pm[3][kMaxPieces], np_[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int lo = (int)floorf((q3[a] - 1.001f) * inv), hi = (int)floorf((q3[a] + 1.001f) * inv);
+      const int Amin = cube_lo((double)lo * leaf), Amax = cube_hi((double)(hi + 1) * leaf);
+      int n = 0;
+      for (int A = Amin; A <= Amax; A++) {
+        if (abs(A - ctr[a]) > halfw[a]) continue;
+        const int wv = A + cenv[a];
+        if (wv < 0 || wv >= wdim[a]) continue;
+        // voxels that can hold points of cube A: from the voxel containing its lower face to the one containing its upper face
+        const int base = cube_voxel_base(A, inv);
+        const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
+        for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2) && ia <= ib; blk++) {
+          if (n >= kMaxPieces || (unsigned)blk > 63u) break;
+          int m4 = 0;
+#pragma unroll
+          for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
+          // wave-uniform by construction: keep the piece tables in scalar registers (they would otherwise cost ~72 VGPRs)
+          pa[a][n] = __builtin_amdgcn_readfirstlane(A); pb[a][n] = __builtin_amdgcn_readfirstlane(blk);
+          pm[a][n] = __builtin_amdgcn_readfirstlane(m4); n++;
+        }
+      }
+      np_[a] = __builtin_amdgcn_readfirstlane(n);
     }
-    // merge the per-lane lists: five rounds of wavefront-min extraction
+    __shared__ u64 s_cand[4][256];
+    __shared__ u64 s_best[4][8];
+    u64* my_cand = s_cand[threadIdx.x >> 6];
+    const int nblocks = np_[0] * np_[1] * np_[2];
+    int produced = 0;   // wave-uniform running size of the work list
+    for (int bb0 = 0; bb0 < nblocks; bb0 += 64) {
+      const int bb = bb0 + lane;
+      u64 occ = 0ull;
+      int Ai = 0, bx = 0, Aj = 0, by = 0, Ak = 0, bz = 0;
+      if (bb < nblocks) {
+        const int ex = bb % np_[0], ey = (bb / np_[0]) % np_[1], ez = bb / (np_[0] * np_[1]);
+        int mx = 0, my = 0, mz = 0;
+#pragma unroll
+        for (int e = 0; e < kMaxPieces; e++) {  // select this lane's pieces without dynamic register indexing
+          if (e == ex) { Ai = pa[0][e]; bx = pb[0][e]; mx = pm[0][e]; }
+          if (e == ey) { Aj = pa[1][e]; by = pb[1][e]; my = pm[1][e]; }
+          if (e == ez) { Ak = pa[2][e]; bz = pb[2][e]; mz = pm[2][e]; }
+        }
+        const u64 bkey = pack_key(Ai, Aj, Ak, bx, by, bz) | (1ull << 63);
+        unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
+        for (;;) {
+          const ulonglong2 e = T.blk[bs];
+          if (e.x == 0ull) break;
+          if (e.x == bkey) { occ = e.y; break; }
+          bs = (bs + 1) & T.bslots_mask;
+        }
+        // voxels of the block inside the search box: bit = z * 16 + y * 4 + x
+        const u64 ex4 = (u64)mx * 0x1111111111111111ull;
+        const u64 ey4 = ((u64)((my & 1) * 0xF) | ((u64)(((my >> 1) & 1) * 0xF) << 4) | ((u64)(((my >> 2) & 1) * 0xF) << 8) | ((u64)(((my >> 3) & 1) * 0xF) << 12)) * 0x0001000100010001ull;
+        const u64 ez4 = ((mz & 1) ? 0xFFFFull : 0ull) | ((mz & 2) ? 0xFFFFull << 16 : 0ull) | ((mz & 4) ? 0xFFFFull << 32 : 0ull) | ((mz & 8) ? 0xFFFFull << 48 : 0ull);
+        occ &= ex4 & ey4 & ez4;
+      }
+      // flatten: exclusive prefix of the per-lane voxel counts, then every lane appends its voxel keys
+      const int mine = __popcll(occ);
+      int inc = mine;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      int o = produced + inc - mine;
+      while (occ) {
+        const int bit = __ffsll((long long)occ) - 1;
+        occ &= occ - 1;
+        if (o < 256) my_cand[o] = pack_key(Ai, Aj, Ak, (bx << 2) | (bit & 3), (by << 2) | ((bit >> 2) & 3), (bz << 2) | (bit >> 4));
+        o++;
+      }
+      produced += __shfl(inc, 63);
+    }
+    lds_sync_wave();
+    const int ncand = min(produced, 256);
+    // phase 3: one voxel per lane and trip: probe, fetch the centroid, squared distance -> key (f32 d2 bits | slot) back into the list
+    for (int w = lane; w < ncand; w += 64) {
+      const u64 key = my_cand[w];
+      unsigned s = (unsigned)mix64(key) & T.mask;
+      u64 out = ~0ull;
+      for (;;) {
+        const u64 k = T.keys[s];
+        if (k == 0ull) break;
+        if (k == key) {
+          const int n = T.count[s];
+          float4 p = T.sum[s];
+          if (n > 0) {
+            if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+            const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
+            out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | s;
+          }
+          break;
+        }
+        s = (s + 1) & T.mask;
+      }
+      my_cand[w] = out;
+    }
+    u64* my_best = s_best[threadIdx.x >> 6];
+    if (lane < 8) my_best[lane] = ~0ull;
+    lds_sync_wave();
+    // phase 4: the five smallest keys by rank counting (keys are unique: distinct slots); ~30 candidates on average
+    for (int w = lane; w < ncand; w += 64) {
+      const u64 mine = my_cand[w];
+      if (mine == ~0ull) continue;
+      int rank = 0;
+      for (int t = 0; t < ncand; t++) rank += my_cand[t] < mine;
+      if (rank < 5) my_best[rank] = mine;
+    }
+    lds_sync_wave();
     float nd[5];
     unsigned ns[5];
+#pragma unroll
     for (int r = 0; r < 5; r++) {
-      u64 key = ((u64)__float_as_uint(top.d[0]) << 32) | top.id[0];
-      u64 m = key;
-      for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_xor(m, d); m = o < m ? o : m; }
+      const u64 m = my_best[r];
       nd[r] = __uint_as_float((unsigned)(m >> 32));
       ns[r] = (unsigned)(m & 0xffffffffu);
-      if (key == m && top.id[0] != 0xffffffffu) top.pop();
     }
-    if (ns[4] != 0xffffffffu && nd[4] < 1.0f) {
-      double P[5][3];
+    // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in
+    // registers and pure per-query math, so they should not hold 64 lanes and ~130 VGPRs hostage here)
+    if (lane == 0) {
+      const bool ok = ns[4] != 0xffffffffu && nd[4] < 1.0f;  // LM:479 / LM:547
+#pragma unroll
+      for (int j = 0; j < 5; j++) nn[slot * 5 + j] = ok ? (int)ns[j] : -1;
+    }
+  } else if (lane == 0) {
+    nn[slot * 5] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
+                                                 VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr, const int* __restrict__ nn,
+                                                 FactorTable F, int outer) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= kMapFactorCap) return;
+  const int kind = slot < kStackCapCorner ? 0 : 1;
+  const int i = kind ? slot - kStackCapCorner : slot;
+  const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
+  int type = 0;
+  if (ms->do_optimize && i < nst && nn[slot * 5] >= 0) {
+    const VoxelTable T = kind ? T1 : T0;
+    const float4 pointOri = kind ? stack1[i] : stack0[i];
+    double P[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int s = nn[slot * 5 + j];
+      const int n = T.count[s];
+      float4 p = T.sum[s];
+      if (n > 1) { const float nnf = (float)n; p.x = p.x / nnf; p.y = p.y / nnf; p.z = p.z / nnf; }
+      P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
+    }
+    double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
+    if (kind == 0) {  // LM:481-517
+      double center[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) center[a] = center[a] + P[j][a];
+      for (int a = 0; a < 3; a++) center[a] = center[a] / 5.0;
+      double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
       for (int j = 0; j < 5; j++) {
-        const int n = T.count[ns[j]];
-        float4 p = T.sum[ns[j]];
-        if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
-        P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
+        const double z[3] = {P[j][0] - center[0], P[j][1] - center[1], P[j][2] - center[2]};
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a][b] = cov[a][b] + z[a] * z[b];
       }
-      double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
-      if (kind == 0) {  // LM:481-517
-        double center[3] = {0, 0, 0};
-        for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) center[a] = center[a] + P[j][a];
-        for (int a = 0; a < 3; a++) center[a] = center[a] / 5.0;
-        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int j = 0; j < 5; j++) {
-          const double z[3] = {P[j][0] - center[0], P[j][1] - center[1], P[j][2] - center[2]};
-          for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a][b] = cov[a][b] + z[a] * z[b];
-        }
-        double ev[3], evec[3][3];
-        sym_eig3(cov, ev, evec);
-        if (ev[2] > 3 * ev[1]) {
-          for (int a = 0; a < 3; a++) { A3[a] = 0.1 * evec[a][2] + center[a]; B3[a] = -0.1 * evec[a][2] + center[a]; }
-          type = 1;
-        }
-      } else {          // LM:545-581
-        double matA0[15], matB0[5], nrm[3];
-        for (int j = 0; j < 5; j++) { matA0[j * 3] = P[j][0]; matA0[j * 3 + 1] = P[j][1]; matA0[j * 3 + 2] = P[j][2]; matB0[j] = -1.0; }
-        if (householder_ls_5x3(matA0, matB0, nrm)) {
-          const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-          const double negative_OA_dot_norm = 1 / nn;
-          nrm[0] = nrm[0] / nn; nrm[1] = nrm[1] / nn; nrm[2] = nrm[2] / nn;
-          bool planeValid = true;
-          for (int j = 0; j < 5; j++)
-            if (fabs(nrm[0] * P[j][0] + nrm[1] * P[j][1] + nrm[2] * P[j][2] + negative_OA_dot_norm) > 0.2) { planeValid = false; break; }
-          if (planeValid) { A3[0] = nrm[0]; A3[1] = nrm[1]; A3[2] = nrm[2]; B3[0] = negative_OA_dot_norm; type = 3; }
-        }
+      double e_mid, e_max, dir[3];
+      sym_eig3_top(cov, &e_mid, &e_max, dir);
+      if (e_max > 3 * e_mid) {
+        for (int a = 0; a < 3; a++) { A3[a] = 0.1 * dir[a] + center[a]; B3[a] = -0.1 * dir[a] + center[a]; }
+        type = 1;
       }
-      if (type && lane == 0) {
-        const int cap = F.cap;
-        F.p[slot] = pointOri.x; F.p[cap + slot] = pointOri.y; F.p[2 * cap + slot] = pointOri.z;
-        F.A[slot] = A3[0]; F.A[cap + slot] = A3[1]; F.A[2 * cap + slot] = A3[2];
-        F.B[slot] = B3[0]; F.B[cap + slot] = B3[1]; F.B[2 * cap + slot] = B3[2];
+    } else {          // LM:545-581
+      double matA0[15], matB0[5], nrm[3];
+#pragma unroll
+      for (int j = 0; j < 5; j++) { matA0[j * 3] = P[j][0]; matA0[j * 3 + 1] = P[j][1]; matA0[j * 3 + 2] = P[j][2]; matB0[j] = -1.0; }
+      if (householder_ls_5x3(matA0, matB0, nrm)) {
+        const double nn_ = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        const double negative_OA_dot_norm = 1 / nn_;
+        nrm[0] = nrm[0] / nn_; nrm[1] = nrm[1] / nn_; nrm[2] = nrm[2] / nn_;
+        bool planeValid = true;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+          if (fabs(nrm[0] * P[j][0] + nrm[1] * P[j][1] + nrm[2] * P[j][2] + negative_OA_dot_norm) > 0.2) planeValid = false;
+        if (planeValid) { A3[0] = nrm[0]; A3[1] = nrm[1]; A3[2] = nrm[2]; B3[0] = negative_OA_dot_norm; type = 3; }
       }
+    }
+    if (type) {
+      const int cap = F.cap;
+      F.p[slot] = pointOri.x; F.p[cap + slot] = pointOri.y; F.p[2 * cap + slot] = pointOri.z;
+      F.A[slot] = A3[0]; F.A[cap + slot] = A3[1]; F.A[2 * cap + slot] = A3[2];
+      F.B[slot] = B3[0]; F.B[cap + slot] = B3[1]; F.B[2 * cap + slot] = B3[2];
     }
   }
-  if (lane == 0) {
-    F.type[slot] = type;
-    if (type) { atomicAdd(&fr->n_factors[outer][kind], 1); atomicAdd(&F.rowcnt[slot >> 6], 1); }
+  F.type[slot] = type;
+  // one atomic per wavefront and counter
+  const unsigned long long m = __ballot(type != 0);
+  if (m && (threadIdx.x & 63) == 0) {
+    atomicAdd(&fr->n_factors[outer][kind], __popcll(m));
+    atomicAdd(&F.rowcnt[slot >> 6], __popcll(m));
   }
 }
 
@@ -602,6 +700,16 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
     for (unsigned probe = 0; probe <= T.mask && !done; probe++, s = (s + 1) & T.mask) {
       const u64 old = atomicCAS(&T.keys[s], 0ull, key);
       if (old == 0ull || old == key) {
+        if (old == 0ull) {  // new voxel: publish it in its block's occupancy mask
+          const u64 bkey = pack_key(Ai, Aj, Ak, lx >> 2, ly >> 2, lz >> 2) | (1ull << 63);
+          unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
+          bool bdone = false;
+          for (unsigned bp = 0; bp <= T.bslots_mask && !bdone; bp++, bs = (bs + 1) & T.bslots_mask) {
+            const u64 bold = atomicCAS(&T.blk[bs].x, 0ull, bkey);
+            if (bold == 0ull || bold == bkey) { atomicOr(&T.blk[bs].y, 1ull << (((lz & 3) << 4) | ((ly & 3) << 2) | (lx & 3))); bdone = true; }
+          }
+          if (!bdone) atomicOr(&fr->error, kErrMapFull);
+        }
         const int pos = atomicAdd(&T.pend_cnt[s], 1);
         if (pos < kPendCap) T.pend[(size_t)s * kPendCap + pos] = i; else atomicOr(&fr->error, kErrMapFull);
         if (pos == 0) {
@@ -710,6 +818,9 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     ok = ok && dmalloc(allocs, st, &T.keys, slots) && dmalloc(allocs, st, &T.sum, slots) && dmalloc(allocs, st, &T.count, slots) &&
          dmalloc(allocs, st, &T.pend_cnt, slots) && dmalloc(allocs, st, &T.pend, slots * kPendCap);
     T.mask = (unsigned)(slots - 1);
+    const size_t bslots = slots / 2;
+    ok = ok && dmalloc(allocs, st, &T.blk, bslots);
+    T.bslots_mask = (unsigned)(bslots - 1);
     DsScratch& D = m->ds[k];
     D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
@@ -728,7 +839,7 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
          dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 9 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1);
   }
-  ok = ok && dmalloc(allocs, st, &m->rec, 2);
+  ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nn, 5 * (size_t)kMapFactorCap);
   ok = ok && dmalloc(allocs, st, &m->registered, (size_t)cfg.max_points);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
@@ -760,7 +871,9 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
                      m->stack[0], m->stack[1], fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
-                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->F[outer], outer);
+                 m->inv_leaf[0], m->inv_leaf[1], ms, m->nn);
+    hipLaunchKernelGGL(k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nn,
+                       m->F[outer], outer);
     lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
   hipLaunchKernelGGL(k_map_update, dim3(1), dim3(64), 0, st, ms, traj_row14);
