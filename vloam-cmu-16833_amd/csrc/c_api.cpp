@@ -172,10 +172,13 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         ALLOC(h->sr[k].less_flat, (size_t)P);
       }
       for (int k = 0; k < 2; k++) {
-        h->grid[k].mask[0] = kGridBucketsCorner - 1; h->grid[k].mask[1] = kGridBucketsSurf - 1;
-        ALLOC(h->grid[k].start[0], kGridBucketsCorner + 2); ALLOC(h->grid[k].start[1], kGridBucketsSurf + 2);
-        ALLOC(h->grid[k].fill[0], kGridBucketsCorner); ALLOC(h->grid[k].fill[1], kGridBucketsSurf);
-        ALLOC(h->grid[k].items[0], kMaxLessSharp); ALLOC(h->grid[k].items[1], (size_t)P);
+        for (int g = 0; g < 4; g++) {
+          h->grid[k].mask[g] = kGridBuckets[g] - 1;
+          ALLOC(h->grid[k].cnt[g], kGridBuckets[g]);
+          ALLOC(h->grid[k].start[g], kGridBuckets[g] + 2);
+          ALLOC(h->grid[k].fill[g], kGridBuckets[g]);
+          ALLOC(h->grid[k].items[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
+        }
       }
       ALLOC(h->lo, 1);
       vloam_status s = alloc_factor_table(h, &h->lo_F, kMaxLoFactors);

@@ -5,14 +5,18 @@
 
 namespace vloam {
 
-// Uniform 1 m hash grid over one sweep's lessSharp / lessFlat cloud (the device-side stand-in for the two
-// pcl::KdTreeFLANN::setInputCloud calls at laser_odometry.cpp:525-526): bucket = hash(floor(x), floor(y), floor(z)).
-constexpr int kGridBucketsCorner = 1 << 14, kGridBucketsSurf = 1 << 16;
+// Two uniform hash grids over one sweep's lessSharp / lessFlat cloud (the device-side stand-in for the two
+// pcl::KdTreeFLANN::setInputCloud calls at laser_odometry.cpp:525-526): a 1 m grid for the expanding exact search and a 5 m
+// grid whose 27-cell neighbourhood covers DISTANCE_SQ_THRESHOLD = 25 for the rare queries without a close neighbour.
+// Grid index g = kind + 2 * level (kind 0 corner / 1 surf, level 0 = 1 m / 1 = 5 m); bucket = hash(cell) & mask.
+constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 12, 1 << 12};
+constexpr int kGridMaxBuckets = 1 << 15;
 struct LoGrid {
-  int* start[2];   // [buckets + 1] exclusive offsets (after the scan), kind 0 corner / 1 surf
-  int* fill[2];    // [buckets] scatter cursors
-  int* items[2];   // [n] point indices grouped by bucket
-  int mask[2];
+  int* cnt[4];     // [buckets] points per bucket (count pass); zeroed again by the scan pass
+  int* start[4];   // [buckets + 1] exclusive offsets
+  int* fill[4];    // [buckets] scatter cursors (zeroed by the scan pass)
+  int* items[4];   // [n] point indices grouped by bucket
+  int mask[4];
 };
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,
                           ProfHook* ph = nullptr);

@@ -44,9 +44,7 @@ __device__ __forceinline__ unsigned grid_hash(int ix, int iy, int iz) {
   h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
   return h;
 }
-__device__ __forceinline__ unsigned grid_bucket(float x, float y, float z, int mask) {
-  return grid_hash((int)floorf(x), (int)floorf(y), (int)floorf(z)) & (unsigned)mask;
-}
+__device__ __forceinline__ int coarse_cell(float v) { return (int)floorf(v / 5.0f); }
 
 __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                        const FrameScalars* __restrict__ S, LoGrid G) {
@@ -55,24 +53,30 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 p = pts[i];
-    atomicAdd(&G.start[kind][grid_bucket(p.x, p.y, p.z, G.mask[kind])], 1);
+    atomicAdd(&G.cnt[kind][grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind]], 1);
+    atomicAdd(&G.cnt[kind + 2][grid_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z)) & (unsigned)G.mask[kind + 2]], 1);
   }
 }
 __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
+  __shared__ int buf[kGridMaxBuckets];  // the whole counter array goes through LDS: coalesced in, coalesced out
   __shared__ int sums[1024];
-  const int kind = blockIdx.x, tid = threadIdx.x;
-  const int nb = G.mask[kind] + 1;
-  int* a = G.start[kind];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int nb = G.mask[g] + 1;
+  int* cnt = G.cnt[g];
+  for (int k = tid; k < nb; k += 1024) { buf[k] = cnt[k]; cnt[k] = 0; G.fill[g][k] = 0; }
+  __syncthreads();
   const int per = nb / 1024;
   const int lo = tid * per;
   int s = 0;
-  for (int k = 0; k < per; k++) s += a[lo + k];
+  for (int k = 0; k < per; k++) s += buf[lo + k];
   sums[tid] = s;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? sums[tid - d] : 0; __syncthreads(); sums[tid] += v; __syncthreads(); }
   int run = tid ? sums[tid - 1] : 0;
-  for (int k = 0; k < per; k++) { const int c = a[lo + k]; a[lo + k] = run; G.fill[kind][lo + k] = 0; run += c; }
-  if (tid == 1023) a[nb] = sums[1023];
+  for (int k = 0; k < per; k++) { const int c = buf[lo + k]; buf[lo + k] = run; run += c; }
+  __syncthreads();
+  for (int k = tid; k < nb; k += 1024) G.start[g][k] = buf[k];
+  if (tid == 1023) G.start[g][nb] = sums[1023];
 }
 __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                          const FrameScalars* __restrict__ S, LoGrid G) {
@@ -81,8 +85,10 @@ __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restric
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 p = pts[i];
-    const unsigned b = grid_bucket(p.x, p.y, p.z, G.mask[kind]);
+    const unsigned b = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
     G.items[kind][G.start[kind][b] + atomicAdd(&G.fill[kind][b], 1)] = i;
+    const unsigned c = grid_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z)) & (unsigned)G.mask[kind + 2];
+    G.items[kind + 2][G.start[kind + 2][c] + atomicAdd(&G.fill[kind + 2][c], 1)] = i;
   }
 }
 
@@ -115,28 +121,73 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     const int gmask = G.mask[kind];
     const int cx = (int)floorf(sel.x), cy = (int)floorf(sel.y), cz = (int)floorf(sel.z);
     u64 best = ~0ull;
-    for (int R = 1; R <= 5 && n > 0; R++) {
+    bool exact = false;
+    for (int R = 1; R <= 2 && n > 0; R++) {
       const int w = 2 * R + 1, ncell = w * w * w;
       u64 loc = ~0ull;
-      for (int cc = lane; cc < ncell; cc += 64) {
-        const int ox = cc % w - R, oy = (cc / w) % w - R, oz = cc / (w * w) - R;
-        if (R > 1 && abs(ox) < R && abs(oy) < R && abs(oz) < R) continue;  // interior was scanned at the previous radius
-        const unsigned b = grid_hash(cx + ox, cy + oy, cz + oz) & (unsigned)gmask;
-        const int e = gstart[b + 1];
-        for (int t = gstart[b]; t < e; t++) {
-          const int j = gitems[t];
-          const float4 c = cand[j];
-          const float d0 = sel.x - c.x, d1 = sel.y - c.y, d2 = sel.z - c.z;
-          const float d = d0 * d0 + d1 * d1 + d2 * d2;
-          const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
-          loc = key < loc ? key : loc;
+      // four cells per lane and trip: their bucket bounds are fetched together, then only non-empty buckets are walked
+      for (int cc0 = lane; cc0 < ncell; cc0 += 4 * 64) {
+        int bs[4], be[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int cc = cc0 + u * 64;
+          bs[u] = 0; be[u] = 0;
+          if (cc < ncell) {
+            const int ox = cc % w - R, oy = (cc / w) % w - R, oz = cc / (w * w) - R;
+            if (!(R > 1 && abs(ox) < R && abs(oy) < R && abs(oz) < R)) {  // interior was scanned at the previous radius
+              const unsigned b = grid_hash(cx + ox, cy + oy, cz + oz) & (unsigned)gmask;
+              bs[u] = gstart[b]; be[u] = gstart[b + 1];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          for (int t = bs[u]; t < be[u]; t++) {
+            const int j = gitems[t];
+            const float4 c = cand[j];
+            const float d0 = sel.x - c.x, d1 = sel.y - c.y, d2 = sel.z - c.z;
+            const float d = d0 * d0 + d1 * d1 + d2 * d2;
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
+            loc = key < loc ? key : loc;
+          }
         }
       }
       loc = wave_min_u64(loc);
       best = loc < best ? loc : best;
       const float bd = __uint_as_float((unsigned)(best >> 32));
       const float bound = (float)(R * R) * 0.999999f;
-      if (best != ~0ull && bd <= bound) break;
+      if (best != ~0ull && bd <= bound) { exact = true; break; }
+    }
+    if (!exact && n > 0) {
+      // no neighbour within 2 m: sweep the 27 cells of the 5 m grid around the query — together they contain every point
+      // within 5 m, and anything farther is rejected by DISTANCE_SQ_THRESHOLD below.  Lanes stride over each cell's points.
+      const int* cstart = G.start[kind + 2];
+      const int* citems = G.items[kind + 2];
+      const int cmask = G.mask[kind + 2];
+      const int ccx = coarse_cell(sel.x), ccy = coarse_cell(sel.y), ccz = coarse_cell(sel.z);
+      u64 loc = ~0ull;
+      for (int cc = 0; cc < 27; cc++) {
+        const unsigned b = grid_hash(ccx + cc % 3 - 1, ccy + (cc / 3) % 3 - 1, ccz + cc / 9 - 1) & (unsigned)cmask;
+        const int e = cstart[b + 1];
+        for (int t0 = cstart[b] + lane; t0 < e; t0 += 4 * 64) {
+          int js[4];
+          float4 cs[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int t = t0 + u * 64; js[u] = t < e ? citems[t] : -1; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) cs[u] = js[u] >= 0 ? cand[js[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (js[u] < 0) continue;
+            const float d0 = sel.x - cs[u].x, d1 = sel.y - cs[u].y, d2 = sel.z - cs[u].z;
+            const float d = d0 * d0 + d1 * d1 + d2 * d2;
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)js[u];
+            loc = key < loc ? key : loc;
+          }
+        }
+      }
+      loc = wave_min_u64(loc);
+      best = loc < best ? loc : best;
     }
     const float dmin = __uint_as_float((unsigned)(best >> 32));
     if (best != ~0ull && dmin < 25.0f) {  // DISTANCE_SQ_THRESHOLD, LO:272 / LO:359
@@ -286,10 +337,8 @@ void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, co
 }
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
   (void)ph;
-  (void)hipMemsetAsync(G.start[0], 0, sizeof(int) * (size_t)(G.mask[0] + 2), st);
-  (void)hipMemsetAsync(G.start[1], 0, sizeof(int) * (size_t)(G.mask[1] + 2), st);
   hipLaunchKernelGGL(k_lo_grid_count, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
-  hipLaunchKernelGGL(k_lo_grid_scan, dim3(2), dim3(1024), 0, st, G);
+  hipLaunchKernelGGL(k_lo_grid_scan, dim3(4), dim3(1024), 0, st, G);
   hipLaunchKernelGGL(k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
 }
 void lo_set_prior_launch(hipStream_t st, LOState* lo) { hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo); }
