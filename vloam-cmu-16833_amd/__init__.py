@@ -321,6 +321,12 @@ class LaserOdometry:
     def solveLO(self):
         self._pose = self.hd.laser_odometry()
 
+    # the public pose members of the reference class (laser_odometry.h:86-98), x y z w
+    q_w_curr = property(lambda self: self._pose[0])
+    t_w_curr = property(lambda self: self._pose[1])
+    q_last_curr = property(lambda self: self._pose[2])
+    t_last_curr = property(lambda self: self._pose[3])
+
     def output(self):
         qw, tw, _, _ = self._pose
         skip = (self.hd.frame_count() + (0 if self.hd.cfg.with_mapping else 0)) % self.hd.cfg.mapping_skip_frame != 0
@@ -345,6 +351,9 @@ class LaserMapping:
 
     def solveMapping(self):
         self.pose = self.hd.laser_mapping()
+
+    q_w_curr = property(lambda self: self.pose[0])   # laser_mapping.h:129-130
+    t_w_curr = property(lambda self: self.pose[1])
 
 
 class LidarOdometryMapping:
