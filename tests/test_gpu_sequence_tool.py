@@ -1,0 +1,44 @@
+"""GPU: the §8f harness end to end — sweeps from KITTI-format .bin files through the façade mirrors, LO/MO rows written in the
+reference's results format, compared with rows derived from the oracle's poses through the same VloamTF algebra."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_run_sequence_rows_match_oracle(vl, orc, sweeps, tmp_path):
+    kio = importlib.import_module("vloam_amd.kitti_io")
+    vel = tmp_path / "velodyne_points" / "data"
+    os.makedirs(vel)
+    n = 5
+    clouds = []
+    for k in range(n):
+        c = sweeps(64, 512, k)
+        c = c[np.isfinite(c[:, 0])]
+        kio.save_kitti_bin(vel / ("%010d.bin" % k), c)
+        clouds.append(kio.load_kitti_bin(vel / ("%010d.bin" % k)))
+    out = tmp_path / "res"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_sequence.py"), "--velodyne", str(vel), "--out", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lo = kio.read_trajectory(out / "LO0.txt")
+    mo = kio.read_trajectory(out / "MO0.txt")
+    assert lo.shape == (n, 4, 4) and mo.shape == (n, 4, 4)
+
+    o = orc.Oracle(scan_line=64, mapping_skip_frame=2)
+    tf = kio.VloamTF(kio.make_T([0, 0, 0.0074, 0.99997], [0.81, -0.32, 0.80]), kio.make_T([0.5, -0.5, 0.5, -0.5], [1.08, -0.32, 0.72]))
+    for k, c in enumerate(clouds):
+        o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm, _, _ = o.map_pose()
+        row_lo = tf.LO2Cam0StartFrame(qw, tw, k)
+        row_mo = tf.MO2Cam0StartFrame(qm, tm, k)
+        # "%f" keeps 6 decimals: rows agree to the printed precision (poses agree to ~1e-9)
+        assert np.allclose(lo[k, :3], row_lo[:3], atol=2e-6), k
+        assert np.allclose(mo[k, :3], row_mo[:3], atol=2e-6), k

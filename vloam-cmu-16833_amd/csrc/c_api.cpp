@@ -54,6 +54,7 @@ struct vloam_handle {
   LOState* lo = nullptr;
   FactorTable lo_F{};
   int* lo_corr[2] = {nullptr, nullptr};
+  long long* lo_cyc[2] = {nullptr, nullptr};  // debug: per-slot shader-clock cycles of k_lo_assoc (NN, walks, emit, exact radius)
   LMRecord* lo_rec = nullptr;  // [2]
   double* lo_resid[2] = {nullptr, nullptr};
   double* traj = nullptr;      // [max_frames][14]
@@ -128,7 +129,9 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
     set_err("only support velodyne with 16, 32 or 64 scan line!");  // scan_registration.cpp:54-58
     return VLOAM_ERR_INVALID;
   }
-  if (cfg->max_points < 64 || cfg->max_frames < 1 || cfg->mapping_skip_frame < 1) { set_err("bad capacity"); return VLOAM_ERR_INVALID; }
+  if (cfg->max_points < 64 || cfg->max_points > (1 << 24) || cfg->max_frames < 1 || cfg->mapping_skip_frame < 1) {  // 24-bit point tags
+    set_err("bad capacity"); return VLOAM_ERR_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device visible: libvloam_hip has no CPU fallback");
@@ -164,6 +167,7 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       ALLOC(a.dbg_sort, (size_t)P);
       ALLOC(a.dbg_picked, (size_t)P);
       ALLOC(a.dbg_label, (size_t)P);
+      ALLOC(a.dbg_cyc, (size_t)kMaxRings * 8);
       ALLOC(a.dbg_feat_idx, 3 * kMaxLessSharp);
       h->sr[1] = a;
       for (int k = 0; k < 2; k++) {
@@ -176,14 +180,13 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
           h->grid[k].mask[g] = kGridBuckets[g] - 1;
           ALLOC(h->grid[k].cnt[g], kGridBuckets[g]);
           ALLOC(h->grid[k].start[g], kGridBuckets[g] + 2);
-          ALLOC(h->grid[k].fill[g], kGridBuckets[g]);
-          ALLOC(h->grid[k].items[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
+          ALLOC(h->grid[k].pts[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
         }
       }
       ALLOC(h->lo, 1);
       vloam_status s = alloc_factor_table(h, &h->lo_F, kMaxLoFactors);
       if (s != VLOAM_OK) return s;
-      for (int k = 0; k < 2; k++) { ALLOC(h->lo_corr[k], kMaxLoFactors * 4); ALLOC(h->lo_resid[k], 3 * kMaxLoFactors); }
+      for (int k = 0; k < 2; k++) { ALLOC(h->lo_corr[k], kMaxLoFactors * 4); ALLOC(h->lo_resid[k], 3 * kMaxLoFactors); if (h->cfg.debug) ALLOC(h->lo_cyc[k], 4 * kMaxLoFactors); }
       ALLOC(h->lo_rec, 2);
       ALLOC(h->traj, (size_t)cfg->max_frames * 14);
       LOState init;
@@ -246,7 +249,7 @@ static vloam_status enqueue_lo(vloam_handle* h) {
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
-                      h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], &h->prof);
+                      h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], h->lo_cyc[outer], &h->prof);
       lm_launch(h->stream, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
     }
   }
@@ -478,6 +481,7 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
       case 1: return copy_out(b.dbg_sort, sizeof(int) * S.N2, buf, cap, n);
       case 2: return copy_out(b.dbg_picked, sizeof(int) * S.N2, buf, cap, n);
       case 3: return copy_out(b.dbg_label, sizeof(int) * S.N2, buf, cap, n);
+      case 11: return copy_out(b.dbg_cyc, sizeof(long long) * kMaxRings * 8, buf, cap, n);
       case 4: return copy_out(&b.S->scanStartInd[0], sizeof(int) * kMaxRings, buf, cap, n);
       case 5: return copy_out(&b.S->scanEndInd[0], sizeof(int) * kMaxRings, buf, cap, n);
       case 6: return copy_out(b.dbg_feat_idx, sizeof(int) * S.n_sharp, buf, cap, n);
@@ -501,6 +505,8 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
       case 1: return copy_out(h->lo_corr[outer] + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
       case 2: return copy_out(h->lo_rec + outer, sizeof(LMRecord), buf, cap, n);
       case 3: return copy_out(h->lo_resid[outer], sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
+      case 4: if (!h->lo_cyc[outer]) return VLOAM_ERR_INVALID;
+              return copy_out(h->lo_cyc[outer], sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);
     }
     return VLOAM_ERR_INVALID;
   }

@@ -125,9 +125,9 @@ __device__ __forceinline__ double huber(double sq, double a, double* cost) {
 }
 // Branch-free form given |r| (straight-line code lets the compiler interleave several factors per lane, which is what
 // hides the ~12-cycle dependent f64 latency when only one wavefront sits on each SIMD).
-__device__ __forceinline__ double huber_sel(double sq, double rr, double a, double* cost) {
+__device__ __forceinline__ double huber_sel(double sq, double rr, double a, double sqrt_a, double* cost) {
   const bool out = sq > a * a;
-  const double sc_out = sqrt(fmax(DBL_MIN, a / fmax(rr, DBL_MIN)));
+  const double sc_out = sqrt_a * rsqrt(fmax(rr, DBL_MIN));  // sqrt(a / |r|)
   *cost += out ? 0.5 * (2.0 * a * rr - a * a) : 0.5 * sq;
   return out ? sc_out : 1.0;
 }
@@ -135,13 +135,13 @@ __device__ __forceinline__ double huber_sel(double sq, double rr, double a, doub
 // LidarEdgeFactor (lidarFactor.hpp:21-45) with lp = R p + t:  r = ((lp - a) x (lp - b)) / |a - b| == v x (lp - a),
 // v = (b - a) / |a - b| (precomputed by k_lm_compact into B);  d r / d lp = [v]x;  d lp / d delta = -2 [R p]x
 // (EigenQuaternionParameterization, q+ = exp(delta) * q);  [v]x (-2 [rp]x) = -2 (rp v^T - (v . rp) I).
-__device__ __forceinline__ void eval_edge(D3 p, D3 A, D3 v, const double (&Rm)[9], D3 t, double huber_a, double (&acc)[kAcc], double* r3) {
+__device__ __forceinline__ void eval_edge(D3 p, D3 A, D3 v, const double (&Rm)[9], D3 t, double huber_a, double sqrt_a, double (&acc)[kAcc], double* r3) {
   const D3 rp = d3(Rm[0] * p.x + Rm[1] * p.y + Rm[2] * p.z, Rm[3] * p.x + Rm[4] * p.y + Rm[5] * p.z, Rm[6] * p.x + Rm[7] * p.y + Rm[8] * p.z);
   const D3 lp = rp + t;
   const D3 r = cross(v, lp - A);
   r3[0] = r.x; r3[1] = r.y; r3[2] = r.z;
   const double sq = r.x * r.x + r.y * r.y + r.z * r.z;
-  const double sc = huber_sel(sq, sqrt(sq), huber_a, &acc[0]);
+  const double sc = huber_sel(sq, sqrt(sq), huber_a, sqrt_a, &acc[0]);
   const double vr = dot(v, rp);
   const double s2 = -2.0 * sc;
   const D3 sv = d3(sc * v.x, sc * v.y, sc * v.z);
@@ -161,12 +161,13 @@ __device__ __forceinline__ void eval_edge(D3 p, D3 A, D3 v, const double (&Rm)[9
 
 // LidarPlaneFactor / LidarPlaneNormFactor (lidarFactor.hpp:72-93, 115-127) in the common form r = n . lp + d
 // (k_lm_compact rewrites the plane factor's (lp - j) . n as n . lp - n . j);  d r / d lp = n^T,  n^T (-2 [rp]x) = -2 (n x rp)^T.
-__device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&Rm)[9], D3 t, double huber_a, double (&acc)[kAcc], double* r3) {
+__device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&Rm)[9], D3 t, double huber_a, double sqrt_a, double (&acc)[kAcc],
+                                           double* r3) {
   const D3 rp = d3(Rm[0] * p.x + Rm[1] * p.y + Rm[2] * p.z, Rm[3] * p.x + Rm[4] * p.y + Rm[5] * p.z, Rm[6] * p.x + Rm[7] * p.y + Rm[8] * p.z);
   const D3 lp = rp + t;
   const double r0 = dot(n, lp) + d;
   r3[0] = r0; r3[1] = 0.0; r3[2] = 0.0;
-  const double sc = huber_sel(r0 * r0, fabs(r0), huber_a, &acc[0]);
+  const double sc = huber_sel(r0 * r0, fabs(r0), huber_a, sqrt_a, &acc[0]);
   const D3 nr = cross(n, rp);
   const double s2 = -2.0 * sc;
   const double J[6] = {s2 * nr.x, s2 * nr.y, s2 * nr.z, n.x * sc, n.y * sc, n.z * sc};
@@ -214,6 +215,7 @@ struct LmShared {
   double cand[kAcc];   // accumulators at the candidate
   double x[8], xc[8];
   double mcc;          // model_cost_change of the pending candidate
+  double gmax_c, xnorm_c;  // gradient max-norm / |x| at the point just evaluated (computed by helper lanes in parallel)
   double scale[6], diagonal[6], best[8];  // trust-region state that must survive the evaluations (kept out of registers)
   int scan[kLmThreads], scan2[kLmThreads];
   int n_edge;
@@ -221,10 +223,24 @@ struct LmShared {
   int n_valid;
 };
 
+// Factors owned by a lane stay in its registers across the evaluations of a solve (one workgroup = 256 lanes x 512 VGPRs):
+// edge factor e = lane + 256 m (m < kCacheE) and plane factor q = lane + 256 m (m < kCacheP) are fetched once — the first
+// evaluation issues all of those loads together — and later evaluations touch no memory at all.  Unused slots hold zeros,
+// which evaluate to an exactly-zero contribution, so the evaluation itself is straight-line code: with a single wavefront
+// per SIMD the only way to hide the dependent f64 latency is to let independent factors interleave in one basic block.
+// p is an f32 point by construction (cloud coordinates) and is kept as f32.
+constexpr int kCacheE = 4, kCacheP = 6;
+struct LmCache {
+  float pe[kCacheE][3];
+  double de[kCacheE][6];  // a, v
+  float pp[kCacheP][3];
+  double dp[kCacheP][4];  // n, d
+};
+
 // Evaluate the compacted factors at x: cost, g = J^T r, H = J^T J (upper triangle) -> s_out[kAcc] (LDS).
 template <bool QUAT>
-__device__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh, double* s_out,
-                            bool store_resid) {
+__device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
+                                            double* s_out, bool first, LmCache& C) {
   const int tid = threadIdx.x;
   double acc[kAcc];
 #pragma unroll
@@ -233,57 +249,108 @@ __device__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const
   double xl[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) xl[i] = x[i];
-  // rotation matrix of q = (x, y, z, w) as Eigen's toRotationMatrix() builds it (q is unit up to rounding)
-  double Rm[9];
-  {
-    const double tx = 2 * xl[0], ty = 2 * xl[1], tz = 2 * xl[2];
-    const double twx = tx * xl[3], twy = ty * xl[3], twz = tz * xl[3];
-    const double txx = tx * xl[0], txy = ty * xl[0], txz = tz * xl[0], tyy = ty * xl[1], tyz = tz * xl[1], tzz = tz * xl[2];
-    Rm[0] = 1 - (tyy + tzz); Rm[1] = txy - twz; Rm[2] = txz + twy;
-    Rm[3] = txy + twz; Rm[4] = 1 - (txx + tzz); Rm[5] = tyz - twx;
-    Rm[6] = txz - twy; Rm[7] = tyz + twx; Rm[8] = 1 - (txx + tyy);
-  }
-  const D3 tt = d3(xl[4], xl[5], xl[6]);
-  // kTrip factors per lane and trip, straight-line: their loads are all in flight before the first is consumed and the
-  // independent dependency chains interleave (one workgroup has to hide memory AND f64 latency by itself).
-  constexpr int kTrip = 4;
-  auto run = [&](int lo, int hi, auto&& body) {
-    for (int k0 = lo + tid; k0 < hi; k0 += kTrip * kLmThreads) {
-      double v[kTrip][9];
-      bool live[kTrip];
+  const double sqrt_a = sqrt(huber_a);
+  if (QUAT) {
+    // rotation matrix of q = (x, y, z, w) as Eigen's toRotationMatrix() builds it (q is unit up to rounding)
+    double Rm[9];
+    {
+      const double tx = 2 * xl[0], ty = 2 * xl[1], tz = 2 * xl[2];
+      const double twx = tx * xl[3], twy = ty * xl[3], twz = tz * xl[3];
+      const double txx = tx * xl[0], txy = ty * xl[0], txz = tz * xl[0], tyy = ty * xl[1], tyz = tz * xl[1], tzz = tz * xl[2];
+      Rm[0] = 1 - (tyy + tzz); Rm[1] = txy - twz; Rm[2] = txz + twy;
+      Rm[3] = txy + twz; Rm[4] = 1 - (txx + tzz); Rm[5] = tyz - twx;
+      Rm[6] = txz - twy; Rm[7] = tyz + twx; Rm[8] = 1 - (txx + tyy);
+    }
+    const D3 tt = d3(xl[4], xl[5], xl[6]);
+    const int n_plane = n_valid - n_edge;
+    const double* cp = F.cpack;
+    if (first) {
 #pragma unroll
-      for (int u = 0; u < kTrip; u++) {
-        const int k = k0 + u * kLmThreads;
-        live[u] = k < hi;
-        const int kk = live[u] ? k : k0;
+      for (int m = 0; m < kCacheE; m++) {
+        const int k = tid + m * kLmThreads;
+        const bool live = k < n_edge;
 #pragma unroll
-        for (int a = 0; a < 9; a++) v[u][a] = F.cpack[a * cap + kk];
+        for (int a = 0; a < 3; a++) C.pe[m][a] = live ? (float)cp[a * cap + k] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; a++) C.de[m][a] = live ? cp[(3 + a) * cap + k] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < kTrip; u++) {
-        double r3[3];
-        body(u, v[u], live[u], r3);
-        if (store_resid && live[u]) {
-          const int slot = F.cslot[k0 + u * kLmThreads];
-          F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
-        }
+      for (int m = 0; m < kCacheP; m++) {
+        const int q = tid + m * kLmThreads;
+        const bool live = q < n_plane;
+#pragma unroll
+        for (int a = 0; a < 3; a++) C.pp[m][a] = live ? (float)cp[a * cap + n_edge + q] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; a++) C.dp[m][a] = live ? cp[(3 + a) * cap + n_edge + q] : 0.0;
       }
     }
-  };
-  if (QUAT) {
-    // compact order == slot order: the edge factors (corner slots) come first, then the plane factors
-    run(0, n_edge, [&](int, const double (&w)[9], bool live, double* r3) {
-      if (live) eval_edge(d3(w[0], w[1], w[2]), d3(w[3], w[4], w[5]), d3(w[6], w[7], w[8]), Rm, tt, huber_a, acc, r3);
-    });
-    run(n_edge, n_valid, [&](int, const double (&w)[9], bool live, double* r3) {
-      if (live) eval_plane(d3(w[0], w[1], w[2]), d3(w[3], w[4], w[5]), w[6], Rm, tt, huber_a, acc, r3);
-    });
+    auto put_resid = [&](int k, const double* r3) {
+      const int slot = F.cslot[k];
+      F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
+    };
+    // ---- edge factors (compact order == slot order: they come first)
+#pragma unroll
+    for (int g = 0; g < kCacheE; g += 1)
+      if (g * kLmThreads < n_edge) {
+        double r3[1][3];
+#pragma unroll
+        for (int u = 0; u < 1; u++)
+          if (g + u < kCacheE)
+          eval_edge(d3((double)C.pe[g + u][0], (double)C.pe[g + u][1], (double)C.pe[g + u][2]), d3(C.de[g + u][0], C.de[g + u][1], C.de[g + u][2]),
+                    d3(C.de[g + u][3], C.de[g + u][4], C.de[g + u][5]), Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+        if (first)
+#pragma unroll
+          for (int u = 0; u < 1; u++) { const int k = tid + (g + u) * kLmThreads; if (g + u < kCacheE && k < n_edge) put_resid(k, r3[u]); }
+      }
+    for (int base = kCacheE * kLmThreads; base < n_edge; base += 2 * kLmThreads) {  // beyond the cache: streamed
+      double w[2][9], r3[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int k = base + u * kLmThreads + tid;
+#pragma unroll
+        for (int a = 0; a < 9; a++) w[u][a] = k < n_edge ? cp[a * cap + k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        eval_edge(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), d3(w[u][6], w[u][7], w[u][8]), Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+      if (first)
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int k = base + u * kLmThreads + tid; if (k < n_edge) put_resid(k, r3[u]); }
+    }
+    // ---- plane factors, two per basic block
+#pragma unroll
+    for (int g = 0; g < kCacheP; g += 2)
+      if (g * kLmThreads < n_plane) {
+        double r3[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          if (g + u < kCacheP)
+          eval_plane(d3((double)C.pp[g + u][0], (double)C.pp[g + u][1], (double)C.pp[g + u][2]), d3(C.dp[g + u][0], C.dp[g + u][1], C.dp[g + u][2]),
+                     C.dp[g + u][3], Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+        if (first)
+#pragma unroll
+          for (int u = 0; u < 2; u++) { const int q = tid + (g + u) * kLmThreads; if (g + u < kCacheP && q < n_plane) put_resid(n_edge + q, r3[u]); }
+      }
+    for (int base = kCacheP * kLmThreads; base < n_plane; base += 4 * kLmThreads) {
+      double w[4][7], r3[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = base + u * kLmThreads + tid;
+#pragma unroll
+        for (int a = 0; a < 7; a++) w[u][a] = q < n_plane ? cp[a * cap + n_edge + q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) eval_plane(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), w[u][6], Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+      if (first)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = base + u * kLmThreads + tid; if (q < n_plane) put_resid(n_edge + q, r3[u]); }
+    }
   } else {
     for (int k = tid; k < n_valid; k += kLmThreads) {
       double r3[3];
       eval_vo(F.ctype[k], d3(F.cpack[k], F.cpack[cap + k], F.cpack[2 * cap + k]), d3(F.cpack[3 * cap + k], F.cpack[4 * cap + k], F.cpack[5 * cap + k]),
               xl, huber_a, acc, r3);
-      if (store_resid) {
+      if (first) {
         const int slot = F.cslot[k];
         F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
       }
@@ -318,46 +385,72 @@ __device__ __forceinline__ double Hget(const double* acc, int a, int b) {
   return acc[7 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
 }
 
-// 6x6 SPD solve by Cholesky on the packed lower triangle, in place (fully unrolled: lives in registers).
+// 6x6 SPD solve by Cholesky on the packed lower triangle, in place (fully unrolled: lives in registers).  Column by column
+// with one reciprocal square root per pivot and no divisions — f64 div / sqrt are ~150-cycle dependent sequences here and
+// this runs on a single lane.
 #define LIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
 __device__ __forceinline__ bool chol6_solve(double (&L)[21], const double (&rhs)[6], double (&y)[6]) {
   bool ok = true;
+  double inv[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++)
+  for (int j = 0; j < 6; j++) {
+    double s = L[LIDX(j, j)];
 #pragma unroll
-    for (int j = 0; j <= i; j++) {
-      double s = L[LIDX(i, j)];
+    for (int k = 0; k < j; k++) s -= L[LIDX(j, k)] * L[LIDX(j, k)];
+    ok = ok && (s > 0.0);
+    inv[j] = rsqrt(s);
+    L[LIDX(j, j)] = s * inv[j];
 #pragma unroll
-      for (int k = 0; k < j; k++) s -= L[LIDX(i, k)] * L[LIDX(j, k)];
-      if (i == j) { ok = ok && (s > 0.0); L[LIDX(i, i)] = sqrt(s); }
-      else L[LIDX(i, j)] = s / L[LIDX(j, j)];
+    for (int i = j + 1; i < 6; i++) {
+      double t = L[LIDX(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[LIDX(i, k)] * L[LIDX(j, k)];
+      L[LIDX(i, j)] = t * inv[j];
     }
+  }
   double z[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) { double s = rhs[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[LIDX(i, k)] * z[k];
-    z[i] = s / L[LIDX(i, i)]; }
+    z[i] = s * inv[i]; }
 #pragma unroll
   for (int i = 5; i >= 0; i--) { double s = z[i];
 #pragma unroll
     for (int k = i + 1; k < 6; k++) s -= L[LIDX(k, i)] * y[k];
-    y[i] = s / L[LIDX(i, i)]; }
+    y[i] = s * inv[i]; }
   return ok;
+}
+
+// sin(n) / n and cos(n) from n^2.  The trust-region step is a small rotation: below |n| = 0.5 both are short alternating
+// series in n^2 (next term < 1e-25 relative), with no square root, division or argument reduction.
+__device__ __forceinline__ void sinc_cos(double n2, double* sinc, double* c) {
+  if (n2 < 0.25) {
+    double s = 1.0 / 121645100408832000.0, q = 1.0 / 6402373705728000.0;  // 1/19!, 1/18!
+    s = 1.0 / 355687428096000.0 - n2 * s;   q = 1.0 / 20922789888000.0 - n2 * q;   // 1/17!, 1/16!
+    s = 1.0 / 1307674368000.0 - n2 * s;     q = 1.0 / 87178291200.0 - n2 * q;       // 1/15!, 1/14!
+    s = 1.0 / 6227020800.0 - n2 * s;        q = 1.0 / 479001600.0 - n2 * q;         // 1/13!, 1/12!
+    s = 1.0 / 39916800.0 - n2 * s;          q = 1.0 / 3628800.0 - n2 * q;           // 1/11!, 1/10!
+    s = 1.0 / 362880.0 - n2 * s;            q = 1.0 / 40320.0 - n2 * q;             // 1/9!, 1/8!
+    s = 1.0 / 5040.0 - n2 * s;              q = 1.0 / 720.0 - n2 * q;               // 1/7!, 1/6!
+    s = 1.0 / 120.0 - n2 * s;               q = 1.0 / 24.0 - n2 * q;                // 1/5!, 1/4!
+    s = 1.0 / 6.0 - n2 * s;                 q = 0.5 - n2 * q;                       // 1/3!, 1/2!
+    *sinc = 1.0 - n2 * s;                   *c = 1.0 - n2 * q;
+  } else {
+    const double n = sqrt(n2);
+    double sn, cs;
+    sincos(n, &sn, &cs);
+    *sinc = sn / n; *c = cs;
+  }
 }
 
 template <bool QUAT>
 __device__ __forceinline__ void lm_plus_t(const double* x, const double (&delta)[6], double* out) {
-  if (QUAT) {  // EigenQuaternionParameterization::Plus: x_plus = (sin|d|/|d| d, cos|d|) * x
-    const double n = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
-    if (n > 0.0) {
-      const double s = sin(n) / n;
-      const double dq[4] = {s * delta[0], s * delta[1], s * delta[2], cos(n)};
-      quat_mul(dq, x, out);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) out[i] = x[i];
-    }
+  if (QUAT) {  // EigenQuaternionParameterization::Plus: x_plus = (sin|d|/|d| d, cos|d|) * x   (|d| == 0 gives x back exactly)
+    double sc, cs;
+    sinc_cos(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2], &sc, &cs);
+    const double dq[4] = {sc * delta[0], sc * delta[1], sc * delta[2], cs};
+    quat_mul(dq, x, out);
 #pragma unroll
     for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + delta[3 + i];
   } else {
@@ -385,12 +478,12 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     const int nrows = F.cap >> 6;
     int c = 0, ce = 0;
     for (int r = tid; r < nrows; r += kLmThreads) { const int q = F.rowcnt[r]; c += q; if (r < edge_rows) ce += q; }
-    sh.scan[tid] = c;
-    sh.scan2[tid] = ce;
+    for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d); ce += __shfl_xor(ce, d); }
+    if ((tid & 63) == 0) { sh.scan[tid >> 6] = c; sh.scan2[tid >> 6] = ce; }
     __syncthreads();
     if (tid == 0) {
       int t = 0, te = 0;
-      for (int w = 0; w < kLmThreads; w++) { t += sh.scan[w]; te += sh.scan2[w]; }
+      for (int w = 0; w < kLmThreads / 64; w++) { t += sh.scan[w]; te += sh.scan2[w]; }
       sh.n_valid = t; sh.n_edge = te;
     }
     for (int r = tid; r < nrows; r += kLmThreads) F.rowcnt[r] = 0;
@@ -400,8 +493,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
   long long cyc_eval = 0, cyc_serial = 0, t_mark;
   const int n_valid = sh.n_valid, n_edge = sh.n_edge;
 
+  LmCache cache;
   t_mark = clock64();
-  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true);
+  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache);
   cyc_eval += clock64() - t_mark;
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
@@ -422,15 +516,21 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     return m;
   };
 
+  // helper lanes on other wavefronts take the slow scalar pieces (f64 sqrt / div / sincos) off thread 0's critical path
+  auto x_norm_of = [&](const double* xx) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < na; i++) s += xx[i] * xx[i];
+    return sqrt(s);
+  };
+  if (tid >= 192 && tid < 198) sh.scale[tid - 192] = 1.0 / (1.0 + sqrt(Hget(sh.cur, tid - 192, tid - 192)));  // jacobi_scaling, fixed at iteration 0
+  if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.cur);
+  if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
+  __syncthreads();
   if (tid == 0) {
     x_cost = sh.cur[0];
-#pragma unroll
-    for (int a = 0; a < 6; a++) sh.scale[a] = 1.0 / (1.0 + sqrt(Hget(sh.cur, a, a)));  // jacobi_scaling, fixed at iteration 0
-    gmax = grad_max(sh.x, sh.cur);
-    { double s = 0;
-#pragma unroll
-      for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i];
-      x_norm = sqrt(s); }
+    gmax = sh.gmax_c;
+    x_norm = sh.xnorm_c;
     current_cost = x_cost;
     it_cost = x_cost;
 #pragma unroll
@@ -474,10 +574,11 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
 #pragma unroll
           for (int a = 0; a < 6; a++) sh.diagonal[a] = fmin(fmax(Hget(cur, a, a) * sc6[a] * sc6[a], 1e-6), 1e32);
         }
+        const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
-          for (int b = 0; b <= a; b++) L[LIDX(a, b)] = Hget(cur, a, b) * sc6[a] * sc6[b] + (a == b ? sh.diagonal[a] / radius : 0.0);
+          for (int b = 0; b <= a; b++) L[LIDX(a, b)] = Hget(cur, a, b) * sc6[a] * sc6[b] + (a == b ? sh.diagonal[a] * inv_radius : 0.0);
         bool ok = chol6_solve(L, gs, y);
 #pragma unroll
         for (int a = 0; a < 6; a++) ok = ok && isfinite(y[a]);
@@ -517,9 +618,13 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
-    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false);
+    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache);
     cyc_eval += clock64() - t_mark;
     t_mark = clock64();
+    // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
+    if (tid == 64) sh.gmax_c = grad_max(sh.xc, sh.cand);
+    if (tid == 128) sh.xnorm_c = x_norm_of(sh.xc);
+    bool accepted = false;
     if (tid == 0) {
       n_evals++;
       const double model_cost_change = sh.mcc;
@@ -538,16 +643,12 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
       if (!stop) {
         it_rho = candidate_cost >= DBL_MAX ? -DBL_MAX : (current_cost - candidate_cost) / model_cost_change;
         if (it_rho > 1e-3) {  // HandleSuccessfulStep
+          accepted = true;
 #pragma unroll
           for (int i = 0; i < na; i++) sh.x[i] = sh.xc[i];
 #pragma unroll
           for (int i = 0; i < kAcc; i++) sh.cur[i] = sh.cand[i];
-          { double s = 0;
-#pragma unroll
-            for (int i = 0; i < na; i++) s += sh.x[i] * sh.x[i];
-            x_norm = sqrt(s); }
           x_cost = candidate_cost;
-          gmax = grad_max(sh.x, sh.cur);
           it_cost = x_cost; it_success = true;
           { const double c = 2.0 * it_rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - c * c * c); }
           radius = fmin(1e16, radius);
@@ -556,7 +657,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
           current_cost = candidate_cost;
         } else {              // HandleUnsuccessfulStep
           it_success = false;
-          radius = radius / decrease_factor;
+          radius = radius * (1.0 / decrease_factor);  // decrease_factor is a power of two: exact, and folded to a multiply
           decrease_factor *= 2.0;
           reuse_diagonal = true;
           it_cost = candidate_cost;
@@ -565,6 +666,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
       sh.go = stop ? 0 : 1;
     }
     __syncthreads();
+    if (accepted) { gmax = sh.gmax_c; x_norm = sh.xnorm_c; }
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     __syncthreads();

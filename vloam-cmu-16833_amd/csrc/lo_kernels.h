@@ -9,13 +9,12 @@ namespace vloam {
 // pcl::KdTreeFLANN::setInputCloud calls at laser_odometry.cpp:525-526): a 1 m grid for the expanding exact search and a 5 m
 // grid whose 27-cell neighbourhood covers DISTANCE_SQ_THRESHOLD = 25 for the rare queries without a close neighbour.
 // Grid index g = kind + 2 * level (kind 0 corner / 1 surf, level 0 = 1 m / 1 = 5 m); bucket = hash(cell) & mask.
-constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 12, 1 << 12};
+constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 12, 1 << 14};
 constexpr int kGridMaxBuckets = 1 << 15;
 struct LoGrid {
-  int* cnt[4];     // [buckets] points per bucket (count pass); zeroed again by the scan pass
+  int* cnt[4];     // [buckets] points per bucket (count pass); counted back down to zero by the scatter pass
   int* start[4];   // [buckets + 1] exclusive offsets
-  int* fill[4];    // [buckets] scatter cursors (zeroed by the scan pass)
-  int* items[4];   // [n] point indices grouped by bucket
+  float4* pts[4];  // [n] the points grouped by bucket: (x, y, z, bits: index | ring << 24)
   int mask[4];
 };
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,
@@ -24,7 +23,7 @@ void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4
 // Slot layout of the LO factor table: [0, kMaxSharp) corner features, [kMaxSharp, kMaxLoFactors) plane features.
 // corr: [kMaxLoFactors][4] ints (feature index or -1, closest, 2nd, 3rd).
 void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
-                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, ProfHook* ph = nullptr);
+                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc, ProfHook* ph = nullptr);
 void lo_set_prior_launch(hipStream_t st, LOState* lo);
 void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph = nullptr);
 

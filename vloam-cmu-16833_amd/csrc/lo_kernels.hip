@@ -45,59 +45,193 @@ __device__ __forceinline__ unsigned grid_hash(int ix, int iy, int iz) {
   return h;
 }
 __device__ __forceinline__ int coarse_cell(float v) { return (int)floorf(v / 5.0f); }
+// The 5 m level is keyed by (cell, group of 4 scan lines): the second / third neighbour searches only want points within two
+// scan lines of the closest point, i.e. at most two groups, instead of every line crossing those 15 m.
+constexpr int kRingGroupShift = 2;
+__device__ __forceinline__ unsigned coarse_hash(int ix, int iy, int iz, int grp) { return grid_hash(ix, iy, iz) ^ ((unsigned)grp * 0x9E3779B1u); }
+// bucket-ordered copies carry (point index, ring id) in .w: one fetch per candidate instead of index -> point
+__device__ __forceinline__ unsigned pack_tag(int j, int ring) { return (unsigned)j | ((unsigned)ring << 24); }
+__device__ __forceinline__ int tag_index(unsigned t) { return (int)(t & 0xffffffu); }
+__device__ __forceinline__ int tag_ring(unsigned t) { return (int)(t >> 24); }
+
+// Ring-ordered clouds put long runs of consecutive points into the same cell: one atomic per run of equal buckets inside a
+// wavefront instead of one per point.  *off = position inside the run, *len = run length (valid on every lane of the run),
+// *head_lane = first lane of the run.  All 64 lanes must be active.
+__device__ __forceinline__ void wave_runs(unsigned b, int lane, int* head_lane, int* off, int* len) {
+  const unsigned prev = __shfl_up(b, 1);
+  const u64 H = __ballot(lane == 0 || prev != b);
+  const int hl = 63 - __clzll((long long)(H & ((2ull << lane) - 1ull)));
+  const u64 rest = hl == 63 ? 0ull : (H >> (hl + 1));
+  const int next = rest ? hl + __ffsll((long long)rest) : 64;
+  *head_lane = hl; *off = lane - hl; *len = next - hl;
+}
 
 __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                        const FrameScalars* __restrict__ S, LoGrid G) {
-  const int kind = blockIdx.y;
+  const int kind = blockIdx.y, lane = threadIdx.x & 63;
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const float4 p = pts[i];
-    atomicAdd(&G.cnt[kind][grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind]], 1);
-    atomicAdd(&G.cnt[kind + 2][grid_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z)) & (unsigned)G.mask[kind + 2]], 1);
+  for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    unsigned bf = 0xffffffffu, bc = 0xffffffffu;
+    if (i < n) {
+      const float4 p = pts[i];
+      bf = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
+      bc = coarse_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift) & (unsigned)G.mask[kind + 2];
+    }
+    int hl, off, len;
+    wave_runs(bf, lane, &hl, &off, &len);
+    if (off == 0 && i < n) atomicAdd(&G.cnt[kind][bf], len);
+    wave_runs(bc, lane, &hl, &off, &len);
+    if (off == 0 && i < n) atomicAdd(&G.cnt[kind + 2][bc], len);
   }
 }
+
+// Exclusive scan of the bucket counters, one workgroup per grid.  Every thread owns `per` consecutive counters (whole 16-byte
+// vectors, registers only), wavefront scans + one LDS hop join them.  The counters themselves are left alone: the scatter
+// pass counts them back down to zero.
 __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
-  __shared__ int buf[kGridMaxBuckets];  // the whole counter array goes through LDS: coalesced in, coalesced out
-  __shared__ int sums[1024];
-  const int g = blockIdx.x, tid = threadIdx.x;
+  __shared__ int wsum[16];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = G.mask[g] + 1;
-  int* cnt = G.cnt[g];
-  for (int k = tid; k < nb; k += 1024) { buf[k] = cnt[k]; cnt[k] = 0; G.fill[g][k] = 0; }
-  __syncthreads();
-  const int per = nb / 1024;
-  const int lo = tid * per;
+  const int per = nb / 1024;  // 4, 8 or 32 (kGridBuckets)
+  const int4* src = (const int4*)(G.cnt[g] + tid * per);
+  int4 v[8];
   int s = 0;
-  for (int k = 0; k < per; k++) s += buf[lo + k];
-  sums[tid] = s;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    v[q] = make_int4(0, 0, 0, 0);
+    if (q * 4 < per) v[q] = src[q];
+    s += v[q].x + v[q].y + v[q].z + v[q].w;
+  }
+  int inc = s;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? sums[tid - d] : 0; __syncthreads(); sums[tid] += v; __syncthreads(); }
-  int run = tid ? sums[tid - 1] : 0;
-  for (int k = 0; k < per; k++) { const int c = buf[lo + k]; buf[lo + k] = run; run += c; }
-  __syncthreads();
-  for (int k = tid; k < nb; k += 1024) G.start[g][k] = buf[k];
-  if (tid == 1023) G.start[g][nb] = sums[1023];
+  int run = inc - s;
+  for (int w = 0; w < wave; w++) run += wsum[w];
+  int4* dst = (int4*)(G.start[g] + tid * per);
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    if (q * 4 < per) {
+      int4 o;
+      o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
+      dst[q] = o;
+    }
+  if (tid == 1023) G.start[g][nb] = run;
 }
+
 __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                          const FrameScalars* __restrict__ S, LoGrid G) {
-  const int kind = blockIdx.y;
+  const int kind = blockIdx.y, lane = threadIdx.x & 63;
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const float4 p = pts[i];
-    const unsigned b = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
-    G.items[kind][G.start[kind][b] + atomicAdd(&G.fill[kind][b], 1)] = i;
-    const unsigned c = grid_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z)) & (unsigned)G.mask[kind + 2];
-    G.items[kind + 2][G.start[kind + 2][c] + atomicAdd(&G.fill[kind + 2][c], 1)] = i;
+  for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    unsigned bf = 0xffffffffu, bc = 0xffffffffu;
+    float4 packed = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+      const float4 p = pts[i];
+      bf = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
+      bc = coarse_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift) & (unsigned)G.mask[kind + 2];
+      packed = make_float4(p.x, p.y, p.z, __uint_as_float(pack_tag(i, (int)p.w)));
+    }
+    int hl, off, len, pos = 0;
+    wave_runs(bf, lane, &hl, &off, &len);
+    if (off == 0 && i < n) pos = G.start[kind][bf] + atomicSub(&G.cnt[kind][bf], len) - len;
+    pos = __shfl(pos, hl);
+    if (i < n) G.pts[kind][pos + off] = packed;
+    wave_runs(bc, lane, &hl, &off, &len);
+    if (off == 0 && i < n) pos = G.start[kind + 2][bc] + atomicSub(&G.cnt[kind + 2][bc], len) - len;
+    pos = __shfl(pos, hl);
+    if (i < n) G.pts[kind + 2][pos + off] = packed;
   }
 }
 
 constexpr unsigned kBack = 0x40000000u;
 
+// Visit every point stored in the (2R+1)^3 block of cells around (cx, cy, cz) — only its outer shell when `shell` — with the
+// whole wavefront: the cells' bucket ranges are fetched by up to 64 lanes at once, concatenated by a wavefront prefix sum,
+// and the concatenated list is consumed 4 x 64 items per trip (each lane finds its item's bucket by a 6-step search over the
+// prefix sums), so a block costs two dependent memory round trips however its points are spread over the cells.
+// The visitor is a small value type (taken and returned by value, so that it stays in registers): v.visit(point).
+template <class V>
+__device__ __forceinline__ V for_each_candidate(const int* __restrict__ gstart, const float4* __restrict__ gpts, unsigned gmask, int cx,
+                                                int cy, int cz, int R, bool shell, int g0, int ng, int lane, V v) {
+  const int w = 2 * R + 1, w3 = w * w * w, ncell = w3 * ng;  // ng ring groups per cell (1 with g0 = 0 on the 1 m level)
+  for (int cc0 = 0; cc0 < ncell; cc0 += 64) {
+    const int cc = cc0 + lane;
+    int bs = 0, cnt = 0;
+    if (cc < ncell) {
+      const int ci = cc % w3, grp = g0 + cc / w3;
+      const int ox = ci % w - R, oy = (ci / w) % w - R, oz = ci / (w * w) - R;
+      if (!(shell && abs(ox) < R && abs(oy) < R && abs(oz) < R)) {  // the interior was scanned at the previous radius
+        const unsigned b = coarse_hash(cx + ox, cy + oy, cz + oz, grp) & gmask;
+        bs = gstart[b];
+        cnt = gstart[b + 1] - bs;
+      }
+    }
+    int inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    const int total = __shfl(inc, 63);
+    const int rel = bs - (inc - cnt);  // item i of the concatenation that falls into this lane's bucket sits at rel + i
+    for (int i0 = 0; i0 < total; i0 += 4 * 64) {
+      int t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * 64 + lane;
+        int lo = 0;  // number of lanes whose inclusive sum is <= i == the lane owning item i
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const int v = __shfl(inc, lo + step - 1); if (v <= i) lo += step; }
+        const int base = __shfl(rel, lo);  // every lane takes part in the exchange, whether or not its item exists
+        t[u] = i < total ? base + i : -1;
+      }
+      float4 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) c[u] = t[u] >= 0 ? gpts[t[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (t[u] >= 0) v.visit(c[u]);
+    }
+  }
+  return v;
+}
+
+struct VisitNearest {  // LO:269 / LO:356: nearest candidate, ties to the lowest index
+  float3 sel;
+  u64 loc;
+  __device__ __forceinline__ void visit(float4 c) {
+    const float d = sqdist(c, sel);
+    const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)tag_index(__float_as_uint(c.w));
+    loc = key < loc ? key : loc;
+  }
+};
+struct VisitAdjacent {  // LO:279-324 / LO:368-417 as a class filter (see k_lo_assoc)
+  float3 sel;
+  int idx, ringA;
+  bool is_corner;
+  u64 l2, l3;
+  int visited;
+  __device__ __forceinline__ void visit(float4 c) {
+    const unsigned tag = __float_as_uint(c.w);
+    const int j = tag_index(tag), rj = tag_ring(tag);
+    visited++;
+    const float d = sqdist(c, sel);
+    const bool fwd = j > idx;
+    const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
+    const bool ok = d < 25.0f && j != idx && rj <= ringA + 2 && rj >= ringA - 2;  // (double)rj > ringA + 2.5 <=> rj > ringA + 2
+    const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : rj == ringA;   // LO:287-299, 311-323 / LO:376-381, 402-407
+    const bool to3 = !is_corner && rj != ringA;                                    // LO:383-389, 409-415
+    if (ok && to2) l2 = key < l2 ? key : l2;
+    if (ok && to3) l3 = key < l3 ? key : l3;
+  }
+};
+
+
 __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sharp, const float4* __restrict__ flat,
                                                   const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
                                                   const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
-                                                  const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr) {
+                                                  const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
+                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (slot >= kMaxLoFactors) return;
@@ -105,6 +239,9 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   const int i = is_corner ? slot : slot - kMaxSharp;
   const int nfeat = is_corner ? Sc->n_sharp : Sc->n_flat;
   int type = 0, ia = -1, ib = -1, ic = -1;
+  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  int exact_dbg = -1, stage2_dbg = -1, cand_dbg = 0;
+  if (dbg_cyc) t0 = clock64();
   if (i < nfeat) {
     const float4 pf = is_corner ? sharp[i] : flat[i];
     const float3 sel = transform_to_start(pf, lo->para_q, lo->para_t);  // LO:268 / LO:355
@@ -113,145 +250,60 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     // ---- exact nearest neighbour (pcl::KdTreeFLANN::nearestKSearch k = 1, flann::L2_Simple<float>), LO:269 / LO:356.
     // Expanding search over the 1 m hash grid: after every cell within Chebyshev radius R of the query's cell has been
     // scanned, any unseen point is farther than R metres; the search stops as soon as the best distance is inside that
-    // bound (or at R = 5, beyond which DISTANCE_SQ_THRESHOLD = 25 rejects the match anyway).  Key = (f32 d2 bits, index)
-    // so ties resolve to the lowest index irrespective of visiting order.
+    // bound.  Queries without a neighbour inside 2 m sweep the 27 cells of the 5 m grid, which hold every point within 5 m
+    // (DISTANCE_SQ_THRESHOLD = 25 rejects anything farther).  Key = (f32 d2 bits, index): ties resolve to the lowest index
+    // irrespective of visiting order.
     const int kind = is_corner ? 0 : 1;
-    const int* gstart = G.start[kind];
-    const int* gitems = G.items[kind];
-    const int gmask = G.mask[kind];
-    const int cx = (int)floorf(sel.x), cy = (int)floorf(sel.y), cz = (int)floorf(sel.z);
+    const int fcx = (int)floorf(sel.x), fcy = (int)floorf(sel.y), fcz = (int)floorf(sel.z);
+    const int ccx = coarse_cell(sel.x), ccy = coarse_cell(sel.y), ccz = coarse_cell(sel.z);
+    // stage 0: fine R = 1 block, 1: fine R = 2 shell, 2: coarse 27 cells.  bound = squared radius fully covered so far.
+    // kernel-argument arrays are only ever indexed with constants (a runtime index would move the struct into scratch)
+    const int* fstart = is_corner ? G.start[0] : G.start[1];
+    const int* cstart = is_corner ? G.start[2] : G.start[3];
+    const float4* fpts = is_corner ? G.pts[0] : G.pts[1];
+    const float4* cpts = is_corner ? G.pts[2] : G.pts[3];
+    const unsigned fmask = (unsigned)(is_corner ? G.mask[0] : G.mask[1]), cmask = (unsigned)(is_corner ? G.mask[2] : G.mask[3]);
+    // stage 0: 1 m level, R = 1 block; 1: R = 2 shell; 2: the 27 cells of the 5 m level, ring groups [g0, g0 + ng)
+#define LO_SCAN_STAGE(stage, g0, ng, vis)                                                                                   \
+  ((stage) < 2 ? for_each_candidate(fstart, fpts, fmask, fcx, fcy, fcz, (stage) + 1, (stage) == 1, 0, 1, lane, vis)          \
+               : for_each_candidate(cstart, cpts, cmask, ccx, ccy, ccz, 1, false, g0, ng, lane, vis))
+    auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 1 ? 4.0f * 0.999999f : 3.0e38f); };  // squared radius fully covered
     u64 best = ~0ull;
-    bool exact = false;
-    for (int R = 1; R <= 2 && n > 0; R++) {
-      const int w = 2 * R + 1, ncell = w * w * w;
-      u64 loc = ~0ull;
-      // four cells per lane and trip: their bucket bounds are fetched together, then only non-empty buckets are walked
-      for (int cc0 = lane; cc0 < ncell; cc0 += 4 * 64) {
-        int bs[4], be[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int cc = cc0 + u * 64;
-          bs[u] = 0; be[u] = 0;
-          if (cc < ncell) {
-            const int ox = cc % w - R, oy = (cc / w) % w - R, oz = cc / (w * w) - R;
-            if (!(R > 1 && abs(ox) < R && abs(oy) < R && abs(oz) < R)) {  // interior was scanned at the previous radius
-              const unsigned b = grid_hash(cx + ox, cy + oy, cz + oz) & (unsigned)gmask;
-              bs[u] = gstart[b]; be[u] = gstart[b + 1];
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          for (int t = bs[u]; t < be[u]; t++) {
-            const int j = gitems[t];
-            const float4 c = cand[j];
-            const float d0 = sel.x - c.x, d1 = sel.y - c.y, d2 = sel.z - c.z;
-            const float d = d0 * d0 + d1 * d1 + d2 * d2;
-            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
-            loc = key < loc ? key : loc;
-          }
-        }
-      }
-      loc = wave_min_u64(loc);
+    for (int stage = 0; stage < 3 && n > 0; stage++) {
+      VisitNearest vn;
+      vn.sel = sel; vn.loc = ~0ull;
+      vn = LO_SCAN_STAGE(stage, 0, kMaxRings >> kRingGroupShift, vn);
+      const u64 loc = wave_min_u64(vn.loc);
       best = loc < best ? loc : best;
-      const float bd = __uint_as_float((unsigned)(best >> 32));
-      const float bound = (float)(R * R) * 0.999999f;
-      if (best != ~0ull && bd <= bound) { exact = true; break; }
-    }
-    if (!exact && n > 0) {
-      // no neighbour within 2 m: sweep the 27 cells of the 5 m grid around the query — together they contain every point
-      // within 5 m, and anything farther is rejected by DISTANCE_SQ_THRESHOLD below.  Lanes stride over each cell's points.
-      const int* cstart = G.start[kind + 2];
-      const int* citems = G.items[kind + 2];
-      const int cmask = G.mask[kind + 2];
-      const int ccx = coarse_cell(sel.x), ccy = coarse_cell(sel.y), ccz = coarse_cell(sel.z);
-      u64 loc = ~0ull;
-      for (int cc = 0; cc < 27; cc++) {
-        const unsigned b = grid_hash(ccx + cc % 3 - 1, ccy + (cc / 3) % 3 - 1, ccz + cc / 9 - 1) & (unsigned)cmask;
-        const int e = cstart[b + 1];
-        for (int t0 = cstart[b] + lane; t0 < e; t0 += 4 * 64) {
-          int js[4];
-          float4 cs[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const int t = t0 + u * 64; js[u] = t < e ? citems[t] : -1; }
-#pragma unroll
-          for (int u = 0; u < 4; u++) cs[u] = js[u] >= 0 ? cand[js[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (js[u] < 0) continue;
-            const float d0 = sel.x - cs[u].x, d1 = sel.y - cs[u].y, d2 = sel.z - cs[u].z;
-            const float d = d0 * d0 + d1 * d1 + d2 * d2;
-            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)js[u];
-            loc = key < loc ? key : loc;
-          }
-        }
-      }
-      loc = wave_min_u64(loc);
-      best = loc < best ? loc : best;
+      if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= stage_bound(stage)) { exact_dbg = stage; break; }
     }
     const float dmin = __uint_as_float((unsigned)(best >> 32));
+    if (dbg_cyc) t1 = clock64();
     if (best != ~0ull && dmin < 25.0f) {  // DISTANCE_SQ_THRESHOLD, LO:272 / LO:359
       const int idx = (int)(best & 0xffffffffu);
       const int ringA = (int)cand[idx].w;  // closestPointScanID
+      // ---- second (and third) point: the reference walks the ring-sorted cloud upwards from idx + 1 until the scan line
+      // exceeds ringA + NEARBY_SCAN and downwards from idx - 1 until it drops below ringA - NEARBY_SCAN, keeping the nearest
+      // point with d2 < 25 per class, first strictly smaller wins (LO:279-324 / LO:368-417).  On a ring-sorted cloud that is
+      // the minimum of (d2, visiting order) over { j != idx, |ring_j - ringA| <= 2 } split into classes by (j > idx, ring_j),
+      // so it is answered by the same expanding grid search, with the class filter applied to every candidate.
       u64 b2 = ~0ull, b3 = ~0ull;
-      // Both walks stream the candidate array in trips of kU x 64 points whose loads are all issued before the first is
-      // examined (the stop test is applied afterwards, chunk by chunk, exactly in visiting order; points fetched beyond the
-      // stop are simply ignored) — otherwise every 64-point chunk would cost a full dependent memory round trip.
-      constexpr int kU = 8;
-      // ---- increasing scan line, LO:279-300 / LO:368-391
-      bool stopped = false;
-      for (int base = idx + 1; base < n && !stopped; base += 64 * kU) {
-        float4 c[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) { const int j = base + u * 64 + lane; c[u] = j < n ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int j = base + u * 64 + lane;
-          const bool in = j < n && !stopped;
-          const int rj = (int)c[u].w;
-          const bool stop = in && ((double)rj > (double)ringA + 2.5);  // NEARBY_SCAN
-          const u64 sm = __ballot(stop);
-          const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
-          if (in && lane < first_stop) {
-            const float d = sqdist(c[u], sel);
-            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)(j - idx);
-            if (d < 25.0f) {
-              if (is_corner) { if (!(rj <= ringA)) b2 = key < b2 ? key : b2; }
-              else if (rj <= ringA) b2 = key < b2 ? key : b2;
-              else b3 = key < b3 ? key : b3;
-            }
-          }
-          stopped = stopped || sm != 0;
-        }
+      const int glo = max(ringA - 2, 0) >> kRingGroupShift, ghi = min(ringA + 2, kMaxRings - 1) >> kRingGroupShift;
+      for (int stage = 0; stage < 3; stage++) {
+        VisitAdjacent va;
+        va.sel = sel; va.idx = idx; va.ringA = ringA; va.is_corner = is_corner; va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
+        va = LO_SCAN_STAGE(stage, glo, ghi - glo + 1, va);
+        cand_dbg += va.visited;
+        const u64 l2 = wave_min_u64(va.l2);
+        b2 = l2 < b2 ? l2 : b2;
+        if (!is_corner) { const u64 l3 = wave_min_u64(va.l3); b3 = l3 < b3 ? l3 : b3; }
+        const bool done2 = b2 != ~0ull && __uint_as_float((unsigned)(b2 >> 32)) <= stage_bound(stage);
+        const bool done3 = is_corner || (b3 != ~0ull && __uint_as_float((unsigned)(b3 >> 32)) <= stage_bound(stage));
+        stage2_dbg = stage;
+        if (done2 && done3) break;
       }
-      // ---- decreasing scan line, LO:303-324 / LO:394-417
-      stopped = false;
-      for (int base = idx - 1; base >= 0 && !stopped; base -= 64 * kU) {
-        float4 c[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) { const int j = base - u * 64 - lane; c[u] = j >= 0 ? cand[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int j = base - u * 64 - lane;
-          const bool in = j >= 0 && !stopped;
-          const int rj = (int)c[u].w;
-          const bool stop = in && ((double)rj < (double)ringA - 2.5);
-          const u64 sm = __ballot(stop);
-          const int first_stop = sm ? __ffsll((long long)sm) - 1 : 64;
-          if (in && lane < first_stop) {
-            const float d = sqdist(c[u], sel);
-            const u64 key = ((u64)__float_as_uint(d) << 32) | (kBack + (unsigned)(idx - j));
-            if (d < 25.0f) {
-              if (is_corner) { if (!(rj >= ringA)) b2 = key < b2 ? key : b2; }
-              else if (rj >= ringA) b2 = key < b2 ? key : b2;
-              else b3 = key < b3 ? key : b3;
-            }
-          }
-          stopped = stopped || sm != 0;
-        }
-      }
-      b2 = wave_min_u64(b2);
-      b3 = wave_min_u64(b3);
+#undef LO_SCAN_STAGE
+      if (dbg_cyc) t2 = clock64();
       auto decode = [&](u64 k) {
         const unsigned o = (unsigned)(k & 0xffffffffu);
         return o >= kBack ? idx - (int)(o - kBack) : idx + (int)o;
@@ -290,6 +342,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   if (lane == 0) {
     F.type[slot] = type;
     if (type) atomicAdd(&F.rowcnt[slot >> 6], 1);
+    if (dbg_cyc) { t3 = clock64(); dbg_cyc[slot * 4] = t1 - t0; dbg_cyc[slot * 4 + 1] = t2 - t1; dbg_cyc[slot * 4 + 2] = t3 - t2; dbg_cyc[slot * 4 + 3] = (exact_dbg & 0xff) | ((stage2_dbg & 0xff) << 8) | ((long long)cand_dbg << 16); }
     corr[slot * 4 + 0] = type ? i : -1;
     corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
   }
@@ -332,8 +385,9 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
 }
 
 void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
-                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr);
+                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc,
+                     ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc);
 }
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
   (void)ph;

@@ -37,9 +37,13 @@ struct VoxelTable {       // structure of arrays, open addressing, linear probin
 
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
   unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
-  int* cnt;                  // [hash] points per voxel (pass 1), then fill cursor (pass 3)
-  int* slot_off;             // [hash] start of the voxel's segment in seg
-  unsigned long long* uniq;  // [stack_cap] keys of occupied voxels (unordered)
+  int* cnt;                  // [hash] points per voxel (pass 1)
+  int* fill;                 // [hash] fill cursor of pass 3
+  int* suidx;                // [hash] index of the slot's voxel in uniq
+  unsigned long long* uniq;  // [stack_cap] keys of occupied voxels (arrival order)
+  int* uslot;                // [stack_cap] hash slot of uniq[i]
+  int* rank;                 // [stack_cap] output rank of uniq[i] (pass 2; zero between sweeps)
+  int* off;                  // [stack_cap] start of uniq[i]'s segment in seg (pass 2; zero between sweeps)
   int* point_slot;           // [max_points] hash slot of every sweep point
   int* seg;                  // [max_points] point indices grouped by voxel
   int* rank_slot;            // [stack_cap] hash slot of the t-th voxel in VoxelGrid output order

@@ -4,7 +4,7 @@
 //   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448)
 //   k_map_purge     grid      only does work after a roll: drops voxels whose cube left the 21x21x11 window
 //   k_map_ds_count  grid      pcl::VoxelGrid of the scan features (LM:432-440), pass 1: hash sweep points to voxels, count
-//   k_map_ds_sort   2 WGs     pass 2: LDS bitonic sort of the occupied voxel keys (= output order), segment offsets
+//   k_map_ds_rank   grid      pass 2: output rank + segment start of every occupied voxel by whole-chip counting
 //   k_map_ds_scatter grid     pass 3: group point indices by voxel
 //   k_map_ds_reduce grid      pass 4: per voxel, input-ordered f32 centroid
 //   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN by probing the voxel hash in a +-1 m box, 3x3 eigen /
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__
       const u64 old = atomicCAS(&D.keys[s], 0ull, key);
       if (old == 0ull) {  // new voxel
         const int u = atomicAdd(&fr->n_uniq[kind], 1);
-        if (u < D.stack_cap) D.uniq[u] = key; else atomicOr(&fr->error, kErrStackFull);
+        if (u < D.stack_cap) { D.uniq[u] = key; D.uslot[u] = (int)s; D.suidx[s] = u; } else atomicOr(&fr->error, kErrStackFull);
       }
       if (old == 0ull || old == key) { atomicAdd(&D.cnt[s], 1); found = (int)s; break; }
     }
@@ -201,74 +201,63 @@ __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__
   }
 }
 
-// pass 2: output order (LDS bitonic sort of the occupied voxel keys) + segment offsets (block scan)
-constexpr int kEmitThreads = 1024;
-__global__ __launch_bounds__(kEmitThreads) void k_map_ds_sort(DsScratch D0, DsScratch D1, MapFrame* fr, MapState* ms) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64* K = (u64*)smem;
-  const int kind = blockIdx.x, tid = threadIdx.x;
+// pass 2: output order.  VoxelGrid emits voxels sorted by key; with only a few thousand occupied voxels the whole chip ranks
+// them by counting: tile (256 keys) x (512 entries), rank = #keys below mine, off = #points in voxels below mine (which is the
+// voxel's segment start, so no scan pass is needed).  Partial results are added up with integer atomics (order-free).
+constexpr int kRankKeys = 256, kRankChunk = 512;
+__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const MapFrame* __restrict__ fr) {
+  __shared__ __attribute__((aligned(16))) u64 s_key[kRankChunk];
+  __shared__ __attribute__((aligned(16))) int s_cnt[kRankChunk];
+  const int kind = blockIdx.y, tid = threadIdx.x;
   const DsScratch D = kind ? D1 : D0;
   const int u = min(fr->n_uniq[kind], D.stack_cap);
-  int P = 2;
-  while (P < u) P <<= 1;
-  for (int t = tid; t < P; t += kEmitThreads) K[t] = t < u ? D.uniq[t] : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= P; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < P / 2; t += kEmitThreads) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-        const bool up = (i & k) == 0;
-        const u64 x = K[i], y = K[l];
-        if ((x > y) == up) { K[i] = y; K[l] = x; }
-      }
-      __syncthreads();
+  const int nkg = (u + kRankKeys - 1) / kRankKeys, nch = (u + kRankChunk - 1) / kRankChunk;
+  for (int tile = blockIdx.x; tile < nkg * nch; tile += gridDim.x) {
+    const int kg = tile / nch, ch = tile % nch;
+    __syncthreads();
+    for (int e = tid; e < kRankChunk; e += kRankKeys) {
+      const int j = ch * kRankChunk + e;
+      s_key[e] = j < u ? D.uniq[j] : ~0ull;
+      s_cnt[e] = j < u ? D.cnt[D.uslot[j]] : 0;
     }
-  // per-thread contiguous chunk of ranks: slot lookup, local count sum, block scan of the sums, offsets
-  const int per = (u + kEmitThreads - 1) / kEmitThreads;
-  const int lo = tid * per, hi = min(lo + per, u);
-  int local = 0;
-  for (int t = lo; t < hi; t++) {
-    const u64 key = K[t];
-    unsigned s = (unsigned)mix64(key) & D.hash_mask;
-    while (D.keys[s] != key) s = (s + 1) & D.hash_mask;
-    D.rank_slot[t] = (int)s;
-    local += D.cnt[s];
-  }
-  __syncthreads();
-  int* sums = (int*)smem;  // keys are no longer needed
-  sums[tid] = local;
-  __syncthreads();
-  for (int d = 1; d < kEmitThreads; d <<= 1) {
-    const int v = tid >= d ? sums[tid - d] : 0;
     __syncthreads();
-    sums[tid] += v;
-    __syncthreads();
-  }
-  int run = tid ? sums[tid - 1] : 0;
-  for (int t = lo; t < hi; t++) {
-    const int s = D.rank_slot[t];
-    D.rank_off[t] = run;
-    D.slot_off[s] = run;
-    run += D.cnt[s];
-    D.cnt[s] = 0;  // becomes the fill cursor of pass 3
-  }
-  if (tid == kEmitThreads - 1) D.rank_off[u] = sums[kEmitThreads - 1];
-  if (tid == 0) {
-    fr->n_stack[kind] = u;
-    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
+    const int i = kg * kRankKeys + tid;
+    const u64 mine = i < u ? D.uniq[i] : 0ull;  // 0 is below every key: contributes nothing
+    int rank = 0, off = 0;
+#pragma unroll 4
+    for (int e = 0; e < kRankChunk; e += 2) {
+      const ulonglong2 k2 = *(const ulonglong2*)&s_key[e];
+      const int2 c2 = *(const int2*)&s_cnt[e];
+      const bool l0 = k2.x < mine, l1 = k2.y < mine;
+      rank += (int)l0 + (int)l1;
+      off += (l0 ? c2.x : 0) + (l1 ? c2.y : 0);
+    }
+    if (rank) { atomicAdd(&D.rank[i], rank); atomicAdd(&D.off[i], off); }
   }
 }
 
-// pass 3: group the point indices by voxel
-__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1) {
+// pass 3: group the point indices by voxel (segment start = off of the voxel); the same launch publishes the output order
+__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, MapFrame* fr,
+                                                        MapState* ms) {
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int s = D.point_slot[i];
     if (s < 0) continue;
-    const int pos = D.slot_off[s] + atomicAdd(&D.cnt[s], 1);
+    const int pos = D.off[D.suidx[s]] + atomicAdd(&D.fill[s], 1);
     D.seg[pos] = i;
+  }
+  const int u = min(fr->n_uniq[kind], D.stack_cap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < u; i += gridDim.x * 256) {
+    const int r = D.rank[i], o = D.off[i], s = D.uslot[i];
+    D.rank_slot[r] = s;
+    D.rank_off[r] = o;
+    if (r == u - 1) D.rank_off[u] = o + D.cnt[s];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    fr->n_stack[kind] = u;
+    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
   }
 }
 
@@ -329,7 +318,8 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
       const float nn = (float)cnt;
       stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
       const int s = D.rank_slot[t];
-      D.keys[s] = 0ull; D.cnt[s] = 0;  // leave the scratch hash clean for the next sweep
+      D.keys[s] = 0ull; D.cnt[s] = 0; D.fill[s] = 0;  // leave the scratch clean for the next sweep
+      D.rank[t] = 0; D.off[t] = 0;
     }
   }
 }
@@ -825,7 +815,9 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
     const size_t hs = (size_t)D.hash_mask + 1;
-    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.slot_off, hs) &&
+    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.fill, hs) && dmalloc(allocs, st, &D.suidx, hs) &&
+         dmalloc(allocs, st, &D.uslot, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.rank, (size_t)D.stack_cap) &&
+         dmalloc(allocs, st, &D.off, (size_t)D.stack_cap) &&
          dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.point_slot, (size_t)cfg.max_points) &&
          dmalloc(allocs, st, &D.seg, (size_t)cfg.max_points) && dmalloc(allocs, st, &D.rank_slot, (size_t)D.stack_cap) &&
          dmalloc(allocs, st, &D.rank_off, (size_t)D.stack_cap + 1);
@@ -850,8 +842,6 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
   init.parameters[3] = 1.0; init.q_wmap_wodom[3] = 1.0; init.q_wodom_curr[3] = 1.0;  // LM:74-91
   init.cenW = 10; init.cenH = 10; init.cenD = 5;                                      // laser_mapping.h:76-78
   if (hipMemcpyAsync(m->state, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
-  if (hipFuncSetAttribute((const void*)k_map_ds_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kStackCapSurf * (int)sizeof(u64)) != hipSuccess)
-    return VLOAM_ERR_HIP;
   return hipStreamSynchronize(st) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -865,8 +855,8 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   hipLaunchKernelGGL(k_map_purge, dim3(256, 2), dim3(256), 0, st, m->tab[0], m->tab[1], ms, fr);
   VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
                m->inv_leaf[0], m->inv_leaf[1], fr);
-  hipLaunchKernelGGL(k_map_ds_sort, dim3(2), dim3(kEmitThreads), kStackCapSurf * sizeof(u64), st, m->ds[0], m->ds[1], fr, ms);
-  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1]);
+  hipLaunchKernelGGL(k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], fr);
+  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], fr, ms);
   hipLaunchKernelGGL(k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
                      m->stack[0], m->stack[1], fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458

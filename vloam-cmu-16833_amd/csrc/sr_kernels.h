@@ -23,6 +23,7 @@ struct SRBuffers {
   // parity hooks (cfg.debug)
   float* dbg_curv;
   int *dbg_sort, *dbg_picked, *dbg_label;
+  long long* dbg_cyc;   // [kMaxRings][8] shader-clock cycles of k_sr_ring's phases (debug)
   int* dbg_feat_idx;    // [3][kMaxLessSharp]
 };
 

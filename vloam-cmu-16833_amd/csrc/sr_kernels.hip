@@ -5,7 +5,7 @@
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
 //
 // Kernels (one sweep = 5 launches, no host synchronisation):
-//   k_sr_first_last  1 WG        first / last surviving point -> startOri / endOri            SR:157-176
+//   k_sr_first_last  n/1024 WGs  first / last surviving point (last-ticket fold) -> startOri / endOri  SR:157-176
 //   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
 //   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, 6 sector sorts (one wavefront each,
@@ -67,32 +67,45 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, FrameScalars* S) {
-  __shared__ int s_first, s_last;
-  __shared__ float s_xy[4];
-  const int tid = threadIdx.x;
+// Every workgroup reports the first / last surviving point of its 1024-point slice; the workgroup that draws the last ticket
+// folds the slices (a sweep has ~128 of them) and derives startOri / endOri.  One pass over the input at full width instead
+// of a latency-bound walk from both ends.
+__global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, FrameScalars* S,
+                                                        int2* __restrict__ slice /* [gridDim.x] */) {
+  __shared__ int s_first, s_last, s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
-  // both ends are fetched in the same trip; the winning threads hand their point over through LDS (no dependent reload)
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid, j = n - 1 - base - tid;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-    const bool need_f = s_first == INT_MAX, need_l = s_last < 0;
-    if (need_f && i < n) p = in[i];
-    if (need_l && j >= 0) q = in[j];
-    const bool vf = need_f && i < n && sr_survives_s1(p.x, p.y, p.z, thres);
-    const bool vl = need_l && j >= 0 && sr_survives_s1(q.x, q.y, q.z, thres);
-    // i grows and j shrinks with the lane id: the lowest valid lane of a wavefront holds its min i / max j
-    const unsigned long long mf = __ballot(vf), ml = __ballot(vl);
-    if (vf && (tid & 63) == __ffsll((long long)mf) - 1) atomicMin(&s_first, i);
-    if (vl && (tid & 63) == __ffsll((long long)ml) - 1) atomicMax(&s_last, j);
-    __syncthreads();
-    if (vf && s_first == i) { s_xy[0] = p.x; s_xy[1] = p.y; }
-    if (vl && s_last == j) { s_xy[2] = q.x; s_xy[3] = q.y; }
-    __syncthreads();
-    if (s_first != INT_MAX && s_last >= 0) break;
+  const int i = blockIdx.x * 1024 + tid;
+  bool v = false;
+  if (i < n) { const float4 p = in[i]; v = sr_survives_s1(p.x, p.y, p.z, thres); }
+  const unsigned long long m = __ballot(v);
+  if (m != 0ull) {
+    if (lane == __ffsll((long long)m) - 1) atomicMin(&s_first, i);
+    if (lane == 63 - __clzll((long long)m)) atomicMax(&s_last, i);
   }
+  __syncthreads();
   if (tid == 0) {
+    slice[blockIdx.x] = make_int2(s_first, s_last);
+    __threadfence();
+    s_ticket = atomicAdd(&S->fl_ticket, 1);
+  }
+  __syncthreads();
+  if (s_ticket != (int)gridDim.x - 1) return;
+  __threadfence();
+  // last workgroup: fold the slices
+  int f = INT_MAX, l = -1;
+  for (int b = tid; b < (int)gridDim.x; b += 1024) {
+    const int2 fl = slice[b];
+    f = min(f, fl.x); l = max(l, fl.y);
+  }
+  if (tid == 0) { s_first = INT_MAX; s_last = -1; }
+  __syncthreads();
+  for (int d = 32; d > 0; d >>= 1) { f = min(f, __shfl_xor(f, d)); l = max(l, __shfl_xor(l, d)); }
+  if (lane == 0) { atomicMin(&s_first, f); atomicMax(&s_last, l); }
+  __syncthreads();
+  if (tid == 0) {
+    S->fl_ticket = 0;
     S->first_valid = s_first == INT_MAX ? -1 : s_first;
     S->last_valid = s_last;
     S->istar = INT_MAX;
@@ -102,8 +115,9 @@ __global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict
       S->error = kErrEmpty;
       S->startOri = 0.f; S->endOri = 0.f;
     } else {
-      float startOri = -atan2f(s_xy[1], s_xy[0]);                                    // SR:166
-      float endOri = (float)((double)(-atan2f(s_xy[3], s_xy[2])) + 2 * M_PI);        // SR:167
+      const float4 pf = in[s_first], pl = in[s_last];
+      float startOri = -atan2f(pf.y, pf.x);                                          // SR:166
+      float endOri = (float)((double)(-atan2f(pl.y, pl.x)) + 2 * M_PI);              // SR:167
       if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
       else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
       S->startOri = startOri; S->endOri = endOri;
@@ -251,6 +265,27 @@ __device__ int block_exclusive_scan(int* a, int n, int* scratch /* kRingThreads 
   return total;
 }
 
+// One stage of the network for `nthreads` cooperating lanes: each lane fetches both operands of up to four compare-exchanges
+// before writing any of them back (the exchanges of a stage touch disjoint pairs), so the LDS round trips overlap.
+__device__ __forceinline__ void bitonic_stage(u64* a, int P, int j, int k, int tid, int nthreads) {
+  for (int t0 = tid; t0 < P / 2; t0 += 4 * nthreads) {
+    u64 x[4], y[4];
+    int ii[4], ll[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = t0 + u * nthreads;
+      ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      ll[u] = ii[u] | j;
+      if (t < P / 2) { x[u] = a[ii[u]]; y[u] = a[ll[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = t0 + u * nthreads;
+      if (t < P / 2 && ((x[u] > y[u]) == ((ii[u] & k) == 0))) { a[ii[u]] = y[u]; a[ll[u]] = x[u]; }
+    }
+  }
+}
+
 __device__ __forceinline__ void bitonic_step(u64* a, int t, int j, int k) {
   const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
   const int l = i | j;
@@ -281,7 +316,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
                                                           int* __restrict__ less_sharp_idx, int* __restrict__ flat_idx,
                                                           float4* __restrict__ ring_ds, float* __restrict__ dbg_curv,
                                                           int* __restrict__ dbg_sort, int* __restrict__ dbg_picked,
-                                                          int* __restrict__ dbg_label) {
+                                                          int* __restrict__ dbg_label, long long* __restrict__ dbg_cyc /* [rings][8] */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* px = (float*)smem;                          // [kMaxRingLen]
   float* py = px + kMaxRingLen;
@@ -297,8 +332,14 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   int* s_ep = s_sp + 8;                                              // [kSectors]    region so its base stays 16-B aligned)
   float* s_red = (float*)(s_ep + 8);                                 // [6]
   int* s_ncand_p = (int*)(s_red + 8);
+  int* s_leak_lo = s_ncand_p + 8;                                     // [kSectors] lowest / highest local index marked by
+  int* s_leak_hi = s_leak_lo + 8;                                    // [kSectors] sector s's picks (unclipped)
 
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long tstamp[8];
+  int nstamp = 0;
+#define SR_STAMP() do { if (dbg_cyc) tstamp[nstamp] = clock64(); nstamp++; } while (0)
+  SR_STAMP();
   const int len = S->ring_count[r], off = S->ring_off[r];
   const int start = off + 5, end = off + len - 6;  // SR:278-280
   if (tid < kSectors * 3) (&S->sect_cnt[r][0][0])[tid] = 0;
@@ -316,6 +357,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     s_ep[tid] = start + (end - start) * (tid + 1) / 6 - 1;  // SR:320
   }
   __syncthreads();
+  SR_STAMP();
 
   // ---- curvature (SR:288-303) + sort keys, one wavefront per sector
   if (wave < kSectors) {
@@ -341,12 +383,13 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     // SR:323 std::sort by curvature (canonical tie order: index ascending) — wavefront-local bitonic network in LDS
     for (int k = 2; k <= P; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = lane; t < P / 2; t += 64) bitonic_step(K, t, j, k);
+        bitonic_stage(K, P, j, k, lane, 64);
         lds_fence_wave();
       }
     if (dbg_sort) for (int t = lane; t < seclen; t += 64) dbg_sort[off + sp + t] = off + (int)(K[t] & 0xffffffffu);
   }
   __syncthreads();
+  SR_STAMP();
 
   // ---- neighbour-suppression reach of every point, computed once in parallel (SR:353-376 walks outwards while consecutive
   // points are closer than sqrt(0.05) m): fwd[l] / bwd[l] = how many of l+1..l+5 / l-1..l-5 a pick at l would mark.
@@ -361,21 +404,38 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   }
   __syncthreads();
 
-  // ---- greedy picks, sector after sector (the suppression leaks into the next sector).  One wavefront per sector; 64 sorted
-  // candidates per trip live in registers, a pick knocks out the lanes inside its reach without re-reading LDS.
-  for (int s = 0; s < kSectors; s++) {
-    if (wave == s) {
-      const int seclen = s_ep[s] - s_sp[s] + 1;
+  // ---- greedy picks.  The reference walks the six sectors in order and a pick's neighbour suppression can spill over the
+  // sector boundary (SR:353-376), so sector s + 1 formally depends on sector s.  The spill reaches at most 5 points and only
+  // matters if one of them would otherwise be selected, so all six sectors run at once (one wavefront each) without incoming
+  // marks; afterwards the boundaries are checked in order and a sector is redone — with the marks of its predecessor applied
+  // first — only when a spilled-on point had been selected.  Marks are clipped to the own sector while picking (a later
+  // sector must not disturb an earlier one); the full extents are applied at the end so that `picked` ends up exactly like
+  // cloudNeighborPicked.  64 sorted candidates per trip live in registers, a pick knocks out the lanes inside its reach
+  // without re-reading LDS.
+  auto run_sector = [&](int s, int in_hi) {
+    const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
+    if (in_hi >= 0) {  // redo: forget the speculative result, then apply the predecessor's spill
+      for (int l = sp_l + lane; l <= ep_l; l += 64) { picked[l] = (l <= in_hi) ? 1 : 0; label[l] = 0; }
+      lds_fence_wave();
+    }
+    {
+      const int seclen = ep_l - sp_l + 1;
       const u64* K = keys + s * kSectCap;
       int* o_sharp = sharp_idx + (r * kSectors + s) * kMaxSharpPerSect;
       int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
       int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
       int n_sharp = 0, n_less = 0, n_flat = 0;
+      int leak_lo = INT_MAX, leak_hi = -1;
       auto reach = [&](int l, int* a, int* b) {  // candidates are >= 5 away from both ring ends, so l +- 5 is in range
         int f = 0, k = 0;
         while (f < 5 && gap[l + f] == 0) f++;       // SR:353-364
         while (k < 5 && gap[l - 1 - k] == 0) k++;   // SR:365-376
         *a = k; *b = f;
+      };
+      auto mark = [&](int lo_m, int hi_m) {  // at most 11 marks
+        const int l = lo_m + lane;
+        if (l <= hi_m && l >= sp_l && l <= ep_l) picked[l] = 1;
+        leak_lo = min(leak_lo, lo_m); leak_hi = max(leak_hi, hi_m);
       };
       // SR:327-378, descending curvature
       int largestPickedNum = 0;
@@ -409,7 +469,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
             break;
           }
           const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
-          if (lane <= hi_m - lo_m) picked[lo_m + lane] = 1;   // at most 11 marks
+          mark(lo_m, hi_m);
           elig = elig && (l < lo_m || l > hi_m);
         }
         if (m != __ballot(in)) done = true;  // sorted: everything further down is <= 0.1
@@ -440,16 +500,41 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
           smallestPickedNum++;
           if (smallestPickedNum >= 4) { done = true; break; }  // the 4th flat point is emitted but not suppressed (SR:390-394)
           const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
-          if (lane <= hi_m - lo_m) picked[lo_m + lane] = 1;
+          mark(lo_m, hi_m);
           elig = elig && (l < lo_m || l > hi_m);
         }
         if (m != __ballot(in)) done = true;
         lds_fence_wave();
       }
-      if (lane == 0) { S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat; }
+      if (lane == 0) {
+        S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
+        s_leak_lo[s] = leak_lo; s_leak_hi[s] = leak_hi;
+      }
     }
-    __syncthreads();
+  };
+  if (wave < kSectors) run_sector(wave, -1);
+  __syncthreads();
+  if (wave == 0) {
+    for (int s = 1; s < kSectors; s++) {
+      const int sp_l = s_sp[s] - off, in_hi = min(s_leak_hi[s - 1], s_ep[s] - off);
+      bool hit = false;
+      if (in_hi >= sp_l) hit = (lane <= in_hi - sp_l) && label[sp_l + lane] != 0;   // the spill covers at most 5 points
+      if (__ballot(hit) != 0ull) { run_sector(s, in_hi); lds_fence_wave(); }
+    }
+    // full mark extents (beyond the own sector), as the reference leaves them behind
+    for (int s = 0; s < kSectors; s++) {
+      const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
+      const int lo_m = s_leak_lo[s], hi_m = s_leak_hi[s];
+      if (hi_m < 0) continue;
+      if (lane < 8) {
+        const int lb = lo_m + lane, lf = ep_l + 1 + lane;
+        if (lb < sp_l) picked[lb] = 1;
+        if (lf <= hi_m) picked[lf] = 1;
+      }
+    }
   }
+  __syncthreads();
+  SR_STAMP();
   if (dbg_picked) for (int l = tid; l < len; l += kRingThreads) { dbg_picked[off + l] = picked[l]; dbg_label[off + l] = label[l]; }
 
   // ---- lessFlat (SR:424-430) + per-ring pcl::VoxelGrid leaf 0.2 (SR:433-437)
@@ -522,11 +607,13 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     K2[t] = key;
   }
   __syncthreads();
+  SR_STAMP();
   for (int k = 2; k <= P2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < P2 / 2; t += kRingThreads) bitonic_step(K2, t, j, k);
+      bitonic_stage(K2, P2, j, k, tid, kRingThreads);
       __syncthreads();
     }
+  SR_STAMP();
   // voxel heads -> output rank
   for (int t = tid; t < ncand; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 12) != (K2[t - 1] >> 12)) ? 1 : 0;
   __syncthreads();
@@ -545,6 +632,9 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     }
   }
   if (tid == 0) S->ring_ds_cnt[r] = nvox;
+  SR_STAMP();
+  if (dbg_cyc && tid == 0) for (int q = 0; q < 7; q++) dbg_cyc[r * 8 + q] = q + 1 < nstamp ? tstamp[q + 1] - tstamp[q] : 0;
+#undef SR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,7 +699,7 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
 // ------------------------------------------------------------------------------------------------
 size_t sr_ring_smem_bytes() {
   return sizeof(float) * 4 * kMaxRingLen + sizeof(u64) * kSectors * kSectCap + sizeof(int) * (kMaxRingLen + kRingThreads) +
-         3 * kMaxRingLen + 32 * sizeof(int);
+         3 * kMaxRingLen + 64 * sizeof(int);
 }
 
 hipError_t sr_init() {
@@ -618,12 +708,12 @@ hipError_t sr_init() {
 
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph) {
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(1), dim3(1024), 0, st, d_in, n, min_range, b.S);
+  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nblk), dim3(1024), 0, st, d_in, n, min_range, b.S, (int2*)b.blockhist);
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
   VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud);
   VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-                     debug ? b.dbg_label : nullptr);
+                     debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr);
   VLOAM_LAUNCH(ph, kKSrCompact, st, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
                      b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr);
   return hipGetLastError();
