@@ -44,7 +44,8 @@ __device__ __forceinline__ unsigned grid_hash(int ix, int iy, int iz) {
   h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
   return h;
 }
-__device__ __forceinline__ int coarse_cell(float v) { return (int)floorf(v / 5.0f); }
+// f64 quotient: two points closer than 5 m must never end up two cells apart through rounding of the division
+__device__ __forceinline__ int coarse_cell(float v) { return (int)floor((double)v / 5.0); }
 // The 5 m level is keyed by (cell, group of 4 scan lines): the second / third neighbour searches only want points within two
 // scan lines of the closest point, i.e. at most two groups, instead of every line crossing those 15 m.
 constexpr int kRingGroupShift = 2;
@@ -150,48 +151,127 @@ __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restric
 
 constexpr unsigned kBack = 0x40000000u;
 
-// Visit every point stored in the (2R+1)^3 block of cells around (cx, cy, cz) — only its outer shell when `shell` — with the
-// whole wavefront: the cells' bucket ranges are fetched by up to 64 lanes at once, concatenated by a wavefront prefix sum,
-// and the concatenated list is consumed 4 x 64 items per trip (each lane finds its item's bucket by a 6-step search over the
-// prefix sums), so a block costs two dependent memory round trips however its points are spread over the cells.
+// Visit every point stored in the (2R+1)^3 block of cells around (cx, cy, cz) minus the inner block of radius Rin (-1: none),
+// times `ng` ring groups on the 5 m level, with the whole wavefront.  Lane l owns cells l, l + 64, ... (KC per lane): all bucket ranges
+// are fetched in one trip, concatenated by a wavefront prefix sum, and the concatenated list is consumed 4 x 64 items per
+// trip (each lane finds its item's owner by a 6-step search over the prefix sums), so a block costs two dependent memory
+// round trips plus one per 256 points, however the points are spread over the cells.
 // The visitor is a small value type (taken and returned by value, so that it stays in registers): v.visit(point).
-template <class V>
+// A block holding more than max_total points is not visited at all (*skipped = true).
+// KC: cells per lane; UB: points per lane and trip (all of a trip's loads are in flight together — a cold neighbourhood costs
+// a full HBM round trip per trip); R / Rin are compile-time so the cell decoding divides by constants.
+template <int KC, int UB, int R, int Rin, class V>
 __device__ __forceinline__ V for_each_candidate(const int* __restrict__ gstart, const float4* __restrict__ gpts, unsigned gmask, int cx,
-                                                int cy, int cz, int R, bool shell, int g0, int ng, int lane, V v) {
-  const int w = 2 * R + 1, w3 = w * w * w, ncell = w3 * ng;  // ng ring groups per cell (1 with g0 = 0 on the 1 m level)
-  for (int cc0 = 0; cc0 < ncell; cc0 += 64) {
-    const int cc = cc0 + lane;
-    int bs = 0, cnt = 0;
+                                                int cy, int cz, int g0, int ng, int lane, V v, int max_total, bool* skipped,
+                                                int* s_inc, int* s_rel, long long* tm = nullptr) {
+  if (tm) tm[0] = clock64();
+  constexpr int w = 2 * R + 1, w3 = w * w * w;
+  const int ncell = w3 * ng;  // ng ring groups per cell (1 with g0 = 0 on the 1 m level)
+  int bs[KC], cnt[KC], mine = 0;
+#pragma unroll
+  for (int q = 0; q < KC; q++) {
+    const int cc = q * 64 + lane;
+    bs[q] = 0; cnt[q] = 0;
     if (cc < ncell) {
       const int ci = cc % w3, grp = g0 + cc / w3;
       const int ox = ci % w - R, oy = (ci / w) % w - R, oz = ci / (w * w) - R;
-      if (!(shell && abs(ox) < R && abs(oy) < R && abs(oz) < R)) {  // the interior was scanned at the previous radius
+      if (!(abs(ox) <= Rin && abs(oy) <= Rin && abs(oz) <= Rin)) {  // the block of radius Rin was scanned by an earlier stage
         const unsigned b = coarse_hash(cx + ox, cy + oy, cz + oz, grp) & gmask;
-        bs = gstart[b];
-        cnt = gstart[b + 1] - bs;
+        bs[q] = gstart[b];
+        cnt[q] = gstart[b + 1] - bs[q];
       }
     }
-    int inc = cnt;
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-    const int total = __shfl(inc, 63);
-    const int rel = bs - (inc - cnt);  // item i of the concatenation that falls into this lane's bucket sits at rel + i
-    for (int i0 = 0; i0 < total; i0 += 4 * 64) {
-      int t[4];
+    mine += cnt[q];
+  }
+  int inc = mine;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  const int total = __shfl(inc, 63);
+  const int exc = inc - mine;
+  if (tm) tm[1] = clock64();
+  *skipped = total > max_total;  // the caller prefers a tighter block first (wavefront-uniform)
+  if (total > max_total) return v;
+  if constexpr (KC > 2) {
+    static_assert(KC * 64 <= 512, "LDS slice holds 512 cells");
+    int run = exc;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u * 64 + lane;
-        int lo = 0;  // number of lanes whose inclusive sum is <= i == the lane owning item i
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const int v = __shfl(inc, lo + step - 1); if (v <= i) lo += step; }
-        const int base = __shfl(rel, lo);  // every lane takes part in the exchange, whether or not its item exists
-        t[u] = i < total ? base + i : -1;
-      }
-      float4 c[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) c[u] = t[u] >= 0 ? gpts[t[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (t[u] >= 0) v.visit(c[u]);
+    for (int q = 0; q < KC; q++) {
+      s_rel[lane * KC + q] = bs[q] - run;
+      run += cnt[q];
+      s_inc[lane * KC + q] = run;
     }
+    for (int e = KC * 64 + lane; e < 512; e += 64) s_inc[e] = 0x7fffffff;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i0 = 0; i0 < total; i0 += UB * 64) {
+    // owner lane of every item by a 6-step search over the inclusive sums, then the owner's cell; the UB searches advance in
+    // lock step so that each step's cross-lane reads are issued back to back (every lane takes part in every exchange)
+    int t[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) t[u] = -1;
+    if constexpr (KC > 2) {
+      // many cells per lane: the cell-level prefix sums (lane-major order) were staged in this wavefront's LDS slice; every
+      // item finds its cell by a 9-step binary search there (plain LDS reads instead of 21 cross-lane exchanges per item)
+#pragma unroll
+      for (int ug = 0; ug < UB; ug += 4)
+        if (i0 + ug * 64 < total) {
+          int pos[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) pos[u] = 0;  // number of cells whose inclusive sum is <= i
+#pragma unroll
+          for (int step = 256; step > 0; step >>= 1) {
+            int vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) vv[u] = s_inc[pos[u] + step - 1];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (vv[u] <= i0 + (ug + u) * 64 + lane) pos[u] += step;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + (ug + u) * 64 + lane;
+            t[ug + u] = i < total ? s_rel[pos[u] & 511] + i : -1;
+          }
+        }
+    } else {
+#pragma unroll
+    for (int ug = 0; ug < UB; ug += 4)
+      if (i0 + ug * 64 < total) {  // wavefront-uniform: groups past the end of the list cost nothing
+        int lo[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lo[u] = 0;  // number of lanes whose inclusive sum is <= i == the lane owning item i
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+          int vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) vv[u] = __shfl(inc, lo[u] + step - 1);
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (vv[u] <= i0 + (ug + u) * 64 + lane) lo[u] += step;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = __shfl(exc, lo[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = i0 + (ug + u) * 64 + lane - r[u];
+        int tt[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int q = 0; q < KC; q++) {
+          int cq[4], bq[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { cq[u] = __shfl(cnt[q], lo[u]); bq[u] = __shfl(bs[q], lo[u]); }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (tt[u] < 0) { if (r[u] < cq[u]) tt[u] = bq[u] + r[u]; else r[u] -= cq[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) t[ug + u] = i0 + (ug + u) * 64 + lane < total ? tt[u] : -1;
+      }
+    }
+    if (tm) tm[2] = clock64();
+    float4 c[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) c[u] = gpts[t[u] >= 0 ? t[u] : 0];  // unconditional: all UB loads go out back to back
+#pragma unroll
+    for (int u = 0; u < UB; u++) if (t[u] >= 0) v.visit(c[u]);
+    if (tm) { tm[3] = clock64(); tm[4] = total; }
   }
   return v;
 }
@@ -232,14 +312,17 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
                                                   const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
                                                   const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
                                                   long long* __restrict__ dbg_cyc /* [slots][4] or null */) {
+  __shared__ int s_inc_all[4][512], s_rel_all[4][512];  // per-wavefront staging of cell prefix sums (for_each_candidate, KC > 2)
   const int lane = threadIdx.x & 63;
+  int* s_inc = s_inc_all[threadIdx.x >> 6];
+  int* s_rel = s_rel_all[threadIdx.x >> 6];
   const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (slot >= kMaxLoFactors) return;
   const bool is_corner = slot < kMaxSharp;
   const int i = is_corner ? slot : slot - kMaxSharp;
   const int nfeat = is_corner ? Sc->n_sharp : Sc->n_flat;
   int type = 0, ia = -1, ib = -1, ic = -1;
-  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, tdbg = 0;
   int exact_dbg = -1, stage2_dbg = -1, cand_dbg = 0;
   if (dbg_cyc) t0 = clock64();
   if (i < nfeat) {
@@ -253,7 +336,6 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     // bound.  Queries without a neighbour inside 2 m sweep the 27 cells of the 5 m grid, which hold every point within 5 m
     // (DISTANCE_SQ_THRESHOLD = 25 rejects anything farther).  Key = (f32 d2 bits, index): ties resolve to the lowest index
     // irrespective of visiting order.
-    const int kind = is_corner ? 0 : 1;
     const int fcx = (int)floorf(sel.x), fcy = (int)floorf(sel.y), fcz = (int)floorf(sel.z);
     const int ccx = coarse_cell(sel.x), ccy = coarse_cell(sel.y), ccz = coarse_cell(sel.z);
     // stage 0: fine R = 1 block, 1: fine R = 2 shell, 2: coarse 27 cells.  bound = squared radius fully covered so far.
@@ -264,18 +346,32 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     const float4* cpts = is_corner ? G.pts[2] : G.pts[3];
     const unsigned fmask = (unsigned)(is_corner ? G.mask[0] : G.mask[1]), cmask = (unsigned)(is_corner ? G.mask[2] : G.mask[3]);
     // stage 0: 1 m level, R = 1 block; 1: R = 2 shell; 2: the 27 cells of the 5 m level, ring groups [g0, g0 + ng)
-#define LO_SCAN_STAGE(stage, g0, ng, vis)                                                                                   \
-  ((stage) < 2 ? for_each_candidate(fstart, fpts, fmask, fcx, fcy, fcz, (stage) + 1, (stage) == 1, 0, 1, lane, vis)          \
-               : for_each_candidate(cstart, cpts, cmask, ccx, ccy, ccz, 1, false, g0, ng, lane, vis))
-    auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 1 ? 4.0f * 0.999999f : 3.0e38f); };  // squared radius fully covered
+    // Search plan, for the closest point and again for the second / third point: (0) the radius-1 block of the 1 m level
+    // (after radius R every unseen point is farther than R metres); (1) if that is not conclusive, the 27 cells of the 5 m
+    // level, which hold every point within DISTANCE_SQ_THRESHOLD — final, but only taken when the neighbourhood is sparse
+    // (<= kSparse points, fetched in ONE trip: features far from everything); otherwise (2, 3) the radius-2 and radius-3 shells of the 1 m level,
+    // which are conclusive in any dense neighbourhood, and (4) the 5 m level unconditionally.
+    constexpr int kSparse = 1024, kAll = 0x7fffffff;
+    constexpr int kGroups = kMaxRings >> kRingGroupShift;
+    auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 2 ? 4.0f * 0.999999f : (stage == 3 ? 9.0f * 0.999999f : 3.0e38f)); };
     u64 best = ~0ull;
-    for (int stage = 0; stage < 3 && n > 0; stage++) {
+    for (int stage = 0; stage < 5 && n > 0; stage++) {
       VisitNearest vn;
       vn.sel = sel; vn.loc = ~0ull;
-      vn = LO_SCAN_STAGE(stage, 0, kMaxRings >> kRingGroupShift, vn);
+      bool skipped = false;
+      if (stage == 0) vn = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else if (stage == 1) {
+        long long tm[5] = {0, 0, 0, 0, 0};
+        vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
+        if (dbg_cyc) tdbg = ((tm[1] - tm[0]) & 0xffff) | (((tm[2] - tm[1]) & 0xffff) << 16) | (((tm[3] - tm[2]) & 0xffff) << 32) | ((tm[4] & 0xffff) << 48);
+      }
+      else if (stage == 2) vn = for_each_candidate<2, 4, 2, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else if (stage == 3) vn = for_each_candidate<6, 4, 3, 2>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
+      if (skipped) continue;
       const u64 loc = wave_min_u64(vn.loc);
       best = loc < best ? loc : best;
-      if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= stage_bound(stage)) { exact_dbg = stage; break; }
+      if (stage == 1 || (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= stage_bound(stage))) { exact_dbg = stage; break; }
     }
     const float dmin = __uint_as_float((unsigned)(best >> 32));
     if (dbg_cyc) t1 = clock64();
@@ -289,10 +385,16 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
       // so it is answered by the same expanding grid search, with the class filter applied to every candidate.
       u64 b2 = ~0ull, b3 = ~0ull;
       const int glo = max(ringA - 2, 0) >> kRingGroupShift, ghi = min(ringA + 2, kMaxRings - 1) >> kRingGroupShift;
-      for (int stage = 0; stage < 3; stage++) {
+      for (int stage = 0; stage < 5; stage++) {
         VisitAdjacent va;
         va.sel = sel; va.idx = idx; va.ringA = ringA; va.is_corner = is_corner; va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
-        va = LO_SCAN_STAGE(stage, glo, ghi - glo + 1, va);
+        bool skipped = false;
+        if (stage == 0) va = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        else if (stage == 1) va = for_each_candidate<1, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups x 27 cells
+        else if (stage == 2) va = for_each_candidate<2, 4, 2, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        else if (stage == 3) va = for_each_candidate<6, 4, 3, 2>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        else va = for_each_candidate<1, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        if (skipped) continue;
         cand_dbg += va.visited;
         const u64 l2 = wave_min_u64(va.l2);
         b2 = l2 < b2 ? l2 : b2;
@@ -300,9 +402,8 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
         const bool done2 = b2 != ~0ull && __uint_as_float((unsigned)(b2 >> 32)) <= stage_bound(stage);
         const bool done3 = is_corner || (b3 != ~0ull && __uint_as_float((unsigned)(b3 >> 32)) <= stage_bound(stage));
         stage2_dbg = stage;
-        if (done2 && done3) break;
+        if (stage == 1 || (done2 && done3)) break;
       }
-#undef LO_SCAN_STAGE
       if (dbg_cyc) t2 = clock64();
       auto decode = [&](u64 k) {
         const unsigned o = (unsigned)(k & 0xffffffffu);
@@ -342,7 +443,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   if (lane == 0) {
     F.type[slot] = type;
     if (type) atomicAdd(&F.rowcnt[slot >> 6], 1);
-    if (dbg_cyc) { t3 = clock64(); dbg_cyc[slot * 4] = t1 - t0; dbg_cyc[slot * 4 + 1] = t2 - t1; dbg_cyc[slot * 4 + 2] = t3 - t2; dbg_cyc[slot * 4 + 3] = (exact_dbg & 0xff) | ((stage2_dbg & 0xff) << 8) | ((long long)cand_dbg << 16); }
+    if (dbg_cyc) { t3 = clock64(); dbg_cyc[slot * 4] = t1 - t0; dbg_cyc[slot * 4 + 1] = t2 - t1; dbg_cyc[slot * 4 + 2] = tdbg; dbg_cyc[slot * 4 + 3] = (exact_dbg & 0xff) | ((stage2_dbg & 0xff) << 8) | ((long long)cand_dbg << 16); }
     corr[slot * 4 + 0] = type ? i : -1;
     corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
   }

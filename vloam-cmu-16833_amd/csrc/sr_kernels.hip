@@ -13,6 +13,7 @@
 //   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <type_traits>
 #include <math.h>
 #include "sr_kernels.h"
 
@@ -26,6 +27,24 @@ __device__ __forceinline__ void lds_fence_wave() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+
+// Wavefront-wide unsigned max / min through DPP row operations (no LDS crossbar, a handful of cycles per step): quad swaps,
+// row rotations, then the row_bcast15 / row_bcast31 carries of gfx9; the result lands in lane 63 and is broadcast.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_max_step(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);  // lanes without a source keep 0
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_max_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_step<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_max_step<0x128, 0xf>(v);  // row_ror:8   -> every lane holds the max of its row of 16
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast15 -> rows 1 and 3 fold in the row below
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast31 -> rows 2 and 3 fold in lane 31
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
 
 // SR:157 removeNaNFromPointCloud + SR:100-129 removeClosedPointCloud
 __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float thres) {
@@ -328,12 +347,15 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   unsigned char* picked = (unsigned char*)(scan_tmp + kRingThreads);  // [kMaxRingLen]
   signed char* label = (signed char*)(picked + kMaxRingLen);         // [kMaxRingLen]
   unsigned char* gap = (unsigned char*)(label + kMaxRingLen);        // [kMaxRingLen]
-  int* s_sp = (int*)(gap + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
+  unsigned char* reachb = gap + kMaxRingLen;                         // [kMaxRingLen]
+  int* s_sp = (int*)(reachb + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
   int* s_ep = s_sp + 8;                                              // [kSectors]    region so its base stays 16-B aligned)
   float* s_red = (float*)(s_ep + 8);                                 // [6]
   int* s_ncand_p = (int*)(s_red + 8);
   int* s_leak_lo = s_ncand_p + 8;                                     // [kSectors] lowest / highest local index marked by
   int* s_leak_hi = s_leak_lo + 8;                                    // [kSectors] sector s's picks (unclipped)
+  int* s_zone = s_leak_hi + 8;                                       // [kSectors] incoming spill the sector was computed with
+  int* s_any = s_zone + 8;
 
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long tstamp[8];
@@ -359,41 +381,9 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   __syncthreads();
   SR_STAMP();
 
-  // ---- curvature (SR:288-303) + sort keys, one wavefront per sector
-  if (wave < kSectors) {
-    const int sp = s_sp[wave] - off, ep = s_ep[wave] - off;  // local indices
-    const int seclen = ep - sp + 1;
-    int P = 2;
-    while (P < seclen) P <<= 1;
-    u64* K = keys + wave * kSectCap;
-    for (int t = lane; t < P; t += 64) {
-      u64 key = ~0ull;
-      if (t < seclen) {
-        const int i = sp + t;
-        float dX = px[i - 5] + px[i - 4] + px[i - 3] + px[i - 2] + px[i - 1] - 10 * px[i] + px[i + 1] + px[i + 2] + px[i + 3] + px[i + 4] + px[i + 5];
-        float dY = py[i - 5] + py[i - 4] + py[i - 3] + py[i - 2] + py[i - 1] - 10 * py[i] + py[i + 1] + py[i + 2] + py[i + 3] + py[i + 4] + py[i + 5];
-        float dZ = pz[i - 5] + pz[i - 4] + pz[i - 3] + pz[i - 2] + pz[i - 1] - 10 * pz[i] + pz[i + 1] + pz[i + 2] + pz[i + 3] + pz[i + 4] + pz[i + 5];
-        float c = dX * dX + dY * dY + dZ * dZ;
-        if (dbg_curv) dbg_curv[off + i] = c;
-        key = ((u64)__float_as_uint(c) << 32) | (unsigned)i;  // c >= 0: the bit pattern orders like the value; ties -> lower index first
-      }
-      K[t] = key;
-    }
-    lds_fence_wave();
-    // SR:323 std::sort by curvature (canonical tie order: index ascending) — wavefront-local bitonic network in LDS
-    for (int k = 2; k <= P; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        bitonic_stage(K, P, j, k, lane, 64);
-        lds_fence_wave();
-      }
-    if (dbg_sort) for (int t = lane; t < seclen; t += 64) dbg_sort[off + sp + t] = off + (int)(K[t] & 0xffffffffu);
-  }
-  __syncthreads();
-  SR_STAMP();
-
   // ---- neighbour-suppression reach of every point, computed once in parallel (SR:353-376 walks outwards while consecutive
-  // points are closer than sqrt(0.05) m): fwd[l] / bwd[l] = how many of l+1..l+5 / l-1..l-5 a pick at l would mark.
-  // gapf[l] = 1 when dist2(p[l+1], p[l]) > 0.05 (stored in the `label` scratch bytes' sibling array `gap`).
+  // points are closer than sqrt(0.05) m): gap[l] = 1 when dist2(p[l+1], p[l]) > 0.05; reach[l] = (how many of l-1..l-5) |
+  // (how many of l+1..l+5) << 4 a pick at l would mark.
   for (int l = tid; l < len; l += kRingThreads) {
     unsigned char g = 1;
     if (l + 1 < len) {
@@ -403,124 +393,178 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     gap[l] = g;
   }
   __syncthreads();
+  for (int l = 5 + tid; l < len - 5; l += kRingThreads) {  // picks are >= 5 away from both ring ends
+    int f = 0, k = 0;
+    while (f < 5 && gap[l + f] == 0) f++;       // SR:353-364
+    while (k < 5 && gap[l - 1 - k] == 0) k++;   // SR:365-376
+    reachb[l] = (unsigned char)(k | (f << 4));
+  }
 
-  // ---- greedy picks.  The reference walks the six sectors in order and a pick's neighbour suppression can spill over the
-  // sector boundary (SR:353-376), so sector s + 1 formally depends on sector s.  The spill reaches at most 5 points and only
+  auto curvature = [&](int i) {  // SR:288-303
+    const float dX = px[i - 5] + px[i - 4] + px[i - 3] + px[i - 2] + px[i - 1] - 10 * px[i] + px[i + 1] + px[i + 2] + px[i + 3] + px[i + 4] + px[i + 5];
+    const float dY = py[i - 5] + py[i - 4] + py[i - 3] + py[i - 2] + py[i - 1] - 10 * py[i] + py[i + 1] + py[i + 2] + py[i + 3] + py[i + 4] + py[i + 5];
+    const float dZ = pz[i - 5] + pz[i - 4] + pz[i - 3] + pz[i - 2] + pz[i - 1] - 10 * pz[i] + pz[i + 1] + pz[i + 2] + pz[i + 3] + pz[i + 4] + pz[i + 5];
+    return dX * dX + dY * dY + dZ * dZ;
+  };
+
+  // ---- debug only: the reference's std::sort of every sector (SR:323, canonical tie order: index ascending), as a
+  // wavefront-local bitonic network in LDS.  The production path below never sorts.
+  if (dbg_sort && wave < kSectors) {
+    const int sp = s_sp[wave] - off, ep = s_ep[wave] - off;  // local indices
+    const int seclen = ep - sp + 1;
+    int P = 2;
+    while (P < seclen) P <<= 1;
+    u64* K = keys + wave * kSectCap;
+    for (int t = lane; t < P; t += 64) {
+      u64 key = ~0ull;
+      if (t < seclen) key = ((u64)__float_as_uint(curvature(sp + t)) << 32) | (unsigned)(sp + t);  // c >= 0: bits order like the value
+      K[t] = key;
+    }
+    lds_fence_wave();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        bitonic_stage(K, P, j, k, lane, 64);
+        lds_fence_wave();
+      }
+    for (int t = lane; t < seclen; t += 64) dbg_sort[off + sp + t] = off + (int)(K[t] & 0xffffffffu);
+  }
+  __syncthreads();
+  SR_STAMP();
+
+  // ---- greedy picks (SR:325-422).  The reference sorts each sector by curvature and walks the sorted list from the top (2
+  // sharp + 18 less-sharp picks) and from the bottom (4 flat picks), skipping points suppressed by earlier picks.  Walking a
+  // sorted list and taking the first eligible entry is the same as taking the arg-max (arg-min) over the eligible entries,
+  // and at most 24 entries are ever taken — so nothing is sorted: every lane keeps the curvatures of its sector points in
+  // registers (point t of the sector lives in lane t % 64, slot t / 64) with one eligibility bit each, and a pick is one
+  // wavefront arg-max (two DPP reductions: curvature bits, then index among the ties — descending (c, index) order for the
+  // sharp walk, ascending for the flat walk, exactly the sorted list's order).
+  //
+  // The sectors of a ring are walked in order by the reference and a pick's neighbour suppression can spill over the sector
+  // boundary (SR:353-376), so sector s + 1 formally depends on sector s.  The spill reaches at most 5 points and only
   // matters if one of them would otherwise be selected, so all six sectors run at once (one wavefront each) without incoming
   // marks; afterwards the boundaries are checked in order and a sector is redone — with the marks of its predecessor applied
   // first — only when a spilled-on point had been selected.  Marks are clipped to the own sector while picking (a later
   // sector must not disturb an earlier one); the full extents are applied at the end so that `picked` ends up exactly like
-  // cloudNeighborPicked.  64 sorted candidates per trip live in registers, a pick knocks out the lanes inside its reach
-  // without re-reading LDS.
-  auto run_sector = [&](int s, int in_hi) {
+  // cloudNeighborPicked.
+  auto run_sector_q = [&](auto kq_tag, int s, int in_hi, bool redo) {
+    constexpr int kQ = decltype(kq_tag)::value;   // register slots per lane: sector length <= 64 kQ
     const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
-    if (in_hi >= 0) {  // redo: forget the speculative result, then apply the predecessor's spill
+    const int seclen = ep_l - sp_l + 1;
+    if (redo) {  // forget the previous result, then apply the predecessor's spill
       for (int l = sp_l + lane; l <= ep_l; l += 64) { picked[l] = (l <= in_hi) ? 1 : 0; label[l] = 0; }
       lds_fence_wave();
     }
-    {
-      const int seclen = ep_l - sp_l + 1;
-      const u64* K = keys + s * kSectCap;
-      int* o_sharp = sharp_idx + (r * kSectors + s) * kMaxSharpPerSect;
-      int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
-      int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
-      int n_sharp = 0, n_less = 0, n_flat = 0;
-      int leak_lo = INT_MAX, leak_hi = -1;
-      auto reach = [&](int l, int* a, int* b) {  // candidates are >= 5 away from both ring ends, so l +- 5 is in range
-        int f = 0, k = 0;
-        while (f < 5 && gap[l + f] == 0) f++;       // SR:353-364
-        while (k < 5 && gap[l - 1 - k] == 0) k++;   // SR:365-376
-        *a = k; *b = f;
-      };
-      auto mark = [&](int lo_m, int hi_m) {  // at most 11 marks
-        const int l = lo_m + lane;
-        if (l <= hi_m && l >= sp_l && l <= ep_l) picked[l] = 1;
-        leak_lo = min(leak_lo, lo_m); leak_hi = max(leak_hi, hi_m);
-      };
-      // SR:327-378, descending curvature
-      int largestPickedNum = 0;
-      bool done = false;
-      for (int top = seclen - 1; top >= 0 && !done; top -= 64) {
-        const int pos = top - lane;
-        const bool in = pos >= 0;
-        const u64 key = in ? K[pos] : 0ull;
-        const float c = __uint_as_float((unsigned)(key >> 32));
-        const int l = in ? (int)(key & 0xffffffffu) : 8;
-        const bool cand = in && ((double)c > 0.1);
-        const u64 m = __ballot(cand);
-        if (m == 0) break;
-        int ra, rb;
-        reach(l, &ra, &rb);
-        bool elig = cand && picked[l] == 0;
-        while (true) {
-          const u64 e = __ballot(elig);
-          if (e == 0) break;
-          const int f = __ffsll((long long)e) - 1;
-          const int lf = __builtin_amdgcn_readlane(l, f);
-          largestPickedNum++;
-          if (largestPickedNum <= 2) {
-            if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; }
-            n_sharp++; n_less++;
-          } else if (largestPickedNum <= 20) {
-            if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; }
-            n_less++;
-          } else {
-            done = true;
-            break;
-          }
-          const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
-          mark(lo_m, hi_m);
-          elig = elig && (l < lo_m || l > hi_m);
+    unsigned cb[kQ];                      // curvature bits of point sp_l + q * 64 + lane
+    unsigned sharp_bits = 0, flat_bits = 0, elig = 0;
+#pragma unroll
+    for (int q = 0; q < kQ; q++) {
+      cb[q] = 0;
+      if (q * 64 < seclen) {
+        const int t = q * 64 + lane;
+        if (t < seclen) {
+          const int i = sp_l + t;
+          const float c = curvature(i);
+          if (dbg_curv) dbg_curv[off + i] = c;
+          cb[q] = __float_as_uint(c);   // c >= 0: the bit pattern orders like the value
+          if ((double)c > 0.1) sharp_bits |= 1u << q;
+          if ((double)c < 0.1) flat_bits |= 1u << q;
+          if (i > in_hi) elig |= 1u << q;
         }
-        if (m != __ballot(in)) done = true;  // sorted: everything further down is <= 0.1
-        lds_fence_wave();
       }
-      // SR:380-422, ascending curvature
-      int smallestPickedNum = 0;
-      done = false;
-      for (int base = 0; base < seclen && !done; base += 64) {
-        const int pos = base + lane;
-        const bool in = pos < seclen;
-        const u64 key = in ? K[pos] : 0ull;
-        const float c = __uint_as_float((unsigned)(key >> 32));
-        const int l = in ? (int)(key & 0xffffffffu) : 8;
-        const bool cand = in && ((double)c < 0.1);
-        const u64 m = __ballot(cand);
-        if (m == 0) break;
-        int ra, rb;
-        reach(l, &ra, &rb);
-        bool elig = cand && picked[l] == 0;
-        while (true) {
-          const u64 e = __ballot(elig);
-          if (e == 0) break;
-          const int f = __ffsll((long long)e) - 1;
-          const int lf = __builtin_amdgcn_readlane(l, f);
-          if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; }
-          n_flat++;
-          smallestPickedNum++;
-          if (smallestPickedNum >= 4) { done = true; break; }  // the 4th flat point is emitted but not suppressed (SR:390-394)
-          const int lo_m = lf - __builtin_amdgcn_readlane(ra, f), hi_m = lf + __builtin_amdgcn_readlane(rb, f);
-          mark(lo_m, hi_m);
-          elig = elig && (l < lo_m || l > hi_m);
-        }
-        if (m != __ballot(in)) done = true;
-        lds_fence_wave();
+    }
+    int* o_sharp = sharp_idx + (r * kSectors + s) * kMaxSharpPerSect;
+    int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
+    int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
+    int n_sharp = 0, n_less = 0, n_flat = 0;
+    int leak_lo = INT_MAX, leak_hi = -1;
+    auto suppress = [&](int lf) {  // SR:353-376 around local index lf
+      const int rb = reachb[lf];
+      const int lo_m = lf - (rb & 15), hi_m = lf + (rb >> 4);
+      const int l = lo_m + lane;  // at most 11 marks
+      if (l <= hi_m && l >= sp_l && l <= ep_l) picked[l] = 1;
+      leak_lo = min(leak_lo, lo_m); leak_hi = max(leak_hi, hi_m);
+      const int tlo = max(lo_m - sp_l, 0), thi = min(hi_m - sp_l, seclen - 1);
+      for (int q = tlo >> 6; q <= (thi >> 6); q++) {  // one or two slots
+        const int t = q * 64 + lane;
+        if (t >= tlo && t <= thi) elig &= ~(1u << q);
       }
-      if (lane == 0) {
-        S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
-        s_leak_lo[s] = leak_lo; s_leak_hi[s] = leak_hi;
+    };
+    // SR:327-378, descending curvature
+    for (int picks = 1;; picks++) {
+      const unsigned m = elig & sharp_bits;
+      unsigned bh = 0, bl = 0;
+#pragma unroll
+      for (int q = 0; q < kQ; q++)
+        if (q * 64 < seclen && ((m >> q) & 1u) && cb[q] >= bh) { bh = cb[q]; bl = (unsigned)(sp_l + q * 64 + lane); }  // >=: higher index wins ties
+      const unsigned mh = wave_max_u32(bh);  // candidates have c > 0.1, i.e. non-zero bits
+      if (mh == 0) break;
+      const int lf = (int)wave_max_u32(bh == mh ? bl : 0u);
+      if (picks <= 2) {
+        if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; }
+        n_sharp++; n_less++;
+      } else if (picks <= 20) {
+        if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; }
+        n_less++;
+      } else {
+        break;
       }
+      suppress(lf);
+    }
+    // SR:380-422, ascending curvature
+    for (int picks = 1;; picks++) {
+      const unsigned m = elig & flat_bits;
+      unsigned bh = 0xffffffffu, bl = 0xffffffffu;
+#pragma unroll
+      for (int q = 0; q < kQ; q++)
+        if (q * 64 < seclen && ((m >> q) & 1u) && (bl == 0xffffffffu || cb[q] < bh)) { bh = cb[q]; bl = (unsigned)(sp_l + q * 64 + lane); }  // <: lower index wins ties
+      if (__ballot(bl != 0xffffffffu) == 0ull) break;
+      const unsigned mh = wave_min_u32(bl != 0xffffffffu ? bh : 0xffffffffu);
+      const int lf = (int)wave_min_u32((bl != 0xffffffffu && bh == mh) ? bl : 0xffffffffu);
+      if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; }
+      n_flat++;
+      if (picks >= 4) break;  // the 4th flat point is emitted but not suppressed (SR:390-394)
+      suppress(lf);
+    }
+    lds_fence_wave();
+    if (lane == 0) {
+      S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
+      s_leak_lo[s] = leak_lo; s_leak_hi[s] = leak_hi;
+      s_zone[s] = in_hi;
     }
   };
-  if (wave < kSectors) run_sector(wave, -1);
+  auto run_sector = [&](int s, int in_hi, bool redo) {
+    if (s_ep[s] - s_sp[s] + 1 <= 6 * 64) run_sector_q(std::integral_constant<int, 6>{}, s, in_hi, redo);   // HDL-64E: ~330 points per sector
+    else run_sector_q(std::integral_constant<int, kSectCap / 64>{}, s, in_hi, redo);
+  };
+  if (wave < kSectors) run_sector(wave, -1, false);
   __syncthreads();
-  if (wave == 0) {
-    for (int s = 1; s < kSectors; s++) {
-      const int sp_l = s_sp[s] - off, in_hi = min(s_leak_hi[s - 1], s_ep[s] - off);
-      bool hit = false;
-      if (in_hi >= sp_l) hit = (lane <= in_hi - sp_l) && label[sp_l + lane] != 0;   // the spill covers at most 5 points
-      if (__ballot(hit) != 0ull) { run_sector(s, in_hi); lds_fence_wave(); }
+  // fixed point over the boundaries: a sector is redone when the spill it was computed with differs from its predecessor's
+  // current spill in a way that can matter.  Sector 0 never changes, so after round k sectors 0..k are final.
+  for (int round = 0; round < kSectors - 1; round++) {
+    if (tid == 0) *s_any = 0;
+    __syncthreads();
+    bool redo = false;
+    int in_hi = -1;
+    if (wave >= 1 && wave < kSectors) {
+      const int sp_l = s_sp[wave] - off, ep_l = s_ep[wave] - off;
+      in_hi = min(s_leak_hi[wave - 1], ep_l);
+      if (in_hi < sp_l) in_hi = -1;
+      const int used = s_zone[wave];
+      if (in_hi > used) {        // the spill grew: matters only if a newly covered point (at most 5) had been selected
+        const int l = max(used + 1, sp_l) + lane;
+        redo = __ballot(l <= in_hi && label[l] != 0) != 0ull;
+        if (!redo && lane == 0) s_zone[wave] = in_hi;
+      } else if (in_hi < used) {  // the spill shrank: points that were blocked are free again
+        redo = true;
+      }
+      if (redo && lane == 0) *s_any = 1;
     }
+    __syncthreads();  // every wavefront has read its predecessor's spill before anything is redone
+    if (*s_any == 0) break;
+    if (redo) run_sector(wave, in_hi, true);
+    __syncthreads();
+  }
+  if (wave == 0) {
     // full mark extents (beyond the own sector), as the reference leaves them behind
     for (int s = 0; s < kSectors; s++) {
       const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
@@ -539,7 +583,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
 
   // ---- lessFlat (SR:424-430) + per-ring pcl::VoxelGrid leaf 0.2 (SR:433-437)
   const int c_lo = 5, c_hi = len - 7;  // local range covered by the six sectors: [start, end-1]
-  const int ncov = c_hi - c_lo + 1;
+
   // bounding box of the candidates (getMinMax3D)
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   int mycnt = 0;
@@ -591,43 +635,58 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     min_b[a] = (int)floorf(mn[a] * inv);
     div_b[a] = (int)floorf(mx[a] * inv) - min_b[a] + 1;
   }
-  int P2 = 2;
-  while (P2 < ncov) P2 <<= 1;
-  u64* K2 = keys;  // P2 <= kMaxRingLen <= kSectors * kSectCap
-  for (int t = tid; t < P2; t += kRingThreads) {
-    u64 key = ~0ull;
-    const int l = c_lo + t;
-    if (t < ncov && label[l] <= 0) {
-      int ijk0 = (int)(floorf(px[l] * inv) - (float)min_b[0]);
-      int ijk1 = (int)(floorf(py[l] * inv) - (float)min_b[1]);
-      int ijk2 = (int)(floorf(pz[l] * inv) - (float)min_b[2]);
-      int idx = ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1];
-      key = ((u64)(unsigned)idx << 12) | (unsigned)l;  // stable: input order inside a voxel
+  // Consecutive ring points mostly fall into the same 0.2 m voxel, so the sort runs over RUNS (maximal stretches of
+  // consecutive candidates sharing a voxel), not points: key = (voxel index, first point of the run).  Sorted runs of one
+  // voxel are in input order and so are the points inside a run, hence summing run after run reproduces the
+  // input-order f32 sums of pcl::VoxelGrid exactly, with a network several times smaller.
+  u64* K2 = keys;                      // [<= kMaxRingLen] run keys
+  int* vox = (int*)(keys + kMaxRingLen);  // [kMaxRingLen] voxel index of every covered point (-1: not a candidate)
+  for (int l = tid; l < len; l += kRingThreads) {
+    int idx = -1;
+    if (l >= c_lo && l <= c_hi && label[l] <= 0) {
+      const int ijk0 = (int)(floorf(px[l] * inv) - (float)min_b[0]);
+      const int ijk1 = (int)(floorf(py[l] * inv) - (float)min_b[1]);
+      const int ijk2 = (int)(floorf(pz[l] * inv) - (float)min_b[2]);
+      idx = ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1];
     }
-    K2[t] = key;
+    vox[l] = idx;
   }
   __syncthreads();
+  for (int l = tid; l < len; l += kRingThreads) iscratch[l] = (vox[l] >= 0 && (l == 0 || vox[l - 1] != vox[l])) ? 1 : 0;
+  __syncthreads();
+  const int nrun = block_exclusive_scan(iscratch, len, scan_tmp);
+  int P2 = 2;
+  while (P2 < nrun) P2 <<= 1;
+  for (int l = tid; l < len; l += kRingThreads)
+    if (vox[l] >= 0 && (l == 0 || vox[l - 1] != vox[l])) K2[iscratch[l]] = ((u64)(unsigned)vox[l] << 12) | (unsigned)l;
+  for (int t = nrun + tid; t < P2; t += kRingThreads) K2[t] = ~0ull;
+  __syncthreads();
   SR_STAMP();
+  // a stage with stride j <= 64 only moves data inside 128-element blocks that belong to one wavefront (64 consecutive
+  // compare-exchanges), so only the wide strides need a workgroup barrier
   for (int k = 2; k <= P2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       bitonic_stage(K2, P2, j, k, tid, kRingThreads);
-      __syncthreads();
+      const int next_j = j > 1 ? j >> 1 : k;  // first stride of the next merge level
+      if (j > 64 || next_j > 64) __syncthreads(); else lds_fence_wave();
     }
+  __syncthreads();
   SR_STAMP();
   // voxel heads -> output rank
-  for (int t = tid; t < ncand; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 12) != (K2[t - 1] >> 12)) ? 1 : 0;
+  for (int t = tid; t < nrun; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 12) != (K2[t - 1] >> 12)) ? 1 : 0;
   __syncthreads();
-  const int nvox = block_exclusive_scan(iscratch, ncand, scan_tmp);
-  for (int t = tid; t < ncand; t += kRingThreads) {
+  const int nvox = block_exclusive_scan(iscratch, nrun, scan_tmp);
+  for (int t = tid; t < nrun; t += kRingThreads) {
     const u64 vid = K2[t] >> 12;
     if (t == 0 || vid != (K2[t - 1] >> 12)) {
-      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in sorted order
-      int u = t;
-      for (; u < ncand && (K2[u] >> 12) == vid; u++) {
-        const int l = (int)(K2[u] & 0xfffu);
-        sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l];
-      }
-      const float cnt = (float)(u - t);
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in input order
+      int npt = 0;
+      for (int u = t; u < nrun && (K2[u] >> 12) == vid; u++)
+        for (int l = (int)(K2[u] & 0xfffu); l < len && vox[l] == (int)vid; l++) {
+          sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l];
+          npt++;
+        }
+      const float cnt = (float)npt;
       out[iscratch[t]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     }
   }
@@ -699,7 +758,7 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
 // ------------------------------------------------------------------------------------------------
 size_t sr_ring_smem_bytes() {
   return sizeof(float) * 4 * kMaxRingLen + sizeof(u64) * kSectors * kSectCap + sizeof(int) * (kMaxRingLen + kRingThreads) +
-         3 * kMaxRingLen + 64 * sizeof(int);
+         4 * kMaxRingLen + 64 * sizeof(int);
 }
 
 hipError_t sr_init() {
