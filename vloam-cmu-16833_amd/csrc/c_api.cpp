@@ -42,14 +42,22 @@ static void set_err(const char* fmt, ...) {
 struct vloam_handle {
   vloam_config cfg;
   int device = 0;
-  hipStream_t stream = nullptr;
+  // Three in-order streams, one per stage of the façade: scan registration of sweep k + 1 overlaps laser odometry of sweep k
+  // and laser mapping of sweep k - 1 (each stage only needs the previous stage's result of the SAME sweep plus its own state
+  // of the previous sweep).  Cross-stage edges are HIP events; SR output lives in kSets rotating buffer sets so that a stage
+  // running ahead never overwrites what a slower stage still reads.
+  hipStream_t stream = nullptr;   // scan registration (+ NN grid build); also creation / VO work
+  hipStream_t s_lo = nullptr;     // laser odometry
+  hipStream_t s_map = nullptr;    // laser mapping
+  static constexpr int kSets = 3;
+  hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {};  // "stage finished for the sweep in set c"
   std::vector<void*> allocs;
   int frame = 0;        // sweeps fully enqueued
   int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
   int nblk_max = 0;
   // scan registration
   float4* d_in = nullptr;
-  SRBuffers sr[2];      // ping-pong halves: only S / less_sharp / less_flat differ
+  SRBuffers sr[kSets];  // rotating sets: S, cloud and the feature clouds are per set, the scratch arrays are shared (SR stream only)
   // laser odometry
   LOState* lo = nullptr;
   FactorTable lo_F{};
@@ -58,12 +66,12 @@ struct vloam_handle {
   LMRecord* lo_rec = nullptr;  // [2]
   double* lo_resid[2] = {nullptr, nullptr};
   double* traj = nullptr;      // [max_frames][14]
-  LoGrid grid[2];              // per ping-pong half: NN grid over that sweep's lessSharp / lessFlat
+  LoGrid grid[kSets];          // per set: NN grid over that sweep's lessSharp / lessFlat
   // mapping + vo
   MapContext map;
   VOContext vo;
   // timing
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cfg.timing: begin / end of SR, LO, mapping
   double stage_ms[4] = {0, 0, 0, 0};
   int timed_scans = 0;
   int last_n_in = 0;
@@ -95,7 +103,7 @@ static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap)
   ALLOC(F->resid, 3 * (size_t)cap);
   ALLOC(F->ctype, cap);
   ALLOC(F->cslot, cap);
-  ALLOC(F->cpack, 9 * (size_t)cap);
+  ALLOC(F->cpack, 11 * (size_t)cap);
   ALLOC(F->rowcnt, (size_t)cap / 64 + 1);
   return VLOAM_OK;
 }
@@ -145,7 +153,8 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
   *out = nullptr;
   vloam_status st = VLOAM_OK;
   do {
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s_lo, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
     const int P = cfg->max_points;
     h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
@@ -156,26 +165,26 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       ALLOC(a.ori, (size_t)P);
       ALLOC(a.blockhist, (size_t)h->nblk_max * kMaxRings);
       ALLOC(a.blockoff, (size_t)h->nblk_max * kMaxRings);
-      ALLOC(a.cloud, (size_t)P);
       ALLOC(a.sharp_idx, kMaxSharp);
       ALLOC(a.less_sharp_idx, kMaxLessSharp);
       ALLOC(a.flat_idx, kMaxFlat);
       ALLOC(a.ring_ds, (size_t)kMaxRings * kMaxRingLen);
-      ALLOC(a.sharp, kMaxSharp);
-      ALLOC(a.flat, kMaxFlat);
       ALLOC(a.dbg_curv, (size_t)P);
       ALLOC(a.dbg_sort, (size_t)P);
       ALLOC(a.dbg_picked, (size_t)P);
       ALLOC(a.dbg_label, (size_t)P);
       ALLOC(a.dbg_cyc, (size_t)kMaxRings * 8);
       ALLOC(a.dbg_feat_idx, 3 * kMaxLessSharp);
-      h->sr[1] = a;
-      for (int k = 0; k < 2; k++) {
+      for (int k = 1; k < vloam_handle::kSets; k++) h->sr[k] = a;
+      for (int k = 0; k < vloam_handle::kSets; k++) {
         ALLOC(h->sr[k].S, 1);
+        ALLOC(h->sr[k].cloud, (size_t)P);
+        ALLOC(h->sr[k].sharp, kMaxSharp);
+        ALLOC(h->sr[k].flat, kMaxFlat);
         ALLOC(h->sr[k].less_sharp, kMaxLessSharp);
         ALLOC(h->sr[k].less_flat, (size_t)P);
       }
-      for (int k = 0; k < 2; k++) {
+      for (int k = 0; k < vloam_handle::kSets; k++) {
         for (int g = 0; g < 4; g++) {
           h->grid[k].mask[g] = kGridBuckets[g] - 1;
           ALLOC(h->grid[k].cnt[g], kGridBuckets[g]);
@@ -197,7 +206,12 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       s = vo_create(&h->vo, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("vo_create failed"); return VLOAM_ERR_HIP; }
-      for (int k = 0; k < 5; k++) HIPCHK(hipEventCreate(&h->ev[k]));
+      for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&h->ev[k]));
+      for (int k = 0; k < vloam_handle::kSets; k++) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_sr[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_lo[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming));
+      }
       HIPCHK(hipStreamSynchronize(h->stream));
       return VLOAM_OK;
     };
@@ -211,11 +225,13 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamSynchronize(st);
   for (void* p : h->allocs) (void)hipFree(p);
-  for (int k = 0; k < 5; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  for (int k = 0; k < vloam_handle::kSets; k++)
+    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
   delete h;
   return VLOAM_OK;
 }
@@ -227,14 +243,29 @@ vloam_status vloam_reset_frame(vloam_handle* h) {
 }
 
 // ------------------------------------------------------------------ stage enqueue helpers
+static inline int set_of(int frame) { return frame % vloam_handle::kSets; }
+static vloam_status sync_all(vloam_handle* h) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->s_lo));
+  HIPCHK(hipStreamSynchronize(h->s_map));
+  return VLOAM_OK;
+}
+
 static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (h->frame >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
-  const int cur = h->frame & 1;
+  const int k = h->frame, cur = set_of(k);
+  // set `cur` still holds sweep k - 3: read by odometry of sweeps k - 3 (current) and k - 2 (previous), mapping of sweep k - 3
+  if (k >= 2) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_lo[set_of(k - 2)], 0));
+  if (k >= 3 && h->cfg.with_mapping) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map[set_of(k - 3)], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof));
+  // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
+  lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
+  HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
   h->last_n_in = n;
   h->stage = 1;
   return VLOAM_OK;
@@ -242,44 +273,49 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
 
 static vloam_status enqueue_lo(vloam_handle* h) {
   if (h->stage != 1) { set_err("laser odometry called before scan registration"); return VLOAM_ERR_ORDER; }
-  const int cur = h->frame & 1, prev = cur ^ 1;
+  const int cur = set_of(h->frame), prev = set_of(h->frame + vloam_handle::kSets - 1);
+  HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_sr[cur], 0));
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->s_lo));
   if (h->frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
     for (int outer = 0; outer < 2; outer++) {  // laser_odometry.cpp:211
-      if (!h->cfg.detach_VO_LO) lo_set_prior_launch(h->stream, h->lo);
+      if (!h->cfg.detach_VO_LO) lo_set_prior_launch(h->s_lo, h->lo);
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
-      lo_assoc_launch(h->stream, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
+      lo_assoc_launch(h->s_lo, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
                       h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], h->lo_cyc[outer], &h->prof);
-      lm_launch(h->stream, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
+      lm_launch(h->s_lo, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
     }
   }
-  lo_finish_launch(h->stream, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);
-  // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
-  lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
+  lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);
   HIPCHK(hipGetLastError());
-  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->s_lo));
+  HIPCHK(hipEventRecord(h->ev_lo[cur], h->s_lo));
   h->stage = 2;
   return VLOAM_OK;
 }
 
 static vloam_status enqueue_map(vloam_handle* h) {
   if (h->stage != 2) { set_err("laser mapping called before laser odometry"); return VLOAM_ERR_ORDER; }
-  const int cur = h->frame & 1;
+  const int cur = set_of(h->frame);
+  HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_lo[cur], 0));
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[4], h->s_map));
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
   const bool skip = ((h->frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->stream, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, &h->prof);
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, &h->prof);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
-  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+  if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[5], h->s_map));
+  HIPCHK(hipEventRecord(h->ev_map[cur], h->s_map));
   return VLOAM_OK;
 }
 
 static vloam_status finish_frame(vloam_handle* h) {
-  if (h->cfg.timing) {
-    HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->cfg.timing) {  // per-stage times need the sweep drained: timing mode gives up the overlap between sweeps
+    vloam_status s = sync_all(h);
+    if (s != VLOAM_OK) return s;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stage_ms[0] += ms;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); h->stage_ms[1] += ms;
-    if (h->cfg.with_mapping) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stage_ms[2] += ms; }
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stage_ms[1] += ms;
+    if (h->cfg.with_mapping) { HIPCHK(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); h->stage_ms[2] += ms; }
     h->timed_scans++;
   }
   h->frame++;
@@ -306,8 +342,8 @@ vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int
 
 static vloam_status read_sr_error(vloam_handle* h, int cur) {
   int err = 0;
-  HIPCHK(hipMemcpyAsync(&err, &h->sr[cur].S->error, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  HIPCHK(hipMemcpy(&err, &h->sr[cur].S->error, sizeof(int), hipMemcpyDeviceToHost));
   if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
   if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
   return VLOAM_OK;
@@ -318,8 +354,8 @@ vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int ca
   HIPCHK(hipSetDevice(h->device));
   // after finish_frame() the sweep just processed is frame-1
   const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
-  const int cur = f & 1;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  const int cur = set_of(f);
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   FrameScalars S;
   HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
   const float4* src = nullptr;
@@ -342,8 +378,8 @@ vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double
   if (!h || !q || !t) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
   double buf[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
-  HIPCHK(hipMemcpyAsync(h->lo->prior_q, buf, sizeof(buf), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpyAsync(h->lo->prior_q, buf, sizeof(buf), hipMemcpyHostToDevice, h->s_lo));
+  HIPCHK(hipStreamSynchronize(h->s_lo));
   return VLOAM_OK;
 }
 
@@ -352,7 +388,7 @@ vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3],
   HIPCHK(hipSetDevice(h->device));
   vloam_status s = enqueue_lo(h);
   if (s != VLOAM_OK) return s;
-  s = read_sr_error(h, h->frame & 1);
+  s = read_sr_error(h, set_of(h->frame));
   if (s != VLOAM_OK) return s;
   LOState lo;
   HIPCHK(hipMemcpy(&lo, h->lo, sizeof(lo), hipMemcpyDeviceToHost));
@@ -369,7 +405,8 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
   HIPCHK(hipSetDevice(h->device));
   vloam_status s = enqueue_map(h);
   if (s != VLOAM_OK) return s;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  s = sync_all(h);
+  if (s != VLOAM_OK) return s;
   MapState ms;
   HIPCHK(hipMemcpy(&ms, h->map.state, sizeof(ms), hipMemcpyDeviceToHost));
   if (q_map) memcpy(q_map, ms.parameters, sizeof(double) * 4);
@@ -402,11 +439,11 @@ vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
 vloam_status vloam_sync(vloam_handle* h) {
   if (!h) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   if (h->frame > 0) {
     // surface sticky device-side errors of the last sweep
     int err = 0;
-    HIPCHK(hipMemcpy(&err, &h->sr[(h->frame - 1) & 1].S->error, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&err, &h->sr[set_of(h->frame - 1)].S->error, sizeof(int), hipMemcpyDeviceToHost));
     if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
     if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
     int merr = 0;
@@ -421,7 +458,7 @@ vloam_status vloam_sync(vloam_handle* h) {
 vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double* poses14) {
   if (!h || !poses14 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   if (count) HIPCHK(hipMemcpy(poses14, h->traj + (size_t)first * 14, sizeof(double) * 14 * (size_t)count, hipMemcpyDeviceToHost));
   return VLOAM_OK;
 }
@@ -469,9 +506,9 @@ static vloam_status copy_out(const void* d_src, size_t bytes, void* buf, long lo
 vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, long long cap, long long* n) {
   if (!h) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
-  const int cur = f & 1;
+  const int cur = set_of(f);
   if (stage == 0) {
     FrameScalars S;
     HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
@@ -520,7 +557,7 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
 vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_launches) {
   if (!h || !name) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   int id = kKNone;
   for (int k = 1; k < kKCount; k++) if (strcmp(name, kKernelNames[k]) == 0) id = k;
   if (id == kKNone && name[0] != 0) { set_err("unknown kernel %s", name); return VLOAM_ERR_INVALID; }
@@ -538,7 +575,7 @@ vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_lau
 vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches) {
   if (!h || !total_ms || !launches) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   double tot = 0;
   for (int k = 0; k < h->prof.used; k++) {
     float ms = 0;
@@ -561,11 +598,11 @@ vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans) {
 vloam_status vloam_get_counts(vloam_handle* h, long long c[16]) {
   if (!h || !c) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   memset(c, 0, sizeof(long long) * 16);
   if (h->frame == 0) return VLOAM_OK;
   const int f = (h->stage == 0) ? h->frame - 1 : h->frame;
-  const int cur = f & 1, prev = cur ^ 1;
+  const int cur = set_of(f), prev = set_of(f + vloam_handle::kSets - 1);
   FrameScalars S, Sp;
   HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&Sp, h->sr[prev].S, sizeof(Sp), hipMemcpyDeviceToHost));

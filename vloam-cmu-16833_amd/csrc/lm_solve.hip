@@ -133,29 +133,29 @@ __device__ __forceinline__ double huber_sel(double sq, double rr, double a, doub
 }
 
 // LidarEdgeFactor (lidarFactor.hpp:21-45) with lp = R p + t:  r = ((lp - a) x (lp - b)) / |a - b| == v x (lp - a),
-// v = (b - a) / |a - b| (precomputed by k_lm_compact into B);  d r / d lp = [v]x;  d lp / d delta = -2 [R p]x
-// (EigenQuaternionParameterization, q+ = exp(delta) * q);  [v]x (-2 [rp]x) = -2 (rp v^T - (v . rp) I).
-__device__ __forceinline__ void eval_edge(D3 p, D3 A, D3 v, const double (&Rm)[9], D3 t, double huber_a, double sqrt_a, double (&acc)[kAcc], double* r3) {
+// v = (b - a) / |a - b|.  r lies in the plane normal to v: with an orthonormal pair (e1, e2), e1 x e2 = v (k_lm_compact),
+// r = c1 e2 - c2 e1 where c_i = e_i . lp + d_i, d_i = -(e_i . a).  (c1, c2) is r in rotated coordinates, and J^T J, J^T r,
+// |r|^2 (hence the Huber weight) are invariant under an orthonormal change of residual coordinates — so the factor is
+// evaluated as TWO point-to-plane rows sharing one weight instead of three generic rows:  d c_i / d lp = e_i^T,
+// d lp / d delta = -2 [R p]x (EigenQuaternionParameterization, q+ = exp(delta) * q),  e^T (-2 [rp]x) = -2 (e x rp)^T.
+__device__ __forceinline__ void eval_edge(D3 p, D3 e1, D3 e2, double d1, double d2, const double (&Rm)[9], D3 t, double huber_a, double sqrt_a,
+                                          double (&acc)[kAcc], double* r3, bool want_r3) {
   const D3 rp = d3(Rm[0] * p.x + Rm[1] * p.y + Rm[2] * p.z, Rm[3] * p.x + Rm[4] * p.y + Rm[5] * p.z, Rm[6] * p.x + Rm[7] * p.y + Rm[8] * p.z);
   const D3 lp = rp + t;
-  const D3 r = cross(v, lp - A);
-  r3[0] = r.x; r3[1] = r.y; r3[2] = r.z;
-  const double sq = r.x * r.x + r.y * r.y + r.z * r.z;
+  const double c1 = dot(e1, lp) + d1, c2 = dot(e2, lp) + d2;
+  if (want_r3) { r3[0] = c1 * e2.x - c2 * e1.x; r3[1] = c1 * e2.y - c2 * e1.y; r3[2] = c1 * e2.z - c2 * e1.z; }
+  const double sq = c1 * c1 + c2 * c2;
   const double sc = huber_sel(sq, sqrt(sq), huber_a, sqrt_a, &acc[0]);
-  const double vr = dot(v, rp);
   const double s2 = -2.0 * sc;
-  const D3 sv = d3(sc * v.x, sc * v.y, sc * v.z);
   {
-    const double J[6] = {s2 * (rp.x * v.x - vr), s2 * (rp.x * v.y), s2 * (rp.x * v.z), 0.0, -sv.z, sv.y};
-    accumulate_row(acc, J, r.x * sc);
+    const D3 nr = cross(e1, rp);
+    const double J[6] = {s2 * nr.x, s2 * nr.y, s2 * nr.z, e1.x * sc, e1.y * sc, e1.z * sc};
+    accumulate_row(acc, J, c1 * sc);
   }
   {
-    const double J[6] = {s2 * (rp.y * v.x), s2 * (rp.y * v.y - vr), s2 * (rp.y * v.z), sv.z, 0.0, -sv.x};
-    accumulate_row(acc, J, r.y * sc);
-  }
-  {
-    const double J[6] = {s2 * (rp.z * v.x), s2 * (rp.z * v.y), s2 * (rp.z * v.z - vr), -sv.y, sv.x, 0.0};
-    accumulate_row(acc, J, r.z * sc);
+    const D3 nr = cross(e2, rp);
+    const double J[6] = {s2 * nr.x, s2 * nr.y, s2 * nr.z, e2.x * sc, e2.y * sc, e2.z * sc};
+    accumulate_row(acc, J, c2 * sc);
   }
 }
 
@@ -232,7 +232,7 @@ struct LmShared {
 constexpr int kCacheE = 4, kCacheP = 6;
 struct LmCache {
   float pe[kCacheE][3];
-  double de[kCacheE][6];  // a, v
+  double de[kCacheE][8];  // e1, e2, d1, d2
   float pp[kCacheP][3];
   double dp[kCacheP][4];  // n, d
 };
@@ -240,8 +240,9 @@ struct LmCache {
 // Evaluate the compacted factors at x: cost, g = J^T r, H = J^T J (upper triangle) -> s_out[kAcc] (LDS).
 template <bool QUAT>
 __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
-                                            double* s_out, bool first, LmCache& C) {
+                                            double* s_out, bool first, LmCache& C, long long* cyc_factors) {
   const int tid = threadIdx.x;
+  const long long tf0 = clock64();
   double acc[kAcc];
 #pragma unroll
   for (int i = 0; i < kAcc; i++) acc[i] = 0.0;
@@ -272,7 +273,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int a = 0; a < 3; a++) C.pe[m][a] = live ? (float)cp[a * cap + k] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 6; a++) C.de[m][a] = live ? cp[(3 + a) * cap + k] : 0.0;
+        for (int a = 0; a < 8; a++) C.de[m][a] = live ? cp[(3 + a) * cap + k] : 0.0;
       }
 #pragma unroll
       for (int m = 0; m < kCacheP; m++) {
@@ -297,22 +298,23 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         for (int u = 0; u < 1; u++)
           if (g + u < kCacheE)
           eval_edge(d3((double)C.pe[g + u][0], (double)C.pe[g + u][1], (double)C.pe[g + u][2]), d3(C.de[g + u][0], C.de[g + u][1], C.de[g + u][2]),
-                    d3(C.de[g + u][3], C.de[g + u][4], C.de[g + u][5]), Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+                    d3(C.de[g + u][3], C.de[g + u][4], C.de[g + u][5]), C.de[g + u][6], C.de[g + u][7], Rm, tt, huber_a, sqrt_a, acc, r3[u], first);
         if (first)
 #pragma unroll
           for (int u = 0; u < 1; u++) { const int k = tid + (g + u) * kLmThreads; if (g + u < kCacheE && k < n_edge) put_resid(k, r3[u]); }
       }
     for (int base = kCacheE * kLmThreads; base < n_edge; base += 2 * kLmThreads) {  // beyond the cache: streamed
-      double w[2][9], r3[2][3];
+      double w[2][11], r3[2][3];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int k = base + u * kLmThreads + tid;
 #pragma unroll
-        for (int a = 0; a < 9; a++) w[u][a] = k < n_edge ? cp[a * cap + k] : 0.0;
+        for (int a = 0; a < 11; a++) w[u][a] = k < n_edge ? cp[a * cap + k] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 2; u++)
-        eval_edge(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), d3(w[u][6], w[u][7], w[u][8]), Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+        eval_edge(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), d3(w[u][6], w[u][7], w[u][8]), w[u][9], w[u][10], Rm, tt, huber_a, sqrt_a, acc,
+                  r3[u], first);
       if (first)
 #pragma unroll
         for (int u = 0; u < 2; u++) { const int k = base + u * kLmThreads + tid; if (k < n_edge) put_resid(k, r3[u]); }
@@ -356,6 +358,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       }
     }
   }
+  *cyc_factors += clock64() - tf0;
   // block reduction without cross-lane shuffles (a chain of ds_bpermute round trips is what dominated this kernel):
   // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
 #pragma unroll
@@ -460,7 +463,7 @@ __device__ __forceinline__ void lm_plus_t(const double* x, const double (&delta)
 }
 
 template <bool QUAT>
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
+__global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag) {
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
@@ -490,12 +493,12 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     __syncthreads();
   }
   const long long t_pro = clock64();
-  long long cyc_eval = 0, cyc_serial = 0, t_mark;
+  long long cyc_eval = 0, cyc_serial = 0, cyc_fac = 0, t_mark;
   const int n_valid = sh.n_valid, n_edge = sh.n_edge;
 
   LmCache cache;
   t_mark = clock64();
-  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache);
+  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac);
   cyc_eval += clock64() - t_mark;
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
-    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache);
+    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac);
     cyc_eval += clock64() - t_mark;
     t_mark = clock64();
     // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
@@ -681,7 +684,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(FactorTable F, int edge
     rec->n_iterations = n_rec < kLmMaxTrace ? n_rec : kLmMaxTrace;
     rec->termination = termination;
     rec->n_evals = n_evals;
-    rec->cyc[0] = (double)(t_pro - t_start); rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
+    rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
+    (void)t_pro; rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
     rec->cyc[3] = (double)(clock64() - t_start);
   }
 }
@@ -699,23 +703,38 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
   const int cap = F.cap;
   const int k = (r << 6) + lane;
   const int ty = F.type[k];
-  double v[9];
+  double v[11];
 #pragma unroll
   for (int a = 0; a < 3; a++) { v[a] = F.p[a * cap + k]; v[3 + a] = F.A[a * cap + k]; v[6 + a] = F.B[a * cap + k]; }
+  v[9] = 0.0; v[10] = 0.0;
   const unsigned long long m = __ballot(ty != 0);
   if (ty) {
     const int o = off + __popcll(m & ((1ull << lane) - 1ull));
     F.ctype[o] = ty; F.cslot[o] = k;
     if (quat && ty == 1) {
-      const double dx = v[3] - v[6], dy = v[4] - v[7], dz = v[5] - v[8];
+      // line direction v = (b - a) / |a - b| (lidarFactor.hpp:37-42 divides by de.norm()), then an orthonormal pair with
+      // e1 x e2 = v: e1 = normalize(v x axis of the smallest |v| component), e2 = v x e1; d_i = -(e_i . a)
+      const double ax = v[3], ay = v[4], az = v[5];
+      const double dx = v[6] - ax, dy = v[7] - ay, dz = v[8] - az;
       const double dn = sqrt(dx * dx + dy * dy + dz * dz);
-      v[6] = -dx / dn; v[7] = -dy / dn; v[8] = -dz / dn;
+      const double vx = dx / dn, vy = dy / dn, vz = dz / dn;
+      const double fx = fabs(vx), fy = fabs(vy), fz = fabs(vz);
+      double e1x, e1y, e1z;
+      if (fx <= fy && fx <= fz) { e1x = 0.0; e1y = vz; e1z = -vy; }        // v x (1, 0, 0)
+      else if (fy <= fz) { e1x = -vz; e1y = 0.0; e1z = vx; }              // v x (0, 1, 0)
+      else { e1x = vy; e1y = -vx; e1z = 0.0; }                             // v x (0, 0, 1)
+      const double en = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+      e1x /= en; e1y /= en; e1z /= en;
+      const double e2x = vy * e1z - vz * e1y, e2y = vz * e1x - vx * e1z, e2z = vx * e1y - vy * e1x;
+      v[3] = e1x; v[4] = e1y; v[5] = e1z; v[6] = e2x; v[7] = e2y; v[8] = e2z;
+      v[9] = -(e1x * ax + e1y * ay + e1z * az);
+      v[10] = -(e2x * ax + e2y * ay + e2z * az);
     } else if (quat && ty == 2) {  // LidarPlaneFactor (lp - j) . n  ->  n . lp + d with d = -(n . j); A := n, B.x := d
       const double d = -(v[6] * v[3] + v[7] * v[4] + v[8] * v[5]);
       v[3] = v[6]; v[4] = v[7]; v[5] = v[8]; v[6] = d;
     }
 #pragma unroll
-    for (int a = 0; a < 9; a++) F.cpack[a * cap + o] = v[a];
+    for (int a = 0; a < 11; a++) F.cpack[a * cap + o] = v[a];
   }
 }
 

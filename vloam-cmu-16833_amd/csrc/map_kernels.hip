@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
   const int tid = threadIdx.x;
   if (tid == 0) {
     // LaserMapping::input LM:182-195: q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom
-    for (int k = 0; k < 4; k++) ms->q_wodom_curr[k] = lo->q_w_curr[k];
-    for (int k = 0; k < 3; k++) ms->t_wodom_curr[k] = lo->t_w_curr[k];
+    // the odometry pose of THIS sweep as k_lo_finish logged it (the live LOState may already belong to the next sweep: the
+    // odometry stream runs ahead of the mapping stream)
+    (void)lo;
+    for (int k = 0; k < 4; k++) ms->q_wodom_curr[k] = traj_row14[k];
+    for (int k = 0; k < 3; k++) ms->t_wodom_curr[k] = traj_row14[4 + k];
     double q[4], t[3];
     dquat_mul(ms->q_wmap_wodom, ms->q_wodom_curr, q);
     dquat_rot(ms->q_wmap_wodom, ms->t_wodom_curr, t);
@@ -828,7 +831,7 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     ok = ok && dmalloc(allocs, st, &F.type, (size_t)F.cap) && dmalloc(allocs, st, &F.p, 3 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.A, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.B, 3 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.ctype, (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 9 * (size_t)F.cap) &&
+         dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 11 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1);
   }
   ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nn, 5 * (size_t)kMapFactorCap);

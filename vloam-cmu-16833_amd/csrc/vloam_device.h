@@ -101,7 +101,7 @@ struct FactorTable {
   double* resid;  // [3][cap] raw residuals at the initial point (parity hook)
   int* ctype;     // [cap]    k_lm_solve's compacted copy (accepted factors only, slot order)
   int* cslot;     // [cap]    original slot of every compacted factor
-  double* cpack;  // [9][cap] p, A, B of the compacted factors
+  double* cpack;  // [11][cap] compacted factors: p, then (e1, e2, d1, d2) of an edge / (n, d) of a plane / A, B otherwise
   int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
   int cap;
 };

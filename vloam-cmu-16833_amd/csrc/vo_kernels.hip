@@ -233,7 +233,7 @@ vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, st
   ok = ok && dmalloc(allocs, st, &v->F.type, kVoMaxMatches) && dmalloc(allocs, st, &v->F.p, 3 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.A, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.B, 3 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.ctype, kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.cslot, kVoMaxMatches) && dmalloc(allocs, st, &v->F.cpack, 9 * kVoMaxMatches) &&
+       dmalloc(allocs, st, &v->F.cslot, kVoMaxMatches) && dmalloc(allocs, st, &v->F.cpack, 11 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.rowcnt, kVoMaxMatches / 64 + 1);
   ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->counters, 2);
