@@ -176,6 +176,24 @@ def main():
         for hh in hs:
             hh.close()
 
+    # ---- extra: latency of ONE sweep (enqueue + drain, nothing in flight), on a fresh session.  The headline value streams the
+    # sequence: the three stage streams overlap consecutive sweeps, so 1 / value is a throughput period, not a latency.
+    latency = None
+    if world == 1:
+        hl = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + 40)
+        for k in range(W):
+            hl.process_scan_device(base_ptr + k * stride, n_pts)
+        hl.sync()
+        L = min(32, K)
+        l0 = time.perf_counter()
+        for k in range(W, W + L):
+            hl.process_scan_device(base_ptr + k * stride, n_pts)
+            hl.sync()
+        l1 = time.perf_counter()
+        latency = {"ms_per_sweep": 1e3 * (l1 - l0) / L, "sweeps": L,
+                   "note": "one sweep at a time (vloam_sync after each): no overlap between consecutive sweeps"}
+        hl.close()
+
     out = None
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)
@@ -197,6 +215,9 @@ def main():
                          "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
             "counts_last_sweep": counts,
         }
+        out["config"]["pipelining"] = "SR / LO / mapping of consecutive sweeps overlap on three HIP streams (one sequence, one GPU)"
+        if latency:
+            out["latency"] = latency
         if multi_session:
             out["multi_session"] = multi_session
         if world == 1 and not args.no_cpu_baseline:

@@ -283,10 +283,13 @@ static vloam_status enqueue_lo(vloam_handle* h) {
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->s_lo, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
                       h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], h->lo_cyc[outer], &h->prof);
-      lm_launch(h->s_lo, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof);
+      // the second solve also integrates the pose and writes the trajectory row (laser_odometry.cpp:530-531)
+      lm_launch(h->s_lo, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof, outer == 1 ? h->lo : nullptr,
+                outer == 1 ? h->traj + (size_t)h->frame * 14 : nullptr);
     }
+  } else {
+    lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)h->frame * 14, false, &h->prof);
   }
-  lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)h->frame * 14, h->frame > 0, &h->prof);
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->s_lo));
   HIPCHK(hipEventRecord(h->ev_lo[cur], h->s_lo));

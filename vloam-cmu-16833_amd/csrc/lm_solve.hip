@@ -174,6 +174,79 @@ __device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&
   accumulate_row(acc, J, r0 * sc);
 }
 
+// ---- packets: NW factors evaluated side by side.  With one wavefront per SIMD nothing hides the ~8-cycle dependent f64
+// latency except independent instructions next to each other, and the compiler keeps source order inside a basic block: every
+// step below is written for all NW factors at once, so the per-factor dependency chains (rotate, residual, Huber weight,
+// Jacobian row) interleave NW-fold.  The accumulation is 27 independent FMAs per row already.
+template <int NW>
+__device__ __forceinline__ void rotate_pk(const double (&p)[NW][3], const double (&Rm)[9], double (&rp)[NW][3]) {
+#pragma unroll
+  for (int u = 0; u < NW; u++) rp[u][0] = Rm[0] * p[u][0] + Rm[1] * p[u][1] + Rm[2] * p[u][2];
+#pragma unroll
+  for (int u = 0; u < NW; u++) rp[u][1] = Rm[3] * p[u][0] + Rm[4] * p[u][1] + Rm[5] * p[u][2];
+#pragma unroll
+  for (int u = 0; u < NW; u++) rp[u][2] = Rm[6] * p[u][0] + Rm[7] * p[u][1] + Rm[8] * p[u][2];
+}
+// one point-to-plane row per factor: c = n . (rp + t) + d, J = sc [-2 (n x rp), n]
+template <int NW>
+__device__ __forceinline__ void row_pk(const double (&rp)[NW][3], const double (&n)[NW][3], const double (&c)[NW], const double (&sc)[NW],
+                                       double (&acc)[kAcc]) {
+  double J[NW][6];
+#pragma unroll
+  for (int u = 0; u < NW; u++) {
+    const double s2 = -2.0 * sc[u];
+    J[u][0] = s2 * (n[u][1] * rp[u][2] - n[u][2] * rp[u][1]);
+    J[u][1] = s2 * (n[u][2] * rp[u][0] - n[u][0] * rp[u][2]);
+    J[u][2] = s2 * (n[u][0] * rp[u][1] - n[u][1] * rp[u][0]);
+    J[u][3] = n[u][0] * sc[u]; J[u][4] = n[u][1] * sc[u]; J[u][5] = n[u][2] * sc[u];
+  }
+#pragma unroll
+  for (int u = 0; u < NW; u++) accumulate_row(acc, J[u], c[u] * sc[u]);
+}
+template <int NW>
+__device__ __forceinline__ void huber_pk(const double (&sq)[NW], const double (&rr)[NW], double a, double sqrt_a, double (&sc)[NW], double* cost) {
+  double so[NW];
+#pragma unroll
+  for (int u = 0; u < NW; u++) so[u] = sqrt_a * rsqrt(fmax(rr[u], DBL_MIN));  // sqrt(a / |r|)
+#pragma unroll
+  for (int u = 0; u < NW; u++) {
+    const bool out = sq[u] > a * a;
+    *cost += out ? 0.5 * (2.0 * a * rr[u] - a * a) : 0.5 * sq[u];
+    sc[u] = out ? so[u] : 1.0;
+  }
+}
+template <int NW>
+__device__ __forceinline__ void eval_plane_pk(const double (&p)[NW][3], const double (&n)[NW][3], const double (&d)[NW], const double (&Rm)[9], D3 t,
+                                              double huber_a, double sqrt_a, double (&acc)[kAcc], double (&r0)[NW]) {
+  double rp[NW][3], sq[NW], rr[NW], sc[NW];
+  rotate_pk<NW>(p, Rm, rp);
+#pragma unroll
+  for (int u = 0; u < NW; u++) r0[u] = n[u][0] * (rp[u][0] + t.x) + n[u][1] * (rp[u][1] + t.y) + n[u][2] * (rp[u][2] + t.z) + d[u];
+#pragma unroll
+  for (int u = 0; u < NW; u++) { sq[u] = r0[u] * r0[u]; rr[u] = fabs(r0[u]); }
+  huber_pk<NW>(sq, rr, huber_a, sqrt_a, sc, &acc[0]);
+  row_pk<NW>(rp, n, r0, sc, acc);
+}
+// edge factors as two rows sharing one weight (see eval_edge)
+template <int NW>
+__device__ __forceinline__ void eval_edge_pk(const double (&p)[NW][3], const double (&e1)[NW][3], const double (&e2)[NW][3], const double (&d1)[NW],
+                                             const double (&d2)[NW], const double (&Rm)[9], D3 t, double huber_a, double sqrt_a,
+                                             double (&acc)[kAcc], double (&c1)[NW], double (&c2)[NW]) {
+  double rp[NW][3], sq[NW], rr[NW], sc[NW];
+  rotate_pk<NW>(p, Rm, rp);
+#pragma unroll
+  for (int u = 0; u < NW; u++) c1[u] = e1[u][0] * (rp[u][0] + t.x) + e1[u][1] * (rp[u][1] + t.y) + e1[u][2] * (rp[u][2] + t.z) + d1[u];
+#pragma unroll
+  for (int u = 0; u < NW; u++) c2[u] = e2[u][0] * (rp[u][0] + t.x) + e2[u][1] * (rp[u][1] + t.y) + e2[u][2] * (rp[u][2] + t.z) + d2[u];
+#pragma unroll
+  for (int u = 0; u < NW; u++) sq[u] = c1[u] * c1[u] + c2[u] * c2[u];
+#pragma unroll
+  for (int u = 0; u < NW; u++) rr[u] = sqrt(sq[u]);
+  huber_pk<NW>(sq, rr, huber_a, sqrt_a, sc, &acc[0]);
+  row_pk<NW>(rp, e1, c1, sc, acc);
+  row_pk<NW>(rp, e2, c2, sc, acc);
+}
+
 // CostFunctor32 / CostFunctor22 on (angle_axis[3], t[3]) — dual numbers == Ceres autodiff
 __device__ __forceinline__ void eval_vo(int type, D3 p, D3 A, const double* x, double huber_a, double (&acc)[kAcc], double* r3) {
   Dual6 w[3] = {dvar(x[0], 0), dvar(x[1], 1), dvar(x[2], 2)};
@@ -229,7 +302,7 @@ struct LmShared {
 // which evaluate to an exactly-zero contribution, so the evaluation itself is straight-line code: with a single wavefront
 // per SIMD the only way to hide the dependent f64 latency is to let independent factors interleave in one basic block.
 // p is an f32 point by construction (cloud coordinates) and is kept as f32.
-constexpr int kCacheE = 4, kCacheP = 6;
+constexpr int kCacheE = 3, kCacheP = 6;
 struct LmCache {
   float pe[kCacheE][3];
   double de[kCacheE][8];  // e1, e2, d1, d2
@@ -289,63 +362,84 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       const int slot = F.cslot[k];
       F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
     };
-    // ---- edge factors (compact order == slot order: they come first)
+    // ---- edge factors (compact order == slot order: they come first).  Cached slots in packets of kPkE, streamed ones too.
+    constexpr int kPkE = 3, kPkP = 2;
+    auto edge_packet = [&](const double (&p)[kPkE][3], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], const double (&d1)[kPkE],
+                           const double (&d2)[kPkE], int k0 /* compact index of lane's first factor */, int kstride) {
+      double c1[kPkE], c2[kPkE];
+      eval_edge_pk<kPkE>(p, e1, e2, d1, d2, Rm, tt, huber_a, sqrt_a, acc, c1, c2);
+      if (first)
 #pragma unroll
-    for (int g = 0; g < kCacheE; g += 1)
+        for (int u = 0; u < kPkE; u++) {
+          const int k = k0 + u * kstride;
+          if (k < n_edge) {  // r = c1 e2 - c2 e1
+            const double r3[3] = {c1[u] * e2[u][0] - c2[u] * e1[u][0], c1[u] * e2[u][1] - c2[u] * e1[u][1], c1[u] * e2[u][2] - c2[u] * e1[u][2]};
+            put_resid(k, r3);
+          }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < kCacheE; g += kPkE)
       if (g * kLmThreads < n_edge) {
-        double r3[1][3];
+        double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
-        for (int u = 0; u < 1; u++)
-          if (g + u < kCacheE)
-          eval_edge(d3((double)C.pe[g + u][0], (double)C.pe[g + u][1], (double)C.pe[g + u][2]), d3(C.de[g + u][0], C.de[g + u][1], C.de[g + u][2]),
-                    d3(C.de[g + u][3], C.de[g + u][4], C.de[g + u][5]), C.de[g + u][6], C.de[g + u][7], Rm, tt, huber_a, sqrt_a, acc, r3[u], first);
-        if (first)
+        for (int u = 0; u < kPkE; u++) {
+          const int m = g + u < kCacheE ? g + u : kCacheE - 1;
+          const bool have = g + u < kCacheE;  // compile-time: slots past the cache evaluate zeros
 #pragma unroll
-          for (int u = 0; u < 1; u++) { const int k = tid + (g + u) * kLmThreads; if (g + u < kCacheE && k < n_edge) put_resid(k, r3[u]); }
+          for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pe[m][a] : 0.0; e1[u][a] = have ? C.de[m][a] : 0.0; e2[u][a] = have ? C.de[m][3 + a] : 0.0; }
+          d1[u] = have ? C.de[m][6] : 0.0; d2[u] = have ? C.de[m][7] : 0.0;
+        }
+        edge_packet(p, e1, e2, d1, d2, tid + g * kLmThreads, kLmThreads);
       }
-    for (int base = kCacheE * kLmThreads; base < n_edge; base += 2 * kLmThreads) {  // beyond the cache: streamed
-      double w[2][11], r3[2][3];
+    for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * kLmThreads; base < n_edge; base += kPkE * kLmThreads) {  // beyond the cache: streamed
+      double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < kPkE; u++) {
         const int k = base + u * kLmThreads + tid;
+        const bool live = k < n_edge;
 #pragma unroll
-        for (int a = 0; a < 11; a++) w[u][a] = k < n_edge ? cp[a * cap + k] : 0.0;
+        for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + k] : 0.0; e1[u][a] = live ? cp[(3 + a) * cap + k] : 0.0; e2[u][a] = live ? cp[(6 + a) * cap + k] : 0.0; }
+        d1[u] = live ? cp[9 * cap + k] : 0.0; d2[u] = live ? cp[10 * cap + k] : 0.0;
       }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-        eval_edge(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), d3(w[u][6], w[u][7], w[u][8]), w[u][9], w[u][10], Rm, tt, huber_a, sqrt_a, acc,
-                  r3[u], first);
-      if (first)
-#pragma unroll
-        for (int u = 0; u < 2; u++) { const int k = base + u * kLmThreads + tid; if (k < n_edge) put_resid(k, r3[u]); }
+      edge_packet(p, e1, e2, d1, d2, base + tid, kLmThreads);
     }
-    // ---- plane factors, two per basic block
-#pragma unroll
-    for (int g = 0; g < kCacheP; g += 2)
-      if (g * kLmThreads < n_plane) {
-        double r3[2][3];
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-          if (g + u < kCacheP)
-          eval_plane(d3((double)C.pp[g + u][0], (double)C.pp[g + u][1], (double)C.pp[g + u][2]), d3(C.dp[g + u][0], C.dp[g + u][1], C.dp[g + u][2]),
-                     C.dp[g + u][3], Rm, tt, huber_a, sqrt_a, acc, r3[u]);
-        if (first)
-#pragma unroll
-          for (int u = 0; u < 2; u++) { const int q = tid + (g + u) * kLmThreads; if (g + u < kCacheP && q < n_plane) put_resid(n_edge + q, r3[u]); }
-      }
-    for (int base = kCacheP * kLmThreads; base < n_plane; base += 4 * kLmThreads) {
-      double w[4][7], r3[4][3];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int q = base + u * kLmThreads + tid;
-#pragma unroll
-        for (int a = 0; a < 7; a++) w[u][a] = q < n_plane ? cp[a * cap + n_edge + q] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) eval_plane(d3(w[u][0], w[u][1], w[u][2]), d3(w[u][3], w[u][4], w[u][5]), w[u][6], Rm, tt, huber_a, sqrt_a, acc, r3[u]);
+    // ---- plane factors
+    auto plane_packet = [&](const double (&p)[kPkP][3], const double (&n)[kPkP][3], const double (&d)[kPkP], int q0, int qstride) {
+      double r0[kPkP];
+      eval_plane_pk<kPkP>(p, n, d, Rm, tt, huber_a, sqrt_a, acc, r0);
       if (first)
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int q = base + u * kLmThreads + tid; if (q < n_plane) put_resid(n_edge + q, r3[u]); }
+        for (int u = 0; u < kPkP; u++) {
+          const int q = q0 + u * qstride;
+          if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3); }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < kCacheP; g += kPkP)
+      if (g * kLmThreads < n_plane) {
+        double p[kPkP][3], n[kPkP][3], d[kPkP];
+#pragma unroll
+        for (int u = 0; u < kPkP; u++) {
+          const int m = g + u < kCacheP ? g + u : kCacheP - 1;
+          const bool have = g + u < kCacheP;
+#pragma unroll
+          for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pp[m][a] : 0.0; n[u][a] = have ? C.dp[m][a] : 0.0; }
+          d[u] = have ? C.dp[m][3] : 0.0;
+        }
+        plane_packet(p, n, d, tid + g * kLmThreads, kLmThreads);
+      }
+    for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * kLmThreads; base < n_plane; base += kPkP * kLmThreads) {
+      double p[kPkP][3], n[kPkP][3], d[kPkP];
+#pragma unroll
+      for (int u = 0; u < kPkP; u++) {
+        const int q = base + u * kLmThreads + tid;
+        const bool live = q < n_plane;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + n_edge + q] : 0.0; n[u][a] = live ? cp[(3 + a) * cap + n_edge + q] : 0.0; }
+        d[u] = live ? cp[6 * cap + n_edge + q] : 0.0;
+      }
+      plane_packet(p, n, d, base + tid, kLmThreads);
     }
   } else {
     for (int k = tid; k < n_valid; k += kLmThreads) {
@@ -462,9 +556,33 @@ __device__ __forceinline__ void lm_plus_t(const double* x, const double (&delta)
   }
 }
 
+// t_w_curr += q_w_curr * t_last_curr;  q_w_curr = q_w_curr * q_last_curr  (laser_odometry.cpp:530-531), then the trajectory row.
+// x = (q_last_curr, t_last_curr) as just solved.  Same expressions as k_lo_finish.
+__device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
+  const double* q = lo->q_w_curr;
+  const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  const double vx = x[4], vy = x[5], vz = x[6];
+  double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+  cx = cx + cx; cy = cy + cy; cz = cz + cz;
+  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  const double t0 = lo->t_w_curr[0] + ((vx + w * cx) + dx), t1 = lo->t_w_curr[1] + ((vy + w * cy) + dy), t2 = lo->t_w_curr[2] + ((vz + w * cz) + dz);
+  double r[4];
+  r[0] = q[3] * x[0] + q[0] * x[3] + q[1] * x[2] - q[2] * x[1];
+  r[1] = q[3] * x[1] + q[1] * x[3] + q[2] * x[0] - q[0] * x[2];
+  r[2] = q[3] * x[2] + q[2] * x[3] + q[0] * x[1] - q[1] * x[0];
+  r[3] = q[3] * x[3] - q[0] * x[0] - q[1] * x[1] - q[2] * x[2];
+  lo->t_w_curr[0] = t0; lo->t_w_curr[1] = t1; lo->t_w_curr[2] = t2;
+  for (int k = 0; k < 4; k++) lo->q_w_curr[k] = r[k];
+  if (traj_row14) {
+    for (int k = 0; k < 4; k++) traj_row14[k] = r[k];
+    traj_row14[4] = t0; traj_row14[5] = t1; traj_row14[6] = t2;
+    for (int k = 0; k < 7; k++) traj_row14[7 + k] = traj_row14[k];  // until mapping overwrites it, the map pose equals the odometry pose
+  }
+}
+
 template <bool QUAT>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
-                                                         double huber_a, const int* enable_flag) {
+                                                         double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj) {
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
   if (enable_flag && *enable_flag == 0) {
@@ -680,6 +798,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int i = 0; i < na; i++) x_io[i] = sh.best[i];
 #pragma unroll
     for (int i = 0; i < 7; i++) rec->x_out[i] = i < na ? sh.best[i] : 0.0;
+    if (fin_lo) lo_integrate(fin_lo, sh.best, fin_traj);  // LaserOdometry's pose integration rides on its last solve
     rec->final_cost = minimum_cost;
     rec->n_iterations = n_rec < kLmMaxTrace ? n_rec : kLmMaxTrace;
     rec->termination = termination;
@@ -739,13 +858,13 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
 }
 
 void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
-               const int* d_enable, ProfHook* ph) {
+               const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj) {
   const int edge_rows = n_edge_slots >> 6;
   hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
   if (quat)
-    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<true>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable);
+    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<true>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj);
   else
-    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<false>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable);
+    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<false>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj);
 }
 
 }  // namespace vloam

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   const int i = is_corner ? slot : slot - kMaxSharp;
   const int nfeat = is_corner ? Sc->n_sharp : Sc->n_flat;
   int type = 0, ia = -1, ib = -1, ic = -1;
-  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, tdbg = 0;
+  long long t0 = 0, t1 = 0, t2 = 0, tdbg = 0;
   int exact_dbg = -1, stage2_dbg = -1, cand_dbg = 0;
   if (dbg_cyc) t0 = clock64();
   if (i < nfeat) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   if (lane == 0) {
     F.type[slot] = type;
     if (type) atomicAdd(&F.rowcnt[slot >> 6], 1);
-    if (dbg_cyc) { t3 = clock64(); dbg_cyc[slot * 4] = t1 - t0; dbg_cyc[slot * 4 + 1] = t2 - t1; dbg_cyc[slot * 4 + 2] = tdbg; dbg_cyc[slot * 4 + 3] = (exact_dbg & 0xff) | ((stage2_dbg & 0xff) << 8) | ((long long)cand_dbg << 16); }
+    if (dbg_cyc) { dbg_cyc[slot * 4] = t1 - t0; dbg_cyc[slot * 4 + 1] = t2 - t1; dbg_cyc[slot * 4 + 2] = tdbg; dbg_cyc[slot * 4 + 3] = (exact_dbg & 0xff) | ((stage2_dbg & 0xff) << 8) | ((long long)cand_dbg << 16); }
     corr[slot * 4 + 0] = type ? i : -1;
     corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
   }
