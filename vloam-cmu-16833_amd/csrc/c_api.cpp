@@ -50,7 +50,8 @@ struct vloam_handle {
   hipStream_t s_lo = nullptr;     // laser odometry
   hipStream_t s_map = nullptr;    // laser mapping
   static constexpr int kSets = 3;
-  hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {};  // "stage finished for the sweep in set c"
+  hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
+  static_assert(kSets == MapContext::kSets, "the stack sets rotate with the SR buffer sets");
   std::vector<void*> allocs;
   int frame = 0;        // sweeps fully enqueued
   int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
@@ -211,6 +212,7 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         HIPCHK(hipEventCreateWithFlags(&h->ev_sr[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_lo[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_stack[k], hipEventDisableTiming));
       }
       HIPCHK(hipStreamSynchronize(h->stream));
       return VLOAM_OK;
@@ -229,7 +231,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
-    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
   delete h;
@@ -266,6 +268,11 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
+  // the mapping stage's VoxelGrid of the scan features only needs this sweep's clouds: run it here, off the mapping stream
+  if (h->cfg.with_mapping && ((k + 1) % h->cfg.mapping_skip_frame) == 0) {
+    if (map_stack_enqueue(&h->map, h->stream, h->sr[cur], cur, &h->prof) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }
+    HIPCHK(hipEventRecord(h->ev_stack[cur], h->stream));
+  }
   h->last_n_in = n;
   h->stage = 1;
   return VLOAM_OK;
@@ -301,10 +308,11 @@ static vloam_status enqueue_map(vloam_handle* h) {
   if (h->stage != 2) { set_err("laser mapping called before laser odometry"); return VLOAM_ERR_ORDER; }
   const int cur = set_of(h->frame);
   HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_lo[cur], 0));
+  HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_stack[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[4], h->s_map));
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
   const bool skip = ((h->frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, &h->prof);
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, cur, &h->prof);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[5], h->s_map));
   HIPCHK(hipEventRecord(h->ev_map[cur], h->s_map));

@@ -51,6 +51,12 @@ struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_map
   int hash_mask, stack_cap;
 };
 
+struct StackInfo {        // per stack set: counters of the scan-feature VoxelGrid (written on the scan-registration stream)
+  int n_uniq[2];          // occupied voxels while counting (returns to 0 when the set is consumed)
+  int n_stack[2];         // laserCloudCornerStackNum / laserCloudSurfStackNum
+  int error;
+};
+
 struct MapFrame {         // per-sweep device counters
   int n_uniq[2];
   int n_stack[2];
@@ -67,7 +73,10 @@ struct MapContext {
   VoxelTable tab[2];       // 0 corner, 1 surf
   int* cube_cnt = nullptr; // [2][kCubeNum] points per cube, window-relative index (== the reference's array index)
   DsScratch ds[2];
-  float4* stack[2] = {nullptr, nullptr};      // laserCloudCornerStack / laserCloudSurfStack (sensor frame)
+  static constexpr int kSets = 3;             // == the SR buffer sets of the handle (same rotation)
+  float4* stack_sets[kSets][2] = {};          // laserCloudCornerStack / laserCloudSurfStack (sensor frame), one pair per set
+  StackInfo* stack_info[kSets] = {};
+  float4* stack[2] = {nullptr, nullptr};      // the pair of the sweep mapping is working on (host-side alias)
   float4* stack_map[2] = {nullptr, nullptr};  // the same points in the map frame (at insert time)
   int* touched[2] = {nullptr, nullptr};       // table slots that received points this sweep
   int* deferred[2] = {nullptr, nullptr};      // slots holding raw points outside the valid block
@@ -80,8 +89,9 @@ struct MapContext {
 };
 
 vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs);
+vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph);
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
-                         bool skip_frame, ProfHook* ph);
+                         bool skip_frame, int set, ProfHook* ph);
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n);
 vloam_status map_error(MapContext* m, int* err_bits);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);

@@ -81,7 +81,7 @@ __device__ __forceinline__ void dquat_rot(const double* q, const double* v, doub
 
 // ---------------------------------------------------------------------------------------------- prepare
 __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr, const LOState* lo, int* cube_cnt, int skip_frame,
-                                                     double* traj_row14) {
+                                                     double* traj_row14, StackInfo* si) {
   __shared__ int shift[3];
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
       while (cK >= kCubeD - 3) { cK--; ms->cenD--; shift[2]--; }
       ms->centerCube[0] = cI; ms->centerCube[1] = cJ; ms->centerCube[2] = cK;
       if (shift[0] | shift[1] | shift[2]) fr->rolled = 1;
-      for (int k = 0; k < 2; k++) { fr->n_uniq[k] = 0; fr->n_stack[k] = 0; fr->n_touched[k] = 0; }
+      // the scan features were voxelised on the scan-registration stream (k_map_ds_*): adopt this sweep's stack
+      for (int k = 0; k < 2; k++) { fr->n_stack[k] = si->n_stack[k]; fr->n_touched[k] = 0; }
+      ms->n_corner_stack = si->n_stack[0]; ms->n_surf_stack = si->n_stack[1];
+      if (si->error) { atomicOr(&fr->error, si->error); si->error = 0; }
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
     }
   }
@@ -181,7 +184,7 @@ __device__ __forceinline__ u64 ds_key(float4 p, float inv) {
 // pass 1: voxel membership + per-voxel counts
 __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                       const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
-                                                      float inv1, MapFrame* fr) {
+                                                      float inv1, StackInfo* fr) {
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const float inv = kind ? inv1 : inv0;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__
 // them by counting: tile (256 keys) x (512 entries), rank = #keys below mine, off = #points in voxels below mine (which is the
 // voxel's segment start, so no scan pass is needed).  Partial results are added up with integer atomics (order-free).
 constexpr int kRankKeys = 256, kRankChunk = 512;
-__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const MapFrame* __restrict__ fr) {
+__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const StackInfo* __restrict__ fr) {
   __shared__ __attribute__((aligned(16))) u64 s_key[kRankChunk];
   __shared__ __attribute__((aligned(16))) int s_cnt[kRankChunk];
   const int kind = blockIdx.y, tid = threadIdx.x;
@@ -240,8 +243,7 @@ __global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScrat
 }
 
 // pass 3: group the point indices by voxel (segment start = off of the voxel); the same launch publishes the output order
-__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, MapFrame* fr,
-                                                        MapState* ms) {
+__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, StackInfo* fr) {
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
@@ -258,10 +260,7 @@ __global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __re
     D.rank_off[r] = o;
     if (r == u - 1) D.rank_off[u] = o + D.cnt[s];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    fr->n_stack[kind] = u;
-    if (kind == 0) ms->n_corner_stack = u; else ms->n_surf_stack = u;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_stack[kind] = u;
 }
 
 // pass 4: one wavefront per output voxel.  The atomics of pass 3 appended the members in arbitrary order; VoxelGrid sums in
@@ -271,7 +270,7 @@ __device__ __forceinline__ float rl(float v, int src) { return __int_as_float(__
 
 __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                        DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
-                                                       const MapFrame* __restrict__ fr) {
+                                                       StackInfo* __restrict__ fr) {
   __shared__ int s_idx[4][1024];
   __shared__ int s_sorted[4][1024];
   const int kind = blockIdx.y;
@@ -280,6 +279,7 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
   float4* stack = kind ? stack1 : stack0;
   const int u = min(fr->n_stack[kind], D.stack_cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_uniq[kind] = 0;  // this set's arrival counter, ready for its next sweep
   for (int t = blockIdx.x * 4 + wave; t < u; t += gridDim.x * 4) {
     const int b0 = D.rank_off[t], cnt = D.rank_off[t + 1] - b0;
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
@@ -815,6 +815,7 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     ok = ok && dmalloc(allocs, st, &T.blk, bslots);
     T.bslots_mask = (unsigned)(bslots - 1);
     DsScratch& D = m->ds[k];
+    if (k == 0) for (int c = 0; c < MapContext::kSets; c++) ok = ok && dmalloc(allocs, st, &m->stack_info[c], 1);
     D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
     const size_t hs = (size_t)D.hash_mask + 1;
@@ -824,7 +825,9 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
          dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.point_slot, (size_t)cfg.max_points) &&
          dmalloc(allocs, st, &D.seg, (size_t)cfg.max_points) && dmalloc(allocs, st, &D.rank_slot, (size_t)D.stack_cap) &&
          dmalloc(allocs, st, &D.rank_off, (size_t)D.stack_cap + 1);
-    ok = ok && dmalloc(allocs, st, &m->stack[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->stack_map[k], (size_t)D.stack_cap) &&
+    for (int c = 0; c < MapContext::kSets; c++) ok = ok && dmalloc(allocs, st, &m->stack_sets[c][k], (size_t)D.stack_cap);
+    m->stack[k] = m->stack_sets[0][k];
+    ok = ok && dmalloc(allocs, st, &m->stack_map[k], (size_t)D.stack_cap) &&
          dmalloc(allocs, st, &m->touched[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->deferred[k], (size_t)D.stack_cap);
     FactorTable& F = m->F[k];
     F.cap = kMapFactorCap;
@@ -848,20 +851,29 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
   return hipStreamSynchronize(st) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
+// pcl::VoxelGrid of this sweep's lessSharp / lessFlat clouds (LM:432-440) -> stack set `set`.  Needs nothing but the scan
+// registration output, so it is enqueued on the scan-registration stream, ahead of the mapping stage that consumes it.
+vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph) {
+  StackInfo* si = m->stack_info[set];
+  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+               m->inv_leaf[0], m->inv_leaf[1], si);
+  hipLaunchKernelGGL(k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si);
+  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si);
+  hipLaunchKernelGGL(k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+                     m->stack_sets[set][0], m->stack_sets[set][1], si);
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
-                         bool skip_frame, ProfHook* ph) {
-  (void)cfg;
+                         bool skip_frame, int set, ProfHook* ph) {
+  (void)cfg; (void)cur;
   MapState* ms = m->state;
   MapFrame* fr = m->frame;
-  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14);
+  m->stack[0] = m->stack_sets[set][0]; m->stack[1] = m->stack_sets[set][1];
+  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
+               m->stack_info[set]);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   hipLaunchKernelGGL(k_map_purge, dim3(256, 2), dim3(256), 0, st, m->tab[0], m->tab[1], ms, fr);
-  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
-               m->inv_leaf[0], m->inv_leaf[1], fr);
-  hipLaunchKernelGGL(k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], fr);
-  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], fr, ms);
-  hipLaunchKernelGGL(k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
-                     m->stack[0], m->stack[1], fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
                  m->inv_leaf[0], m->inv_leaf[1], ms, m->nn);
