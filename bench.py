@@ -39,7 +39,9 @@ def algorithmic_bytes(kernel, c):
     F = c["F_corner"] + c["F_plane"]
     if kernel == "k_lo_assoc":  # features + both candidate clouds read once, one 76-byte factor record written per factor
         return 16 * n_feat + 16 * (c["C"] + c["S"]) + 76 * F
-    if kernel == "k_lm_solve":  # every evaluation re-reads the 76-byte factor records
+    if kernel == "k_lm_solve":  # every evaluation consumes the factor records (76 B each); average over the solves of a sweep
+        if c["K_m"] > 0:  # 2 odometry + 2 mapping solves per sweep
+            return 76 * (F * c["E_o"] + c["K_m"] * c["E_m"]) / 4.0
         return 76 * F * max(c["E_o"], 2) / 2.0
     if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
         return 16 * c["N2"] + 16 * c["n_lessFlat"] + 4 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"])
@@ -112,7 +114,8 @@ def main():
     base_ptr, stride = d_clouds.data_ptr(), n_pts * 16
 
     h = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
-    kernel = args.kernel or ("k_map_assoc" if with_mapping else "k_lo_assoc")
+    # the kernel with the largest share of GPU time in the committed rocprofv3 summaries (profiles/r01_{lo,map}_kernel_stats.txt)
+    kernel = args.kernel or ("k_lm_solve" if with_mapping else "k_sr_ring")
 
     def barrier():
         if dist is not None:

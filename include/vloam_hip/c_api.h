@@ -92,7 +92,9 @@ vloam_status vloam_set_lo_prior(vloam_handle* h, const double q_xyzw[4], const d
  * Outputs (any may be NULL): world pose q_w_curr/t_w_curr and the frame-to-frame q_last_curr/t_last_curr. */
 vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]);
 
-/* == LaserMapping::input + solveMapping (laser_mapping.cpp:167-196,198-708).  Outputs the map-frame pose. */
+/* == LaserMapping::input + solveMapping + the pose of publish() (laser_mapping.cpp:167-196,198-708,718-757).  Outputs the
+ * map-frame pose publish() reports: q_w_curr / t_w_curr after a mapped sweep, the high-frequency pose
+ * q_wmap_wodom * q_wodom_curr after a sweep skipped by mapping_skip_frame. */
 vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[3]);
 
 /* Whole façade for one sweep, enqueued with NO host synchronisation:

@@ -146,6 +146,12 @@ class Oracle:
         self.L.orc_get_map_pose(self.h, _p(qw, D), _p(tw, D), _p(qm, D), _p(tm, D))
         return qw, tw, qm, tm
 
+    def map_published_pose(self):
+        """(q, t) that LaserMapping::publish reports: the optimised pose, or the high-frequency pose on a skipped frame."""
+        q, t = np.zeros(4), np.zeros(3)
+        self.L.orc_get_map_published_pose(self.h, _p(q, D), _p(t, D))
+        return q, t
+
     def map_num_outer(self):
         return self.L.orc_map_num_outer(self.h)
 

@@ -150,6 +150,18 @@ void orc_get_map_pose(orc_handle* h, double* q_w, double* t_w, double* q_wmap_wo
   q_wmap_wodom[0] = lm.q_wmap_wodom.x; q_wmap_wodom[1] = lm.q_wmap_wodom.y; q_wmap_wodom[2] = lm.q_wmap_wodom.z; q_wmap_wodom[3] = lm.q_wmap_wodom.w;
   t_wmap_wodom[0] = lm.t_wmap_wodom.x; t_wmap_wodom[1] = lm.t_wmap_wodom.y; t_wmap_wodom[2] = lm.t_wmap_wodom.z;
 }
+// the pose LaserMapping::publish hands to VloamTF::world_MOT_base_last (laser_mapping.cpp:718-757): q_w_curr after a mapped
+// frame, the high-frequency pose after a skipped one
+void orc_get_map_published_pose(orc_handle* h, double* q, double* t) {
+  LaserMapping& lm = h->p->lm;
+  if (lm.skip_frame) {
+    q[0] = lm.q_w_curr_highfreq.x; q[1] = lm.q_w_curr_highfreq.y; q[2] = lm.q_w_curr_highfreq.z; q[3] = lm.q_w_curr_highfreq.w;
+    t[0] = lm.t_w_curr_highfreq.x; t[1] = lm.t_w_curr_highfreq.y; t[2] = lm.t_w_curr_highfreq.z;
+  } else {
+    for (int i = 0; i < 4; i++) q[i] = lm.parameters[i];
+    for (int i = 0; i < 3; i++) t[i] = lm.parameters[4 + i];
+  }
+}
 int orc_map_num_outer(orc_handle* h) { return (int)h->p->lm.debug.size(); }
 int orc_get_map_solve(orc_handle* h, int outer, double* qt_in7, double* qt_out7, double* trace, int cap_iters, int* n_iters,
                       double* H0, double* g0, int* termination, double* costs2, int* corner_surf_num2, double* residuals0,

@@ -400,9 +400,12 @@ void LaserMapping::input(const Cloud& cornerLast, const Cloud& surfLast, const C
   }
   q_wodom_curr = q_wodom_curr_;
   t_wodom_curr = t_wodom_curr_;
-  if (!skip_frame) {  // :191-195 (the skip branch only feeds the high-frequency publisher)
-    Quat<double> q = qmul(q_wmap_wodom, q_wodom_curr);
-    V3<double> t = rotate(q_wmap_wodom, t_wodom_curr) + t_wmap_wodom;
+  // :186-195 transformAssociateToMap: a skipped frame only refreshes the high-frequency pose that publish() sends out
+  Quat<double> q = qmul(q_wmap_wodom, q_wodom_curr);
+  V3<double> t = rotate(q_wmap_wodom, t_wodom_curr) + t_wmap_wodom;
+  if (skip_frame) {
+    q_w_curr_highfreq = q; t_w_curr_highfreq = t;
+  } else {
     parameters[0] = q.x; parameters[1] = q.y; parameters[2] = q.z; parameters[3] = q.w;
     parameters[4] = t.x; parameters[5] = t.y; parameters[6] = t.z;
   }

@@ -99,6 +99,9 @@ class LaserMapping {
   void solveMapping();                                          // laser_mapping.cpp:198-708
   // state / outputs
   double parameters[7];  // q_w_curr (x,y,z,w), t_w_curr
+  Quat<double> q_w_curr_highfreq{0, 0, 0, 1};  // laser_mapping.cpp:186-190 (what publish() reports on a skipped frame, :743-757)
+  V3<double> t_w_curr_highfreq{0, 0, 0};
+  bool skip_frame = false;
   Quat<double> q_wmap_wodom, q_wodom_curr;
   V3<double> t_wmap_wodom, t_wodom_curr;
   int frameCount = 0;
@@ -123,7 +126,6 @@ class LaserMapping {
   int laserCloudCenWidth = 10, laserCloudCenHeight = 10, laserCloudCenDepth = 5;
   std::vector<Cloud> laserCloudCornerArray, laserCloudSurfArray;
   Cloud laserCloudCornerLast, laserCloudSurfLast, laserCloudFullRes;
-  bool skip_frame = false;
   void pointAssociateToMap(const PointXYZI& pi, PointXYZI* po) const;  // laser_mapping.cpp:146-155
   void transformUpdate();                                               // laser_mapping.cpp:140-144
   template <class Shift> void roll(Shift);

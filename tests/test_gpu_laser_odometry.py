@@ -44,7 +44,7 @@ def compare_outer(d, o, outer):
     assert qdist(rec["x_out"][:4], s["q_out"]) < POSE_TOL and np.linalg.norm(rec["x_out"][4:] - s["t_out"]) < POSE_TOL
 
 
-@pytest.mark.parametrize("shape,nframes", [((64, 512), 6), ((64, 2048), 4)])
+@pytest.mark.parametrize("shape,nframes", [((64, 512), 20), ((64, 2048), 4)])
 def test_laser_odometry_parity(vl, orc, sweeps, shape, nframes):
     h = vl.Handle(0, scan_line=shape[0], debug=1, with_mapping=0)
     o = orc.Oracle(scan_line=shape[0], with_mapping=False)

@@ -36,7 +36,7 @@ def test_run_sequence_rows_match_oracle(vl, orc, sweeps, tmp_path):
     for k, c in enumerate(clouds):
         o.process(c)
         qw, tw, _, _ = o.lo_pose()
-        qm, tm, _, _ = o.map_pose()
+        qm, tm = o.map_published_pose()
         row_lo = tf.LO2Cam0StartFrame(qw, tw, k)
         row_mo = tf.MO2Cam0StartFrame(qm, tm, k)
         # "%f" keeps 6 decimals: rows agree to the printed precision (poses agree to ~1e-9)

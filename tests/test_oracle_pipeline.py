@@ -170,3 +170,33 @@ def test_vo_oracle_pieces(orc, synth):
     z = v.query_depth(0, ix * 5 + 2.0, iy * 5 + 2.0)
     nb = [bd[(ix + a) * 75 + (iy + b)] for a in range(-2, 3) for b in range(-2, 3) if bc[(ix + a) * 75 + (iy + b)] > 0]
     assert z == -1.0 or (min(nb) - 1e-3 <= z <= max(nb) + 1e-3)
+
+
+def test_published_map_pose_on_skipped_frames(orc, sweeps):
+    """mapping_skip_frame = 2: after a skipped sweep publish() reports q_wmap_wodom * q_wodom_curr (laser_mapping.cpp:186-190,
+    743-757) while q_w_curr keeps the last optimised pose; after a mapped sweep both coincide."""
+    import numpy as np
+    o = orc.Oracle(with_mapping=True, mapping_skip_frame=2)
+
+    def qmul(a, b):
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+    def rot(q, v):
+        u, w = q[:3], q[3]
+        uv = 2 * np.cross(u, v)
+        return v + w * uv + np.cross(u, uv)
+
+    for k in range(6):
+        o.process(sweeps(64, 256, k))
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm, qwm, twm = o.map_pose()
+        qp, tp = o.map_published_pose()
+        if (k + 1) % 2 == 0:   # mapped sweep
+            assert np.array_equal(qp, qm) and np.array_equal(tp, tm)
+        else:                  # skipped: high-frequency pose from the last map correction
+            assert np.allclose(qp, qmul(qwm, qw), atol=1e-14) and np.allclose(tp, rot(qwm, tw) + twm, atol=1e-12)
+            if k > 1:
+                assert np.linalg.norm(tp - tm) > 0.1   # q_w_curr still holds the previous mapped sweep

@@ -5,6 +5,7 @@
 #include "../../include/vloam_hip/c_api.h"
 
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -186,6 +187,14 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         ALLOC(h->sr[k].less_flat, (size_t)P);
       }
       for (int k = 0; k < vloam_handle::kSets; k++) {
+        ALLOC(h->grid[k].occ, 4 * kMaxRings);
+        ALLOC(h->grid[k].stops, 4 * kStopLen);
+        {
+          int arm[4 * kMaxRings];
+          for (int q = 0; q < 4 * kMaxRings; q++) arm[q] = ((q / kMaxRings) & 1) ? -1 : INT_MAX;
+          HIPCHK(hipMemcpyAsync(h->grid[k].occ, arm, sizeof(arm), hipMemcpyHostToDevice, h->stream));
+          HIPCHK(hipStreamSynchronize(h->stream));
+        }
         for (int g = 0; g < 4; g++) {
           h->grid[k].mask[g] = kGridBuckets[g] - 1;
           ALLOC(h->grid[k].cnt[g], kGridBuckets[g]);
@@ -418,10 +427,12 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
   if (s != VLOAM_OK) return s;
   s = sync_all(h);
   if (s != VLOAM_OK) return s;
-  MapState ms;
-  HIPCHK(hipMemcpy(&ms, h->map.state, sizeof(ms), hipMemcpyDeviceToHost));
-  if (q_map) memcpy(q_map, ms.parameters, sizeof(double) * 4);
-  if (t_map) memcpy(t_map, ms.parameters + 4, sizeof(double) * 3);
+  // what LaserMapping::publish reports (laser_mapping.cpp:718-757): q_w_curr / t_w_curr after a mapped sweep, the
+  // high-frequency pose q_wmap_wodom * q_wodom_curr after a skipped one — the map half of this sweep's trajectory row
+  double row[14];
+  HIPCHK(hipMemcpy(row, h->traj + (size_t)h->frame * 14, sizeof(row), hipMemcpyDeviceToHost));
+  if (q_map) memcpy(q_map, row + 7, sizeof(double) * 4);
+  if (t_map) memcpy(t_map, row + 11, sizeof(double) * 3);
   return finish_frame(h);
 }
 

@@ -281,8 +281,11 @@ __device__ __forceinline__ void eval_vo(int type, D3 p, D3 A, const double* x, d
   }
 }
 
+// row stride of the transpose buffer: == 8 (mod 32) doubles, so that the 8 rows a wavefront reads in the column pass land in
+// different 64-bit banks (a 256-double stride would put all of them in the same 8 banks)
+constexpr int kRedStride = kLmThreads + 8;
 struct LmShared {
-  double red[kAcc * kLmThreads];  // [value][thread] transpose buffer of the block reduction
+  double red[kAcc * kRedStride];  // [value][thread] transpose buffer of the block reduction (rows padded against bank conflicts)
   double part[8 * kAcc];          // [sub-sum][value]
   double cur[kAcc];    // accumulators at x
   double cand[kAcc];   // accumulators at the candidate
@@ -456,11 +459,11 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   // block reduction without cross-lane shuffles (a chain of ds_bpermute round trips is what dominated this kernel):
   // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
 #pragma unroll
-  for (int i = 0; i < kAcc; i++) sh.red[i * kLmThreads + tid] = acc[i];
+  for (int i = 0; i < kAcc; i++) sh.red[i * kRedStride + tid] = acc[i];
   __syncthreads();
   if (tid < 8 * kAcc) {
     const int i = tid >> 3, sub = tid & 7;
-    const double* col = sh.red + i * kLmThreads + sub;
+    const double* col = sh.red + i * kRedStride + sub;
     double s = 0.0;
 #pragma unroll 8
     for (int j = 0; j < kLmThreads / 8; j++) s += col[8 * j];

@@ -10,11 +10,14 @@ namespace vloam {
 // grid whose 27-cell neighbourhood covers DISTANCE_SQ_THRESHOLD = 25 for the rare queries without a close neighbour.
 // Grid index g = kind + 2 * level (kind 0 corner / 1 surf, level 0 = 1 m / 1 = 5 m); bucket = hash(cell) & mask.
 constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 12, 1 << 14};
+constexpr int kStopLen = kMaxRings + 4;
 constexpr int kGridMaxBuckets = 1 << 15;
 struct LoGrid {
   int* cnt[4];     // [buckets] points per bucket (count pass); counted back down to zero by the scatter pass
   int* start[4];   // [buckets + 1] exclusive offsets
   float4* pts[4];  // [n] the points grouped by bucket: (x, y, z, bits: index | ring << 24)
+  int* occ;        // [2 kinds][first, last][kMaxRings] first / last index of every stored scan line (armed: INT_MAX / -1)
+  int* stops;      // [2 kinds][2][kStopLen] where the reference's adjacent-line walks break (see k_lo_assoc)
   int mask[4];
 };
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,

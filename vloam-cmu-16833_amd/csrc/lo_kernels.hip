@@ -75,16 +75,24 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
   for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
     const int i = base + threadIdx.x;
     unsigned bf = 0xffffffffu, bc = 0xffffffffu;
+    int line = -1;
     if (i < n) {
       const float4 p = pts[i];
       bf = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
       bc = coarse_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift) & (unsigned)G.mask[kind + 2];
+      line = (int)p.w;
     }
     int hl, off, len;
     wave_runs(bf, lane, &hl, &off, &len);
     if (off == 0 && i < n) atomicAdd(&G.cnt[kind][bf], len);
     wave_runs(bc, lane, &hl, &off, &len);
     if (off == 0 && i < n) atomicAdd(&G.cnt[kind + 2][bc], len);
+    // first / last index of every stored scan line (one atomic per run of equal lines)
+    wave_runs((unsigned)line, lane, &hl, &off, &len);
+    if (i < n && line >= 0 && line < kMaxRings) {
+      if (off == 0) atomicMin(&G.occ[(kind * 2 + 0) * kMaxRings + line], i);
+      if (off == len - 1) atomicMax(&G.occ[(kind * 2 + 1) * kMaxRings + line], i);
+    }
   }
 }
 
@@ -120,6 +128,24 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
       dst[q] = o;
     }
   if (tid == 1023) G.start[g][nb] = run;
+  // walk stops of the corner (g == 0) / surf (g == 1) cloud: stops[v] = first index with line >= v (v = 0 .. kStopLen - 1),
+  // stops[kStopLen + v] = last index with line <= v - 3; then the occurrence table is re-armed for the next sweep
+  if (g < 2 && wave == 0) {
+    int* first = G.occ + (g * 2 + 0) * kMaxRings;
+    int* last = G.occ + (g * 2 + 1) * kMaxRings;
+    int f = first[lane], l = last[lane];  // kMaxRings == 64 lanes
+    first[lane] = INT_MAX; last[lane] = -1;
+    for (int d = 1; d < 64; d <<= 1) {  // suffix min of f, prefix max of l
+      const int of = __shfl_down(f, d), ol = __shfl_up(l, d);
+      if (lane + d < 64) f = min(f, of);
+      if (lane >= d) l = max(l, ol);
+    }
+    int* stops = G.stops + g * 2 * kStopLen;
+    stops[lane] = f;
+    stops[kStopLen + 3 + lane] = l;
+    if (lane < kStopLen - 64) stops[64 + lane] = INT_MAX;
+    if (lane < 3) stops[kStopLen + lane] = -1;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
@@ -288,6 +314,7 @@ struct VisitNearest {  // LO:269 / LO:356: nearest candidate, ties to the lowest
 struct VisitAdjacent {  // LO:279-324 / LO:368-417 as a class filter (see k_lo_assoc)
   float3 sel;
   int idx, ringA;
+  int stop_f, stop_b;  // the indices at which the reference's upward / downward walk breaks (exclusive bounds)
   bool is_corner;
   u64 l2, l3;
   int visited;
@@ -298,9 +325,11 @@ struct VisitAdjacent {  // LO:279-324 / LO:368-417 as a class filter (see k_lo_a
     const float d = sqdist(c, sel);
     const bool fwd = j > idx;
     const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
-    const bool ok = d < 25.0f && j != idx && rj <= ringA + 2 && rj >= ringA - 2;  // (double)rj > ringA + 2.5 <=> rj > ringA + 2
-    const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : rj == ringA;   // LO:287-299, 311-323 / LO:376-381, 402-407
-    const bool to3 = !is_corner && rj != ringA;                                    // LO:383-389, 409-415
+    const bool ok = d < 25.0f && j != idx && j < stop_f && j > stop_b;
+    // corner: upward walk skips scan lines <= ringA (LO:287-289), downward walk skips >= ringA (LO:311-313);
+    // plane: upward, scan line <= ringA feeds the 2nd point, above it the 3rd (LO:376-389); downward mirrored (LO:402-415)
+    const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : (fwd ? rj <= ringA : rj >= ringA);
+    const bool to3 = !is_corner && !to2;
     if (ok && to2) l2 = key < l2 ? key : l2;
     if (ok && to3) l3 = key < l3 ? key : l3;
   }
@@ -381,13 +410,20 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
       // ---- second (and third) point: the reference walks the ring-sorted cloud upwards from idx + 1 until the scan line
       // exceeds ringA + NEARBY_SCAN and downwards from idx - 1 until it drops below ringA - NEARBY_SCAN, keeping the nearest
       // point with d2 < 25 per class, first strictly smaller wins (LO:279-324 / LO:368-417).  On a ring-sorted cloud that is
-      // the minimum of (d2, visiting order) over { j != idx, |ring_j - ringA| <= 2 } split into classes by (j > idx, ring_j),
-      // so it is answered by the same expanding grid search, with the class filter applied to every candidate.
+      // the minimum of (d2, visiting order) over the index interval between the two break points, split into classes by
+      // (j > idx, ring_j), so it is answered by the same expanding grid search with the class filter applied to every candidate.
       u64 b2 = ~0ull, b3 = ~0ull;
+      // Where the walks break.  The stored scan line int(intensity) of a point of scan line r is r or r - 1 (the fractional part
+      // 0.1 * relTime lies in (-0.05, 0.15): SR:237-265), so the clouds are only ALMOST sorted by it: the upward walk breaks at
+      // the first point anywhere with a line > ringA + NEARBY_SCAN, the downward walk at the last one with a line below
+      // ringA - NEARBY_SCAN, and points beyond a break are never looked at even if their own line is in range.
+      const int* stops = is_corner ? G.stops : G.stops + 2 * kStopLen;
+      const int stop_f = stops[ringA + 3], stop_b = stops[kStopLen + ringA];  // first index with line >= ringA + 3, last with line <= ringA - 3
       const int glo = max(ringA - 2, 0) >> kRingGroupShift, ghi = min(ringA + 2, kMaxRings - 1) >> kRingGroupShift;
       for (int stage = 0; stage < 5; stage++) {
         VisitAdjacent va;
-        va.sel = sel; va.idx = idx; va.ringA = ringA; va.is_corner = is_corner; va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
+        va.sel = sel; va.idx = idx; va.ringA = ringA; va.stop_f = stop_f; va.stop_b = stop_b; va.is_corner = is_corner;
+        va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
         bool skipped = false;
         if (stage == 0) va = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
         else if (stage == 1) va = for_each_candidate<1, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups x 27 cells

@@ -68,7 +68,11 @@ class SynthSequence:
         self.n_rings, self.n_azimuth, self.n_sweeps = n_rings, n_azimuth, n_sweeps
         self.seed_noise, self.noise_sigma = seed_noise, noise_sigma
         el = np.deg2rad(beam_elevations_deg(n_rings))
-        az = -2.0 * np.pi * np.arange(n_azimuth) / n_azimuth  # clockwise so ori = -atan2(y, x) increases
+        # clockwise so ori = -atan2(y, x) increases.  A fixed per-column jitter keeps the firing azimuths off a perfect grid: on a
+        # perfect grid whole columns sit EXACTLY on the reference's +-pi/2 unwrap thresholds (scan_registration.cpp:237-261),
+        # where a 1-ulp difference between two atan2f implementations flips relTime — and with it int(intensity) — by a turn.
+        jit = np.random.default_rng(seed_scene + 7).uniform(-0.35, 0.35, n_azimuth)
+        az = -2.0 * np.pi * (np.arange(n_azimuth) + jit) / n_azimuth
         ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
         d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (n_rings, n_azimuth))], -1)
         self.dirs = d.reshape(-1, 3)  # ring-major
