@@ -56,6 +56,21 @@ def algorithmic_bytes(kernel, c):
     return 0
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_summary.py wrote the table).
+    A PMC pass cannot run inside this process, so the number is read from profiles/ — None when the table is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_hbm_traffic.txt" % workload)
+    try:
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 5 and f[0].split("<")[0] == kernel:
+                return float(f[-1]), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    except OSError:
+        pass
+    return None, None
+
+
 def sweep_bytes(c, with_mapping):
     """B_SR + B_LO (+ B_MAP) per sweep from measured counts."""
     n_feat_all = c["n_sharp"] + c["n_lessSharp"] + c["n_flat"] + c["n_lessFlat"]
@@ -204,6 +219,7 @@ def main():
         b_sr, b_lo, b_map = sweep_bytes(counts, with_mapping)
         kb = algorithmic_bytes(kernel, counts)
         avg_ms = k_ms / max(k_launches, 1)
+        traffic, traffic_src = pmc_traffic(args.workload, kernel)
         achieved = kb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "scans/sec end-to-end odometry on 64x2048 cloud", "value": value, "unit": "scans/s", "n_gpus": world, "steps": K,
@@ -212,7 +228,8 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "points_per_sweep": int(n_pts), "sequences": world,
                        "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": kb,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": kb,
                          "avg_launch_us": 1e3 * avg_ms, "launches_timed": k_launches,
                          "sweep_algorithmic_bytes": {"B_SR": b_sr, "B_LO": b_lo, "B_MAP": b_map},
                          "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
