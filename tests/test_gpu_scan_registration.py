@@ -53,7 +53,8 @@ def unwrap_bounds(startOri, endOri):
     return [s - np.pi / 2, s + 1.5 * np.pi, s + np.pi, e - 1.5 * np.pi, e + np.pi / 2]
 
 
-@pytest.mark.parametrize("shape,k", [((64, 512), 0), ((64, 512), 3), ((64, 2048), 0), ((64, 2048), 5), ((16, 1024), 1)])
+@pytest.mark.parametrize("shape,k", [((64, 512), 0), ((64, 512), 3), ((64, 2048), 0), ((64, 2048), 5), ((16, 1024), 1), ((32, 1024), 2),
+                                     ((64, 4000), 1)])  # 4000 columns: sectors longer than 384 points (the wide register path of the picks)
 def test_scan_registration_parity(vl, orc, sweeps, shape, k):
     cloud = sweeps(shape[0], shape[1], k)
     h, o = run_both(vl, orc, cloud, scan_line=shape[0])
