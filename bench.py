@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--azimuth", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=48, help="sweeps of the same sequence timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vo-frames", type=int, default=8, help="extra leg: frames of the VO residual stack to time (0 = skip)")
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
                     help="extra leg: this many independent sequences driven concurrently on ONE GPU (own handle + stream each); 0 = skip")
     args = ap.parse_args()
@@ -212,6 +213,24 @@ def main():
                    "note": "one sweep at a time (vloam_sync after each): no overlap between consecutive sweeps"}
         hl.close()
 
+    # ---- extra: the depth-enhanced VO residual stack (configs[3]'s GPU part) on synthetic matches, host-synchronous API
+    # (cloud and matches come from host memory, the solved motion goes back): vloam_vo_process_point_cloud + vloam_vo_solve
+    vo_stage = None
+    if world == 1 and args.vo_frames > 0:
+        hv = vl.Handle(local_rank, scan_line=args.rings, with_mapping=0, max_points=max(n_pts, 1024))
+        hv.vo_set_calib(*synth.kitti_like_calib())
+        nf = min(args.vo_frames, W + K - 1)
+        ms_ = [synth.synth_matches(seq, k) for k in range(1, nf + 1)]
+        hv.vo_process_point_cloud(host[0])
+        v0 = time.perf_counter()
+        for k in range(1, nf + 1):
+            hv.vo_process_point_cloud(host[k])
+            hv.vo_solve(ms_[k - 1][0], ms_[k - 1][1], np.zeros(3), np.zeros(3))
+        v1 = time.perf_counter()
+        vo_stage = {"ms_per_frame": 1e3 * (v1 - v0) / nf, "frames": nf, "matches": int(ms_[0][0].shape[0]),
+                    "note": "projection + 5-px bucket depth map + 3-NN depth lookup + K^-1 QR + <=100-iteration LM, incl. the 2 MB H2D copy"}
+        hv.close()
+
     out = None
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)
@@ -238,6 +257,8 @@ def main():
         out["config"]["pipelining"] = "SR / LO / mapping of consecutive sweeps overlap on three HIP streams (one sequence, one GPU)"
         if latency:
             out["latency"] = latency
+        if vo_stage:
+            out["vo_stage"] = vo_stage
         if multi_session:
             out["multi_session"] = multi_session
         if world == 1 and not args.no_cpu_baseline:

@@ -38,18 +38,26 @@ __global__ __launch_bounds__(256) void k_vo_project(const float4* __restrict__ i
 }
 
 __global__ __launch_bounds__(1024) void k_vo_scan(int* bcount, int* bfill) {
-  __shared__ int sums[1024];
-  const int tid = threadIdx.x;
-  const int per = (kBuckets + 1023) / 1024;
-  const int lo = tid * per, hi = min(lo + per, kBuckets);
-  int s = 0;
-  for (int k = lo; k < hi; k++) s += bcount[k];
-  sums[tid] = s;
+  constexpr int kPer = (kBuckets + 1023) / 1024;  // 19: odd, so a lane stride of kPer words is LDS-bank-conflict free
+  __shared__ int buf[1024 * kPer];                 // the counters pass through LDS: coalesced in, coalesced out
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 1024 * kPer; k += 1024) buf[k] = k < kBuckets ? bcount[k] : 0;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? sums[tid - d] : 0; __syncthreads(); sums[tid] += v; __syncthreads(); }
-  int run = tid ? sums[tid - 1] : 0;
-  for (int k = lo; k < hi; k++) { const int c = bcount[k]; bcount[k] = run; bfill[k] = 0; run += c; }
-  if (tid == 1023) bcount[kBuckets] = sums[1023];
+  const int lo = tid * kPer;
+  int v[kPer], s = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) { v[k] = buf[lo + k]; s += v[k]; }
+  int inc = s;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int run = inc - s;
+  for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+  for (int k = 0; k < kPer; k++) { buf[lo + k] = run; run += v[k]; }
+  __syncthreads();
+  for (int k = tid; k <= kBuckets; k += 1024) { bcount[k] = buf[k]; if (k < kBuckets) bfill[k] = 0; }  // buf[kBuckets] == total (the tail counters are 0)
 }
 
 __global__ __launch_bounds__(256) void k_vo_scatter(const float4* __restrict__ uvd, int n, const int* __restrict__ boff, int* bfill,
@@ -85,27 +93,46 @@ __global__ __launch_bounds__(256) void k_vo_fold(const float4* __restrict__ uvd,
   M.bx[b] = x; M.by[b] = y; M.bd[b] = d; M.bc[b] = count;
 }
 
-// PCU:302-387
-__device__ float query_depth(const DepthMapDev& M, float x, float y) {
+// PCU:302-387.  The reference collects the occupied buckets of the 5 x 5 neighbourhood, std::sorts them by distance and
+// interpolates over the three nearest (if at least 10 are occupied).  Only the three smallest distances are ever used, so
+// they are kept in registers by stable insertion (ties keep scan order == the canonical tie order of the sort).
+__device__ __forceinline__ float query_depth(const DepthMapDev& M, float x, float y) {
   const int searching_radius = 2;
   const int index_x = (int)(x / kGrid), index_y = (int)(y / kGrid);
-  float nx[25], ny[25], nd[25], ndist[25];
+  float d0 = 3.0e38f, d1 = 3.0e38f, d2 = 3.0e38f, z0 = 0.f, z1 = 0.f, z2 = 0.f;  // distances ascending, depths alongside
   int cnt = 0;
-  for (int ix = index_x - searching_radius; ix <= index_x + searching_radius; ++ix)
-    for (int iy = index_y - searching_radius; iy <= index_y + searching_radius; ++iy)
-      if (ix >= 0 && ix < kBW && iy >= 0 && iy < kBH && M.bc[ix * kBH + iy] > 0) {
-        const int b = ix * kBH + iy;
-        const float bx = M.bx[b], by = M.by[b];
-        const double dx = (double)(x - bx), dy = (double)(y - by);
-        const float dist = (float)sqrt(dx * dx + dy * dy);  // std::sqrt(std::pow(float, 2) + std::pow(float, 2)) in double
-        int pos = cnt;  // stable insertion by distance (std::sort in the reference; canonical tie order = scan order)
-        while (pos > 0 && dist < ndist[pos - 1]) { nx[pos] = nx[pos - 1]; ny[pos] = ny[pos - 1]; nd[pos] = nd[pos - 1]; ndist[pos] = ndist[pos - 1]; pos--; }
-        nx[pos] = bx; ny[pos] = by; nd[pos] = M.bd[b]; ndist[pos] = dist;
-        cnt++;
+  // two fully unrolled passes so that the 25 occupancy loads, then the loads of the occupied buckets, are each in flight
+  // together (a loop over the neighbourhood would be 25 dependent round trips)
+  int occ[25];
+#pragma unroll
+  for (int q = 0; q < 25; q++) {
+    const int ix = index_x - searching_radius + q / 5, iy = index_y - searching_radius + q % 5;  // same order as the reference's loops
+    occ[q] = (ix >= 0 && ix < kBW && iy >= 0 && iy < kBH) ? M.bc[ix * kBH + iy] : 0;
+  }
+  float bxs[25], bys[25], bds[25];
+#pragma unroll
+  for (int q = 0; q < 25; q++) {
+    const int b = (index_x - searching_radius + q / 5) * kBH + (index_y - searching_radius + q % 5);
+    bxs[q] = 0.f; bys[q] = 0.f; bds[q] = 0.f;
+    if (occ[q] > 0) { bxs[q] = M.bx[b]; bys[q] = M.by[b]; bds[q] = M.bd[b]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 25; q++)
+    if (occ[q] > 0) {
+      const double dx = (double)(x - bxs[q]), dy = (double)(y - bys[q]);
+      const float dist = (float)sqrt(dx * dx + dy * dy);  // std::sqrt(std::pow(float, 2) + std::pow(float, 2)) in double
+      const float bd = bds[q];
+      if (dist < d2) {
+        if (dist < d1) {
+          d2 = d1; z2 = z1;
+          if (dist < d0) { d1 = d0; z1 = z0; d0 = dist; z0 = bd; }
+          else { d1 = dist; z1 = bd; }
+        } else { d2 = dist; z2 = bd; }
       }
+      cnt++;
+    }
   if (cnt < 10) return -1.0f;
-  return (nd[0] * ndist[1] * ndist[2] + nd[1] * ndist[0] * ndist[2] + nd[2] * ndist[0] * ndist[1]) /
-         (0.0001f + ndist[1] * ndist[2] + ndist[0] * ndist[2] + ndist[0] * ndist[1]);
+  return (z0 * d1 * d2 + z1 * d0 * d2 + z2 * d0 * d1) / (0.0001f + d1 * d2 + d0 * d2 + d0 * d1);
 }
 
 // op-for-op twin of oracle/orc_vo.cpp solve3x3_colpiv_qr_f32 (P_rect0.leftCols(3).colPivHouseholderQr().solve, VO:350-355)
@@ -180,7 +207,6 @@ __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_u
         type = 4;
         obs[0] = r0[0]; obs[1] = r0[1]; obs[2] = r0[2];
         obs[3] = (double)r1[0] / (double)r1[2]; obs[4] = (double)r1[1] / (double)r1[2];
-        atomicAdd(&counters[0], 1);
       } else {           // VO:393-415
         p0[0] = (float)px; p0[1] = (float)py; p0[2] = 1.0f;
         p1[0] = (float)cx; p1[1] = (float)cy; p1[2] = 1.0f;
@@ -189,13 +215,19 @@ __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_u
         type = 5;
         obs[0] = (double)r0[0] / (double)r0[2]; obs[1] = (double)r0[1] / (double)r0[2];
         obs[2] = (double)r1[0] / (double)r1[2]; obs[3] = (double)r1[1] / (double)r1[2];
-        atomicAdd(&counters[1], 1);
       }
     }
   }
   const int cap = F.cap;
   F.type[j] = type;
-  if (type) atomicAdd(&F.rowcnt[j >> 6], 1);
+  {  // one atomic per wavefront and counter (a wavefront is exactly one 64-slot row of the factor table)
+    const unsigned long long m32 = __ballot(type == 4), m22 = __ballot(type == 5);
+    if ((threadIdx.x & 63) == 0) {
+      if (m32) atomicAdd(&counters[0], __popcll(m32));
+      if (m22) atomicAdd(&counters[1], __popcll(m22));
+      if (m32 | m22) atomicAdd(&F.rowcnt[j >> 6], __popcll(m32 | m22));
+    }
+  }
   if (type == 4) {
     F.p[j] = obs[0]; F.p[cap + j] = obs[1]; F.p[2 * cap + j] = obs[2];
     F.A[j] = obs[3]; F.A[cap + j] = obs[4]; F.A[2 * cap + j] = 0;
