@@ -1,11 +1,12 @@
 // Levenberg–Marquardt on one workgroup: the whole ceres::Solve() of the reference
 // (laser_odometry.cpp:457-463, laser_mapping.cpp:609-617, visual_odometry.cpp:423) runs inside ONE
-// kernel launch.  A prologue compacts the accepted factors (slot order, deterministic) so every later
-// evaluation streams dense arrays; 8 wavefronts evaluate the residual blocks (closed-form Jacobians in the tangent
-// space of EigenQuaternionParameterization, Huber corrector), reduce the 6x6 J^T J / J^T r / cost
-// with wavefront shuffles + a fixed-order LDS pass (bit-reproducible), and lane 0 runs the
+// kernel launch.  k_lm_compact (many workgroups) packs the accepted factors in slot order (deterministic) and
+// pre-digests them (edge -> orthonormal pair across the line, plane -> normal + offset); k_lm_solve then keeps them in the
+// registers of 256 lanes, evaluates the residual blocks with closed-form Jacobians in the tangent space of
+// EigenQuaternionParameterization and the Huber corrector, reduces the 6x6 J^T J / J^T r / cost through a fixed-order LDS
+// transpose (bit-reproducible; 64-bit cross-lane shuffles are slower than LDS here), and lane 0 runs the
 // trust-region bookkeeping of Ceres 2.0 (Jacobi scaling, LM diagonal clamp, step acceptance,
-// radius schedule, tolerances) on the 6x6 normal equations.  No host round trips, no atomics.
+// radius schedule, tolerances) on the 6x6 normal equations.  No host round trips, no float atomics.
 //
 // Ceres is not vendored by the reference; the algorithm restated here is spelled out in
 // oracle/orc_ceres.cpp (CPU oracle, DENSE_QR on the stacked Jacobian) and SURVEY.md Appendix A.

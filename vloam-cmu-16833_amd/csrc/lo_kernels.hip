@@ -1,10 +1,11 @@
 // laserOdometry data association on gfx950: for every sharp / flat feature of the current sweep,
-// TransformToStart, exact 1-NN in the previous sweep's lessSharp / lessFlat cloud, the adjacent-ring
-// walks for the 2nd (and 3rd) point, and emission of the Ceres residual block as a FactorTable slot.
+// TransformToStart, exact 1-NN in the previous sweep's lessSharp / lessFlat cloud, the adjacent-scan-line
+// searches for the 2nd (and 3rd) point, and emission of the Ceres residual block as a FactorTable slot.
 // Restates LaserOdometry::solveLO, /root/reference/src/lidar_odometry_mapping/src/laser_odometry.cpp:207-444
-// ("LO:<line>").  One wavefront per feature: 64 lanes sweep the candidate array, keep
-// (f32 distance bits << 32 | visit order) keys and reduce them with wavefront shuffles, which
-// reproduces the reference's first-strictly-smaller-wins scans and "lowest index wins" kNN ties.
+// ("LO:<line>").  The kd-trees of the reference become a two-level hash grid built once per sweep
+// (k_lo_grid_count / scan / scatter); one wavefront per feature scans grid blocks with all 64 lanes and keeps
+// (f32 distance bits << 32 | index or visit order) keys, which reproduces the reference's
+// first-strictly-smaller-wins walks and "lowest index wins" kNN ties exactly.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "lo_kernels.h"

@@ -1,5 +1,5 @@
 // scanRegistration on gfx950: NaN / min-range removal, ring + relTime labelling, stable per-ring
-// compaction, 11-tap curvature, per-sector sort, greedy sharp / flat pick, per-ring VoxelGrid(0.2).
+// compaction, 11-tap curvature, greedy sharp / flat pick per sector (== walking the sorted sector), per-ring VoxelGrid(0.2).
 // Restates ScanRegistration::input, /root/reference/src/lidar_odometry_mapping/src/scan_registration.cpp:131-449
 // (cited per step as "SR:<line>").  Integer / index results are bit-identical to the CPU oracle; f32
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
@@ -8,8 +8,8 @@
 //   k_sr_first_last  n/1024 WGs  first / last surviving point (last-ticket fold) -> startOri / endOri  SR:157-176
 //   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
 //   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
-//   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, 6 sector sorts (one wavefront each,
-//                                bitonic in LDS), greedy picks, lessFlat + VoxelGrid(0.2)        SR:288-439
+//   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, sort-free picks (wavefront arg-max rounds, six sectors
+//                                at once + boundary fixed point), lessFlat + VoxelGrid(0.2) over voxel runs  SR:288-439
 //   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
 #include <hip/hip_runtime.h>
 #include <limits.h>
