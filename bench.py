@@ -115,13 +115,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()  # identity on a full node; lets the gloo path share one GPU in tests
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("VLOAM_BENCH_BACKEND", "nccl")  # "nccl" == RCCL; "gloo" only to exercise this path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
+    coll_dev = "cuda" if os.environ.get("VLOAM_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     # ---- synthetic input, one independent sequence per rank, resident in HBM before the timed region
     seq = synth.SynthSequence(n_rings=args.rings, n_azimuth=args.azimuth, n_sweeps=W + K, **multi.rank_sequence_seeds(rank))
     host = np.stack([seq.sweep(k) for k in range(W + K)])
@@ -154,7 +160,7 @@ def main():
 
     elapsed = t1 - t0
     if dist is not None:
-        elapsed = multi.max_over_ranks(dist, elapsed, device="cuda")
+        elapsed = multi.max_over_ranks(dist, elapsed, device=coll_dev)
     k_ms, k_launches = h.profile_read()
     counts = h.counts()
     traj = h.trajectory()
@@ -162,7 +168,7 @@ def main():
     # the one collective of the path: gather the per-sequence trajectories
     trajectories = [traj]
     if dist is not None:
-        trajectories = multi.gather_trajectories(dist, traj, W + K + 8, device="cuda")
+        trajectories = multi.gather_trajectories(dist, traj, W + K + 8, device=coll_dev)
 
     # ---- extra leg (reported separately, never the headline): multi-session throughput of one GPU.  A single sequence is a
     # chain of dependent launches (latency bound); independent sessions on separate streams overlap those latencies.
