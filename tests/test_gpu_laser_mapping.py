@@ -144,3 +144,33 @@ def test_pipelined_burst_matches_oracle(vl, orc, sweeps, skip):
         assert pts.shape == ref.shape
         a, b = lexsort_rows(pts), lexsort_rows(ref)
         assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+
+
+def test_long_run_with_grid_roll(vl, orc, synth):
+    """175 sweeps at 3 m per sweep: ~460 m of travel, far enough for the 21 x 21 x 11 cube window to roll (laser_mapping.cpp:
+    218-402) and for the voxels of the cubes that left it to be dropped.  Also the regime where equal kNN distances occur in
+    the map (canonical tie rule: lowest index of the gathered map cloud).  Poses of every sweep and the final map vs the oracle."""
+    n = 175
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n, speed=30.0)
+    clouds = [seq.sweep(k) for k in range(n)]
+    h = vl.Handle(0, with_mapping=1)
+    for c in clouds:
+        h.process_scan(c)
+    h.sync()
+    tj = h.trajectory()
+    o = orc.Oracle(with_mapping=True)
+    for k, c in enumerate(clouds):
+        o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert qdist(tj[k, 0:4], qw) < 1e-7 and np.linalg.norm(tj[k, 4:7] - tw) < 1e-7, k
+        assert qdist(tj[k, 7:11], qm) < 1e-7 and np.linalg.norm(tj[k, 11:14] - tm) < 1e-7, k
+    st = h.map_state()
+    assert np.array_equal(st["cen"], o.map_info()["cen"]) and not np.array_equal(st["cen"], [10, 10, 5]), "the window must have rolled"
+    assert st["deferred"] == 0
+    for kind in (0, 1):
+        cnt, pts = h.map_dump(kind)
+        ref = oracle_map_points(o, kind)
+        assert pts.shape == ref.shape
+        a, b = lexsort_rows(pts), lexsort_rows(ref)
+        assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind

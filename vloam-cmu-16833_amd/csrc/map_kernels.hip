@@ -3,7 +3,6 @@
 // ("LM:<line>").  One sweep = 13 launches + 2 x (compaction + Levenberg–Marquardt), no host synchronisation; the four
 // k_map_ds_* launches only need the sweep's feature clouds and are enqueued on the scan-registration stream:
 //   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448)
-//   k_map_purge     grid      only does work after a roll: drops voxels whose cube left the 21x21x11 window
 //   k_map_ds_count  grid      pcl::VoxelGrid of the scan features (LM:432-440), pass 1: hash sweep points to voxels, count
 //   k_map_ds_rank   grid      pass 2: output rank + segment start of every occupied voxel by whole-chip counting
 //   k_map_ds_scatter grid     pass 3: group point indices by voxel
@@ -11,9 +10,10 @@
 //   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN through the block-occupancy index of the voxel hash  x2
 //   k_map_fit       1 thread/pt 3x3 eigen / 5x3 least squares, emission of LidarEdgeFactor / LidarPlaneNormFactor (LM:472-581) x2
 //   (k_lm_solve)                                                                                                x2
-//   k_map_update    1 WG      transformUpdate (LM:140-144,636) + trajectory row
-//   k_map_insert    grid      scan voxels -> map frame -> cube -> hash find-or-insert, queue on the voxel (LM:639-683)
-//   k_map_finalize  grid      per touched voxel: stack-ordered f32 accumulation == per-cube VoxelGrid re-filter (LM:689-702)
+//   k_map_insert    grid      transformUpdate (LM:140-144,636) + trajectory row; scan voxels -> map frame -> cube -> hash
+//                             find-or-insert, queue on the voxel (LM:639-683)
+//   k_map_finalize  grid      per touched voxel: stack-ordered f32 accumulation == per-cube VoxelGrid re-filter (LM:689-702);
+//                             after a grid roll also drops the voxels whose cube left the 21x21x11 window
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <limits.h>
@@ -159,12 +159,13 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
   }
 }
 
-// Drop voxels whose cube left the window (the reference clears the slab that wraps, LM:240-241 etc.).
-__global__ __launch_bounds__(256) void k_map_purge(VoxelTable T0, VoxelTable T1, const MapState* ms, const MapFrame* fr) {
-  if (!fr->rolled) return;
-  const VoxelTable T = blockIdx.y ? T1 : T0;
+// Drop voxels whose cube left the window (the reference clears the slab that wraps, LM:240-241 etc.).  Only after a roll.
+// The window is +-500 m around the sensor while queries and inserts stay within the +-125 m valid block, so nothing of the
+// sweep that rolled can touch such a voxel: the sweep's last launch (k_map_finalize) does the purge on its way out, instead
+// of a launch of its own in front of the association.
+__device__ void map_purge(const VoxelTable& T, const MapState* ms, int first, int stride) {
   const int cW = ms->cenW, cH = ms->cenH, cD = ms->cenD;
-  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
+  for (unsigned s = (unsigned)first; s <= T.mask; s += (unsigned)stride) {
     const u64 k = T.keys[s];
     if (k == 0 || T.count[s] == 0) continue;
     int Ai, Aj, Ak;
@@ -479,8 +480,11 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       np_[a] = __builtin_amdgcn_readfirstlane(n);
     }
     __shared__ u64 s_cand[4][256];
+    __shared__ int s_slot[4][256];
     __shared__ u64 s_best[4][8];
+    __shared__ int s_best_slot[4][8];
     u64* my_cand = s_cand[threadIdx.x >> 6];
+    int* my_slot = s_slot[threadIdx.x >> 6];
     const int nblocks = np_[0] * np_[1] * np_[2];
     int produced = 0;   // wave-uniform running size of the work list
     for (int bb0 = 0; bb0 < nblocks; bb0 += 64) {
@@ -525,7 +529,10 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     }
     lds_sync_wave();
     const int ncand = min(produced, 256);
-    // phase 3: one voxel per lane and trip: probe, fetch the centroid, squared distance -> key (f32 d2 bits | slot) back into the list
+    // phase 3: one voxel per lane and trip: probe, fetch the centroid, squared distance -> key back into the list.  Key =
+    // (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the valid cubes
+    // in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so equal
+    // distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
     for (int w = lane; w < ncand; w += 64) {
       const u64 key = my_cand[w];
       unsigned s = (unsigned)mix64(key) & T.mask;
@@ -539,7 +546,12 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
           if (n > 0) {
             if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
             const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
-            out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | s;
+            int Ai, Aj, Ak;
+            unpack_cube(key, &Ai, &Aj, &Ak);
+            const unsigned tie = ((unsigned)(Ai - ctr[0] + 2) << 29) | ((unsigned)(Aj - ctr[1] + 2) << 26) | ((unsigned)(Ak - ctr[2] + 1) << 24) |
+                                 ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
+            out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+            my_slot[w] = (int)s;
           }
           break;
         }
@@ -548,31 +560,31 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       my_cand[w] = out;
     }
     u64* my_best = s_best[threadIdx.x >> 6];
-    if (lane < 8) my_best[lane] = ~0ull;
+    int* my_best_slot = s_best_slot[threadIdx.x >> 6];
+    if (lane < 8) { my_best[lane] = ~0ull; my_best_slot[lane] = -1; }
     lds_sync_wave();
-    // phase 4: the five smallest keys by rank counting (keys are unique: distinct slots); ~30 candidates on average
+    // phase 4: the five smallest keys by rank counting (keys are unique: distinct voxels); ~30 candidates on average
     for (int w = lane; w < ncand; w += 64) {
       const u64 mine = my_cand[w];
       if (mine == ~0ull) continue;
       int rank = 0;
       for (int t = 0; t < ncand; t++) rank += my_cand[t] < mine;
-      if (rank < 5) my_best[rank] = mine;
+      if (rank < 5) { my_best[rank] = mine; my_best_slot[rank] = my_slot[w]; }
     }
     lds_sync_wave();
     float nd[5];
-    unsigned ns[5];
+    int ns[5];
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-      const u64 m = my_best[r];
-      nd[r] = __uint_as_float((unsigned)(m >> 32));
-      ns[r] = (unsigned)(m & 0xffffffffu);
+      nd[r] = __uint_as_float((unsigned)(my_best[r] >> 32));
+      ns[r] = my_best_slot[r];
     }
     // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in
     // registers and pure per-query math, so they should not hold 64 lanes and ~130 VGPRs hostage here)
     if (lane == 0) {
-      const bool ok = ns[4] != 0xffffffffu && nd[4] < 1.0f;  // LM:479 / LM:547
+      const bool ok = ns[4] >= 0 && nd[4] < 1.0f;  // LM:479 / LM:547
 #pragma unroll
-      for (int j = 0; j < 5; j++) nn[slot * 5 + j] = ok ? (int)ns[j] : -1;
+      for (int j = 0; j < 5; j++) nn[slot * 5 + j] = ok ? ns[j] : -1;
     }
   } else if (lane == 0) {
     nn[slot * 5] = -1;
@@ -650,8 +662,9 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
 }
 
 // ---------------------------------------------------------------------------------------------- update / insert / finalize
-__global__ void k_map_update(MapState* ms, double* traj_row14) {
-  if (threadIdx.x != 0) return;
+// transformUpdate + the map half of the trajectory row; done by one lane of k_map_insert (nothing else in that launch reads
+// q_wmap_wodom / t_wmap_wodom)
+__device__ void map_update(MapState* ms, double* traj_row14) {
   // transformUpdate LM:140-144: q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
   const double* q = ms->q_wodom_curr;
   const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
@@ -668,7 +681,9 @@ __global__ void k_map_update(MapState* ms, double* traj_row14) {
 __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ stack0, const float4* __restrict__ stack1,
                                                     float4* __restrict__ smap0, float4* __restrict__ smap1, VoxelTable T0, VoxelTable T1,
                                                     float inv0, float inv1, MapState* ms, MapFrame* fr, int* __restrict__ touched0,
-                                                    int* __restrict__ touched1, int* __restrict__ deferred0, int* __restrict__ deferred1) {
+                                                    int* __restrict__ touched1, int* __restrict__ deferred0, int* __restrict__ deferred1,
+                                                    double* traj_row14) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) map_update(ms, traj_row14);  // LM:636
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
   const float inv = kind ? inv1 : inv0;
@@ -780,6 +795,7 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
       }
     }
   }
+  if (fr->rolled) map_purge(T, ms, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 __global__ void k_map_register(const float4* __restrict__ cloud, const FrameScalars* __restrict__ S, const MapState* __restrict__ ms,
@@ -874,7 +890,6 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
                m->stack_info[set]);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_map_purge, dim3(256, 2), dim3(256), 0, st, m->tab[0], m->tab[1], ms, fr);
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
                  m->inv_leaf[0], m->inv_leaf[1], ms, m->nn);
@@ -882,9 +897,8 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
                        m->F[outer], outer);
     lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
-  hipLaunchKernelGGL(k_map_update, dim3(1), dim3(64), 0, st, ms, traj_row14);
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
-               m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1]);
+               m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14);
   VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
                m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
