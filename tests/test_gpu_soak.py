@@ -1,0 +1,41 @@
+"""-m gpu: whole-pipeline soak — several sensor models, resolutions, speeds, skip factors and scenes, all sweeps enqueued back to
+back (three-stream pipeline), every pose and the final map against the oracle.  These cases found: scan lines whose stored id is
+only almost sorted, equal kNN distances in the map, tiny rings whose sectors are shorter than the 5-point suppression reach."""
+import numpy as np
+import pytest
+
+from test_gpu_laser_mapping import lexsort_rows, oracle_map_points, qdist
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(rings=16, az=1024, n=30, speed=10.0, skip=1, seeds={}),
+    dict(rings=32, az=1024, n=30, speed=10.0, skip=1, seeds={}),
+    dict(rings=64, az=1024, n=40, speed=15.0, skip=1, seeds=dict(seed_scene=77, seed_traj=5, seed_noise=9)),
+    dict(rings=64, az=512, n=60, speed=20.0, skip=3, seeds=dict(seed_scene=4321, seed_traj=11, seed_noise=3)),
+    dict(rings=64, az=2048, n=16, speed=8.0, skip=2, seeds=dict(seed_scene=999, seed_traj=123, seed_noise=77)),
+    dict(rings=64, az=700, n=50, speed=25.0, skip=1, seeds=dict(seed_scene=31337, seed_traj=7, seed_noise=1)),
+]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: "%dx%d_n%d_v%g_skip%d" % (c["rings"], c["az"], c["n"], c["speed"], c["skip"]))
+def test_pipeline_soak(vl, orc, synth, c):
+    seq = synth.SynthSequence(n_rings=c["rings"], n_azimuth=c["az"], n_sweeps=c["n"], speed=c["speed"], **c["seeds"])
+    clouds = [seq.sweep(k) for k in range(c["n"])]
+    h = vl.Handle(0, scan_line=c["rings"], with_mapping=1, mapping_skip_frame=c["skip"])
+    for cl in clouds:
+        h.process_scan(cl)
+    h.sync()
+    tj = h.trajectory()
+    o = orc.Oracle(scan_line=c["rings"], with_mapping=True, mapping_skip_frame=c["skip"])
+    for k, cl in enumerate(clouds):
+        assert o.process(cl) == 0
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert qdist(tj[k, 0:4], qw) < 1e-7 and np.linalg.norm(tj[k, 4:7] - tw) < 1e-7, "LO pose, sweep %d" % k
+        assert qdist(tj[k, 7:11], qm) < 1e-7 and np.linalg.norm(tj[k, 11:14] - tm) < 1e-7, "map pose, sweep %d" % k
+    for kind in (0, 1):
+        cnt, pts = h.map_dump(kind)
+        ref = oracle_map_points(o, kind)
+        assert pts.shape == ref.shape
+        assert np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32)), "map kind %d" % kind

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   };
   if (wave < kSectors) run_sector(wave, -1, false);
   __syncthreads();
-  // fixed point over the boundaries: a sector is redone when the spill it was computed with differs from its predecessor's
+  // fixed point over the boundaries: a sector is redone when the spill it was computed with differs from its predecessors'
   // current spill in a way that can matter.  Sector 0 never changes, so after round k sectors 0..k are final.
   for (int round = 0; round < kSectors - 1; round++) {
     if (tid == 0) *s_any = 0;
@@ -547,7 +547,8 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     int in_hi = -1;
     if (wave >= 1 && wave < kSectors) {
       const int sp_l = s_sp[wave] - off, ep_l = s_ep[wave] - off;
-      in_hi = min(s_leak_hi[wave - 1], ep_l);
+      for (int q = 0; q < wave; q++) in_hi = max(in_hi, s_leak_hi[q]);  // a spill reaches 5 points: several sectors when they are tiny
+      in_hi = min(in_hi, ep_l);
       if (in_hi < sp_l) in_hi = -1;
       const int used = s_zone[wave];
       if (in_hi > used) {        // the spill grew: matters only if a newly covered point (at most 5) had been selected
