@@ -175,6 +175,26 @@ __device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&
   accumulate_row(acc, J, r0 * sc);
 }
 
+// Line through a, b -> what eval_edge consumes: an orthonormal pair (e1, e2) with e1 x e2 = v = (b - a) / |a - b|
+// (lidarFactor.hpp:37-42 divides by de.norm()), e1 = normalize(v x axis of the smallest |v| component), e2 = v x e1, and the
+// offsets d_i = -(e_i . a).  out = e1, e2, d1, d2.
+__device__ __forceinline__ void edge_frame(double ax, double ay, double az, double bx, double by, double bz, double (&out)[8]) {
+  const double dx = bx - ax, dy = by - ay, dz = bz - az;
+  const double dn = sqrt(dx * dx + dy * dy + dz * dz);
+  const double vx = dx / dn, vy = dy / dn, vz = dz / dn;
+  const double fx = fabs(vx), fy = fabs(vy), fz = fabs(vz);
+  double e1x, e1y, e1z;
+  if (fx <= fy && fx <= fz) { e1x = 0.0; e1y = vz; e1z = -vy; }        // v x (1, 0, 0)
+  else if (fy <= fz) { e1x = -vz; e1y = 0.0; e1z = vx; }              // v x (0, 1, 0)
+  else { e1x = vy; e1y = -vx; e1z = 0.0; }                             // v x (0, 0, 1)
+  const double en = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+  e1x /= en; e1y /= en; e1z /= en;
+  const double e2x = vy * e1z - vz * e1y, e2y = vz * e1x - vx * e1z, e2z = vx * e1y - vy * e1x;
+  out[0] = e1x; out[1] = e1y; out[2] = e1z; out[3] = e2x; out[4] = e2y; out[5] = e2z;
+  out[6] = -(e1x * ax + e1y * ay + e1z * az);
+  out[7] = -(e2x * ax + e2y * ay + e2z * az);
+}
+
 // ---- packets: NW factors evaluated side by side.  With one wavefront per SIMD nothing hides the ~8-cycle dependent f64
 // latency except independent instructions next to each other, and the compiler keeps source order inside a basic block: every
 // step below is written for all NW factors at once, so the per-factor dependency chains (rotate, residual, Huber weight,
@@ -312,10 +332,14 @@ struct LmCache {
   double de[kCacheE][8];  // e1, e2, d1, d2
   float pp[kCacheP][3];
   double dp[kCacheP][4];  // n, d
+  unsigned live_e, live_p;  // direct mode: which of this lane's slots hold a factor
 };
 
 // Evaluate the compacted factors at x: cost, g = J^T r, H = J^T J (upper triangle) -> s_out[kAcc] (LDS).
-template <bool QUAT>
+// DIRECT (scan-to-scan odometry, table of exactly 256 x (kCacheE + kCacheP) slots): lane t owns the table slots t + 256 m
+// themselves — corner slots feed its edge cache, plane slots its plane cache — and builds the solver's form of each factor on
+// the fly, so no compaction pass runs at all; empty slots hold zeros and whole-wavefront-empty packets are skipped.
+template <bool QUAT, bool DIRECT>
 __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
                                             double* s_out, bool first, LmCache& C, long long* cyc_factors) {
   const int tid = threadIdx.x;
@@ -342,7 +366,34 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     const D3 tt = d3(xl[4], xl[5], xl[6]);
     const int n_plane = n_valid - n_edge;
     const double* cp = F.cpack;
-    if (first) {
+    if (first && DIRECT) {
+      C.live_e = 0u; C.live_p = 0u;
+#pragma unroll
+      for (int m = 0; m < kCacheE; m++) {
+        const int slot = tid + m * kLmThreads;
+        const bool live = F.type[slot] == 1;
+        double a[3], b[3], fr[8];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { C.pe[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; a[q] = live ? F.A[q * cap + slot] : 0.0; b[q] = live ? F.B[q * cap + slot] : 1.0; }
+        edge_frame(a[0], a[1], a[2], b[0], b[1], b[2], fr);
+#pragma unroll
+        for (int q = 0; q < 8; q++) C.de[m][q] = live ? fr[q] : 0.0;
+        if (live) C.live_e |= 1u << m;
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheP; m++) {
+        const int slot = (kCacheE + m) * kLmThreads + tid;
+        const bool live = F.type[slot] == 2;  // LidarPlaneFactor: (lp - j) . n  ->  n . lp + d, d = -(n . j)
+        double j[3], nn[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { C.pp[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; j[q] = live ? F.A[q * cap + slot] : 0.0; nn[q] = live ? F.B[q * cap + slot] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 3; q++) C.dp[m][q] = nn[q];
+        C.dp[m][3] = -(nn[0] * j[0] + nn[1] * j[1] + nn[2] * j[2]);
+        if (live) C.live_p |= 1u << m;
+      }
+    }
+    if (first && !DIRECT) {
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
         const int k = tid + m * kLmThreads;
@@ -363,7 +414,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       }
     }
     auto put_resid = [&](int k, const double* r3) {
-      const int slot = F.cslot[k];
+      const int slot = DIRECT ? k : F.cslot[k];
       F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
     };
     // ---- edge factors (compact order == slot order: they come first).  Cached slots in packets of kPkE, streamed ones too.
@@ -376,7 +427,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int u = 0; u < kPkE; u++) {
           const int k = k0 + u * kstride;
-          if (k < n_edge) {  // r = c1 e2 - c2 e1
+          if (DIRECT ? ((C.live_e >> u) & 1u) != 0u : k < n_edge) {  // r = c1 e2 - c2 e1
             const double r3[3] = {c1[u] * e2[u][0] - c2[u] * e1[u][0], c1[u] * e2[u][1] - c2[u] * e1[u][1], c1[u] * e2[u][2] - c2[u] * e1[u][2]};
             put_resid(k, r3);
           }
@@ -384,7 +435,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     };
 #pragma unroll
     for (int g = 0; g < kCacheE; g += kPkE)
-      if (g * kLmThreads < n_edge) {
+      if (DIRECT ? __ballot(C.live_e != 0u) != 0ull : g * kLmThreads < n_edge) {
         double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
         for (int u = 0; u < kPkE; u++) {
@@ -396,7 +447,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         }
         edge_packet(p, e1, e2, d1, d2, tid + g * kLmThreads, kLmThreads);
       }
-    for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * kLmThreads; base < n_edge; base += kPkE * kLmThreads) {  // beyond the cache: streamed
+    for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * kLmThreads; !DIRECT && base < n_edge; base += kPkE * kLmThreads) {  // beyond the cache: streamed
       double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
       for (int u = 0; u < kPkE; u++) {
@@ -416,12 +467,13 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int u = 0; u < kPkP; u++) {
           const int q = q0 + u * qstride;
-          if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3); }
+          if (DIRECT) { if ((C.live_p >> (q0 / kLmThreads + u)) & 1u) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(kCacheE * kLmThreads + q, r3); } }
+          else if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3); }
         }
     };
 #pragma unroll
     for (int g = 0; g < kCacheP; g += kPkP)
-      if (g * kLmThreads < n_plane) {
+      if (DIRECT ? __ballot(((C.live_p >> g) & ((1u << kPkP) - 1u)) != 0u) != 0ull : g * kLmThreads < n_plane) {
         double p[kPkP][3], n[kPkP][3], d[kPkP];
 #pragma unroll
         for (int u = 0; u < kPkP; u++) {
@@ -433,7 +485,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         }
         plane_packet(p, n, d, tid + g * kLmThreads, kLmThreads);
       }
-    for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * kLmThreads; base < n_plane; base += kPkP * kLmThreads) {
+    for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * kLmThreads; !DIRECT && base < n_plane; base += kPkP * kLmThreads) {
       double p[kPkP][3], n[kPkP][3], d[kPkP];
 #pragma unroll
       for (int u = 0; u < kPkP; u++) {
@@ -584,7 +636,7 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
   }
 }
 
-template <bool QUAT>
+template <bool QUAT, bool DIRECT>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj) {
   __shared__ LmShared sh;
@@ -620,7 +672,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 
   LmCache cache;
   t_mark = clock64();
-  lm_evaluate<QUAT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac);
+  lm_evaluate<QUAT, DIRECT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac);
   cyc_eval += clock64() - t_mark;
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
@@ -743,7 +795,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
-    lm_evaluate<QUAT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac);
+    lm_evaluate<QUAT, DIRECT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac);
     cyc_eval += clock64() - t_mark;
     t_mark = clock64();
     // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
@@ -835,23 +887,10 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
     const int o = off + __popcll(m & ((1ull << lane) - 1ull));
     F.ctype[o] = ty; F.cslot[o] = k;
     if (quat && ty == 1) {
-      // line direction v = (b - a) / |a - b| (lidarFactor.hpp:37-42 divides by de.norm()), then an orthonormal pair with
-      // e1 x e2 = v: e1 = normalize(v x axis of the smallest |v| component), e2 = v x e1; d_i = -(e_i . a)
-      const double ax = v[3], ay = v[4], az = v[5];
-      const double dx = v[6] - ax, dy = v[7] - ay, dz = v[8] - az;
-      const double dn = sqrt(dx * dx + dy * dy + dz * dz);
-      const double vx = dx / dn, vy = dy / dn, vz = dz / dn;
-      const double fx = fabs(vx), fy = fabs(vy), fz = fabs(vz);
-      double e1x, e1y, e1z;
-      if (fx <= fy && fx <= fz) { e1x = 0.0; e1y = vz; e1z = -vy; }        // v x (1, 0, 0)
-      else if (fy <= fz) { e1x = -vz; e1y = 0.0; e1z = vx; }              // v x (0, 1, 0)
-      else { e1x = vy; e1y = -vx; e1z = 0.0; }                             // v x (0, 0, 1)
-      const double en = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
-      e1x /= en; e1y /= en; e1z /= en;
-      const double e2x = vy * e1z - vz * e1y, e2y = vz * e1x - vx * e1z, e2z = vx * e1y - vy * e1x;
-      v[3] = e1x; v[4] = e1y; v[5] = e1z; v[6] = e2x; v[7] = e2y; v[8] = e2z;
-      v[9] = -(e1x * ax + e1y * ay + e1z * az);
-      v[10] = -(e2x * ax + e2y * ay + e2z * az);
+      double fr[8];
+      edge_frame(v[3], v[4], v[5], v[6], v[7], v[8], fr);
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[3 + q] = fr[q];
     } else if (quat && ty == 2) {  // LidarPlaneFactor (lp - j) . n  ->  n . lp + d with d = -(n . j); A := n, B.x := d
       const double d = -(v[6] * v[3] + v[7] * v[4] + v[8] * v[5]);
       v[3] = v[6]; v[4] = v[7]; v[5] = v[8]; v[6] = d;
@@ -864,11 +903,17 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
 void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj) {
   const int edge_rows = n_edge_slots >> 6;
-  hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
-  if (quat)
-    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<true>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj);
+  const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
+  if (!direct) hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
+  if (direct)
+    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<true, true>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
+                 fin_lo, fin_traj);
+  else if (quat)
+    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<true, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj);
   else
-    VLOAM_LAUNCH(ph, kKLmSolve, st, k_lm_solve<false>, dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj);
+    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<false, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj);
 }
 
 }  // namespace vloam
