@@ -267,16 +267,21 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (h->frame >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
   const int k = h->frame, cur = set_of(k);
-  // set `cur` still holds sweep k - 3: read by odometry of sweeps k - 3 (current) and k - 2 (previous), mapping of sweep k - 3
-  if (k >= 2) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_lo[set_of(k - 2)], 0));
-  if (k >= 3 && h->cfg.with_mapping) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map[set_of(k - 3)], 0));
+  // Set `cur` still holds sweep k - 3: read by odometry of sweeps k - 3 (current) and k - 2 (previous), mapping of sweep k - 3.
+  // The HOST waits for those before enqueueing (it may run at most two sweeps ahead of the odometry, three ahead of the
+  // mapping): a cross-stream barrier packet in front of every sweep costs ~12 us on the stream that bounds the throughput,
+  // a host-side check of an event that has almost always fired costs nothing on the device.
+  if (k >= 2) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - 2)]));
+  if (k >= 3 && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - 3)]));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof));
+  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep): signal now
+  HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
+  // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
   lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
   // the mapping stage's VoxelGrid of the scan features only needs this sweep's clouds: run it here, off the mapping stream
   if (h->cfg.with_mapping && ((k + 1) % h->cfg.mapping_skip_frame) == 0) {
     if (map_stack_enqueue(&h->map, h->stream, h->sr[cur], cur, &h->prof) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }

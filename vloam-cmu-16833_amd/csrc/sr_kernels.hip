@@ -5,7 +5,7 @@
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
 //
 // Kernels (one sweep = 5 launches, no host synchronisation):
-//   k_sr_first_last  n/1024 WGs  first / last surviving point (last-ticket fold) -> startOri / endOri  SR:157-176
+//   k_sr_first_last  n/256 WGs   first / last surviving point per slice (folded by every k_sr_label workgroup)  SR:157-176
 //   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
 //   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, sort-free picks (wavefront arg-max rounds, six sectors
@@ -86,16 +86,18 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Every workgroup reports the first / last surviving point of its 1024-point slice; the workgroup that draws the last ticket
-// folds the slices (a sweep has ~128 of them) and derives startOri / endOri.  One pass over the input at full width instead
-// of a latency-bound walk from both ends.
-__global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, FrameScalars* S,
-                                                        int2* __restrict__ slice /* [gridDim.x] */) {
-  __shared__ int s_first, s_last, s_ticket;
+// First / last surviving point (SR:157-176) in two steps without a single-workgroup stage on the critical path: every 256-lane
+// workgroup of k_sr_first_last reports the first / last surviving point of its slice (one pass over the input at full width);
+// every workgroup of k_sr_label folds the ~512 slice records itself (4 KB from L2) and derives startOri / endOri locally.
+// 256-lane workgroups: small enough to slip onto CUs whose register file is mostly taken by the previous sweep's odometry
+// kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
+constexpr int kFLThreads = 256;
+__global__ __launch_bounds__(kFLThreads) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, int2* __restrict__ slice) {
+  __shared__ int s_first, s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
-  const int i = blockIdx.x * 1024 + tid;
+  const int i = blockIdx.x * kFLThreads + tid;
   bool v = false;
   if (i < n) { const float4 p = in[i]; v = sr_survives_s1(p.x, p.y, p.z, thres); }
   const unsigned long long m = __ballot(v);
@@ -104,58 +106,50 @@ __global__ __launch_bounds__(1024) void k_sr_first_last(const float4* __restrict
     if (lane == 63 - __clzll((long long)m)) atomicMax(&s_last, i);
   }
   __syncthreads();
-  if (tid == 0) {
-    slice[blockIdx.x] = make_int2(s_first, s_last);
-    __threadfence();
-    s_ticket = atomicAdd(&S->fl_ticket, 1);
-  }
-  __syncthreads();
-  if (s_ticket != (int)gridDim.x - 1) return;
-  __threadfence();
-  // last workgroup: fold the slices
-  int f = INT_MAX, l = -1;
-  for (int b = tid; b < (int)gridDim.x; b += 1024) {
-    const int2 fl = slice[b];
-    f = min(f, fl.x); l = max(l, fl.y);
-  }
-  if (tid == 0) { s_first = INT_MAX; s_last = -1; }
-  __syncthreads();
-  for (int d = 32; d > 0; d >>= 1) { f = min(f, __shfl_xor(f, d)); l = max(l, __shfl_xor(l, d)); }
-  if (lane == 0) { atomicMin(&s_first, f); atomicMax(&s_last, l); }
-  __syncthreads();
-  if (tid == 0) {
-    S->fl_ticket = 0;
-    S->first_valid = s_first == INT_MAX ? -1 : s_first;
-    S->last_valid = s_last;
-    S->istar = INT_MAX;
-    S->n_after_s1 = 0;
-    S->error = 0;
-    if (s_last < 0) {
-      S->error = kErrEmpty;
-      S->startOri = 0.f; S->endOri = 0.f;
-    } else {
-      const float4 pf = in[s_first], pl = in[s_last];
-      float startOri = -atan2f(pf.y, pf.x);                                          // SR:166
-      float endOri = (float)((double)(-atan2f(pl.y, pl.x)) + 2 * M_PI);              // SR:167
-      if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
-      else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
-      S->startOri = startOri; S->endOri = endOri;
-    }
-  }
+  if (tid == 0) slice[blockIdx.x] = make_int2(s_first, s_last);
 }
 
 // ------------------------------------------------------------------------------------------------
+// blk: per-workgroup results for k_sr_scatter — [0, nblk): candidate pivot (SR:246-249) or INT_MAX, [nblk, 2 nblk): points
+// surviving S1.  Plain stores, no counters to re-arm between sweeps.
 __global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restrict__ in, int n, float thres, int N_SCANS,
                                                           FrameScalars* S, signed char* __restrict__ sid,
-                                                          float* __restrict__ ori_raw, int* __restrict__ blockhist) {
+                                                          float* __restrict__ ori_raw, int* __restrict__ blockhist,
+                                                          const int2* __restrict__ slice, int nslice, int* __restrict__ blk) {
   __shared__ int hist[kMaxRings];
-  __shared__ int s_istar, s_cnt;
-  const int tid = threadIdx.x;
+  __shared__ int s_istar, s_cnt, s_first, s_last;
+  __shared__ float s_start;
+  const int tid = threadIdx.x, lane = tid & 63;
   if (tid < kMaxRings) hist[tid] = 0;
-  if (tid == 0) { s_istar = INT_MAX; s_cnt = 0; }
+  if (tid == 0) { s_istar = INT_MAX; s_cnt = 0; s_first = INT_MAX; s_last = -1; }
+  __syncthreads();
+  {
+    int f = INT_MAX, l = -1;
+    for (int b = tid; b < nslice; b += kLabelBlock) { const int2 fl = slice[b]; f = min(f, fl.x); l = max(l, fl.y); }
+    for (int d = 32; d > 0; d >>= 1) { f = min(f, __shfl_xor(f, d)); l = max(l, __shfl_xor(l, d)); }
+    if (lane == 0) { atomicMin(&s_first, f); atomicMax(&s_last, l); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float startOri = 0.f, endOri = 0.f;
+    if (s_last >= 0) {
+      const float4 pf = in[s_first], pl = in[s_last];
+      startOri = -atan2f(pf.y, pf.x);                                                // SR:166
+      endOri = (float)((double)(-atan2f(pl.y, pl.x)) + 2 * M_PI);                    // SR:167
+      if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
+      else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
+    }
+    s_start = startOri;
+    if (blockIdx.x == 0) {  // the sweep's first writer of the scalars: also clears the error word
+      S->first_valid = s_first == INT_MAX ? -1 : s_first;
+      S->last_valid = s_last;
+      S->startOri = startOri; S->endOri = endOri;
+      S->error = s_last < 0 ? kErrEmpty : 0;
+    }
+  }
   __syncthreads();
   const int i = blockIdx.x * kLabelBlock + tid;
-  const float startOri = S->startOri;
+  const float startOri = s_start;
   int id = -1;
   bool v1 = false;
   if (i < n) {
@@ -177,10 +171,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restri
   if ((tid & 63) == 0 && mv) atomicAdd(&s_cnt, __popcll(mv));
   __syncthreads();
   if (tid < kMaxRings) blockhist[blockIdx.x * kMaxRings + tid] = hist[tid];
-  if (tid == 0) {
-    if (s_istar != INT_MAX) atomicMin(&S->istar, s_istar);
-    if (s_cnt) atomicAdd(&S->n_after_s1, s_cnt);
-  }
+  if (tid == 0) { blk[blockIdx.x] = s_istar; blk[gridDim.x + blockIdx.x] = s_cnt; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,12 +180,23 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restri
 // single-workgroup scan kernel on the critical path.
 __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __restrict__ in, int n, FrameScalars* S,
                                                             const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
-                                                            const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud) {
+                                                            const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud,
+                                                            const int* __restrict__ blk) {
   __shared__ int wcnt[kLabelBlock / 64][kMaxRings];
+  __shared__ int s_istar, s_nvalid;
   __shared__ int part_before[kLabelBlock / 64][kMaxRings], part_all[kLabelBlock / 64][kMaxRings];
   __shared__ int ring_base[kMaxRings];   // ring offset + points of this ring in earlier workgroups
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = tid; k < (kLabelBlock / 64) * kMaxRings; k += kLabelBlock) (&wcnt[0][0])[k] = 0;
+  if (tid == 0) { s_istar = INT_MAX; s_nvalid = 0; }
+  __syncthreads();
+  {
+    // the pivot of the sweep = the smallest candidate of any label workgroup; the S1 survivor count is a debug scalar
+    int mi = INT_MAX, cnt = 0;
+    for (int b = tid; b < nblk; b += kLabelBlock) { mi = min(mi, blk[b]); cnt += blk[nblk + b]; }
+    for (int d = 32; d > 0; d >>= 1) { mi = min(mi, __shfl_xor(mi, d)); cnt += __shfl_xor(cnt, d); }
+    if (lane == 0) { atomicMin(&s_istar, mi); atomicAdd(&s_nvalid, cnt); }
+  }
   {
     // wavefront w sums blocks w, w + 16, ... for ring = lane
     int before = 0, all = 0;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __rest
       S->ring_off[tid] = roff;
       S->scanStartInd[tid] = roff + 5;         // SR:278
       S->scanEndInd[tid] = roff + all - 6;     // SR:280
-      if (tid == kMaxRings - 1) { S->N2 = inc; S->ring_off[kMaxRings] = inc; }
+      if (tid == kMaxRings - 1) { S->N2 = inc; S->ring_off[kMaxRings] = inc; S->istar = s_istar; S->n_after_s1 = s_nvalid; }
     }
   }
   const int i = blockIdx.x * kLabelBlock + tid;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __rest
     for (int w = 0; w < wave; w++) base += wcnt[w][id];
     const float startOri = S->startOri, endOri = S->endOri;
     float ori = ori_raw[i];
-    if (i <= S->istar) ori = sr_ori_first_half(ori, startOri);
+    if (i <= s_istar) ori = sr_ori_first_half(ori, startOri);
     else ori = sr_ori_second_half(ori, endOri);
     float relTime = (ori - startOri) / (endOri - startOri);  // SR:264
     float4 p = in[i];
@@ -768,9 +770,13 @@ hipError_t sr_init() {
 
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph) {
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nblk), dim3(1024), 0, st, d_in, n, min_range, b.S, (int2*)b.blockhist);
-  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist);
-  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud);
+  const int nslice = (n + kFLThreads - 1) / kFLThreads;
+  int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
+  int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
+  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice), dim3(kFLThreads), 0, st, d_in, n, min_range, slice);
+  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
+               slice, nslice, blk);
+  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk);
   VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                      debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr);
