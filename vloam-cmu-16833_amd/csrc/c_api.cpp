@@ -50,7 +50,7 @@ struct vloam_handle {
   hipStream_t stream = nullptr;   // scan registration (+ NN grid build); also creation / VO work
   hipStream_t s_lo = nullptr;     // laser odometry
   hipStream_t s_map = nullptr;    // laser mapping
-  static constexpr int kSets = 3;
+  static constexpr int kSets = 4;   // 3 suffice for correctness; the 4th keeps the buffer-reuse wait off the critical cycle
   hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
   static_assert(kSets == MapContext::kSets, "the stack sets rotate with the SR buffer sets");
   std::vector<void*> allocs;
@@ -271,8 +271,9 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   // The HOST waits for those before enqueueing (it may run at most two sweeps ahead of the odometry, three ahead of the
   // mapping): a cross-stream barrier packet in front of every sweep costs ~12 us on the stream that bounds the throughput,
   // a host-side check of an event that has almost always fired costs nothing on the device.
-  if (k >= 2) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - 2)]));
-  if (k >= 3 && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - 3)]));
+  constexpr int kS = vloam_handle::kSets;  // set `cur` holds sweep k - kS: odometry of sweeps k - kS and k - kS + 1, mapping of k - kS
+  if (k >= kS - 1) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - (kS - 1))]));
+  if (k >= kS && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - kS)]));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof));
   // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep): signal now
