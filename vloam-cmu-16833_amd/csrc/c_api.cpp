@@ -219,8 +219,8 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&h->ev[k]));
       for (int k = 0; k < vloam_handle::kSets; k++) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_sr[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_lo[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_lo[k], hipEventDisableTiming | hipEventBlockingSync));   // the host throttle sleeps on these
+        HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming | hipEventBlockingSync));
         HIPCHK(hipEventCreateWithFlags(&h->ev_stack[k], hipEventDisableTiming));
       }
       HIPCHK(hipStreamSynchronize(h->stream));
