@@ -68,7 +68,6 @@ struct FrameScalars {
   int sect_cnt[kMaxRings][kSectors][3];  // sharp, lessSharp, flat picks per sector
   int ring_ds_cnt[kMaxRings];            // per-ring VoxelGrid(0.2) output size
   int n_sharp, n_less_sharp, n_flat, n_less_flat;
-  int fl_ticket;                         // k_sr_first_last arrival counter (returns to 0 every sweep)
 };
 
 // ---------------------------------------------------------------- Levenberg–Marquardt
