@@ -87,7 +87,7 @@ def sweep_bytes(c, with_mapping):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("VLOAM_BENCH_WORKLOAD", "lo"))
     ap.add_argument("--kernel", default=os.environ.get("VLOAM_BENCH_KERNEL", ""), help="kernel to bracket with HIP events (default: the dominant one)")
