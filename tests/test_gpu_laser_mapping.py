@@ -146,6 +146,47 @@ def test_pipelined_burst_matches_oracle(vl, orc, sweeps, skip):
         assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
 
 
+@pytest.mark.gpu
+def test_deferred_stages_interleaved_with_stagewise_calls(vl, orc, sweeps):
+    """vloam_process_scan leaves the odometry (one sweep) and the mapping (two sweeps) of what it accepted to later calls;
+    every reader and the stage-wise entry points must drain that backlog first.  Mix bursts, mid-run readbacks and
+    stage-wise sweeps on one handle and compare every pose with the sweep-by-sweep oracle."""
+    n = 16
+    clouds = [sweeps(64, 512, k) for k in range(n)]
+    h = vl.Handle(0, with_mapping=1)
+    o = orc.Oracle(with_mapping=True)
+    ref = []
+    for c in clouds:
+        o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        ref.append((qw, tw, qm, tm))
+    k = 0
+    for c in clouds[:5]:          # burst: backlog of LO(4), MAP(3), MAP(4) when it ends
+        h.process_scan(c); k += 1
+    tj = h.trajectory()           # reader drains
+    assert tj.shape[0] == 5
+    for c in clouds[5:8]:         # stage-wise sweeps right behind a burst
+        h.reset_frame()
+        h.scan_registration(c)
+        qw, tw, _, _ = h.laser_odometry()
+        qm, tm = h.laser_mapping()
+        assert qdist(qw, ref[k][0]) < 1e-7 and np.linalg.norm(np.asarray(tw) - ref[k][1]) < 1e-7, k
+        assert qdist(qm, ref[k][2]) < 1e-7 and np.linalg.norm(np.asarray(tm) - ref[k][3]) < 1e-7, k
+        k += 1
+    for c in clouds[8:11]:        # burst again, then a feature readback (drains) in the middle
+        h.process_scan(c); k += 1
+    assert h.features(2).shape[0] > 0
+    for c in clouds[11:]:
+        h.process_scan(c); k += 1
+    h.sync()
+    tj = h.trajectory()
+    assert tj.shape[0] == n
+    for i in range(n):
+        assert qdist(tj[i, 0:4], ref[i][0]) < 1e-7 and np.linalg.norm(tj[i, 4:7] - ref[i][1]) < 1e-7, i
+        assert qdist(tj[i, 7:11], ref[i][2]) < 1e-7 and np.linalg.norm(tj[i, 11:14] - ref[i][3]) < 1e-7, i
+
+
 def test_long_run_with_grid_roll(vl, orc, synth):
     """175 sweeps at 3 m per sweep: ~460 m of travel, far enough for the 21 x 21 x 11 cube window to roll (laser_mapping.cpp:
     218-402) and for the voxels of the cubes that left it to be dropped.  Also the regime where equal kNN distances occur in

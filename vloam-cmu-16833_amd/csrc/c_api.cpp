@@ -54,7 +54,9 @@ struct vloam_handle {
   hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
   static_assert(kSets == MapContext::kSets, "the stack sets rotate with the SR buffer sets");
   std::vector<void*> allocs;
-  int frame = 0;        // sweeps fully enqueued
+  int frame = 0;        // sweeps accepted (scan registration enqueued)
+  int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
+  int map_done = 0;     // sweeps whose laser mapping has been enqueued
   int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
   int nblk_max = 0;
   // scan registration
@@ -255,7 +257,9 @@ vloam_status vloam_reset_frame(vloam_handle* h) {
 
 // ------------------------------------------------------------------ stage enqueue helpers
 static inline int set_of(int frame) { return frame % vloam_handle::kSets; }
+static vloam_status drain_deferred(vloam_handle* h, int lag_lo, int lag_map);
 static vloam_status sync_all(vloam_handle* h) {
+  { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->s_lo));
   HIPCHK(hipStreamSynchronize(h->s_map));
@@ -275,9 +279,8 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   if (k >= kS - 1) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - (kS - 1))]));
   if (k >= kS && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - kS)]));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof));
-  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep): signal now
-  HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
+  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof,
+                   h->ev_sr[cur]));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
   lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
@@ -293,12 +296,11 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   return VLOAM_OK;
 }
 
-static vloam_status enqueue_lo(vloam_handle* h) {
-  if (h->stage != 1) { set_err("laser odometry called before scan registration"); return VLOAM_ERR_ORDER; }
-  const int cur = set_of(h->frame), prev = set_of(h->frame + vloam_handle::kSets - 1);
+static vloam_status enqueue_lo(vloam_handle* h, int frame) {
+  const int cur = set_of(frame), prev = set_of(frame + vloam_handle::kSets - 1);
   HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_sr[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->s_lo));
-  if (h->frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
+  if (frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
     for (int outer = 0; outer < 2; outer++) {  // laser_odometry.cpp:211
       if (!h->cfg.detach_VO_LO) lo_set_prior_launch(h->s_lo, h->lo);
       FactorTable F = h->lo_F;
@@ -307,30 +309,47 @@ static vloam_status enqueue_lo(vloam_handle* h) {
                       h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], h->lo_cyc[outer], &h->prof);
       // the second solve also integrates the pose and writes the trajectory row (laser_odometry.cpp:530-531)
       lm_launch(h->s_lo, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof, outer == 1 ? h->lo : nullptr,
-                outer == 1 ? h->traj + (size_t)h->frame * 14 : nullptr);
+                outer == 1 ? h->traj + (size_t)frame * 14 : nullptr, outer == 1 ? h->ev_lo[cur] : nullptr);
     }
   } else {
-    lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)h->frame * 14, false, &h->prof);
+    lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)frame * 14, false, &h->prof);
+    HIPCHK(hipEventRecord(h->ev_lo[cur], h->s_lo));
   }
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[3], h->s_lo));
-  HIPCHK(hipEventRecord(h->ev_lo[cur], h->s_lo));
-  h->stage = 2;
   return VLOAM_OK;
 }
 
-static vloam_status enqueue_map(vloam_handle* h) {
-  if (h->stage != 2) { set_err("laser mapping called before laser odometry"); return VLOAM_ERR_ORDER; }
-  const int cur = set_of(h->frame);
+static vloam_status enqueue_map(vloam_handle* h, int frame) {
+  const int cur = set_of(frame);
   HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_lo[cur], 0));
   HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_stack[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[4], h->s_map));
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
-  const bool skip = ((h->frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)h->frame * 14, skip, cur, &h->prof);
+  const bool skip = ((frame + 1) % h->cfg.mapping_skip_frame) != 0;
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)frame * 14, skip, cur, &h->prof);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[5], h->s_map));
   HIPCHK(hipEventRecord(h->ev_map[cur], h->s_map));
+  return VLOAM_OK;
+}
+
+// vloam_process_scan leaves the odometry of its sweep (and the mapping of the sweep before) to the NEXT call: by then the
+// producing stage has normally finished, hipStreamWaitEvent on a completed event inserts nothing, and the ~11 us cross-stream
+// barrier packet disappears from the stream that bounds the throughput.  Everything that reads results drains first (sync_all).
+static vloam_status drain_deferred(vloam_handle* h, int lag_lo, int lag_map) {
+  while (h->lo_done < h->frame - lag_lo) {
+    vloam_status s = enqueue_lo(h, h->lo_done);
+    if (s != VLOAM_OK) return s;
+    h->lo_done++;
+  }
+  if (!h->cfg.with_mapping) { h->map_done = h->lo_done; return VLOAM_OK; }
+  const int lim = h->frame - lag_map < h->lo_done ? h->frame - lag_map : h->lo_done;
+  while (h->map_done < lim) {
+    vloam_status s = enqueue_map(h, h->map_done);
+    if (s != VLOAM_OK) return s;
+    h->map_done++;
+  }
   return VLOAM_OK;
 }
 
@@ -346,6 +365,8 @@ static vloam_status finish_frame(vloam_handle* h) {
   }
   h->frame++;
   h->stage = 0;
+  if (h->lo_done < h->frame) h->lo_done = h->frame;    // stage-wise callers may leave stages out: nothing is owed for this sweep
+  if (h->map_done < h->frame) h->map_done = h->frame;
   return VLOAM_OK;
 }
 
@@ -354,6 +375,7 @@ vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_p
   if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s = finish_frame(h); if (s != VLOAM_OK) return s; }  // previous sweep ended after LO (no mapping call)
+  { vloam_status s = drain_deferred(h, 0, 0); if (s != VLOAM_OK) return s; }               // stages owed by earlier vloam_process_scan calls
   return enqueue_sr(h, (const float4*)d_xyz_pad4, n);
 }
 
@@ -403,6 +425,7 @@ vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int ca
 vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double t[3]) {
   if (!h || !q || !t) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }  // the prior belongs to the NEXT sweep's odometry
   double buf[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
   HIPCHK(hipMemcpyAsync(h->lo->prior_q, buf, sizeof(buf), hipMemcpyHostToDevice, h->s_lo));
   HIPCHK(hipStreamSynchronize(h->s_lo));
@@ -412,8 +435,11 @@ vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double
 vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]) {
   if (!h) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  vloam_status s = enqueue_lo(h);
+  if (h->stage != 1) { set_err("laser odometry called before scan registration"); return VLOAM_ERR_ORDER; }
+  vloam_status s = enqueue_lo(h, h->frame);
   if (s != VLOAM_OK) return s;
+  h->lo_done = h->frame + 1;
+  h->stage = 2;
   s = read_sr_error(h, set_of(h->frame));
   if (s != VLOAM_OK) return s;
   LOState lo;
@@ -429,8 +455,10 @@ vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3],
 vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[3]) {
   if (!h) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  vloam_status s = enqueue_map(h);
+  if (h->stage != 2) { set_err("laser mapping called before laser odometry"); return VLOAM_ERR_ORDER; }
+  vloam_status s = enqueue_map(h, h->frame);
   if (s != VLOAM_OK) return s;
+  h->map_done = h->frame + 1;
   s = sync_all(h);
   if (s != VLOAM_OK) return s;
   // what LaserMapping::publish reports (laser_mapping.cpp:718-757): q_w_curr / t_w_curr after a mapped sweep, the
@@ -443,16 +471,25 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
 }
 
 // ------------------------------------------------------------------ whole façade, asynchronous
+// sweeps by which the odometry / mapping enqueue trails the scan registration enqueue (see drain_deferred); the buffer-reuse
+// waits of enqueue_sr (odometry of sweep k - 3, mapping of sweep k - 4) stay behind what is enqueued here
+static constexpr int kLagLO = 1, kLagMap = 2;
+static_assert(kLagLO <= vloam_handle::kSets - 2 && kLagMap <= vloam_handle::kSets - 1, "deferred stages must be enqueued before enqueue_sr waits for them");
 vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
   if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
   vloam_status s = enqueue_sr(h, (const float4*)d_xyz_pad4, n);
   if (s != VLOAM_OK) return s;
-  s = enqueue_lo(h);
-  if (s != VLOAM_OK) return s;
-  if (h->cfg.with_mapping) { s = enqueue_map(h); if (s != VLOAM_OK) return s; }
-  return finish_frame(h);
+  if (h->cfg.timing) {  // per-stage times: nothing deferred, the sweep is drained in finish_frame
+    s = enqueue_lo(h, h->frame);
+    if (s != VLOAM_OK) return s;
+    if (h->cfg.with_mapping) { s = enqueue_map(h, h->frame); if (s != VLOAM_OK) return s; }
+    return finish_frame(h);
+  }
+  h->frame++;
+  h->stage = 0;
+  return drain_deferred(h, kLagLO, kLagMap);
 }
 
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {

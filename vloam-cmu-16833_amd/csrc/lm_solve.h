@@ -11,7 +11,9 @@ namespace vloam {
 // d_enable (optional): device int; 0 skips the solve entirely (mapping gate, laser_mapping.cpp:448).
 // n_edge_slots: slots [0, n_edge_slots) hold LidarEdgeFactors, the rest plane factors (multiple of 64; ignored when !quat).
 void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
-               const int* d_enable, ProfHook* ph = nullptr, LOState* fin_lo = nullptr, double* fin_traj = nullptr);
+               const int* d_enable, ProfHook* ph = nullptr, LOState* fin_lo = nullptr, double* fin_traj = nullptr,
+               hipEvent_t done = nullptr);
 // fin_lo / fin_traj: when set, the solve's last act is LaserOdometry's pose integration + trajectory row (saves a launch)
+// done: event bound to the solve dispatch (recorded when it completes)
 
 }  // namespace vloam

@@ -901,18 +901,18 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
 }
 
 void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
-               const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj) {
+               const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   if (!direct) hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
   if (direct)
-    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<true, true>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
                  fin_lo, fin_traj);
   else if (quat)
-    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<true, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);
   else
-    VLOAM_LAUNCH(ph, kKLmSolve, st, (k_lm_solve<false, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);
 }
 

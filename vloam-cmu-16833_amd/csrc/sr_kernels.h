@@ -28,6 +28,7 @@ struct SRBuffers {
 };
 
 hipError_t sr_init();
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph = nullptr);
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph = nullptr,
+                     hipEvent_t done = nullptr);  // `done`: recorded when the feature clouds are complete
 
 }  // namespace vloam

@@ -768,7 +768,7 @@ hipError_t sr_init() {
   return hipFuncSetAttribute((const void*)k_sr_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_ring_smem_bytes());
 }
 
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph) {
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done) {
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
   const int nslice = (n + kFLThreads - 1) / kFLThreads;
   int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
@@ -780,7 +780,7 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int
   VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                      debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr);
-  VLOAM_LAUNCH(ph, kKSrCompact, st, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
+  VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
                      b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr);
   return hipGetLastError();
 }
