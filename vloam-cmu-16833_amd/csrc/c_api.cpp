@@ -158,7 +158,9 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
   vloam_status st = VLOAM_OK;
   do {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s_lo, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
+        (cfg->with_mapping && hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess)) {  // no mapping: no third hardware queue
+      set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
+    }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
     const int P = cfg->max_points;
     h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
@@ -262,7 +264,7 @@ static vloam_status sync_all(vloam_handle* h) {
   { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->s_lo));
-  HIPCHK(hipStreamSynchronize(h->s_map));
+  if (h->s_map) HIPCHK(hipStreamSynchronize(h->s_map));
   return VLOAM_OK;
 }
 
