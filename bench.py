@@ -66,14 +66,19 @@ def pmc_traffic(workload, kernel):
     separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_summary.py wrote the table).
     A PMC pass cannot run inside this process, so the number is read from profiles/ — None when the table is missing."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_hbm_traffic.txt" % workload)
+    tot, cnt = 0.0, 0
     try:
         for line in open(path):
+            name = line.split("<")[0].split()[:1]
             f = line.split()
-            if len(f) >= 5 and f[0].split("<")[0] == kernel:
-                return float(f[-1]), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
-    except OSError:
-        pass
-    return None, None
+            if name and name[0] == kernel and len(f) >= 5:  # every instantiation of the kernel, weighted by its launches
+                tot += float(f[-1]) * int(f[-4])
+                cnt += int(f[-4])
+    except (OSError, ValueError):
+        return None, None
+    if cnt == 0:
+        return None, None
+    return tot / cnt, os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
 
 
 def sweep_bytes(c, with_mapping):

@@ -109,6 +109,8 @@ static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap)
   ALLOC(F->cslot, cap);
   ALLOC(F->cpack, 11 * (size_t)cap);
   ALLOC(F->rowcnt, (size_t)cap / 64 + 1);
+  ALLOC(F->gsync, (size_t)kLmSyncDoubles);
+  F->err = nullptr;  // set once the mapping context (owner of the sticky error word) exists
   return VLOAM_OK;
 }
 
@@ -218,6 +220,7 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
       s = map_create(&h->map, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
+      h->lo_F.err = &h->map.frame->error;
       s = vo_create(&h->vo, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("vo_create failed"); return VLOAM_ERR_HIP; }
       for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&h->ev[k]));
@@ -518,6 +521,7 @@ vloam_status vloam_sync(vloam_handle* h) {
     if (s != VLOAM_OK) return s;
     if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
+    if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }
   }
   return VLOAM_OK;
 }

@@ -1,4 +1,4 @@
-// Levenberg–Marquardt on one workgroup: the whole ceres::Solve() of the reference
+// Levenberg–Marquardt in one launch: the whole ceres::Solve() of the reference
 // (laser_odometry.cpp:457-463, laser_mapping.cpp:609-617, visual_odometry.cpp:423) runs inside ONE
 // kernel launch.  k_lm_compact (many workgroups) packs the accepted factors in slot order (deterministic) and
 // pre-digests them (edge -> orthonormal pair across the line, plane -> normal + offset); k_lm_solve then keeps them in the
@@ -7,6 +7,9 @@
 // transpose (bit-reproducible; 64-bit cross-lane shuffles are slower than LDS here), and lane 0 runs the
 // trust-region bookkeeping of Ceres 2.0 (Jacobi scaling, LM diagonal clamp, step acceptance,
 // radius schedule, tolerances) on the 6x6 normal equations.  No host round trips, no float atomics.
+// The scan-to-scan and scan-to-map problems run as FOUR cooperating workgroups (four compute units share the factors, one
+// grid barrier per evaluation, the trust-region bookkeeping replicated in each: see lm_evaluate); the small visual-odometry
+// problem stays on one.
 //
 // Ceres is not vendored by the reference; the algorithm restated here is spelled out in
 // oracle/orc_ceres.cpp (CPU oracle, DENSE_QR on the stacked Jacobian) and SURVEY.md Appendix A.
@@ -339,10 +342,20 @@ struct LmCache {
 // DIRECT (scan-to-scan odometry, table of exactly 256 x (kCacheE + kCacheP) slots): lane t owns the table slots t + 256 m
 // themselves — corner slots feed its edge cache, plane slots its plane cache — and builds the solver's form of each factor on
 // the fly, so no compaction pass runs at all; empty slots hold zeros and whole-wavefront-empty packets are skipped.
-template <bool QUAT, bool DIRECT>
+//
+// NB > 1 (scan-to-map problems, thousands of factors): NB workgroups on NB compute units share the factors — workgroup b, lane t
+// is lane b * 256 + t of an NB * 256 wide virtual workgroup — reduce their own share, publish the kAcc partial sums, meet at a
+// grid barrier and ALL add the partials in workgroup order, so every workgroup holds bit-identical accumulators and runs the
+// (cheap) trust-region bookkeeping redundantly: one barrier per evaluation, nothing to broadcast.  `eval_idx` counts the
+// evaluations of this solve (barrier target and double-buffer parity of the partial sums).
+template <bool QUAT, bool DIRECT, int NB>
 __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
-                                            double* s_out, bool first, LmCache& C, long long* cyc_factors) {
+                                            double* s_out, bool first, LmCache& C, long long* cyc_factors, int eval_idx) {
+  static_assert(NB == 1 || QUAT, "the cooperative form exists for the quaternion problems");
   const int tid = threadIdx.x;
+  const int blk = NB > 1 ? (int)blockIdx.x : 0;
+  const int vt = blk * kLmThreads + tid;     // lane of the virtual workgroup
+  constexpr int VT = NB * kLmThreads;
   const long long tf0 = clock64();
   double acc[kAcc];
 #pragma unroll
@@ -368,10 +381,13 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     const double* cp = F.cpack;
     if (first && DIRECT) {
       C.live_e = 0u; C.live_p = 0u;
+      constexpr int kEdgeSlots = kCacheE * kLmThreads;  // the table's corner part (the plane part follows)
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
-        const int slot = tid + m * kLmThreads;
-        const bool live = F.type[slot] == 1;
+        const int slot_raw = vt + m * VT;
+        const bool in = slot_raw < kEdgeSlots;
+        const int slot = in ? slot_raw : 0;
+        const bool live = in && F.type[slot] == 1;
         double a[3], b[3], fr[8];
 #pragma unroll
         for (int q = 0; q < 3; q++) { C.pe[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; a[q] = live ? F.A[q * cap + slot] : 0.0; b[q] = live ? F.B[q * cap + slot] : 1.0; }
@@ -382,8 +398,10 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       }
 #pragma unroll
       for (int m = 0; m < kCacheP; m++) {
-        const int slot = (kCacheE + m) * kLmThreads + tid;
-        const bool live = F.type[slot] == 2;  // LidarPlaneFactor: (lp - j) . n  ->  n . lp + d, d = -(n . j)
+        const int slot_raw = kEdgeSlots + vt + m * VT;
+        const bool in = slot_raw < cap;
+        const int slot = in ? slot_raw : 0;
+        const bool live = in && F.type[slot] == 2;  // LidarPlaneFactor: (lp - j) . n  ->  n . lp + d, d = -(n . j)
         double j[3], nn[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) { C.pp[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; j[q] = live ? F.A[q * cap + slot] : 0.0; nn[q] = live ? F.B[q * cap + slot] : 0.0; }
@@ -396,7 +414,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     if (first && !DIRECT) {
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
-        const int k = tid + m * kLmThreads;
+        const int k = vt + m * VT;
         const bool live = k < n_edge;
 #pragma unroll
         for (int a = 0; a < 3; a++) C.pe[m][a] = live ? (float)cp[a * cap + k] : 0.f;
@@ -405,7 +423,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       }
 #pragma unroll
       for (int m = 0; m < kCacheP; m++) {
-        const int q = tid + m * kLmThreads;
+        const int q = vt + m * VT;
         const bool live = q < n_plane;
 #pragma unroll
         for (int a = 0; a < 3; a++) C.pp[m][a] = live ? (float)cp[a * cap + n_edge + q] : 0.f;
@@ -418,7 +436,8 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
     };
     // ---- edge factors (compact order == slot order: they come first).  Cached slots in packets of kPkE, streamed ones too.
-    constexpr int kPkE = 3, kPkP = 2;
+    // (with NB workgroups a lane rarely owns more than one edge factor: packets of one instead of evaluating padding)
+    constexpr int kPkE = NB > 1 ? 1 : 3, kPkP = 2;
     auto edge_packet = [&](const double (&p)[kPkE][3], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], const double (&d1)[kPkE],
                            const double (&d2)[kPkE], int k0 /* compact index of lane's first factor */, int kstride) {
       double c1[kPkE], c2[kPkE];
@@ -427,7 +446,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int u = 0; u < kPkE; u++) {
           const int k = k0 + u * kstride;
-          if (DIRECT ? ((C.live_e >> u) & 1u) != 0u : k < n_edge) {  // r = c1 e2 - c2 e1
+          if (DIRECT ? ((C.live_e >> ((k0 - vt) / VT + u)) & 1u) != 0u : k < n_edge) {  // r = c1 e2 - c2 e1
             const double r3[3] = {c1[u] * e2[u][0] - c2[u] * e1[u][0], c1[u] * e2[u][1] - c2[u] * e1[u][1], c1[u] * e2[u][2] - c2[u] * e1[u][2]};
             put_resid(k, r3);
           }
@@ -435,7 +454,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     };
 #pragma unroll
     for (int g = 0; g < kCacheE; g += kPkE)
-      if (DIRECT ? __ballot(C.live_e != 0u) != 0ull : g * kLmThreads < n_edge) {
+      if (DIRECT ? __ballot(((C.live_e >> g) & ((1u << kPkE) - 1u)) != 0u) != 0ull : g * VT < n_edge) {
         double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
         for (int u = 0; u < kPkE; u++) {
@@ -445,19 +464,19 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
           for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pe[m][a] : 0.0; e1[u][a] = have ? C.de[m][a] : 0.0; e2[u][a] = have ? C.de[m][3 + a] : 0.0; }
           d1[u] = have ? C.de[m][6] : 0.0; d2[u] = have ? C.de[m][7] : 0.0;
         }
-        edge_packet(p, e1, e2, d1, d2, tid + g * kLmThreads, kLmThreads);
+        edge_packet(p, e1, e2, d1, d2, vt + g * VT, VT);
       }
-    for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * kLmThreads; !DIRECT && base < n_edge; base += kPkE * kLmThreads) {  // beyond the cache: streamed
+    for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * VT; !DIRECT && base < n_edge; base += kPkE * VT) {  // beyond the cache: streamed
       double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
 #pragma unroll
       for (int u = 0; u < kPkE; u++) {
-        const int k = base + u * kLmThreads + tid;
+        const int k = base + u * VT + vt;
         const bool live = k < n_edge;
 #pragma unroll
         for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + k] : 0.0; e1[u][a] = live ? cp[(3 + a) * cap + k] : 0.0; e2[u][a] = live ? cp[(6 + a) * cap + k] : 0.0; }
         d1[u] = live ? cp[9 * cap + k] : 0.0; d2[u] = live ? cp[10 * cap + k] : 0.0;
       }
-      edge_packet(p, e1, e2, d1, d2, base + tid, kLmThreads);
+      edge_packet(p, e1, e2, d1, d2, base + vt, VT);
     }
     // ---- plane factors
     auto plane_packet = [&](const double (&p)[kPkP][3], const double (&n)[kPkP][3], const double (&d)[kPkP], int q0, int qstride) {
@@ -467,13 +486,13 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int u = 0; u < kPkP; u++) {
           const int q = q0 + u * qstride;
-          if (DIRECT) { if ((C.live_p >> (q0 / kLmThreads + u)) & 1u) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(kCacheE * kLmThreads + q, r3); } }
+          if (DIRECT) { if ((C.live_p >> (q0 / VT + u)) & 1u) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(kCacheE * kLmThreads + q, r3); } }
           else if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3); }
         }
     };
 #pragma unroll
     for (int g = 0; g < kCacheP; g += kPkP)
-      if (DIRECT ? __ballot(((C.live_p >> g) & ((1u << kPkP) - 1u)) != 0u) != 0ull : g * kLmThreads < n_plane) {
+      if (DIRECT ? __ballot(((C.live_p >> g) & ((1u << kPkP) - 1u)) != 0u) != 0ull : g * VT < n_plane) {
         double p[kPkP][3], n[kPkP][3], d[kPkP];
 #pragma unroll
         for (int u = 0; u < kPkP; u++) {
@@ -483,19 +502,19 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
           for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pp[m][a] : 0.0; n[u][a] = have ? C.dp[m][a] : 0.0; }
           d[u] = have ? C.dp[m][3] : 0.0;
         }
-        plane_packet(p, n, d, tid + g * kLmThreads, kLmThreads);
+        plane_packet(p, n, d, vt + g * VT, VT);
       }
-    for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * kLmThreads; !DIRECT && base < n_plane; base += kPkP * kLmThreads) {
+    for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * VT; !DIRECT && base < n_plane; base += kPkP * VT) {
       double p[kPkP][3], n[kPkP][3], d[kPkP];
 #pragma unroll
       for (int u = 0; u < kPkP; u++) {
-        const int q = base + u * kLmThreads + tid;
+        const int q = base + u * VT + vt;
         const bool live = q < n_plane;
 #pragma unroll
         for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + n_edge + q] : 0.0; n[u][a] = live ? cp[(3 + a) * cap + n_edge + q] : 0.0; }
         d[u] = live ? cp[6 * cap + n_edge + q] : 0.0;
       }
-      plane_packet(p, n, d, base + tid, kLmThreads);
+      plane_packet(p, n, d, base + vt, VT);
     }
   } else {
     for (int k = tid; k < n_valid; k += kLmThreads) {
@@ -523,13 +542,35 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     sh.part[sub * kAcc + i] = s;
   }
   __syncthreads();
+  double* gpart = NB > 1 ? F.gsync + 8 + (size_t)(eval_idx & 1) * kLmMaxBlocks * 32 : nullptr;
   if (tid < kAcc) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; w++) s += sh.part[w * kAcc + tid];
-    s_out[tid] = s;
+    if (NB == 1) s_out[tid] = s;
+    else __hip_atomic_store(&gpart[blk * 32 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  if constexpr (NB > 1) {
+    if (tid == 0) {  // grid barrier number eval_idx + 1 of this solve (the counter starts every solve at zero)
+      unsigned* bar = reinterpret_cast<unsigned*>(F.gsync);
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)(eval_idx + 1) * (unsigned)NB;
+      int spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) { if (F.err) atomicOr(F.err, kErrSolverSync); break; }  // never hang the device: flag (vloam_sync reports it) and fall through
+      }
+    }
+    __syncthreads();
+    if (tid < kAcc) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < NB; q++) s += __hip_atomic_load(&gpart[q * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_out[tid] = s;
+    }
+    __syncthreads();
+  }
 }
 
 // packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
@@ -636,13 +677,14 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
   }
 }
 
-template <bool QUAT, bool DIRECT>
+template <bool QUAT, bool DIRECT, int NB>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj) {
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
+  const bool lead = NB == 1 || blockIdx.x == 0;  // the workgroup that owns every global side effect other than its factors' residuals
   if (enable_flag && *enable_flag == 0) {
-    for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
+    if (lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
     return;
   }
   constexpr int na = QUAT ? 7 : 6;
@@ -663,7 +705,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int w = 0; w < kLmThreads / 64; w++) { t += sh.scan[w]; te += sh.scan2[w]; }
       sh.n_valid = t; sh.n_edge = te;
     }
-    for (int r = tid; r < nrows; r += kLmThreads) F.rowcnt[r] = 0;
+    if (NB == 1) for (int r = tid; r < nrows; r += kLmThreads) F.rowcnt[r] = 0;  // NB > 1: once every workgroup has read them (below)
     __syncthreads();
   }
   const long long t_pro = clock64();
@@ -672,8 +714,10 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 
   LmCache cache;
   t_mark = clock64();
-  lm_evaluate<QUAT, DIRECT>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac);
+  int eval_idx = 0;
+  lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac, eval_idx++);
   cyc_eval += clock64() - t_mark;
+  if (NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone is past the first barrier, i.e. past its prologue
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
@@ -711,13 +755,17 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     current_cost = x_cost;
     it_cost = x_cost;
 #pragma unroll
-    for (int i = 0; i < 7; i++) { sh.best[i] = i < na ? sh.x[i] : 0.0; rec->x_in[i] = sh.best[i]; }
+    for (int i = 0; i < 7; i++) sh.best[i] = i < na ? sh.x[i] : 0.0;
+    if (lead) {
 #pragma unroll
-    for (int a = 0; a < 6; a++) { rec->g0[a] = sh.cur[1 + a];
+      for (int i = 0; i < 7; i++) rec->x_in[i] = sh.best[i];
 #pragma unroll
-      for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(sh.cur, a, b); }
-    rec->initial_cost = x_cost;
-    rec->n_factors = n_valid;
+      for (int a = 0; a < 6; a++) { rec->g0[a] = sh.cur[1 + a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(sh.cur, a, b); }
+      rec->initial_cost = x_cost;
+      rec->n_factors = n_valid;
+    }
   }
 
   for (;;) {
@@ -729,7 +777,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         if (it_success && x_cost < minimum_cost) { minimum_cost = x_cost;
 #pragma unroll
           for (int i = 0; i < na; i++) sh.best[i] = sh.x[i]; }
-        if (n_rec < kLmMaxTrace) {
+        if (lead && n_rec < kLmMaxTrace) {
           double* row = rec->trace[n_rec];
           row[0] = it_cost; row[1] = it_cost_change; row[2] = gmax; row[3] = it_step_norm; row[4] = it_rho; row[5] = radius;
           row[6] = it_valid; row[7] = it_success;
@@ -795,7 +843,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
-    lm_evaluate<QUAT, DIRECT>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac);
+    lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac, eval_idx++);
     cyc_eval += clock64() - t_mark;
     t_mark = clock64();
     // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
@@ -849,7 +897,16 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     __syncthreads();
   }
 
-  if (tid == 0) {
+  if constexpr (NB > 1) {  // re-arm the barrier for the next solve: the last workgroup out zeroes both counters (nobody waits any more)
+    if (tid == 0) {
+      unsigned* bar = reinterpret_cast<unsigned*>(F.gsync);
+      if (__hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)NB - 1u) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (tid == 0 && lead) {
 #pragma unroll
     for (int i = 0; i < na; i++) x_io[i] = sh.best[i];
 #pragma unroll
@@ -905,14 +962,22 @@ void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d
   const int edge_rows = n_edge_slots >> 6;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   if (!direct) hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
-  if (direct)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
+  constexpr int kCoop = 4;  // workgroups of the cooperative form (see lm_evaluate)
+  static_assert(kCoop <= kLmMaxBlocks, "partial-sum buffer");
+  if (direct && F.gsync)
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj);
+  else if (direct)
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
                  fin_lo, fin_traj);
+  else if (quat && F.gsync)
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
+                 huber_a, d_enable, fin_lo, fin_traj);
   else if (quat)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);
   else
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);
 }
 

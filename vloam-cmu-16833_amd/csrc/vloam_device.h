@@ -63,6 +63,7 @@ enum ErrorBits : int {
   kErrMapFull = 4,     // voxel hash out of slots
   kErrMapDeferred = 8, // a scan point landed in a cube outside the valid 5x5x3 block
   kErrStackFull = 16,
+  kErrSolverSync = 32,  // a workgroup of a cooperative LM solve gave up waiting at the grid barrier (result of that solve is invalid)
 };
 
 // Per-frame scalars of scan registration (one per sequence).
@@ -114,7 +115,11 @@ struct FactorTable {
   double* cpack;  // [11][cap] compacted factors: p, then (e1, e2, d1, d2) of an edge / (n, d) of a plane / A, B otherwise
   int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
   int cap;
+  double* gsync;  // optional [kLmSyncDoubles]: barrier counters + per-workgroup partial sums of the multi-workgroup solve (null: one workgroup)
+  int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
 };
+constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
+constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 32;  // 2 counters (+ flags) | [parity][workgroup][32] partial accumulators
 
 struct LOState {           // laser odometry state carried across frames (laser_odometry.h:106-146)
   double para_q[4], para_t[3];  // q_last_curr (x,y,z,w), t_last_curr

@@ -267,6 +267,8 @@ vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, st
        dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.ctype, kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.cslot, kVoMaxMatches) && dmalloc(allocs, st, &v->F.cpack, 11 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->F.rowcnt, kVoMaxMatches / 64 + 1);
+  v->F.gsync = nullptr;
+  v->F.err = nullptr;
   ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
        dmalloc(allocs, st, &v->counters, 2);
   v->max_points = cfg.max_points;
