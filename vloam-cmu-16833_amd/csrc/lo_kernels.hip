@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
         vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
         if (dbg_cyc) tdbg = ((tm[1] - tm[0]) & 0xffff) | (((tm[2] - tm[1]) & 0xffff) << 16) | (((tm[3] - tm[2]) & 0xffff) << 32) | ((tm[4] & 0xffff) << 48);
       }
-      else if (stage == 2) vn = for_each_candidate<2, 4, 2, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
-      else if (stage == 3) vn = for_each_candidate<6, 4, 3, 2>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else if (stage == 2) continue;  // (the closest point: both shells in one pass, the few queries that get here are the kernel's tail)
+      else if (stage == 3) vn = for_each_candidate<6, 4, 3, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
       else vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
       if (skipped) continue;
       const u64 loc = wave_min_u64(vn.loc);
