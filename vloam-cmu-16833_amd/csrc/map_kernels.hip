@@ -432,12 +432,15 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
                                                    VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms,
                                                    int* __restrict__ nn) {
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (slot >= kMapFactorCap) return;
-  const int kind = slot < kStackCapCorner ? 0 : 1;
-  const int i = kind ? slot - kStackCapCorner : slot;
-  const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
-  if (ms->do_optimize && i < nst) {
+  // wave d of the launch takes the d-th stack point (corners, then surfs): the waves with work come first in dispatch order
+  // instead of sitting behind the thousands of empty slots between the two parts of the table
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
+  if (d >= nc + nsf || !ms->do_optimize) return;  // (k_map_fit never looks at nn[] of a slot without a stack point)
+  const int kind = d < nc ? 0 : 1;
+  const int i = kind ? d - nc : d;
+  const int slot = kind ? kStackCapCorner + i : i;
+  {
     const VoxelTable T = kind ? T1 : T0;
     const float inv = kind ? inv1 : inv0;
     const float4 pointOri = kind ? stack1[i] : stack0[i];
@@ -586,8 +589,6 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
 #pragma unroll
       for (int j = 0; j < 5; j++) nn[slot * 5 + j] = ok ? ns[j] : -1;
     }
-  } else if (lane == 0) {
-    nn[slot * 5] = -1;
   }
 }
 
