@@ -99,7 +99,10 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
 
 /* Whole façade for one sweep, enqueued with NO host synchronisation:
  * reset -> scanRegistrationIO -> laserOdometryIO -> laserMappingIO (MAIN/src/vloam_main_node.cpp:134,166-168).
- * d_xyz_pad4 is DEVICE memory and must stay valid until vloam_sync().  Poses go to the on-device trajectory log. */
+ * d_xyz_pad4 is DEVICE memory and must stay valid until vloam_sync().  Poses go to the on-device trajectory log.
+ * The odometry / mapping of a sweep may only be ENQUEUED by a later call (they trail the scan registration by one / two
+ * sweeps so that no live cross-stream wait is needed); every call that returns results, vloam_sync() and the stage-wise
+ * entry points first enqueue whatever is still owed, so this is invisible except through the raw device pointer below. */
 vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n);
 /* same with a HOST buffer (staged through pinned memory; returns after the copy is enqueued) */
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n);
@@ -109,7 +112,8 @@ vloam_status vloam_sync(vloam_handle* h);
  * followed by {q_map[4], t_map[3]} (mapping, world_MOT_base_last).  first..first+count-1 -> HOST buffer. */
 vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double* poses14);
 vloam_status vloam_frame_count(vloam_handle* h, int* frames);
-/* device address + byte size of the trajectory log (for an RCCL gather across GPUs) */
+/* device address + byte size of the trajectory log (for an RCCL gather across GPUs); rows are only complete
+ * after vloam_sync() */
 vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long long* bytes);
 
 /* == VisualOdometry::processPointCloud + solveNlsAll (visual_odometry.cpp:157-186,254-450).
