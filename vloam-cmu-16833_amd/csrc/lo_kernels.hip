@@ -382,6 +382,10 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     // (<= kSparse points, fetched in ONE trip: features far from everything); otherwise (2, 3) the radius-2 and radius-3 shells of the 1 m level,
     // which are conclusive in any dense neighbourhood, and (4) the 5 m level unconditionally.
     constexpr int kSparse = 1024, kAll = 0x7fffffff;
+    // points per lane and trip on the 5 m level: 8 (two trips for the largest sparse neighbourhoods) keeps the kernel at 158
+    // VGPRs = 3 wavefronts per SIMD, so that all ~1 800 queries stay resident in one round even while the scan-registration
+    // ring kernel (one 146 KB-LDS workgroup per scan line) holds 51 of the 256 compute units
+    constexpr int kSparseUB = 8;
     constexpr int kGroups = kMaxRings >> kRingGroupShift;
     auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 2 ? 4.0f * 0.999999f : (stage == 3 ? 9.0f * 0.999999f : 3.0e38f)); };
     u64 best = ~0ull;
@@ -392,12 +396,12 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
       if (stage == 0) vn = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
       else if (stage == 1) {
         long long tm[5] = {0, 0, 0, 0, 0};
-        vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
+        vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
         if (dbg_cyc) tdbg = ((tm[1] - tm[0]) & 0xffff) | (((tm[2] - tm[1]) & 0xffff) << 16) | (((tm[3] - tm[2]) & 0xffff) << 32) | ((tm[4] & 0xffff) << 48);
       }
       else if (stage == 2) continue;  // (the closest point: both shells in one pass, the few queries that get here are the kernel's tail)
       else if (stage == 3) vn = for_each_candidate<6, 4, 3, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
-      else vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
       if (skipped) continue;
       const u64 loc = wave_min_u64(vn.loc);
       best = loc < best ? loc : best;
@@ -427,10 +431,10 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
         va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
         bool skipped = false;
         if (stage == 0) va = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
-        else if (stage == 1) va = for_each_candidate<1, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups x 27 cells
+        else if (stage == 1) va = for_each_candidate<1, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups x 27 cells
         else if (stage == 2) va = for_each_candidate<2, 4, 2, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
         else if (stage == 3) va = for_each_candidate<6, 4, 3, 2>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
-        else va = for_each_candidate<1, kSparse / 64, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        else va = for_each_candidate<1, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kAll, &skipped, s_inc, s_rel);
         if (skipped) continue;
         cand_dbg += va.visited;
         const u64 l2 = wave_min_u64(va.l2);
