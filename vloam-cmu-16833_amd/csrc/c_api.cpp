@@ -109,8 +109,8 @@ static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap)
   ALLOC(F->cslot, cap);
   ALLOC(F->cpack, 11 * (size_t)cap);
   ALLOC(F->rowcnt, (size_t)cap / 64 + 1);
-  ALLOC(F->gsync, (size_t)kLmSyncDoubles);
-  F->err = nullptr;  // set once the mapping context (owner of the sticky error word) exists
+  F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated
+  F->err = nullptr;    // set once the mapping context (owner of the sticky error word) exists
   return VLOAM_OK;
 }
 
@@ -221,6 +221,20 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       s = map_create(&h->map, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       h->lo_F.err = &h->map.frame->error;
+      {
+        // sync words of the three cooperative solves (odometry, mapping outer rounds): the fastest of 48 candidate lines
+        constexpr int kCand = 48;
+        constexpr size_t kStride = 4352;  // 4 KB + 256 B: walks page and sub-page address bits; >= one slot
+        static_assert(kStride >= kLmSyncDoubles * sizeof(double), "slots must not overlap");
+        double* pool = nullptr;
+        ALLOC(pool, kCand * kStride / sizeof(double));
+        int order[kCand];
+        if (lm_sync_calibrate(h->stream, pool, kCand, kStride, order) != 0) { set_err("lm_sync_calibrate failed"); return VLOAM_ERR_HIP; }
+        auto slot = [&](int r) { return reinterpret_cast<double*>(reinterpret_cast<char*>(pool) + kStride * (size_t)order[r]); };
+        h->lo_F.gsync = slot(0);
+        h->map.F[0].gsync = slot(1);
+        h->map.F[1].gsync = slot(2);
+      }
       s = vo_create(&h->vo, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("vo_create failed"); return VLOAM_ERR_HIP; }
       for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&h->ev[k]));

@@ -16,4 +16,8 @@ void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d
 // fin_lo / fin_traj: when set, the solve's last act is LaserOdometry's pose integration + trajectory row (saves a launch)
 // done: event bound to the solve dispatch (recorded when it completes)
 
+// Cooperative solves: rank candidate sync-word slots (n_cand slots of kLmSyncDoubles doubles, stride_bytes apart, in `pool`, which carries 256 spare bytes behind the last slot) by
+// the measured round trip of the grid barrier at that address; order_out = slot indices, fastest first.  0 on success.
+int lm_sync_calibrate(hipStream_t st, double* pool, int n_cand, size_t stride_bytes, int* order_out);
+
 }  // namespace vloam

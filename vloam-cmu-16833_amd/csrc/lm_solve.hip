@@ -16,6 +16,11 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 #include "lm_solve.h"
 
 namespace vloam {
@@ -957,13 +962,78 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
   }
 }
 
+// ---- placement of the cooperative solve's sync words.  The grid barrier is a handful of agent-scope atomics and loads on ONE
+// cache line, and on MI355X their round trip depends on which memory channel the line maps to: 1.5 us at most addresses, 2.3 us
+// at some (measured; same answer from one XCD or four).  Five barriers per solve, four solves per sweep: worth choosing.  The
+// probe replays the solver's exact exchange (publish kAcc partials, barrier, read all partials) on a candidate slot.
+constexpr int kCoop = 4;  // workgroups of the cooperative form (see lm_evaluate)
+static_assert(kCoop <= kLmMaxBlocks, "partial-sum buffer");
+__global__ __launch_bounds__(kLmThreads) void k_lm_sync_probe(double* gsync, int iters, double* sink) {
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  unsigned* bar = reinterpret_cast<unsigned*>(gsync);
+  double acc = 0.0;
+  for (int it = 0; it < iters; it++) {
+    double* gpart = gsync + 8 + (size_t)(it & 1) * kLmMaxBlocks * 32;
+    if (tid < kAcc) __hip_atomic_store(&gpart[blk * 32 + tid], (double)(it + blk + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)(it + 1) * (unsigned)kCoop;
+      int spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) break;
+      }
+    }
+    __syncthreads();
+    if (tid < kAcc) {
+#pragma unroll
+      for (int q = 0; q < kCoop; q++) acc += __hip_atomic_load(&gpart[q * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid == 0 && __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)kCoop - 1u) {
+    __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < kAcc && blk == 0) sink[tid] = acc;
+}
+
+// Times every candidate slot (n_cand slots, stride_bytes apart, each kLmSyncDoubles doubles) and returns their indices fastest
+// first.  ~0.5 ms per candidate, once per handle.
+int lm_sync_calibrate(hipStream_t st, double* pool, int n_cand, size_t stride_bytes, int* order_out) {
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+  double* sink = reinterpret_cast<double*>(reinterpret_cast<char*>(pool) + stride_bytes * (size_t)n_cand);  // 256 spare bytes behind the pool
+  std::vector<std::pair<float, int>> t((size_t)n_cand);
+  bool ok = hipMemsetAsync(pool, 0, stride_bytes * (size_t)n_cand, st) == hipSuccess;
+  for (int pass = 0; pass < 2 && ok; pass++)  // pass 0 warms code and TLBs
+    for (int c = 0; c < n_cand && ok; c++) {
+      double* slot = reinterpret_cast<double*>(reinterpret_cast<char*>(pool) + stride_bytes * (size_t)c);
+      ok = hipEventRecord(e0, st) == hipSuccess;
+      hipLaunchKernelGGL(k_lm_sync_probe, dim3(kCoop), dim3(kLmThreads), 0, st, slot, pass ? 192 : 8, sink);
+      ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+      float ms = 0.f;
+      ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      t[(size_t)c] = std::make_pair(ms, c);
+    }
+  ok = ok && hipMemsetAsync(pool, 0, stride_bytes * (size_t)n_cand, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (!ok) return -1;
+  std::sort(t.begin(), t.end());
+  for (int c = 0; c < n_cand; c++) order_out[c] = t[(size_t)c].second;
+  if (getenv("VLOAM_CALIB_DEBUG")) {
+    fprintf(stderr, "lm_sync_calibrate (us per exchange, slot):");
+    for (int c = 0; c < n_cand; c++) fprintf(stderr, " %.2f/%d", 1e3 * t[(size_t)c].first / 192.0, t[(size_t)c].second);
+    fprintf(stderr, "\n");
+  }
+  return 0;
+}
+
 void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   if (!direct) hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
-  constexpr int kCoop = 4;  // workgroups of the cooperative form (see lm_evaluate)
-  static_assert(kCoop <= kLmMaxBlocks, "partial-sum buffer");
   if (direct && F.gsync)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);

@@ -853,7 +853,8 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
          dmalloc(allocs, st, &F.A, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.B, 3 * (size_t)F.cap) &&
          dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.ctype, (size_t)F.cap) &&
          dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 11 * (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1) && dmalloc(allocs, st, &F.gsync, (size_t)kLmSyncDoubles);
+         dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1);
+    F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
   }
   ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nn, 5 * (size_t)kMapFactorCap);
