@@ -966,8 +966,9 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
 // cache line, and on MI355X their round trip depends on which memory channel the line maps to: 1.5 us at most addresses, 2.3 us
 // at some (measured; same answer from one XCD or four).  Five barriers per solve, four solves per sweep: worth choosing.  The
 // probe replays the solver's exact exchange (publish kAcc partials, barrier, read all partials) on a candidate slot.
-constexpr int kCoop = 4;  // workgroups of the cooperative form (see lm_evaluate)
-static_assert(kCoop <= kLmMaxBlocks, "partial-sum buffer");
+constexpr int kCoop = 4;     // workgroups of the cooperative form (see lm_evaluate): the odometry table (<= 2 304 factors) ...
+constexpr int kCoopMap = 6;  // ... and the scan-to-map problems (4-5 000 factors; 4: 4 227, 6: 4 300, 8: 4 298 scans/s on one box)
+static_assert(kCoop <= kLmMaxBlocks && kCoopMap <= kLmMaxBlocks, "partial-sum buffer");
 __global__ __launch_bounds__(kLmThreads) void k_lm_sync_probe(double* gsync, int iters, double* sink) {
   const int tid = threadIdx.x, blk = blockIdx.x;
   unsigned* bar = reinterpret_cast<unsigned*>(gsync);
@@ -1041,7 +1042,7 @@ void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
                  fin_lo, fin_traj);
   else if (quat && F.gsync)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoopMap>), dim3(kCoopMap), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
                  huber_a, d_enable, fin_lo, fin_traj);
   else if (quat)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
