@@ -97,6 +97,43 @@ def test_lm_recovers_known_se3(orc):
     assert r1["trace"][1, 0] < r1["trace"][0, 0] and r1["trace"][1, 7] == 1
 
 
+def test_lm_minimiser_agrees_with_scipy_on_a_robust_problem(orc):
+    """Independent pin of the restated solver + HuberLoss(0.1): on noisy point-to-plane constraints with gross outliers the
+    oracle's LM, run to convergence, must reach the same minimiser of the same robust cost as scipy's trust-region
+    least_squares(loss='huber', f_scale=0.1) — a different algorithm, parameterisation (rotation vector) and code base.
+    (Plane factors only: Ceres robustifies per residual BLOCK, scipy per component; they coincide for 1-row blocks.)"""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    rv_true = np.array([0.02, -0.03, 0.05])
+    t_true = np.array([0.6, -0.2, 0.1])
+    R = Rotation.from_rotvec(rv_true).as_matrix()
+    P, N, D = [], [], []
+    for k in range(400):
+        p = rng.normal(size=3) * 8
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        noise = rng.normal() * 0.02 + (rng.normal() * 1.5 if k % 9 == 0 else 0.0)  # every 9th constraint is an outlier
+        P.append(p); N.append(n); D.append(-float(n @ (R @ p + t_true)) + noise)
+    P, N, D = np.array(P), np.array(N), np.array(D)
+    rows = [[2, *P[k], *N[k], D[k]] for k in range(len(P))]
+    r = orc.solve(rows, [0, 0, 0, 1], [0, 0, 0], quaternion=True, huber_a=0.1, max_iters=200)
+
+    def resid(x):
+        return np.einsum("ij,ij->i", N, Rotation.from_rotvec(x[:3]).apply(P) + x[3:]) + D
+
+    sol = least_squares(resid, np.zeros(6), loss="huber", f_scale=0.1, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
+    q = Rotation.from_rotvec(sol.x[:3]).as_quat()  # x, y, z, w
+    # the restated solver stops like Ceres does, on function_tolerance = 1e-6 (relative cost change), scipy runs to 1e-15:
+    # the two minima agree to what that tolerance leaves open
+    assert r["termination"] == 1
+    assert min(np.linalg.norm(r["p0"] - q), np.linalg.norm(r["p0"] + q)) < 1e-5
+    assert np.linalg.norm(r["p1"] - sol.x[3:]) < 1e-4
+    # same objective: Ceres reports sum rho(r^2) / 2, scipy 0.5 * sum rho(f^2); scipy's (converged) value is the lower one
+    assert 0.0 <= r["final_cost"] - sol.cost < 1e-6 * sol.cost
+    # and the robust fit is close to the truth although 11 % of the constraints are gross outliers
+    assert np.linalg.norm(r["p1"] - t_true) < 0.02
+
+
 def numpy_voxel_grid(pts, leaf):
     """Independent restatement of pcl::VoxelGrid (voxel_grid.hpp): floor(p * (1/leaf)) cells, output by linearised index."""
     inv = np.float32(1.0) / np.float32(leaf)
