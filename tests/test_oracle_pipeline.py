@@ -200,3 +200,89 @@ def test_published_map_pose_on_skipped_frames(orc, sweeps):
             assert np.allclose(qp, qmul(qwm, qw), atol=1e-14) and np.allclose(tp, rot(qwm, tw) + twm, atol=1e-12)
             if k > 1:
                 assert np.linalg.norm(tp - tm) > 0.1   # q_w_curr still holds the previous mapped sweep
+
+
+def test_lo_correspondences_vs_literal_python_walks(orc, sweeps):
+    """Second, independent transcription of the reference's correspondence search (laser_odometry.cpp:266-350 corners,
+    :353-444 planes; TransformToStart :149-167 with DISTORTION == false): brute-force f32 nearest neighbour, then the two
+    literal index walks with their `continue` / `break` rules on int(intensity) and NEARBY_SCAN = 2.5, in plain Python.
+    Must give exactly the oracle's (feature, a, b[, c]) lists for both outer rounds of every sweep."""
+    f32 = np.float32
+
+    def to_start(p, q, t):  # Eigen::Quaterniond * Vector3d, then + t, stored back as f32
+        qv, w = q[:3], q[3]
+        v = p[:3].astype(np.float64)
+        uv = np.cross(qv, v)
+        uv = uv + uv
+        return (v + w * uv + np.cross(qv, uv) + t).astype(f32)
+
+    def sqd(cloud, sel):  # float expression of the reference, evaluated left to right
+        dx, dy, dz = cloud[:, 0] - sel[0], cloud[:, 1] - sel[1], cloud[:, 2] - sel[2]
+        return (dx * dx + dy * dy) + dz * dz
+
+    o = orc.Oracle(scan_line=64, with_mapping=False)
+    n = 4
+    last_c = last_s = None
+    for k in range(n):
+        assert o.process(sweeps(64, 256, k, n_sweeps=n)) == 0
+        if k > 0:
+            sharp, flat = o.cloud(1), o.cloud(3)
+            for outer in range(o.lo_num_outer()):
+                s = o.lo_solve(outer)
+                q, t = s["q_in"], s["t_in"]
+                oc, op = o.lo_corr(outer)
+                # ---- corners
+                line = last_c[:, 3].astype(np.int32)  # int(intensity)
+                mine = []
+                for i in range(sharp.shape[0]):
+                    sel = to_start(sharp[i], q, t)
+                    d = sqd(last_c, sel)
+                    a = int(np.argmin(d))
+                    if not d[a] < f32(25.0):
+                        continue
+                    ring, best, b = line[a], 25.0, -1
+                    for j in range(a + 1, last_c.shape[0]):
+                        if line[j] <= ring:
+                            continue
+                        if line[j] > ring + 2.5:
+                            break
+                        if d[j] < best:
+                            best, b = float(d[j]), j
+                    for j in range(a - 1, -1, -1):
+                        if line[j] >= ring:
+                            continue
+                        if line[j] < ring - 2.5:
+                            break
+                        if d[j] < best:
+                            best, b = float(d[j]), j
+                    if b >= 0:
+                        mine.append((i, a, b))
+                assert np.array_equal(np.array(mine, dtype=np.int32).reshape(-1, 3), oc), (k, outer, "corner")
+                # ---- planes
+                line = last_s[:, 3].astype(np.int32)
+                mine = []
+                for i in range(flat.shape[0]):
+                    sel = to_start(flat[i], q, t)
+                    d = sqd(last_s, sel)
+                    a = int(np.argmin(d))
+                    if not d[a] < f32(25.0):
+                        continue
+                    ring, best2, best3, b, c = line[a], 25.0, 25.0, -1, -1
+                    for j in range(a + 1, last_s.shape[0]):
+                        if line[j] > ring + 2.5:
+                            break
+                        if line[j] <= ring and d[j] < best2:
+                            best2, b = float(d[j]), j
+                        elif line[j] > ring and d[j] < best3:
+                            best3, c = float(d[j]), j
+                    for j in range(a - 1, -1, -1):
+                        if line[j] < ring - 2.5:
+                            break
+                        if line[j] >= ring and d[j] < best2:
+                            best2, b = float(d[j]), j
+                        elif line[j] < ring and d[j] < best3:
+                            best3, c = float(d[j]), j
+                    if b >= 0 and c >= 0:
+                        mine.append((i, a, b, c))
+                assert np.array_equal(np.array(mine, dtype=np.int32).reshape(-1, 4), op), (k, outer, "plane")
+        last_c, last_s = o.cloud(2).copy(), o.cloud(4).copy()
