@@ -286,3 +286,148 @@ def test_lo_correspondences_vs_literal_python_walks(orc, sweeps):
                         mine.append((i, a, b, c))
                 assert np.array_equal(np.array(mine, dtype=np.int32).reshape(-1, 4), op), (k, outer, "plane")
         last_c, last_s = o.cloud(2).copy(), o.cloud(4).copy()
+
+
+@pytest.mark.parametrize("rings,az", [(64, 512), (16, 1024)])
+def test_feature_picks_vs_literal_python_loops(orc, sweeps, rings, az):
+    """Second, independent transcription of scan_registration.cpp:288-422 in plain Python on the oracle's own laserCloud:
+    the 11-tap curvature in the reference's summation order (f32), the per-sector ascending sort (ties by index: the
+    canonical order), the greedy sharp / lessSharp / flat picks with their counters, thresholds (float vs double 0.1 and
+    0.05) and the +-5 neighbour suppression.  Pick lists (in push order), labels and the picked mask must be identical."""
+    f32 = np.float32
+    o = orc.Oracle(scan_line=rings, with_mapping=False)
+    assert o.scan_registration(sweeps(rings, az, 1)) == 0
+    P = o.cloud(0)[:, :3].astype(f32)
+    n = P.shape[0]
+    start, end = o.sr_ints(3), o.sr_ints(4)
+    curv = np.zeros(n, dtype=f32)
+    for i in range(5, n - 5):
+        d = ((((P[i - 5] + P[i - 4]) + P[i - 3]) + P[i - 2]) + P[i - 1]) - f32(10) * P[i]
+        for k in range(1, 6):
+            d = d + P[i + k]
+        curv[i] = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+    picked = np.zeros(n + 8, dtype=np.int32)
+    label = np.zeros(n, dtype=np.int32)
+    sharp, less_sharp, flat = [], [], []
+
+    def gap2(a, b):  # squared distance between consecutive points, float expression compared against the double 0.05
+        d = P[a] - P[b]
+        return float((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+
+    def suppress(ind):
+        picked[ind] = 1
+        for l in range(1, 6):
+            if gap2(ind + l, ind + l - 1) > 0.05:
+                break
+            picked[ind + l] = 1
+        for l in range(-1, -6, -1):
+            if gap2(ind + l, ind + l + 1) > 0.05:
+                break
+            picked[ind + l] = 1
+
+    for r in range(rings):
+        if end[r] - start[r] < 6:
+            continue
+        for j in range(6):
+            sp = start[r] + (end[r] - start[r]) * j // 6
+            ep = start[r] + (end[r] - start[r]) * (j + 1) // 6 - 1
+            order = sorted(range(sp, ep + 1), key=lambda i: (curv[i], i))
+            largest = 0
+            for ind in reversed(order):
+                if picked[ind] == 0 and float(curv[ind]) > 0.1:
+                    largest += 1
+                    if largest <= 2:
+                        label[ind] = 2
+                        sharp.append(ind); less_sharp.append(ind)
+                    elif largest <= 20:
+                        label[ind] = 1
+                        less_sharp.append(ind)
+                    else:
+                        break
+                    suppress(ind)
+            smallest = 0
+            for ind in order:
+                if picked[ind] == 0 and float(curv[ind]) < 0.1:
+                    label[ind] = -1
+                    flat.append(ind)
+                    smallest += 1
+                    if smallest >= 4:  # the 4th flat point is taken but neither marked nor spread (scan_registration.cpp:390-394)
+                        break
+                    suppress(ind)
+    assert np.array_equal(curv[5:n - 5].view(np.uint32), o.sr_curvature()[5:n - 5].view(np.uint32))
+    assert np.array_equal(np.array(sharp, dtype=np.int32), o.sr_ints(5))
+    assert np.array_equal(np.array(less_sharp, dtype=np.int32), o.sr_ints(6))
+    assert np.array_equal(np.array(flat, dtype=np.int32), o.sr_ints(7))
+    assert np.array_equal(label, o.sr_ints(2)[:n])
+    assert np.array_equal(picked[:n], o.sr_ints(1)[:n])
+
+
+@pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512)])
+def test_ring_labelling_vs_literal_python_loop(orc, sweeps, rings, az):
+    """Second, independent transcription of scan_registration.cpp:157-281 in plain Python: NaN / minimum-range removal, the
+    vertical-angle -> scan line tables of the three sensor models, the sequential half-sweep unwrap state machine
+    (halfPassed), relTime, ring-major concatenation and scanStartInd / scanEndInd.  Ring ids, the order of the points and
+    their xyz must match the oracle exactly; intensity (through atan2f: numpy vs glibc, <= 1-2 ulp) within 1e-5 except for
+    points within 5e-6 rad of an unwrap threshold, where one ulp moves relTime by a full turn."""
+    f32, pi = np.float32, np.pi
+    cloud = sweeps(rings, az, 2)
+    o = orc.Oracle(scan_line=rings, minimum_range=5.0, with_mapping=False)
+    assert o.scan_registration(cloud) == 0
+    ok = np.isfinite(cloud[:, :3]).all(axis=1)
+    pts = cloud[ok, :3].astype(f32)
+    d2 = (pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2]  # removeClosedPointCloud (:100-129): < thres^2 is dropped
+    pts = pts[~(d2 < f32(5.0) * f32(5.0))]
+    start = float(f32(-np.arctan2(pts[0, 1], pts[0, 0])))
+    end = float(f32(float(f32(-np.arctan2(pts[-1, 1], pts[-1, 0]))) + 2 * pi))
+    if end - start > 3 * pi:
+        end = float(f32(end - 2 * pi))
+    elif end - start < pi:
+        end = float(f32(end + 2 * pi))
+    scans = [[] for _ in range(rings)]
+    half = False
+    for x, y, z in pts:
+        angle = float(f32(float(f32(np.arctan(z / np.sqrt(x * x + y * y))) * f32(180)) / pi))
+        if rings == 16:
+            sid = int((angle + 15) / 2 + 0.5)
+            if sid > rings - 1 or sid < 0:
+                continue
+        elif rings == 32:
+            sid = int((angle + 92.0 / 3.0) * 3.0 / 4.0)
+            if sid > rings - 1 or sid < 0:
+                continue
+        else:
+            sid = int((2 - angle) * 3.0 + 0.5) if angle >= -8.83 else rings // 2 + int((-8.83 - angle) * 2.0 + 0.5)
+            if angle > 2 or angle < -24.33 or sid > 50 or sid < 0:
+                continue
+        ori = float(f32(-np.arctan2(y, x)))
+        if not half:
+            if ori < start - pi / 2:
+                ori = float(f32(ori + 2 * pi))
+            elif ori > start + pi * 3 / 2:
+                ori = float(f32(ori - 2 * pi))
+            if ori - start > pi:
+                half = True
+        else:
+            ori = float(f32(ori + 2 * pi))
+            if ori < end - pi * 3 / 2:
+                ori = float(f32(ori + 2 * pi))
+            elif ori > end + pi / 2:
+                ori = float(f32(ori - 2 * pi))
+        rel = f32(f32(ori - start) / f32(end - start))
+        scans[sid].append((x, y, z, f32(sid + 0.1 * float(rel)), ori))
+    mine = np.array([p[:4] for s in scans for p in s], dtype=f32)
+    oris = np.array([p[4] for s in scans for p in s])
+    ref = o.cloud(0)
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine[:, :3].view(np.uint32), ref[:, :3].view(np.uint32))      # same points, same order
+    assert np.array_equal(mine[:, 3].astype(np.int32), ref[:, 3].astype(np.int32))      # same scan line
+    off, s_ind, e_ind = 0, [], []
+    for s in scans:
+        s_ind.append(off + 5); off += len(s); e_ind.append(off - 6)
+    assert np.array_equal(np.array(s_ind, dtype=np.int32), o.sr_ints(3)) and np.array_equal(np.array(e_ind, dtype=np.int32), o.sr_ints(4))
+    bad = np.abs(mine[:, 3] - ref[:, 3]) > 1e-5
+    raw = -np.arctan2(ref[:, 1].astype(np.float64), ref[:, 0].astype(np.float64))
+    for b in (start - pi / 2, start + 1.5 * pi, start + pi, end - 1.5 * pi, end + pi / 2):
+        near = np.abs((raw - b + pi) % (2 * pi) - pi) < 5e-6
+        bad &= ~near
+    assert not bad.any(), "relTime differs away from an unwrap threshold (%d points)" % int(bad.sum())
