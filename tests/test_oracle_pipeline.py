@@ -431,3 +431,233 @@ def test_ring_labelling_vs_literal_python_loop(orc, sweeps, rings, az):
         near = np.abs((raw - b + pi) % (2 * pi) - pi) < 5e-6
         bad &= ~near
     assert not bad.any(), "relTime differs away from an unwrap threshold (%d points)" % int(bad.sum())
+
+
+def test_mapping_factors_vs_numpy_transcription(orc, sweeps):
+    """Second, independent transcription of laserMapping's association (laser_mapping.cpp:404-430 gather of the valid cubes,
+    :432-440 VoxelGrid of the scan features, :472-517 corner factors, :538-581 surf factors; pointAssociateToMap :146-155):
+    numpy VoxelGrid, brute-force f32 5-NN (ties to the lowest index), numpy eigh for the line test (lambda_2 > 3 lambda_1,
+    a / b = centre +- 0.1 u) and numpy lstsq for the plane (A n = -1, |n . p + d| <= 0.2 for all five).  The map the sweep
+    sees is dumped from a second oracle that stopped one sweep earlier.  Factor lists (which stack points, in order) must be
+    identical; a / b and (n, d) within 1e-8 (different eigen / least-squares algorithms)."""
+    from test_oracle_math import numpy_voxel_grid
+    f32 = np.float32
+    n = 5
+    clouds = [sweeps(64, 512, k, n_sweeps=n) for k in range(n)]
+    A, B = orc.Oracle(with_mapping=True), orc.Oracle(with_mapping=True)
+    for k in range(n - 1):
+        assert A.process(clouds[k]) == 0 and B.process(clouds[k]) == 0
+    cen_before = A.map_info()["cen"].copy()
+    assert B.process(clouds[n - 1]) == 0
+    info = B.map_info()
+    assert np.array_equal(info["cen"], cen_before), "the cube window rolled during the last sweep: pick another sequence"
+    maps = [np.concatenate([A.map_cube(w, int(c)) for c in info["valid"]], axis=0) for w in (0, 1)]
+    assert maps[0].shape[0] > 10 and maps[1].shape[0] > 50  # the optimisation gate (:448)
+    stacks = [numpy_voxel_grid(B.cloud(2), 0.4), numpy_voxel_grid(B.cloud(4), 0.8)]
+
+    def to_map(p, q, t):  # Eigen::Quaterniond * Vector3d + t, stored as f32
+        qv, w = q[:3], q[3]
+        v = p[:3].astype(np.float64)
+        uv = np.cross(qv, v); uv = uv + uv
+        return (v + w * uv + np.cross(qv, uv) + t).astype(f32)
+
+    def knn5(cloud, sel):
+        dx, dy, dz = cloud[:, 0] - sel[0], cloud[:, 1] - sel[1], cloud[:, 2] - sel[2]
+        d = (dx * dx + dy * dy) + dz * dz
+        order = np.lexsort((np.arange(d.shape[0]), d))[:5]
+        return order, d[order]
+
+    assert B.map_num_outer() == 2
+    for outer in range(2):
+        s = B.map_solve(outer)
+        q, t = s["q_in"], s["t_in"]
+        ci, cab, si, spl = B.map_factors(outer)
+        mine_c, mine_ab, skip = [], [], set()
+        for i, p in enumerate(stacks[0]):
+            idx, d = knn5(maps[0], to_map(p, q, t))
+            if not d[4] < f32(1.0):
+                continue
+            pts = maps[0][idx, :3].astype(np.float64)
+            centre = np.zeros(3)
+            for r in pts:
+                centre = centre + r
+            centre = centre / 5.0
+            cov = np.zeros((3, 3))
+            for r in pts:
+                z = r - centre
+                cov = cov + np.outer(z, z)
+            w, v = np.linalg.eigh(cov)
+            if abs(w[2] - 3 * w[1]) < 1e-9 * max(w[2], 1e-30):
+                skip.add(i)  # on the knife edge two eigen solvers may disagree
+                continue
+            if w[2] > 3 * w[1]:
+                mine_c.append(i)
+                mine_ab.append((0.1 * v[:, 2] + centre, -0.1 * v[:, 2] + centre))
+        keep = np.array([i not in skip for i in ci], dtype=bool)
+        assert np.array_equal(np.array(mine_c, dtype=np.int32), ci[keep]), (outer, "corner factor list")
+        for (a, b), row in zip(mine_ab, cab[keep]):
+            same = np.abs(row[:3] - a).max() < 1e-8 and np.abs(row[3:] - b).max() < 1e-8
+            flipped = np.abs(row[:3] - b).max() < 1e-8 and np.abs(row[3:] - a).max() < 1e-8  # eigenvector sign is free
+            assert same or flipped
+        mine_s, mine_pl = [], []
+        for i, p in enumerate(stacks[1]):
+            idx, d = knn5(maps[1], to_map(p, q, t))
+            if not d[4] < f32(1.0):
+                continue
+            pts = maps[1][idx, :3].astype(np.float64)
+            x = np.linalg.lstsq(pts, -np.ones(5), rcond=None)[0]
+            dd = 1.0 / np.linalg.norm(x)
+            nrm = x / np.linalg.norm(x)
+            if np.all(np.abs(pts @ nrm + dd) <= 0.2):
+                mine_s.append(i)
+                mine_pl.append(np.concatenate([nrm, [dd]]))
+        assert np.array_equal(np.array(mine_s, dtype=np.int32), si), (outer, "surf factor list")
+        assert np.abs(np.array(mine_pl) - spl).max() < 1e-8
+
+
+def test_map_update_vs_numpy_transcription(orc, sweeps):
+    """Second, independent transcription of laserMapping's map update (laser_mapping.cpp:639-683 cube index by C truncation
+    plus the `< 0` correction and push_back, :689-702 VoxelGrid of every valid cube over (previous centroids + new points)):
+    after one more sweep every cube of the window must hold, bit for bit, what the numpy restatement builds from the
+    previous cubes, the numpy-VoxelGrid scan features and the optimised pose."""
+    from test_oracle_math import numpy_voxel_grid
+    f32 = np.float32
+    n = 4
+    clouds = [sweeps(64, 512, k, n_sweeps=n) for k in range(n)]
+    A, B = orc.Oracle(with_mapping=True), orc.Oracle(with_mapping=True)
+    for k in range(n - 1):
+        assert A.process(clouds[k]) == 0 and B.process(clouds[k]) == 0
+    assert B.process(clouds[n - 1]) == 0
+    info = B.map_info()
+    assert np.array_equal(info["cen"], A.map_info()["cen"])
+    cen = info["cen"]
+    W, H, D = 21, 21, 11  # laser_mapping.h:73-75
+    q, t = B.map_pose()[:2]
+    qv, w = q[:3], q[3]
+    touched = set()
+    for which, (cloud_id, leaf) in enumerate(((2, 0.4), (4, 0.8))):
+        stack = numpy_voxel_grid(B.cloud(cloud_id), leaf)
+        pushed = {}
+        for p in stack:
+            v = p[:3].astype(np.float64)
+            uv = np.cross(qv, v); uv = uv + uv
+            sel = (v + w * uv + np.cross(qv, uv) + t).astype(f32)
+            cube = []
+            for a in range(3):
+                c = int((float(sel[a]) + 25.0) / 50.0) + int(cen[a])  # int(): truncation towards zero
+                if float(sel[a]) + 25.0 < 0:
+                    c -= 1
+                cube.append(c)
+            if 0 <= cube[0] < W and 0 <= cube[1] < H and 0 <= cube[2] < D:
+                pushed.setdefault(cube[0] + W * cube[1] + W * H * cube[2], []).append(np.array([sel[0], sel[1], sel[2], p[3]], dtype=f32))
+        valid = set(int(c) for c in info["valid"])
+        for c in sorted(valid | set(pushed)):
+            prev = A.map_cube(which, c)
+            new = np.array(pushed.get(c, []), dtype=f32).reshape(-1, 4)
+            both = np.concatenate([prev, new], axis=0)
+            want = numpy_voxel_grid(both, leaf) if (c in valid and both.shape[0]) else both
+            got = B.map_cube(which, c)
+            assert got.shape == want.shape, (which, c)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (which, c)
+            touched.add(c)
+    assert len(touched) >= 2
+
+
+def test_pose_algebra_vs_numpy(orc, sweeps):
+    """The SE3 bookkeeping between the stages, restated with numpy quaternions: odometry integration t_w += q_w * t_lc,
+    q_w = q_w * q_lc without renormalisation (laser_odometry.cpp:477-478); mapping's initial guess q_w = q_wmap_wodom * q_wodom,
+    t_w = q_wmap_wodom * t_wodom + t_wmap_wodom (laser_mapping.cpp:167-196) and transformUpdate q_wmap_wodom = q_w * q_wodom^-1,
+    t_wmap_wodom = t_w - q_wmap_wodom * t_wodom (:140-144)."""
+    def qmul(a, b):  # (x, y, z, w), Eigen's product
+        ax, ay, az, aw = a; bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                         aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+    def qrot(q, v):
+        uv = np.cross(q[:3], v); uv = uv + uv
+        return v + q[3] * uv + np.cross(q[:3], uv)
+
+    def qinv(q):  # Eigen::Quaternion::inverse(): conjugate / squaredNorm
+        return np.array([-q[0], -q[1], -q[2], q[3]]) / float(q @ q)
+
+    n = 6
+    o = orc.Oracle(with_mapping=True)
+    q_w, t_w = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    q_mo, t_mo = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    for k in range(n):
+        assert o.process(sweeps(64, 512, k, n_sweeps=n)) == 0
+        qw, tw, ql, tl = o.lo_pose()
+        if k > 0:  # the first sweep only initialises (laser_odometry.cpp:196-204)
+            t_w = t_w + qrot(q_w, tl)
+            q_w = qmul(q_w, ql)
+        assert np.abs(qw - q_w).max() < 1e-15 and np.abs(tw - t_w).max() < 1e-14, k
+        if o.map_num_outer() > 0:
+            s0 = o.map_solve(0)
+            assert np.abs(s0["q_in"] - qmul(q_mo, qw)).max() < 1e-15, k
+            assert np.abs(s0["t_in"] - (qrot(q_mo, tw) + t_mo)).max() < 1e-14, k
+        qm, tm, q_mo_new, t_mo_new = o.map_pose()
+        q_mo = qmul(qm, qinv(qw))
+        t_mo = tm - qrot(q_mo, tw)
+        assert np.abs(q_mo_new - q_mo).max() < 1e-14 and np.abs(t_mo_new - t_mo).max() < 1e-13, k
+
+
+def test_vo_bucket_fold_and_query_depth_vs_literal_python(orc, synth):
+    """Second, independent transcription of the depth-map half of the VO path: downsamplePointCloud's order-dependent
+    incremental fold (point_cloud_util.cpp:205-260: first point sets the bucket, later ones add (v - b) / count_before; the
+    float -> int truncation puts x in (-5, 0) into bucket 0) and queryDepth (:302-387: occupied buckets of the 5 x 5 block,
+    < 10 -> -1, distance through double pow / sqrt stored as float, three nearest, the weighted formula in f32 as written).
+    Bit-exact against the oracle's buckets and depths."""
+    f32 = np.float32
+    cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=1)
+    v = orc.VOOracle(cam_T_velo, rect0_T_cam, P)
+    v.reset(); v.process_point_cloud(seq.sweep(0))
+    p2 = v.points2d(0).astype(f32)
+    NW, NH = 249, 75  # ceil(1242 / 5), ceil(375 / 5)
+    bx, by, bd = np.zeros((NW, NH), f32), np.zeros((NW, NH), f32), np.zeros((NW, NH), f32)
+    bc = np.zeros((NW, NH), np.int32)
+    five = f32(5)
+    for x, y, z in p2:
+        ix, iy = int(x / five), int(y / five)  # static_cast<int>: truncation towards zero
+        if 0 <= ix < NW and 0 <= iy < NH:
+            if bc[ix, iy] == 0:
+                bx[ix, iy], by[ix, iy], bd[ix, iy] = x, y, z
+            else:
+                c = f32(bc[ix, iy])
+                bx[ix, iy] = bx[ix, iy] + (x - bx[ix, iy]) / c
+                by[ix, iy] = by[ix, iy] + (y - by[ix, iy]) / c
+                bd[ix, iy] = bd[ix, iy] + (z - bd[ix, iy]) / c
+            bc[ix, iy] += 1
+    ox, oy, od, oc = v.buckets(0)
+    assert np.array_equal(bc.ravel(), oc)
+    for mine, ref in ((bx, ox), (by, oy), (bd, od)):
+        assert np.array_equal(mine.ravel().view(np.uint32), ref.view(np.uint32))
+
+    def query(x, y, r=2):
+        x, y = f32(x), f32(y)
+        ix, iy = int(x / five), int(y / five)
+        nb = []
+        for a in range(ix - r, ix + r + 1):
+            for b in range(iy - r, iy + r + 1):
+                if 0 <= a < NW and 0 <= b < NH and bc[a, b] > 0:
+                    d = f32(np.sqrt(float(x - bx[a, b]) ** 2 + float(y - by[a, b]) ** 2))
+                    nb.append((d, len(nb), bd[a, b]))
+        if len(nb) < 10:
+            return f32(-1.0), False
+        nb.sort(key=lambda e: (e[0], e[1]))
+        tie = nb[0][0] == nb[1][0] or nb[1][0] == nb[2][0] or nb[2][0] == nb[3][0]  # std::sort leaves equal keys in any order
+        (d0, _, z0), (d1, _, z1), (d2, _, z2) = nb[:3]
+        num = (z0 * d1 * d2 + z1 * d0 * d2) + z2 * d0 * d1
+        den = ((f32(0.0001) + d1 * d2) + d0 * d2) + d0 * d1
+        return f32(num / den), tie
+
+    checked = 0
+    for qx in np.arange(3.0, 1240.0, 37.0):
+        for qy in np.arange(2.0, 374.0, 23.0):
+            want, tie = query(qx, qy)
+            if tie:
+                continue
+            got = f32(v.query_depth(0, float(qx), float(qy)))
+            assert got.view(np.uint32) == want.view(np.uint32), (qx, qy, got, want)
+            checked += 1
+    assert checked > 300 and v.query_depth(0, -500.0, -500.0) == -1.0
