@@ -360,6 +360,21 @@ def test_feature_picks_vs_literal_python_loops(orc, sweeps, rings, az):
     assert np.array_equal(np.array(flat, dtype=np.int32), o.sr_ints(7))
     assert np.array_equal(label, o.sr_ints(2)[:n])
     assert np.array_equal(picked[:n], o.sr_ints(1)[:n])
+    # surfPointsLessFlat (:424-439): per ring, every sector point that is not a corner, through VoxelGrid(0.2), rings appended
+    from test_oracle_math import numpy_voxel_grid
+    full = o.cloud(0)
+    parts = []
+    for r in range(rings):
+        if end[r] - start[r] < 6:
+            continue
+        ks = [k for k in range(start[r], end[r]) if label[k] <= 0]  # the six sectors tile [start, end - 1]
+        if ks:
+            parts.append(numpy_voxel_grid(full[ks], 0.2))
+    less_flat = np.concatenate(parts, axis=0)
+    assert less_flat.shape == o.cloud(4).shape and np.array_equal(less_flat.view(np.uint32), o.cloud(4).view(np.uint32))
+    assert np.array_equal(full[np.array(sharp)].view(np.uint32), o.cloud(1).view(np.uint32))
+    assert np.array_equal(full[np.array(less_sharp)].view(np.uint32), o.cloud(2).view(np.uint32))
+    assert np.array_equal(full[np.array(flat)].view(np.uint32), o.cloud(3).view(np.uint32))
 
 
 @pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512)])
