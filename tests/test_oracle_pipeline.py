@@ -676,3 +676,89 @@ def test_vo_bucket_fold_and_query_depth_vs_literal_python(orc, synth):
             assert got.view(np.uint32) == want.view(np.uint32), (qx, qy, got, want)
             checked += 1
     assert checked > 300 and v.query_depth(0, -500.0, -500.0) == -1.0
+
+
+def test_map_window_roll_vs_literal_python_replay(orc, synth):
+    """Replay of the whole map bookkeeping in Python across a 500 m drive (the 21 x 21 x 11 cube window has to roll):
+    centre cube from the initial guess with the `< 0` correction (laser_mapping.cpp:207-216), the six literal shift loops that
+    move the cube grid and clear the slab that wraps (:218-402), the 5 x 5 x 3 valid block in its loop order (:404-420),
+    insertion by truncated cube index (:639-683) and the re-VoxelGrid of the valid cubes (:689-702).  Poses and feature clouds
+    are taken from the oracle, the VoxelGrid primitive from orc.voxel_grid (pinned bit-exact elsewhere).  After EVERY sweep
+    the window position, the valid list, every cube this replay holds and the point totals must equal the oracle's."""
+    f32 = np.float32
+    W, H, D = 21, 21, 11
+    n = 175
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n, speed=30.0)
+    o = orc.Oracle(with_mapping=True)
+    grid = [dict(), dict()]  # (i, j, k) -> (N, 4) f32, corner / surf
+    cen = [10, 10, 5]        # laser_mapping.h:76-78
+    q_mo, t_mo = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    leaf = (0.4, 0.8)
+    rolled = 0
+
+    def qmul(a, b):
+        ax, ay, az, aw = a; bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                         aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+    def qrot(q, v):
+        uv = np.cross(q[:3], v); uv = uv + uv
+        return v + q[3] * uv + np.cross(q[:3], uv)
+
+    def cube_of(x, c):
+        i = int((x + 25.0) / 50.0) + c
+        return i - 1 if x + 25.0 < 0 else i
+
+    def shift(axis, up):
+        """One pass of a `while (centerCube < 3)` (up) / `>= size - 3` (down) loop: every cube moves one index along `axis`."""
+        size = (W, H, D)[axis]
+        for g in grid:
+            new = {}
+            for key, pts in g.items():
+                k2 = list(key)
+                k2[axis] += 1 if up else -1
+                if 0 <= k2[axis] < size:  # the cube that falls off is the one whose (cleared) cloud re-enters at the other end
+                    new[tuple(k2)] = pts
+            g.clear(); g.update(new)
+
+    for k in range(n):
+        assert o.process(seq.sweep(k)) == 0
+        qw, tw, _, _ = o.lo_pose()
+        t_guess = qrot(q_mo, tw) + t_mo
+        cc = [cube_of(float(t_guess[a]), cen[a]) for a in range(3)]
+        for a, size in enumerate((W, H, D)):
+            while cc[a] < 3:
+                shift(a, True); cc[a] += 1; cen[a] += 1; rolled += 1
+            while cc[a] >= size - 3:
+                shift(a, False); cc[a] -= 1; cen[a] -= 1; rolled += 1
+        valid = [i + W * j + W * H * kk for i in range(cc[0] - 2, cc[0] + 3) for j in range(cc[1] - 2, cc[1] + 3)
+                 for kk in range(cc[2] - 1, cc[2] + 2) if 0 <= i < W and 0 <= j < H and 0 <= kk < D]
+        info = o.map_info()
+        assert list(info["cen"]) == cen, k
+        assert list(info["valid"]) == valid, k
+        qm, tm, q_mo, t_mo = o.map_pose()
+        for which, cloud_id in ((0, 2), (1, 4)):
+            stack = orc.voxel_grid(o.cloud(cloud_id), leaf[which])
+            v = stack[:, :3].astype(np.float64)  # pointAssociateToMap for the whole stack (same expression per point)
+            uv = np.cross(qm[:3], v); uv = uv + uv
+            sel = (v + qm[3] * uv + np.cross(qm[:3], uv) + tm).astype(f32)
+            xs = sel.astype(np.float64) + 25.0
+            cube = np.trunc(xs / 50.0).astype(np.int64) + np.array(cen) - (xs < 0)  # int() truncation, then the `< 0` correction
+            inside = np.all((cube >= 0) & (cube < np.array([W, H, D])), axis=1)
+            rows = np.concatenate([sel, stack[:, 3:4]], axis=1).astype(f32)
+            lin = cube[:, 0] + W * cube[:, 1] + W * H * cube[:, 2]
+            for c in np.unique(lin[inside]):  # push_back order inside a cube == stack order
+                key = (int(c) % W, (int(c) // W) % H, int(c) // (W * H))
+                add = rows[inside & (lin == c)]
+                grid[which][key] = np.concatenate([grid[which][key], add]) if key in grid[which] else add
+            for idx in valid:
+                key = (idx % W, (idx // W) % H, idx // (W * H))
+                if key in grid[which] and grid[which][key].shape[0]:
+                    grid[which][key] = orc.voxel_grid(grid[which][key], leaf[which])
+            total = 0
+            for key, pts in grid[which].items():
+                got = o.map_cube(which, key[0] + W * key[1] + W * H * key[2])
+                assert got.shape == pts.shape and np.array_equal(got.view(np.uint32), pts.view(np.uint32)), (k, which, key)
+                total += pts.shape[0]
+            assert total == (info["total_corner"], info["total_surf"])[which], (k, which)
+    assert rolled >= 1, "the drive was too short to roll the window"
