@@ -762,3 +762,53 @@ def test_map_window_roll_vs_literal_python_replay(orc, synth):
                 total += pts.shape[0]
             assert total == (info["total_corner"], info["total_surf"])[which], (k, which)
     assert rolled >= 1, "the drive was too short to roll the window"
+
+
+def test_vo_objective_and_minimum_vs_numpy(orc, synth):
+    """Independent restatement of the VO residual stack (visual_odometry.cpp:283-416 match loop: integer pixels, outlier gate,
+    depth0 decides between CostFunctor32 and CostFunctor22, K^-1 observations; ceres_cost_function.h:54-96,147-185; HuberLoss(0.1)
+    per residual BLOCK) with numpy / scipy rotations: the oracle's counters, its initial and final cost must equal the numpy
+    objective at the same parameters (1e-5: the reference solves K x = v by an f32 QR, numpy by an f32 LU), and the oracle's
+    answer must be a stationary point of that independent objective."""
+    from scipy.spatial.transform import Rotation
+    cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=3)
+    o = orc.VOOracle(cam_T_velo, rect0_T_cam, P, remove_outlier=100)
+    for k in range(2):
+        o.reset()
+        o.process_point_cloud(seq.sweep(k))
+    prev_uv, curr_uv = synth.synth_matches(seq, 1)
+    r = o.solve(prev_uv, curr_uv, np.zeros(3), np.zeros(3))
+    K = np.asarray(P, dtype=np.float32)[:, :3]
+    X32, x32, X22, x22 = [], [], [], []
+    for (pu, pv), (cu, cv) in zip(prev_uv.astype(int), curr_uv.astype(int)):
+        if float(pu - cu) ** 2 + float(pv - cv) ** 2 > 100 * 100:
+            continue
+        d0 = np.float32(o.query_depth(1, float(pu), float(pv)))  # depth map of the PREVIOUS sweep (pinned bit-exact above)
+        b1 = np.linalg.solve(K, np.array([cu, cv, 1.0], dtype=np.float32)).astype(np.float64)
+        if d0 > 0:
+            a0 = np.linalg.solve(K, np.array([pu * d0, pv * d0, d0], dtype=np.float32)).astype(np.float64)
+            X32.append(a0); x32.append(b1[:2] / b1[2])
+        else:
+            a0 = np.linalg.solve(K, np.array([pu, pv, 1.0], dtype=np.float32)).astype(np.float64)
+            X22.append(np.array([a0[0] / a0[2], a0[1] / a0[2], 1.0])); x22.append(np.array([b1[0] / b1[2], b1[1] / b1[2], 1.0]))
+    assert (len(X32), len(X22)) == (r["counter32"], r["counter22"]) and len(X32) > 200 and len(X22) > 0
+    X32, x32, X22, x22 = map(np.array, (X32, x32, X22, x22))
+
+    def rho(s, a=0.1):  # ceres::HuberLoss
+        return np.where(s <= a * a, s, 2 * a * np.sqrt(np.maximum(s, 1e-300)) - a * a)
+
+    def cost(x):
+        R = Rotation.from_rotvec(x[:3])
+        Y = R.apply(X32) + x[3:]
+        r32 = np.stack([Y[:, 0] - Y[:, 2] * x32[:, 0], Y[:, 1] - Y[:, 2] * x32[:, 1]], axis=1)
+        r22 = np.einsum("ij,ij->i", x22, np.cross(x[3:], R.apply(X22)))
+        return 0.5 * (rho((r32 * r32).sum(axis=1)).sum() + rho(r22 * r22).sum())
+
+    x_fin = np.concatenate([r["angles"], r["t"]])
+    assert abs(cost(np.zeros(6)) - r["initial_cost"]) < 1e-5 * r["initial_cost"]
+    assert abs(cost(x_fin) - r["final_cost"]) < 1e-5 * max(r["final_cost"], 1e-12)
+    h = 1e-6
+    grad = lambda x: np.array([(cost(x + h * e) - cost(x - h * e)) / (2 * h) for e in np.eye(6)])
+    assert np.linalg.norm(grad(x_fin)) < 1e-3 * np.linalg.norm(grad(np.zeros(6)))
+    assert r["final_cost"] < 0.5 * r["initial_cost"]
