@@ -557,6 +557,9 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   }
   __syncthreads();
   if constexpr (NB > 1) {
+    // Ordering: the kAcc publishing lanes all sit in wavefront 0, the wavefront of thread 0, so the RELEASE of thread 0's
+    // fetch_add (which waits for that wavefront's outstanding stores) covers every partial sum before the counter moves.
+    static_assert(kAcc <= 64, "the publishers must share thread 0's wavefront");
     if (tid == 0) {  // grid barrier number eval_idx + 1 of this solve (the counter starts every solve at zero)
       unsigned* bar = reinterpret_cast<unsigned*>(F.gsync);
       __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
