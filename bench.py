@@ -4,7 +4,12 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched through
 ``python -m torch.distributed.run --nproc-per-node N …`` (one rank per GPU, RCCL).  A *step* is one
 sweep (64 rings x 2048 azimuth steps = 131 072 points) through the façade
-reset -> scanRegistration -> laserOdometry [-> laserMapping] on inputs already resident in HBM.
+reset -> scanRegistration -> laserOdometry -> laserMapping (lidar_odometry_mapping.cpp:73-154) on inputs
+already resident in HBM.  The default workload is BASELINE.json's configs[2] — the configuration the metric
+("scans/s END-TO-END odometry", SURVEY.md §8d: SR -> LO -> laserMapping) is quoted on: before the W warm-up
+steps the sequence's first ``--map-warmup`` (200) sweeps are streamed through the same handle, untimed, so
+that the voxel-hash local map is at its steady-state size ("~200 scans") when the K timed sweeps run.
+``--workload lo`` is configs[1] (no mapping); the default run reports it as the extra leg ``configs1``.
 Rank r drives its own independent sequence (different scene / trajectory / noise seeds): the path
 shards one-sequence-per-GPU with no data-path collective; the only collective is an
 all-gather of the trajectories after the timed region.  Rank 0 prints ONE JSON line.
@@ -14,14 +19,16 @@ The CPU oracle (oracle/) is used only for the ``cpu_baseline`` leg and the parit
 inside the timed region.
 """
 import argparse
+import glob
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
 
-# Two pipelined sessions own 2 x 3 HIP streams; with the runtime's default of 4 hardware queues their stage streams share
-# queues and serialise behind each other (multi-session leg: 1.0x instead of 1.75x).  Must be set before the HIP runtime loads;
-# the single-session headline value does not depend on it (measured: 6 74x-6 79x scans/s either way).
+# Several pipelined sessions own 3 HIP streams each; with the runtime's default of 4 hardware queues their stage streams share
+# queues and serialise behind each other.  Must be set before the HIP runtime loads; the single-session headline value does
+# not depend on it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -34,7 +41,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 
 WORKLOADS = {
     "lo": "configs[1]: scanRegistration + scan-to-scan laserOdometry ICP, synthetic HDL-64E 64x2048",
-    "map": "configs[2]: scanRegistration + laserOdometry + laserMapping scan-to-map ICP (voxel-hash local map), synthetic HDL-64E 64x2048",
+    "map": "configs[2]: scanRegistration + laserOdometry + laserMapping scan-to-map ICP (voxel-hash local map, ~200 scans), synthetic HDL-64E 64x2048",
+}
+
+# the reference's per-substage timers -> the kernels that do that work here
+REFERENCE_TIMERS = {
+    "scan registration: prepare + sort q time + seperate points (scan_registration.cpp:285,430-432)":
+        ["k_sr_first_last", "k_sr_label", "k_sr_scatter", "k_sr_ring", "k_sr_compact"],
+    "laser odometry: data association (laser_odometry.cpp:453)": ["k_lo_assoc"],
+    "laser odometry / mapping: solver time (laser_odometry.cpp:465, laser_mapping.cpp:618)": ["k_lm_compact", "k_lm_solve"],
+    "laser odometry: build tree -> NN grids (laser_odometry.cpp:525-526)": ["k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter"],
+    "laser mapping: filter time (laser_mapping.cpp:432-446)": ["k_map_ds_count", "k_map_ds_rank", "k_map_ds_scatter", "k_map_ds_reduce"],
+    "laser mapping: shift + build tree (laser_mapping.cpp:422,453) -> none needed: persistent voxel hash": ["k_map_prepare"],
+    "laser mapping: mapping data assosiation (laser_mapping.cpp:606)": ["k_map_assoc", "k_map_fit"],
+    "laser mapping: add points + filter (laser_mapping.cpp:686,705)": ["k_map_insert", "k_map_finalize"],
 }
 
 
@@ -42,30 +62,51 @@ def algorithmic_bytes(kernel, c):
     """ALGORITHMIC (compulsory) bytes one launch of `kernel` moves, from the measured counts of the run."""
     n_feat = c["n_sharp"] + c["n_flat"]
     F = c["F_corner"] + c["F_plane"]
+    nn = c["n_c"] + c["n_s"]
+    n_less = c["n_lessSharp"] + c["n_lessFlat"]
     if kernel == "k_lo_assoc":  # features + both candidate clouds read once, one 76-byte factor record written per factor
         return 16 * n_feat + 16 * (c["C"] + c["S"]) + 76 * F
     if kernel == "k_lm_solve":  # every evaluation consumes the factor records (76 B each); average over the solves of a sweep
         if c["K_m"] > 0:  # 2 odometry + 2 mapping solves per sweep
             return 76 * (F * c["E_o"] + c["K_m"] * c["E_m"]) / 4.0
         return 76 * F * max(c["E_o"], 2) / 2.0
+    if kernel == "k_lm_compact":
+        return 2 * 76 * c["K_m"]
     if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
         return 16 * c["N2"] + 16 * c["n_lessFlat"] + 4 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"])
-    if kernel in ("k_sr_label",):
+    if kernel == "k_sr_first_last":
+        return 16 * c["N_in"]
+    if kernel == "k_sr_label":
         return 16 * c["N_in"] + 5 * c["N_in"]
-    if kernel in ("k_sr_scatter",):
+    if kernel == "k_sr_scatter":
         return 16 * c["N_in"] + 5 * c["N_in"] + 16 * c["N2"]
     if kernel == "k_sr_compact":
         return 32 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"] + c["n_lessFlat"])
-    if kernel == "k_map_assoc":
-        return (c["n_c"] + c["n_s"]) * (16 + 5 * 16) + 76 * c["K_m"]
+    if kernel in ("k_lo_grid_count", "k_lo_grid_scatter"):  # the two less-clouds in; scatter also writes the bucket-ordered copies (2 levels)
+        return 16 * n_less + (2 * 16 * n_less if kernel == "k_lo_grid_scatter" else 0)
+    if kernel in ("k_map_ds_count", "k_map_ds_scatter"):
+        return 16 * n_less + 4 * n_less
+    if kernel == "k_map_ds_reduce":
+        return 16 * n_less + 16 * nn
+    if kernel == "k_map_assoc":   # stack point in, 5 neighbour voxels (32-byte records) looked at, 5 slot ids out
+        return nn * (16 + 5 * 32 + 20)
+    if kernel == "k_map_fit":     # 5 neighbours in, one 76-byte factor record out
+        return nn * (16 + 5 * 32) + 76 * c["K_m"]
+    if kernel == "k_map_insert":  # stack point in, map-frame point out, one voxel record touched
+        return nn * (16 + 16 + 32)
+    if kernel == "k_map_finalize":
+        return nn * (16 + 2 * 32)
     return 0
 
 
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_summary.py wrote the table).
-    A PMC pass cannot run inside this process, so the number is read from profiles/ — None when the table is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_hbm_traffic.txt" % workload)
+    A PMC pass cannot run inside this process, so the number is read from profiles/ (latest round) — None when missing."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_hbm_traffic.txt" % workload)))
+    if not cands:
+        return None, None
+    path = cands[-1]
     tot, cnt = 0.0, 0
     try:
         for line in open(path):
@@ -78,7 +119,7 @@ def pmc_traffic(workload, kernel):
         return None, None
     if cnt == 0:
         return None, None
-    return tot / cnt, os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    return tot / cnt, os.path.relpath(path, ROOT)
 
 
 def sweep_bytes(c, with_mapping):
@@ -94,22 +135,76 @@ def sweep_bytes(c, with_mapping):
     return b_sr, b_lo, b_map
 
 
+# ---------------------------------------------------------------------------------------------------- host-side helpers
+_SEQ = None
+
+
+def _sweep_worker(k):
+    return _SEQ.sweep(k)
+
+
+def make_sweeps(synth, n_total, rings, azimuth, seeds, procs):
+    """The synthetic sequence's first n_total sweeps, ray-cast in parallel worker processes (forked BEFORE the HIP runtime loads)."""
+    global _SEQ
+    _SEQ = synth.SynthSequence(n_rings=rings, n_azimuth=azimuth, n_sweeps=n_total, **seeds)
+    if procs > 1:
+        with mp.get_context("fork").Pool(procs) as pool:
+            out = pool.map(_sweep_worker, range(n_total), chunksize=4)
+    else:
+        out = [_SEQ.sweep(k) for k in range(n_total)]
+    return _SEQ, np.stack(out)
+
+
+def _oracle_worker(args):
+    """One CPU-oracle session over sweeps [0, n) in its own process (the "N sequences on N cores" figure)."""
+    rings, with_mapping, n, path = args
+    import orc
+    host = np.load(path, mmap_mode="r")
+    o = orc.Oracle(scan_line=rings, with_mapping=with_mapping)
+    t0 = time.perf_counter()
+    for k in range(n):
+        o.process(np.asarray(host[k]))
+    return time.perf_counter() - t0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pose_err(row, q_lo, t_lo, q_map, t_map, with_mapping):
+    dt = float(np.linalg.norm(row[4:7] - t_lo))
+    dq = float(min(np.linalg.norm(row[0:4] - q_lo), np.linalg.norm(row[0:4] + q_lo)))
+    if with_mapping:
+        dt = max(dt, float(np.linalg.norm(row[11:14] - t_map)))
+        dq = max(dq, float(min(np.linalg.norm(row[7:11] - q_map), np.linalg.norm(row[7:11] + q_map))))
+    return dt, dq
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("VLOAM_BENCH_WORKLOAD", "lo"))
-    ap.add_argument("--kernel", default=os.environ.get("VLOAM_BENCH_KERNEL", ""), help="kernel to bracket with HIP events (default: the dominant one)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("VLOAM_BENCH_WORKLOAD", "map"))
+    ap.add_argument("--map-warmup", type=int, default=int(os.environ.get("VLOAM_BENCH_MAP_WARMUP", "200")),
+                    help="configs[2]: sweeps streamed (untimed) before the warm-up steps so that the local map is at steady state")
+    ap.add_argument("--kernel", default=os.environ.get("VLOAM_BENCH_KERNEL", ""), help="kernel the roofline object is computed for (default: the one with the largest share of GPU time in this run)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--azimuth", type=int, default=2048)
-    ap.add_argument("--cpu-sample", type=int, default=48, help="sweeps of the same sequence timed on the CPU oracle (rank 0, N=1)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the cpu_baseline leg (whole passes over the sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the HIP-event bracketing of the roofline kernel (for profiler runs)")
+    ap.add_argument("--cpu-cores-leg", type=int, default=24, help="sweeps per process of the 'N sequences on N cores' CPU figure (0 = skip)")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the HIP-event replay (per-kernel table + roofline kernel; for profiler runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (latency, configs[1], multi-session, VO stage)")
     ap.add_argument("--vo-frames", type=int, default=8, help="extra leg: frames of the VO residual stack to time (0 = skip)")
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "2")),
-                    help="extra leg: this many independent sequences driven concurrently on ONE GPU (own handle + stream each); 0 = skip")
+                    help="extra leg: this many independent sequences driven concurrently on ONE GPU (own handle + streams each); 0 = skip")
+    ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,14 +212,42 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     K, W = args.steps, args.warmup
     with_mapping = args.workload == "map"
+    M0 = max(args.map_warmup, 0) if with_mapping else 0
+    T = M0 + W + K
 
-    import torch
+    # ---- synthetic input first (forks worker processes: must happen before torch / the HIP runtime are loaded)
     import conftest
+    import importlib
     vl = conftest.load_pkg()
     synth = conftest.load_synth()
-    import importlib
     multi = importlib.import_module("vloam_amd.multi")
+    cores = os.cpu_count() or 1
+    procs = args.synth_procs or max(1, min(cores // max(world, 1), 16))
+    g0 = time.perf_counter()
+    seq, host = make_sweeps(synth, T, args.rings, args.azimuth, multi.rank_sequence_seeds(rank), procs)
+    synth_s = time.perf_counter() - g0
+    n_pts = host.shape[1]
 
+    # the "N sequences on N cores" CPU leg also forks: run it now, before HIP exists in this process
+    cpu_cores_leg = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_cores_leg > 0 and cores > 1:
+        import tempfile
+        import orc
+        orc.build()  # once, in the parent (the workers only dlopen it)
+        nproc = min(cores, 64)
+        ns = min(args.cpu_cores_leg, T)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sweeps.npy")
+            np.save(path, host[:ns])
+            c0 = time.perf_counter()
+            with mp.get_context("fork").Pool(nproc) as pool:
+                per = pool.map(_oracle_worker, [(args.rings, with_mapping, ns, path)] * nproc)
+            c1 = time.perf_counter()
+        cpu_cores_leg = {"processes": nproc, "value": nproc * ns / (c1 - c0), "unit": "scans/s",
+                         "per_process_scans_per_s": ns / (sum(per) / len(per)),
+                         "sample": "%d independent oracle sessions (one per host core) x the first %d sweeps, %.1f s wall" % (nproc, ns, c1 - c0)}
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()  # identity on a full node; lets the gloo path share one GPU in tests
@@ -138,32 +261,31 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-
     coll_dev = "cuda" if os.environ.get("VLOAM_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
-    # ---- synthetic input, one independent sequence per rank, resident in HBM before the timed region
-    seq = synth.SynthSequence(n_rings=args.rings, n_azimuth=args.azimuth, n_sweeps=W + K, **multi.rank_sequence_seeds(rank))
-    host = np.stack([seq.sweep(k) for k in range(W + K)])
-    n_pts = host.shape[1]
+
+    # ---- one independent sequence per rank, resident in HBM before the timed region
     d_clouds = torch.from_numpy(host).to(torch.device("cuda", local_rank))
     base_ptr, stride = d_clouds.data_ptr(), n_pts * 16
 
-    h = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
-    # the kernel with the largest share of GPU time in the committed rocprofv3 summaries (profiles/r01_{lo,map}_kernel_stats.txt)
-    kernel = args.kernel or ("k_lm_solve" if with_mapping else "k_sr_ring")
+    def new_handle(mapping=with_mapping, frames=T + 8):
+        return vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(mapping), max_points=max(n_pts, 1024), max_frames=frames)
+
+    def stream(hh, lo, hi):
+        for kk in range(lo, hi):
+            hh.process_scan_device(base_ptr + kk * stride, n_pts)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for k in range(W):
-        h.process_scan_device(base_ptr + k * stride, n_pts)
+    h = new_handle()
+    stream(h, 0, M0 + W)   # map warm-up (configs[2]) + the W warm-up steps, untimed
     h.sync()
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(W, W + K):
-        h.process_scan_device(base_ptr + k * stride, n_pts)
+    stream(h, M0 + W, T)
     h.sync()
     torch.cuda.synchronize()
     barrier()
@@ -174,47 +296,60 @@ def main():
         elapsed = multi.max_over_ranks(dist, elapsed, device=coll_dev)
     counts = h.counts()
     traj = h.trajectory()
+    h.close()
 
-    # ---- roofline leg: the dominant kernel's launch duration, HIP events on the kernel's own stream.  A separate replay of
-    # the same K sweeps on a fresh session, so that the event records (marker packets around every launch of that kernel)
-    # do not sit in the timed region above.
-    hk = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
-    for k in range(W):
-        hk.process_scan_device(base_ptr + k * stride, n_pts)
-    hk.sync()
+    # ---- per-kernel leg: every kernel's launch duration, HIP events on the kernel's own stream.  A separate replay of the same
+    # sweeps on a fresh session, so that the event records (marker packets around every launch) do not sit in the timed region.
+    ktable = {}
     if not args.no_kernel_timer:
-        hk.profile_kernel(kernel, 8 * K + 16)
-    for k in range(W, W + K):
-        hk.process_scan_device(base_ptr + k * stride, n_pts)
-    hk.sync()
-    k_ms, k_launches = hk.profile_read() if not args.no_kernel_timer else (0.0, 0)
-    hk.close()
+        hk = new_handle()
+        stream(hk, 0, M0 + W)
+        hk.sync()
+        hk.profile_kernel("*", 48 * K + 64)
+        stream(hk, M0 + W, T)
+        hk.sync()
+        ktable = hk.profile_table()
+        hk.close()
 
     # the one collective of the path: gather the per-sequence trajectories
     trajectories = [traj]
     if dist is not None:
-        trajectories = multi.gather_trajectories(dist, traj, W + K + 8, device=coll_dev)
+        trajectories = multi.gather_trajectories(dist, traj, T + 8, device=coll_dev)
 
-    # ---- extra leg (reported separately, never the headline): multi-session throughput of one GPU.  A single sequence is a
-    # chain of dependent launches (latency bound); independent sessions on separate streams overlap those latencies.
+    extras = world == 1 and not args.no_extras
+    # ---- extra leg: configs[1] (no mapping) on the same K sweeps
+    configs1 = None
+    if extras and with_mapping:
+        h1 = new_handle(mapping=False)
+        stream(h1, M0, M0 + W)
+        h1.sync()
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        stream(h1, M0 + W, T)
+        h1.sync()
+        torch.cuda.synchronize()
+        a1 = time.perf_counter()
+        configs1 = {"workload": WORKLOADS["lo"], "value": K / (a1 - a0), "unit": "scans/s", "ms_per_step": 1e3 * (a1 - a0) / K}
+        h1.close()
+
+    # ---- extra leg (never the headline): multi-session throughput of one GPU.  A single sequence is a chain of dependent
+    # launches (latency bound); independent sessions on separate streams overlap those latencies.
     multi_session = None
-    if args.sessions > 1 and world == 1:
+    if extras and args.sessions > 1:
         import threading
         B = args.sessions
-        hs = [vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + K + 8)
-              for _ in range(B)]
+        hs = [new_handle() for _ in range(B)]
 
         def drive(hh, lo, hi):
-            for kk in range(lo, hi):
-                hh.process_scan_device(base_ptr + kk * stride, n_pts)
+            stream(hh, lo, hi)
             hh.sync()
 
-        ths = [threading.Thread(target=drive, args=(hh, 0, W)) for hh in hs]
+        ths = [threading.Thread(target=drive, args=(hh, 0, M0 + W)) for hh in hs]
         [t.start() for t in ths]
         [t.join() for t in ths]
         torch.cuda.synchronize()
         m0 = time.perf_counter()
-        ths = [threading.Thread(target=drive, args=(hh, W, W + K)) for hh in hs]
+        ths = [threading.Thread(target=drive, args=(hh, M0 + W, T)) for hh in hs]
         [t.start() for t in ths]
         [t.join() for t in ths]
         torch.cuda.synchronize()
@@ -222,23 +357,21 @@ def main():
         same = all(np.array_equal(hh.trajectory(), traj) for hh in hs)
         multi_session = {"sessions": B, "value": B * K / (m1 - m0), "unit": "scans/s", "ms_per_step_all_sessions": 1e3 * (m1 - m0) / K,
                          "trajectories_identical_to_single_session": bool(same),
-                         "note": "B independent handles (3 streams each, one host thread each) on one GPU replaying the same sweeps; one pipelined session "
-                                 "already keeps the launch path busy; beyond ~1.8x the sessions are host-launch bound (all launches of one process go "
-                                 "through the runtime's queue locks); GPU_MAX_HW_QUEUES=" + os.environ.get("GPU_MAX_HW_QUEUES", "") + "; not the headline value"}
+                         "note": "B independent handles (3 streams each, one host thread each) on one GPU replaying the same sweeps; "
+                                 "GPU_MAX_HW_QUEUES=" + os.environ.get("GPU_MAX_HW_QUEUES", "") + "; not the headline value"}
         for hh in hs:
             hh.close()
 
-    # ---- extra: latency of ONE sweep (enqueue + drain, nothing in flight), on a fresh session.  The headline value streams the
-    # sequence: the three stage streams overlap consecutive sweeps, so 1 / value is a throughput period, not a latency.
+    # ---- extra: latency of ONE sweep (enqueue + drain, nothing in flight).  The headline value streams the sequence: the three
+    # stage streams overlap consecutive sweeps, so 1 / value is a throughput period, not a latency.
     latency = None
-    if world == 1:
-        hl = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=W + 40)
-        for k in range(W):
-            hl.process_scan_device(base_ptr + k * stride, n_pts)
+    if extras:
+        hl = new_handle()
+        stream(hl, 0, M0 + W)
         hl.sync()
         L = min(32, K)
         l0 = time.perf_counter()
-        for k in range(W, W + L):
+        for k in range(M0 + W, M0 + W + L):
             hl.process_scan_device(base_ptr + k * stride, n_pts)
             hl.sync()
         l1 = time.perf_counter()
@@ -246,13 +379,12 @@ def main():
                    "note": "one sweep at a time (vloam_sync after each): no overlap between consecutive sweeps"}
         hl.close()
 
-    # ---- extra: the depth-enhanced VO residual stack (configs[3]'s GPU part) on synthetic matches, host-synchronous API
-    # (cloud and matches come from host memory, the solved motion goes back): vloam_vo_process_point_cloud + vloam_vo_solve
+    # ---- extra: the depth-enhanced VO residual stack (configs[3]'s GPU part) on synthetic matches
     vo_stage = None
-    if world == 1 and args.vo_frames > 0:
-        hv = vl.Handle(local_rank, scan_line=args.rings, with_mapping=0, max_points=max(n_pts, 1024))
+    if extras and args.vo_frames > 0:
+        hv = new_handle(mapping=False, frames=64)
         hv.vo_set_calib(*synth.kitti_like_calib())
-        nf = min(args.vo_frames, W + K - 1)
+        nf = min(args.vo_frames, T - 1)
         ms_ = [synth.synth_matches(seq, k) for k in range(1, nf + 1)]
         hv.vo_process_point_cloud(host[0])
         v0 = time.perf_counter()
@@ -261,15 +393,24 @@ def main():
             hv.vo_solve(ms_[k - 1][0], ms_[k - 1][1], np.zeros(3), np.zeros(3))
         v1 = time.perf_counter()
         vo_stage = {"ms_per_frame": 1e3 * (v1 - v0) / nf, "frames": nf, "matches": int(ms_[0][0].shape[0]),
-                    "note": "projection + 5-px bucket depth map + 3-NN depth lookup + K^-1 QR + <=100-iteration LM, incl. the 2 MB H2D copy"}
+                    "note": "projection + 5-px bucket depth map + 3-NN depth lookup + K^-1 QR + <=100-iteration LM, host-synchronous API incl. the 2 MB H2D copy"}
         hv.close()
 
-    out = None
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)
-        assert len(trajectories) == world and all(t.shape == (W + K, 14) for t in trajectories)
+        assert len(trajectories) == world and all(t.shape == (T, 14) for t in trajectories)
         b_sr, b_lo, b_map = sweep_bytes(counts, with_mapping)
+        # per-kernel table of the replay; the roofline object is the kernel with the largest share of GPU time
+        tot_ms = sum(v[0] for v in ktable.values()) or 1.0
+        kernels = {}
+        for name, (ms, n) in sorted(ktable.items(), key=lambda kv: -kv[1][0]):
+            kb = algorithmic_bytes(name, counts)
+            avg_us = 1e3 * ms / n
+            kernels[name] = {"launches_per_sweep": round(n / K, 2), "avg_us": round(avg_us, 2), "share_of_gpu_time": round(ms / tot_ms, 4),
+                             "algorithmic_bytes": int(kb), "achieved_GBs": round(kb / (avg_us * 1e-6) / 1e9, 2) if avg_us > 0 else 0.0}
+        kernel = args.kernel or (next(iter(kernels)) if kernels else ("k_lm_solve" if with_mapping else "k_sr_ring"))
         kb = algorithmic_bytes(kernel, counts)
+        k_ms, k_launches = ktable.get(kernel, (0.0, 0))
         avg_ms = k_ms / max(k_launches, 1)
         traffic, traffic_src = pmc_traffic(args.workload, kernel)
         achieved = kb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -278,7 +419,9 @@ def main():
             "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 points / f64 poses+residuals", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "points_per_sweep": int(n_pts), "sequences": world,
-                       "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run"},
+                       "map_warmup_sweeps": M0, "map_points_at_last_sweep": counts["M"],
+                       "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run",
+                       "pipelining": "SR / LO / mapping of consecutive sweeps overlap on three HIP streams (one sequence, one GPU)"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": kb,
@@ -286,49 +429,53 @@ def main():
                          "sweep_algorithmic_bytes": {"B_SR": b_sr, "B_LO": b_lo, "B_MAP": b_map},
                          "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
             "counts_last_sweep": counts,
+            "kernels": kernels,
+            "reference_timers": {name: round(sum(1e3 * ktable[k][0] for k in ks if k in ktable) / K, 2) for name, ks in REFERENCE_TIMERS.items()
+                                 if any(k in ktable for k in ks)},
+            "host": {"cpu": cpu_model(), "cores": cores, "synth_seconds": round(synth_s, 2), "synth_processes": procs},
         }
-        out["config"]["pipelining"] = "SR / LO / mapping of consecutive sweeps overlap on three HIP streams (one sequence, one GPU)"
         if latency:
             out["latency"] = latency
+        if configs1:
+            out["configs1"] = configs1
         if vo_stage:
             out["vo_stage"] = vo_stage
         if multi_session:
             out["multi_session"] = multi_session
         if world == 1 and not args.no_cpu_baseline:
+            # ONE pass of the CPU oracle over the very same T sweeps (it has to start at sweep 0: the map is part of the state):
+            # cpu_baseline = its rate over the sweeps the GPU's warm-up + timed region covered (same map state), and the per-frame
+            # poses of the whole pass are the parity reference for EVERY frame up to the last timed sweep.
             import orc
-            ns = min(args.cpu_sample, W + K)
-            done, c0 = 0, time.perf_counter()
-            while True:  # whole passes over the first ns sweeps (fresh oracle session each) until ~10 s of CPU work are on the clock
-                o = orc.Oracle(scan_line=args.rings, with_mapping=with_mapping)
-                for k in range(ns):
-                    o.process(host[k])
-                done += ns
-                if time.perf_counter() - c0 >= args.cpu_seconds:
-                    break
-            c1 = time.perf_counter()
-            out["cpu_baseline"] = {"value": done / (c1 - c0), "unit": "scans/s", "cores": 1, "kind": "port",
-                                   "sample": "%d sweeps (%d passes over the first %d sweeps of the same synthetic sequence, %.1f s) through "
-                                             "the CPU oracle (restated reference path, single thread like the reference)"
-                                             % (done, done // ns, ns, c1 - c0)}
-            # parity of the sample: re-run the same sweeps on a fresh handle and compare poses frame by frame
-            hp = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024))
+            o = orc.Oracle(scan_line=args.rings, with_mapping=with_mapping)
             dt_max = dq_max = 0.0
-            np_ = min(ns, 12)
-            for k in range(np_):
-                hp.process_scan(host[k])
-            hp.sync()
-            tj = hp.trajectory()
-            o3 = orc.Oracle(scan_line=args.rings, with_mapping=with_mapping)
-            for k in range(np_):
-                o3.process(host[k])
-                qw, tw, _, _ = o3.lo_pose()
-                dt_max = max(dt_max, float(np.linalg.norm(tj[k, 4:7] - tw)))
-                dq_max = max(dq_max, float(min(np.linalg.norm(tj[k, 0:4] - qw), np.linalg.norm(tj[k, 0:4] + qw))))
-                if with_mapping:
-                    qm, tm, _, _ = o3.map_pose()
-                    dt_max = max(dt_max, float(np.linalg.norm(tj[k, 11:14] - tm)))
-                    dq_max = max(dq_max, float(min(np.linalg.norm(tj[k, 7:11] - qm), np.linalg.norm(tj[k, 7:11] + qm))))
-            out["parity_vs_oracle"] = {"frames": np_, "max_abs_dt_m": dt_max, "max_abs_dq": dq_max, "bar": 1e-4}
+            worst = 0
+            stamps = [time.perf_counter()]
+            st_ms = np.zeros(3)
+            for k in range(T):
+                o.process(host[k])
+                stamps.append(time.perf_counter())
+                if k >= M0:
+                    st_ms += o.stage_ms()
+                qw, tw, _, _ = o.lo_pose()
+                qm, tm = o.map_published_pose() if with_mapping else (qw, tw)
+                dt, dq = pose_err(traj[k], qw, tw, qm, tm, with_mapping)
+                if dt > dt_max:
+                    worst = k
+                dt_max, dq_max = max(dt_max, dt), max(dq_max, dq)
+            # (the pose read-outs above sit between two stamps; they are microseconds against ~50 ms per sweep)
+            steady = stamps[T] - stamps[M0]
+            out["cpu_baseline"] = {"value": (T - M0) / steady, "unit": "scans/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                                   "whole_pass_scans_per_s": T / (stamps[T] - stamps[0]),
+                                   "stage_ms_per_sweep": {"scanRegistration": st_ms[0] / (T - M0), "laserOdometry": st_ms[1] / (T - M0), "laserMapping": st_ms[2] / (T - M0)},
+                                   "sample": "sweeps %d..%d (%.1f s) of one %d-sweep pass (%.1f s) of the CPU oracle over the same synthetic sequence "
+                                             "(restated reference path — NOT the original Ceres/PCL binary, which cannot be built here; single thread like the reference)"
+                                             % (M0, T - 1, steady, T, stamps[T] - stamps[0])}
+            if cpu_cores_leg:
+                out["cpu_baseline"]["n_sequences_on_n_cores"] = cpu_cores_leg
+            out["parity_vs_oracle"] = {"frames": T, "last_frame_checked": T - 1, "covers_timed_region": True, "max_abs_dt_m": dt_max,
+                                       "max_abs_dq": dq_max, "worst_frame": worst, "bar": 1e-4,
+                                       "poses": "laser-odometry world pose + mapping pose of every frame, HIP trajectory of the timed session vs the oracle"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

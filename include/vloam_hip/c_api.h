@@ -140,6 +140,14 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
  * vloam_profile_read returns the summed milliseconds and launch count since the last read. */
 vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_launches);
 vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches);
+/* name "*" brackets every launch of every kernel; vloam_profile_read_table then returns the per-kernel sums, ms[k] / launches[k]
+ * for kernel id k < n_kernels (ids 0..vloam_profile_kernel_count()-1, symbol names through vloam_profile_kernel_name).  This is
+ * also where the reference's per-substage timers map to ("sort q time" / "seperate points" -> k_sr_ring,
+ * "data association" -> k_lo_assoc / k_map_assoc + k_map_fit, "solver time" -> k_lm_compact + k_lm_solve,
+ * "build tree" -> k_lo_grid_*, "filter time" -> k_map_ds_*, "add points" -> k_map_insert + k_map_finalize). */
+vloam_status vloam_profile_read_table(vloam_handle* h, int n_kernels, double* ms, int* launches);
+int vloam_profile_kernel_count(void);
+const char* vloam_profile_kernel_name(int k);
 
 /* Timing of the last vloam_sync()ed scans: HIP-event milliseconds accumulated per stage
  * {scanRegistration, laserOdometry, laserMapping, vo} and number of scans covered. */

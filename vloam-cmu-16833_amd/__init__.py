@@ -184,6 +184,15 @@ class Handle:
         self._chk(self.L.vloam_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_table(self):
+        """{kernel symbol: (total ms, launches)} of the launches recorded since profile_kernel("*", n)."""
+        self.L.vloam_profile_kernel_name.restype = C.c_char_p
+        nk = self.L.vloam_profile_kernel_count()
+        ms = np.zeros(nk)
+        cnt = np.zeros(nk, dtype=np.int32)
+        self._chk(self.L.vloam_profile_read_table(self.h, nk, _fp(ms), _fp(cnt)))
+        return {self.L.vloam_profile_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(1, nk) if cnt[k] > 0}
+
     def stage_ms(self):
         ms = np.zeros(4)
         n = C.c_int(0)

@@ -82,6 +82,7 @@ struct vloam_handle {
   int last_n_in = 0;
   ProfHook prof;
   std::vector<hipEvent_t> prof_events;
+  std::vector<int> prof_kids;
 };
 
 template <class T>
@@ -646,13 +647,16 @@ vloam_status vloam_profile_kernel(vloam_handle* h, const char* name, int max_lau
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   int id = kKNone;
   for (int k = 1; k < kKCount; k++) if (strcmp(name, kKernelNames[k]) == 0) id = k;
+  if (strcmp(name, "*") == 0) id = kKAll;  // every launch of every kernel (vloam_profile_read_table)
   if (id == kKNone && name[0] != 0) { set_err("unknown kernel %s", name); return VLOAM_ERR_INVALID; }
   while ((int)h->prof_events.size() < 2 * max_launches) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
     h->prof_events.push_back(e);
   }
+  h->prof_kids.assign((size_t)max_launches + 1, 0);
   h->prof.id = id;
+  h->prof.kid_of = h->prof_kids.data();
   h->prof.ev = h->prof_events.data();
   h->prof.cap = max_launches;
   h->prof.used = 0;
@@ -673,6 +677,25 @@ vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches
   h->prof.used = 0;
   return VLOAM_OK;
 }
+
+// Per-kernel totals of the recorded launches (all-kernel mode "*", or the one selected kernel): ms[k], launches[k] for kernel id k
+// < n_kernels; names through vloam_profile_kernel_name.  Resets the recorder like vloam_profile_read.
+vloam_status vloam_profile_read_table(vloam_handle* h, int n_kernels, double* ms, int* launches) {
+  if (!h || !ms || !launches || n_kernels < 0) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  for (int k = 0; k < n_kernels; k++) { ms[k] = 0; launches[k] = 0; }
+  for (int k = 0; k < h->prof.used; k++) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, h->prof.ev[2 * k], h->prof.ev[2 * k + 1]));
+    const int kid = h->prof.kid_of[k];
+    if (kid >= 0 && kid < n_kernels) { ms[kid] += t; launches[kid]++; }
+  }
+  h->prof.used = 0;
+  return VLOAM_OK;
+}
+int vloam_profile_kernel_count(void) { return kKCount; }
+const char* vloam_profile_kernel_name(int k) { return (k >= 0 && k < kKCount) ? kKernelNames[k] : ""; }
 
 vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans) {
   if (!h || !ms4) return VLOAM_ERR_INVALID;

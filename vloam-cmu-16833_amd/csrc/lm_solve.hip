@@ -1037,7 +1037,7 @@ void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
-  if (!direct) hipLaunchKernelGGL(k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
+  if (!direct) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
   if (direct && F.gsync)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj);

@@ -533,9 +533,9 @@ void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, co
 }
 void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
   (void)ph;
-  hipLaunchKernelGGL(k_lo_grid_count, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
-  hipLaunchKernelGGL(k_lo_grid_scan, dim3(4), dim3(1024), 0, st, G);
-  hipLaunchKernelGGL(k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
+  VLOAM_LAUNCH(ph, kKLoGridCount, st, k_lo_grid_count, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
+  VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan, dim3(4), dim3(1024), 0, st, G);
+  VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
 }
 void lo_set_prior_launch(hipStream_t st, LOState* lo) { hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo); }
 void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {

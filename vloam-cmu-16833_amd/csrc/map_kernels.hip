@@ -877,10 +877,10 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
   StackInfo* si = m->stack_info[set];
   VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
                m->inv_leaf[0], m->inv_leaf[1], si);
-  hipLaunchKernelGGL(k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si);
-  hipLaunchKernelGGL(k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si);
-  hipLaunchKernelGGL(k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
-                     m->stack_sets[set][0], m->stack_sets[set][1], si);
+  VLOAM_LAUNCH(ph, kKMapDsRank, st, k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si);
+  VLOAM_LAUNCH(ph, kKMapDsScatter, st, k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si);
+  VLOAM_LAUNCH(ph, kKMapDsReduce, st, k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+               m->stack_sets[set][0], m->stack_sets[set][1], si);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -896,8 +896,8 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
                  m->inv_leaf[0], m->inv_leaf[1], ms, m->nn);
-    hipLaunchKernelGGL(k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nn,
-                       m->F[outer], outer);
+    VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nn,
+                 m->F[outer], outer);
     lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
