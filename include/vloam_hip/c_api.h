@@ -124,6 +124,24 @@ vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4
 vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr_uv, int n_match, double angle_axis[3],
                             double t[3], int counters32_22[2]);
 
+/* ---- The coupled per-frame VLOAM loop (configs[3]): MAIN/src/vloam_main_node.cpp:125-180.
+ * vloam_set_extrinsics: base_T_cam0 and velo_T_cam0 as VloamTF::processStaticTransform leaves them (vloam_tf.cpp:55-56), row-major 4x4.
+ * vloam_process_frame[_device]: one callback() with no host round trip — VO->reset / LOAM->reset, processPointCloud on the sweep that is
+ * already in HBM (visual_odometry.cpp:157-186), solveNlsAll for every frame but the first (initial guess = cam0_curr_LOT_cam0_prev of the
+ * previous frame unless reset_VO_to_identity, :258-281), VloamTF::VO2VeloAndBase (vloam_tf.cpp:59-75), scanRegistrationIO, laserOdometryIO
+ * (combined mode detach_VO_LO == 0: para_q / para_t are overwritten by velo_last_VOT_velo_curr at the top of BOTH outer rounds,
+ * laser_odometry.cpp:223-236; publish() refreshes cam0_curr_LOT_cam0_prev, :563-567), laserMappingIO.  prev_uv / curr_uv: n_match integer
+ * pixel pairs in HOST memory, previous frame -> this frame (the image front-end is outside this library); ignored for the first frame.
+ * Like the reference, a VO solve that returns a zero rotation angle makes every later pose NaN (visual_odometry.cpp:427-430 divides by
+ * it); vloam_sync() then reports VLOAM_ERR_INVALID. */
+vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16], const double velo_T_cam0[16]);
+vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match);
+vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match);
+/* world_VOT_base_last per frame as {q xyzw, t} (7 doubles): the VO leg next to the LO / MO legs of vloam_get_trajectory */
+vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, double* poses7);
+/* last frame: VO estimate (angles_0to1, t_0to1), counter32 / counter22, and velo_last_VOT_velo_curr derived from it (any may be NULL) */
+vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t[3], int counters32_22[2], double prior_q[4], double prior_t[3]);
+
 /* Parity hooks (tests only; need cfg.debug = 1 for the per-point arrays).  Copies up to cap elements of
  * the named array into buf (element type given per item) and returns the element count in *n.
  *   stage 0 (scan registration): item 0 curvature f32[N2], 1 sort order i32[N2], 2 picked i32[N2],

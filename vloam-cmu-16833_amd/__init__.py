@@ -227,6 +227,40 @@ class Handle:
         self._chk(self.L.vloam_vo_solve(self.h, _fp(pu), _fp(cu), pu.shape[0], _fp(aa), _fp(tt), _fp(cnt)))
         return aa, tt, int(cnt[0]), int(cnt[1])
 
+    # ---- coupled VLOAM frame loop (configs[3])
+    def set_extrinsics(self, base_T_cam0, velo_T_cam0):
+        a = np.ascontiguousarray(base_T_cam0, dtype=np.float64).reshape(16)
+        b = np.ascontiguousarray(velo_T_cam0, dtype=np.float64).reshape(16)
+        self._chk(self.L.vloam_set_extrinsics(self.h, _fp(a), _fp(b)))
+
+    def _matches(self, prev_uv, curr_uv):
+        if prev_uv is None or curr_uv is None:
+            return None, None, None, None, 0
+        pu = np.ascontiguousarray(prev_uv, dtype=np.int32)
+        cu = np.ascontiguousarray(curr_uv, dtype=np.int32)
+        return pu, cu, _fp(pu), _fp(cu), pu.shape[0]
+
+    def process_frame(self, cloud, prev_uv=None, curr_uv=None):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        pu, cu, pp, cp, n = self._matches(prev_uv, curr_uv)
+        self._chk(self.L.vloam_process_frame(self.h, _fp(cloud), cloud.shape[0], pp, cp, n))
+
+    def process_frame_device(self, dptr, n_pts, prev_uv=None, curr_uv=None):
+        pu, cu, pp, cp, n = self._matches(prev_uv, curr_uv)
+        self._chk(self.L.vloam_process_frame_device(self.h, C.c_void_p(dptr), int(n_pts), pp, cp, n))
+
+    def vo_trajectory(self, first=0, count=None):
+        if count is None:
+            count = self.frame_count() - first
+        out = np.zeros((max(count, 1), 7))
+        self._chk(self.L.vloam_get_vo_trajectory(self.h, first, count, _fp(out)))
+        return out[:count]
+
+    def vo_result(self):
+        aa, t, cnt, pq, pt = np.zeros(3), np.zeros(3), np.zeros(2, dtype=np.int32), np.zeros(4), np.zeros(3)
+        self._chk(self.L.vloam_get_vo_result(self.h, _fp(aa), _fp(t), _fp(cnt), _fp(pq), _fp(pt)))
+        return dict(angles=aa, t=t, counter32=int(cnt[0]), counter22=int(cnt[1]), prior_q=pq, prior_t=pt)
+
     # ---- parity hooks
     def debug_raw(self, stage, item, dtype, max_bytes=1 << 26):
         n = C.c_longlong(0)

@@ -71,6 +71,10 @@ struct vloam_handle {
   LMRecord* lo_rec = nullptr;  // [2]
   double* lo_resid[2] = {nullptr, nullptr};
   double* traj = nullptr;      // [max_frames][14]
+  double* vo_traj = nullptr;   // [max_frames][7] world_VOT_base_last per frame (coupled frame loop)
+  hipEvent_t ev_vo[kSets] = {};     // depth map + matches of the frame in set c are in HBM
+  bool vo_frame[kSets] = {};        // the sweep in set c came through vloam_process_frame (its odometry is preceded by the VO solve)
+  bool have_extrinsics = false;
   LoGrid grid[kSets];          // per set: NN grid over that sweep's lessSharp / lessFlat
   // mapping + vo
   MapContext map;
@@ -216,9 +220,12 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       for (int k = 0; k < 2; k++) { ALLOC(h->lo_corr[k], kMaxLoFactors * 4); ALLOC(h->lo_resid[k], 3 * kMaxLoFactors); if (h->cfg.debug) ALLOC(h->lo_cyc[k], 4 * kMaxLoFactors); }
       ALLOC(h->lo_rec, 2);
       ALLOC(h->traj, (size_t)cfg->max_frames * 14);
+      ALLOC(h->vo_traj, (size_t)cfg->max_frames * 7);
       LOState init;
       memset(&init, 0, sizeof(init));
       init.para_q[3] = 1.0; init.q_w_curr[3] = 1.0; init.prior_q[3] = 1.0;  // laser_odometry.cpp:80-90
+      tf_identity(&init.tf.base_T_cam0); tf_identity(&init.tf.velo_T_cam0); tf_identity(&init.tf.cam0_curr_T_cam0_last);  // visual_odometry.cpp:73-74
+      tf_identity(&init.tf.cam0_curr_LOT_cam0_prev); tf_identity(&init.tf.world_VOT_base_last);                            // vloam_tf.cpp:10-11
       HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
       s = map_create(&h->map, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
@@ -245,6 +252,7 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         HIPCHK(hipEventCreateWithFlags(&h->ev_lo[k], hipEventDisableTiming | hipEventBlockingSync));   // the host throttle sleeps on these
         HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming | hipEventBlockingSync));
         HIPCHK(hipEventCreateWithFlags(&h->ev_stack[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_vo[k], hipEventDisableTiming));
       }
       HIPCHK(hipStreamSynchronize(h->stream));
       return VLOAM_OK;
@@ -263,7 +271,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
-    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
   delete h;
@@ -314,6 +322,7 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   }
   h->last_n_in = n;
   h->stage = 1;
+  h->vo_frame[cur] = false;
   return VLOAM_OK;
 }
 
@@ -321,9 +330,20 @@ static vloam_status enqueue_lo(vloam_handle* h, int frame) {
   const int cur = set_of(frame), prev = set_of(frame + vloam_handle::kSets - 1);
   HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_sr[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->s_lo));
+  const bool coupled = h->vo_frame[cur];  // MAIN/src/vloam_main_node.cpp:125-180: this frame's VO runs in front of its laser odometry
+  const bool use_prior = !h->cfg.detach_VO_LO;
+  if (coupled) {
+    HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_vo[cur], 0));
+    if (frame > 0) {  // Section 4: if (count > 0) VO->solveNlsAll()
+      vloam_status s = vo_solve_enqueue(&h->vo, h->cfg, h->s_lo, frame, h->lo, &h->prof);
+      if (s != VLOAM_OK) { set_err("vo_solve_enqueue failed"); return s; }
+    }
+    // vloam_tf->VO2VeloAndBase(VO->cam0_curr_T_cam0_last) + (combined mode) the first outer round's para_q / para_t overwrite
+    lo_set_prior_launch(h->s_lo, h->lo, use_prior && frame > 0, h->vo.x, frame > 0, h->vo_traj + (size_t)frame * 7, &h->map.frame->error);
+  }
   if (frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
     for (int outer = 0; outer < 2; outer++) {  // laser_odometry.cpp:211
-      if (!h->cfg.detach_VO_LO) lo_set_prior_launch(h->s_lo, h->lo);
+      if (use_prior && !(coupled && outer == 0)) lo_set_prior_launch(h->s_lo, h->lo);  // laser_odometry.cpp:223-236, both rounds (quirk A.8-4)
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
       lo_assoc_launch(h->s_lo, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
@@ -522,6 +542,89 @@ vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
   return vloam_process_scan_device(h, h->d_in, n);
 }
 
+// ------------------------------------------------------------------ coupled VLOAM frame (configs[3])
+// == vloam_tf->processStaticTransform()'s products base_T_cam0 / velo_T_cam0 (vloam_tf.cpp:55-56), row-major 4x4
+vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16], const double velo_T_cam0[16]) {
+  if (!h || !base_T_cam0 || !velo_T_cam0) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  VloamTfState tf;
+  HIPCHK(hipMemcpy(&tf, &h->lo->tf, sizeof(tf), hipMemcpyDeviceToHost));
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) { tf.base_T_cam0.m[r * 3 + c] = base_T_cam0[r * 4 + c]; tf.velo_T_cam0.m[r * 3 + c] = velo_T_cam0[r * 4 + c]; }
+    tf.base_T_cam0.o[r] = base_T_cam0[r * 4 + 3]; tf.velo_T_cam0.o[r] = velo_T_cam0[r * 4 + 3];
+  }
+  tf.coupled = 1;
+  HIPCHK(hipMemcpy(&h->lo->tf, &tf, sizeof(tf), hipMemcpyHostToDevice));
+  h->have_extrinsics = true;
+  return VLOAM_OK;
+}
+
+// One callback() of MAIN/src/vloam_main_node.cpp:125-180 without a host round trip: VO->reset / LOAM->reset, processPointCloud (depth map
+// from the SAME device-resident sweep scan registration reads), solveNlsAll for count > 0 (initial guess = the previous frame's
+// cam0_curr_LOT_cam0_prev, on the device), VO2VeloAndBase (-> velo_last_VOT_velo_curr, read by solveLO when detach_VO_LO == 0),
+// scanRegistrationIO, laserOdometryIO (publish() refreshes cam0_curr_LOT_cam0_prev), laserMappingIO.
+// prev_uv / curr_uv: n_match integer pixel pairs in HOST memory (previous frame -> this frame; ignored for the first frame).
+vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
+  if (!h || !d_xyz_pad4 || n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+  if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
+  if (n_match > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match, kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(h->device));
+  if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
+  vloam_status s = enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+  if (s != VLOAM_OK) return s;
+  const int k = h->frame, cur = set_of(k);
+  // depth map + matches ride on the scan-registration stream (they only need the sweep); the solve itself belongs to the odometry stream
+  s = vo_depth_enqueue(&h->vo, h->stream, (const float4*)d_xyz_pad4, n, k, prev_uv, curr_uv, n_match, &h->prof);
+  if (s != VLOAM_OK) { set_err("vo_depth_enqueue failed"); return s; }
+  HIPCHK(hipEventRecord(h->ev_vo[cur], h->stream));
+  h->vo_frame[cur] = true;
+  if (h->cfg.timing) {
+    s = enqueue_lo(h, h->frame);
+    if (s != VLOAM_OK) return s;
+    if (h->cfg.with_mapping) { s = enqueue_map(h, h->frame); if (s != VLOAM_OK) return s; }
+    return finish_frame(h);
+  }
+  h->frame++;
+  h->stage = 0;
+  return drain_deferred(h, kLagLO, kLagMap);
+}
+
+vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
+  if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
+  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  return vloam_process_frame_device(h, h->d_in, n, prev_uv, curr_uv, n_match);
+}
+
+// world_VOT_base_last of frames first..first+count-1 as {q xyzw, t} (what VO2Cam0StartFrame turns into VO rows, vloam_tf.cpp:77-101)
+vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, double* poses7) {
+  if (!h || !poses7 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  if (count) HIPCHK(hipMemcpy(poses7, h->vo_traj + (size_t)first * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
+  return VLOAM_OK;
+}
+
+// the last frame's VO estimate (angles_0to1, t_0to1), its counter32 / counter22 and the LiDAR-odometry prior derived from it
+vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t[3], int counters32_22[2], double prior_q[4], double prior_t[3]) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  double x[6];
+  int cnt[2];
+  LOState lo;
+  HIPCHK(hipMemcpy(x, h->vo.x, sizeof(x), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cnt, h->vo.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lo, h->lo, sizeof(lo), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; k++) { if (angle_axis) angle_axis[k] = x[k]; if (t) t[k] = x[3 + k]; if (prior_t) prior_t[k] = lo.prior_t[k]; }
+  if (counters32_22) { counters32_22[0] = cnt[0]; counters32_22[1] = cnt[1]; }
+  if (prior_q) for (int k = 0; k < 4; k++) prior_q[k] = lo.prior_q[k];
+  return VLOAM_OK;
+}
+
 vloam_status vloam_sync(vloam_handle* h) {
   if (!h) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
@@ -538,6 +641,7 @@ vloam_status vloam_sync(vloam_handle* h) {
     if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }
+    if (merr & kErrVoDegenerate) { set_err("a VO solve returned a zero rotation angle: poses are NaN from that frame on, as in the reference (visual_odometry.cpp:427-430)"); return VLOAM_ERR_INVALID; }
   }
   return VLOAM_OK;
 }

@@ -678,6 +678,7 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
   r[3] = q[3] * x[3] - q[0] * x[0] - q[1] * x[1] - q[2] * x[2];
   lo->t_w_curr[0] = t0; lo->t_w_curr[1] = t1; lo->t_w_curr[2] = t2;
   for (int k = 0; k < 4; k++) lo->q_w_curr[k] = r[k];
+  tf_lo_publish(lo, x);  // LaserOdometry::publish's LO -> VO prior (laser_odometry.cpp:563-567), coupled mode only
   if (traj_row14) {
     for (int k = 0; k < 4; k++) traj_row14[k] = r[k];
     traj_row14[4] = t0; traj_row14[5] = t1; traj_row14[6] = t2;

@@ -490,11 +490,45 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   }
 }
 
-// LO:223-236 — combined mode overwrites the warm start with the VO prior at the top of each outer round
-__global__ void k_lo_set_prior(LOState* lo) {
-  const int t = threadIdx.x;
-  if (t < 4) lo->para_q[t] = lo->prior_q[t];
-  else if (t < 7) lo->para_t[t - 4] = lo->prior_t[t - 4];
+// LO:223-236 — combined mode overwrites the warm start with the VO prior at the top of each outer round.
+// With vo_row7 != nullptr this launch is also where the frame's visual odometry is PUBLISHED (MAIN/src/vloam_main_node.cpp:158-162):
+//   solveNlsAll's tail (VO:425-430): cam0_curr_T_cam0_last from (angle-axis, t) — only when a solve ran this frame (count > 0)
+//   VloamTF::VO2VeloAndBase (vloam_tf.cpp:59-75): velo_last_VOT_velo_curr -> prior_q / prior_t, world_VOT_base_last *= base_last_VOT_base_curr
+//   the VO row of the trajectory log: world_VOT_base_last as (q xyzw, t)
+__global__ void k_lo_set_prior(LOState* lo, int copy_to_para, const double* vo_x, int vo_solved, double* vo_row7, int* err) {
+  if (threadIdx.x != 0) return;
+  if (vo_row7) {
+    VloamTfState& tf = lo->tf;
+    if (vo_solved) {
+      const double a0 = vo_x[0], a1 = vo_x[1], a2 = vo_x[2];
+      const double angle = sqrt((a0 * a0 + a1 * a1) + a2 * a2);                  // VO:427
+      const double ax = a0 / angle, ay = a1 / angle, az = a2 / angle;            // NaN for a zero angle, exactly like the reference
+      const double d = sqrt((ax * ax + ay * ay) + az * az);                      // Quaternion::setRotation(axis, angle)
+      const double sn = sin(angle * 0.5) / d;
+      const double q[4] = {ax * sn, ay * sn, az * sn, cos(angle * 0.5)};
+      tf_set_rotation(&tf.cam0_curr_T_cam0_last, q);
+      tf.cam0_curr_T_cam0_last.o[0] = vo_x[3]; tf.cam0_curr_T_cam0_last.o[1] = vo_x[4]; tf.cam0_curr_T_cam0_last.o[2] = vo_x[5];
+      if (!(angle > 0.0)) { tf.vo_nan_frames++; if (err) atomicOr(err, kErrVoDegenerate); }
+    }
+    TfDev inv, vi, bi, velo_last, base_last;
+    tf_inverse(tf.cam0_curr_T_cam0_last, &inv);
+    tf_inverse(tf.velo_T_cam0, &vi);
+    tf_inverse(tf.base_T_cam0, &bi);
+    tf_mul(tf.velo_T_cam0, inv, &velo_last); tf_mul(velo_last, vi, &velo_last);  // vloam_tf.cpp:62-63
+    tf_mul(tf.base_T_cam0, inv, &base_last); tf_mul(base_last, bi, &base_last);  // vloam_tf.cpp:65
+    double qb[4];
+    tf_get_rotation(base_last, qb);
+    const bool nan = isnan(base_last.o[0]) || isnan(base_last.o[1]) || isnan(base_last.o[2]) || isnan(qb[0]) || isnan(qb[1]) || isnan(qb[2]) || isnan(qb[3]);
+    if (!nan) tf_mul(tf.world_VOT_base_last, base_last, &tf.world_VOT_base_last);  // vloam_tf.cpp:68-72
+    tf_get_rotation(velo_last, lo->prior_q);                                        // what LO:225-232 reads back through getRotation() / getOrigin()
+    for (int k = 0; k < 3; k++) lo->prior_t[k] = velo_last.o[k];
+    tf_get_rotation(tf.world_VOT_base_last, vo_row7);
+    for (int k = 0; k < 3; k++) vo_row7[4 + k] = tf.world_VOT_base_last.o[k];
+  }
+  if (copy_to_para) {
+    for (int k = 0; k < 4; k++) lo->para_q[k] = lo->prior_q[k];
+    for (int k = 0; k < 3; k++) lo->para_t[k] = lo->prior_t[k];
+  }
 }
 
 // LO:477-478 pose integration (+ trajectory log row); q_w_curr is not renormalised, as in the reference.
@@ -518,6 +552,7 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
     r[3] = q[3] * ql[3] - q[0] * ql[0] - q[1] * ql[1] - q[2] * ql[2];
     for (int k = 0; k < 4; k++) lo->q_w_curr[k] = r[k];
   }
+  tf_lo_publish(lo, lo->para_q);  // LO:563-567 (para_q, para_t are contiguous: q_last_curr, t_last_curr)
   if (traj_row14) {
     for (int k = 0; k < 4; k++) traj_row14[k] = lo->q_w_curr[k];
     for (int k = 0; k < 3; k++) traj_row14[4 + k] = lo->t_w_curr[k];
@@ -537,7 +572,9 @@ void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4
   VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan, dim3(4), dim3(1024), 0, st, G);
   VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
 }
-void lo_set_prior_launch(hipStream_t st, LOState* lo) { hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo); }
+void lo_set_prior_launch(hipStream_t st, LOState* lo, bool copy_to_para, const double* vo_x, bool vo_solved, double* vo_row7, int* err) {
+  hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo, copy_to_para ? 1 : 0, vo_x, vo_solved ? 1 : 0, vo_row7, err);
+}
 void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {
   VLOAM_LAUNCH(ph, kKLoFinish, st, k_lo_finish, dim3(1), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0);
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <math.h>
 #include <stdint.h>
 
 namespace vloam {
@@ -68,6 +69,7 @@ enum ErrorBits : int {
   kErrMapFull = 4,     // voxel hash out of slots
   kErrMapDeferred = 8, // a scan point landed in a cube outside the valid 5x5x3 block
   kErrStackFull = 16,
+  kErrVoDegenerate = 64, // the VO solve returned a zero rotation angle: the reference divides by it (visual_odometry.cpp:427-430) -> NaN poses
   kErrSolverSync = 32,  // a workgroup of a cooperative LM solve gave up waiting at the grid barrier (result of that solve is invalid)
 };
 
@@ -126,11 +128,84 @@ struct FactorTable {
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
 constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 32;  // 2 counters (+ flags) | [parity][workgroup][32] partial accumulators
 
+// ---------------------------------------------------------------- vloam_tf blackboard (coupled VO <-> LiDAR odometry loop)
+// tf2::Transform restated: row-major 3x3 basis + origin, double precision, the same operation order as tf2/LinearMath
+// (Transform::operator*, inverse(), Matrix3x3::setRotation / getRotation, Quaternion::setRotation(axis, angle) / getAxis / getAngle).
+struct TfDev { double m[9]; double o[3]; };
+__host__ __device__ inline void tf_identity(TfDev* t) { for (int k = 0; k < 9; k++) t->m[k] = (k % 4 == 0) ? 1.0 : 0.0; t->o[0] = t->o[1] = t->o[2] = 0.0; }
+__host__ __device__ inline void tf_mul(const TfDev& a, const TfDev& b, TfDev* r) {  // (a.m b.m, a.m b.o + a.o)
+  TfDev t;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t.m[i * 3 + j] = (a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j]) + a.m[i * 3 + 2] * b.m[6 + j];
+  for (int i = 0; i < 3; i++) t.o[i] = ((a.m[i * 3] * b.o[0] + a.m[i * 3 + 1] * b.o[1]) + a.m[i * 3 + 2] * b.o[2]) + a.o[i];
+  *r = t;
+}
+__host__ __device__ inline void tf_inverse(const TfDev& a, TfDev* r) {              // (m^T, m^T * -o)
+  TfDev t;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t.m[i * 3 + j] = a.m[j * 3 + i];
+  const double n[3] = {-a.o[0], -a.o[1], -a.o[2]};
+  for (int i = 0; i < 3; i++) t.o[i] = (t.m[i * 3] * n[0] + t.m[i * 3 + 1] * n[1]) + t.m[i * 3 + 2] * n[2];
+  *r = t;
+}
+__host__ __device__ inline void tf_set_rotation(TfDev* t, const double q[4]) {      // Matrix3x3::setRotation
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double d = ((x * x + y * y) + z * z) + w * w;
+  const double s = 2.0 / d;
+  const double xs = x * s, ys = y * s, zs = z * s;
+  const double wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  t->m[0] = 1.0 - (yy + zz); t->m[1] = xy - wz; t->m[2] = xz + wy;
+  t->m[3] = xy + wz; t->m[4] = 1.0 - (xx + zz); t->m[5] = yz - wx;
+  t->m[6] = xz - wy; t->m[7] = yz + wx; t->m[8] = 1.0 - (xx + yy);
+}
+__host__ __device__ inline void tf_get_rotation(const TfDev& t, double q[4]) {      // Matrix3x3::getRotation
+  const double* m = t.m;
+  const double trace = (m[0] + m[4]) + m[8];
+  if (trace > 0.0) {
+    double s = sqrt(trace + 1.0);
+    q[3] = s * 0.5;
+    s = 0.5 / s;
+    q[0] = (m[7] - m[5]) * s; q[1] = (m[2] - m[6]) * s; q[2] = (m[3] - m[1]) * s;
+  } else {
+    const int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double s = sqrt(((m[i * 4] - m[j * 4]) - m[k * 4]) + 1.0);
+    q[i] = s * 0.5;
+    s = 0.5 / s;
+    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * s;
+    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * s;
+    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * s;
+  }
+}
+
+struct VloamTfState {            // the slice of vloam::VloamTF the per-frame loop reads and writes (vloam_tf.h:34-49)
+  TfDev base_T_cam0, velo_T_cam0;          // static extrinsics (vloam_tf.cpp:55-56), vloam_set_extrinsics
+  TfDev cam0_curr_T_cam0_last;             // VisualOdometry's result as a transform (visual_odometry.cpp:425-430); identity before the first solve
+  TfDev cam0_curr_LOT_cam0_prev;           // LaserOdometry::publish (laser_odometry.cpp:563-567) -> solveNlsAll's initial guess
+  TfDev world_VOT_base_last;               // VO2VeloAndBase accumulates it (vloam_tf.cpp:67-72)
+  int coupled;                             // 1 once the extrinsics are set: LaserOdometry::publish maintains cam0_curr_LOT_cam0_prev
+  int vo_nan_frames;                       // frames whose VO result had a zero rotation angle (NaN transform in the reference, :427-430)
+};
+
 struct LOState {           // laser odometry state carried across frames (laser_odometry.h:106-146)
   double para_q[4], para_t[3];  // q_last_curr (x,y,z,w), t_last_curr
   double q_w_curr[4], t_w_curr[3];
   double prior_q[4], prior_t[3];  // vloam_tf->velo_last_VOT_velo_curr
+  VloamTfState tf;
 };
+
+// LaserOdometry::publish, laser_odometry.cpp:560-567: base_prev_LOT_base_curr = (q_last_curr, t_last_curr);
+// cam0_curr_LOT_cam0_prev = base_T_cam0^-1 * base_prev_LOT_base_curr^-1 * base_T_cam0.  x = (q xyzw, t) as just solved.
+__device__ inline void tf_lo_publish(LOState* lo, const double* x) {
+  if (!lo->tf.coupled) return;
+  TfDev b, bi, ci, r;
+  tf_set_rotation(&b, x);
+  b.o[0] = x[4]; b.o[1] = x[5]; b.o[2] = x[6];
+  tf_inverse(b, &bi);
+  tf_inverse(lo->tf.base_T_cam0, &ci);
+  tf_mul(ci, bi, &r);
+  tf_mul(r, lo->tf.base_T_cam0, &r);
+  lo->tf.cam0_curr_LOT_cam0_prev = r;
+}
 
 struct MapState {          // laser mapping state (laser_mapping.h:141-155)
   double parameters[7];    // q_w_curr (x,y,z,w), t_w_curr

@@ -185,8 +185,24 @@ __device__ void solve3x3_colpiv_qr_f32(const float* A_, const float* b_, float* 
 
 __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_uv, const int* __restrict__ curr_uv, int n_match,
                                                   const vloam_calib* __restrict__ c, DepthMapDev Mprev, int remove_outlier, FactorTable F,
-                                                  double* __restrict__ dbg, int* counters) {
+                                                  double* __restrict__ dbg, int* counters, const LOState* __restrict__ lo, double* x_init,
+                                                  int reset_to_identity) {
   const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j == 0 && x_init) {  // solveNlsAll's initial guess (VO:258-281); the solve behind this launch reads it
+    double a[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    if (!reset_to_identity && lo) {
+      double q[4];
+      tf_get_rotation(lo->tf.cam0_curr_LOT_cam0_prev, q);
+      const double w = q[3] < -1.0 ? -1.0 : (q[3] > 1.0 ? 1.0 : q[3]);
+      const double angle = 2.0 * acos(w);                          // Quaternion::getAngle
+      const double s_squared = 1.0 - q[3] * q[3];                  // Quaternion::getAxis
+      double ax = 1.0, ay = 0.0, az = 0.0;
+      if (!(s_squared < 10.0 * 2.220446049250313e-16)) { const double s = sqrt(s_squared); ax = q[0] / s; ay = q[1] / s; az = q[2] / s; }
+      a[0] = ax * angle; a[1] = ay * angle; a[2] = az * angle;
+      for (int k = 0; k < 3; k++) t[k] = lo->tf.cam0_curr_LOT_cam0_prev.o[k];
+    }
+    for (int k = 0; k < 3; k++) { x_init[k] = a[k]; x_init[3 + k] = t[k]; }
+  }
   if (j >= F.cap) return;
   int type = 0;
   double obs[5] = {0, 0, 0, 0, 0};
@@ -255,8 +271,9 @@ static bool dmalloc(std::vector<void*>& allocs, hipStream_t st, T** p, size_t co
 
 vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs) {
   bool ok = dmalloc(allocs, st, &v->d_calib, 1);
-  for (int k = 0; k < 2 && ok; k++)
-    ok = dmalloc(allocs, st, &v->maps[k].bx, kBuckets) && dmalloc(allocs, st, &v->maps[k].by, kBuckets) &&
+  for (int k = 0; k < VOContext::kSets && ok; k++)
+    ok = dmalloc(allocs, st, &v->d_prev_set[k], 2 * kVoMaxMatches) && dmalloc(allocs, st, &v->d_curr_set[k], 2 * kVoMaxMatches) &&
+         dmalloc(allocs, st, &v->maps[k].bx, kBuckets) && dmalloc(allocs, st, &v->maps[k].by, kBuckets) &&
          dmalloc(allocs, st, &v->maps[k].bd, kBuckets) && dmalloc(allocs, st, &v->maps[k].bc, kBuckets);
   ok = ok && dmalloc(allocs, st, &v->uvd, (size_t)cfg.max_points) && dmalloc(allocs, st, &v->bcount, kBuckets + 1) &&
        dmalloc(allocs, st, &v->bfill, kBuckets) && dmalloc(allocs, st, &v->seg, (size_t)cfg.max_points) &&
@@ -270,7 +287,7 @@ vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, st
   v->F.gsync = nullptr;
   v->F.err = nullptr;
   ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->counters, 2);
+       dmalloc(allocs, st, &v->counters, 4);
   v->max_points = cfg.max_points;
   return ok ? VLOAM_OK : VLOAM_ERR_HIP;
 }
@@ -282,15 +299,44 @@ vloam_status vo_set_calib(VOContext* v, hipStream_t st, const vloam_calib* c) {
   return VLOAM_OK;
 }
 
+static vloam_status vo_depth_launch(VOContext* v, hipStream_t st, const float4* d_in, int n, int set, ProfHook* ph) {
+  if (hipMemsetAsync(v->bcount, 0, sizeof(int) * (kBuckets + 1), st) != hipSuccess) return VLOAM_ERR_HIP;
+  VLOAM_LAUNCH(ph, kKVoProject, st, k_vo_project, dim3(256), dim3(256), 0, st, d_in, n, v->d_calib, v->uvd, v->bcount);
+  hipLaunchKernelGGL(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
+  hipLaunchKernelGGL(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
+  VLOAM_LAUNCH(ph, kKVoFold, st, k_vo_fold, dim3((kBuckets + 255) / 256), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[set]);
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
 vloam_status vo_process_point_cloud(VOContext* v, hipStream_t st, const float4* d_in, int n) {
   if (!v->have_calib) return VLOAM_ERR_ORDER;
   ++v->count;                // VisualOdometry::reset(), VO:86-90
-  v->i = v->count % 2;
-  if (hipMemsetAsync(v->bcount, 0, sizeof(int) * (kBuckets + 1), st) != hipSuccess) return VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_vo_project, dim3(256), dim3(256), 0, st, d_in, n, v->d_calib, v->uvd, v->bcount);
-  hipLaunchKernelGGL(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
-  hipLaunchKernelGGL(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
-  hipLaunchKernelGGL(k_vo_fold, dim3((kBuckets + 255) / 256), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[v->i]);
+  v->i = v->count % VOContext::kSets;
+  return vo_depth_launch(v, st, d_in, n, v->i, nullptr);
+}
+
+// coupled frame loop: the depth map of frame `frame` goes to maps[frame % kSets]; the frame's pixel matches are staged into the same set
+vloam_status vo_depth_enqueue(VOContext* v, hipStream_t st, const float4* d_in, int n, int frame, const int* prev_uv, const int* curr_uv, int n_match,
+                              ProfHook* ph) {
+  if (!v->have_calib) return VLOAM_ERR_ORDER;
+  if (n_match > kVoMaxMatches || n_match < 0) return VLOAM_ERR_CAPACITY;
+  const int set = frame % VOContext::kSets;
+  v->count = frame;
+  v->i = set;
+  v->n_match_set[set] = n_match;
+  if (n_match > 0 && frame > 0) {
+    if (hipMemcpyAsync(v->d_prev_set[set], prev_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+    if (hipMemcpyAsync(v->d_curr_set[set], curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  }
+  return vo_depth_launch(v, st, d_in, n, set, ph);
+}
+
+vloam_status vo_solve_enqueue(VOContext* v, const vloam_config& cfg, hipStream_t st, int frame, LOState* lo, ProfHook* ph) {
+  const int set = frame % VOContext::kSets, prev = (frame + VOContext::kSets - 1) % VOContext::kSets;
+  if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
+  VLOAM_LAUNCH(ph, kKVoMatch, st, k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev_set[set], v->d_curr_set[set], v->n_match_set[set],
+               v->d_calib, v->maps[prev], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters, lo, v->x, cfg.reset_VO_to_identity);
+  lm_launch(st, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr, ph);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -304,8 +350,9 @@ vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, con
   if (hipMemcpyAsync(v->d_curr, curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemcpyAsync(v->x, x, sizeof(x), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib, v->maps[1 - v->i],
-                     cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters);
+  hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib,
+                     v->maps[(v->i + VOContext::kSets - 1) % VOContext::kSets], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters,
+                     (const LOState*)nullptr, (double*)nullptr, 0);
   lm_launch(st, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
   if (hipMemcpyAsync(x, v->x, sizeof(x), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
   int cnt[2];
@@ -327,7 +374,7 @@ static vloam_status copy_dev(const void* src, size_t bytes, void* buf, long long
 // 8: per-match rows f64[n][7]; 9: LM record; 10: projected points f32[n][4] (u, v, depth, bucket id bits)
 vloam_status vo_debug_get(VOContext* v, int item, void* buf, long long cap, long long* n) {
   if (item >= 0 && item < 8) {
-    const DepthMapDev& M = v->maps[item < 4 ? v->i : 1 - v->i];
+    const DepthMapDev& M = v->maps[item < 4 ? v->i : (v->i + VOContext::kSets - 1) % VOContext::kSets];
     switch (item & 3) {
       case 0: return copy_dev(M.bx, sizeof(float) * kBuckets, buf, cap, n);
       case 1: return copy_dev(M.by, sizeof(float) * kBuckets, buf, cap, n);

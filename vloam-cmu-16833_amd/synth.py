@@ -250,6 +250,21 @@ def kitti_like_calib():
     return cam_T_velo, rect0_T_cam, P
 
 
+def kitti_like_extrinsics():
+    """(base_T_cam0, velo_T_cam0) 4x4 f64 as VloamTF::processStaticTransform derives them (vloam_tf.cpp:55-56):
+    base_T_cam0 = base_T_imu * imu_T_cam0, velo_T_cam0 = imu_T_velo^-1 * imu_T_cam0, with KITTI-like statics (kitti2bag's
+    base_link -> imu_link offset, the raw-data imu -> velodyne mount) and the camera of kitti_like_calib()."""
+    cam_T_velo = kitti_like_calib()[0].astype(np.float64)
+    velo_T_cam0 = np.linalg.inv(cam_T_velo)
+    imu_T_velo = np.eye(4)
+    imu_T_velo[:3, 3] = [0.81, -0.32, 0.80]
+    imu_T_velo[:3, :3] = _rot_zyx(0.0148, -0.0021, 0.0009)
+    base_T_imu = np.eye(4)
+    base_T_imu[:3, 3] = [-1.405, 0.32, 0.93]
+    imu_T_cam0 = imu_T_velo @ velo_T_cam0
+    return base_T_imu @ imu_T_cam0, np.linalg.inv(imu_T_velo) @ imu_T_cam0
+
+
 def synth_matches(seq, k, n_match=1400, pixel_noise=0.5, seed=99):
     """Pixel pairs (prev frame k-1 -> current frame k) of scene points visible in both images, standing in for the
     OpenCV front-end (out of scope): integer (truncated) pixel coordinates like visual_odometry.cpp:283-294."""
