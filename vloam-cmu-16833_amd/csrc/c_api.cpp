@@ -152,6 +152,9 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
   if (cfg->max_points < 64 || cfg->max_points > (1 << 24) || cfg->max_frames < 1 || cfg->mapping_skip_frame < 1) {  // 24-bit point tags
     set_err("bad capacity"); return VLOAM_ERR_INVALID;
   }
+  if (!(cfg->mapping_line_resolution >= 0.25f) || !(cfg->mapping_plane_resolution >= 0.25f)) {  // 8-bit voxel index inside a 50 m cube, <= 8 pieces per axis
+    set_err("mapping resolutions below 0.25 m are not supported"); return VLOAM_ERR_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device visible: libvloam_hip has no CPU fallback");
@@ -274,6 +277,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
     for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
+  map_destroy(&h->map);
   delete h;
   return VLOAM_OK;
 }
@@ -461,6 +465,15 @@ vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int ca
   const int m = cnt < cap ? cnt : cap;
   if (xyzi4 && m > 0) HIPCHK(hipMemcpy(xyzi4, src, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost));
   return VLOAM_OK;
+}
+
+// == the /laser_cloud_map product of LaserMapping::publish (laser_mapping.cpp:778-793)
+vloam_status vloam_get_map(vloam_handle* h, float* xyzi4, long long cap, long long* n) {
+  if (!h || !n) return VLOAM_ERR_INVALID;
+  if (!h->cfg.with_mapping) { *n = 0; return VLOAM_OK; }
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  return map_export(&h->map, h->s_map, xyzi4, cap, n);
 }
 
 vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double t[3]) {
@@ -737,6 +750,10 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
               return copy_out(h->lo_cyc[outer], sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);
     }
     return VLOAM_ERR_INVALID;
+  }
+  if (stage == 2 && item == 70) {  // test hook: rebuild both voxel tables now (the production trigger is k_map_finalize's host-mapped flag)
+    if (n) *n = 0;
+    return h->cfg.with_mapping ? map_force_rebuild(&h->map, h->s_map) : VLOAM_OK;
   }
   if (stage == 2) return map_debug_get(&h->map, item, buf, cap, n);
   if (stage == 3) return vo_debug_get(&h->vo, item, buf, cap, n);

@@ -22,18 +22,28 @@ constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
 constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
 constexpr int kDsHashCorner = 1 << 15, kDsHashSurf = 1 << 16;
 
-struct VoxelTable {       // structure of arrays, open addressing, linear probing
-  unsigned long long* keys;  // 0 = empty
-  float4* sum;               // f32 running sum (x, y, z, intensity) in arrival order
-  int* count;                // points in the sum (1 after a valid-cube finalize; 0 = purged)
-  int* pend_cnt;             // stack points queued this sweep
+// One map voxel == one 32-byte record, so that a candidate of the 5-NN search, an insert and a finalize each touch ONE cache line
+// (round 1 kept keys / sums / counts in three arrays: three scattered lines per candidate, 27x the algorithmic traffic).
+struct __attribute__((aligned(32))) VoxelRec {
+  unsigned long long key;    // 0 = empty
+  float sx, sy, sz, si;      // f32 running sum (x, y, z, intensity) in arrival order
+  int count;                 // points in the sum (1 after a valid-cube finalize; 0 = purged, or created this sweep and not finalized yet)
+  int pend_cnt;              // stack points queued this sweep
+};
+static_assert(sizeof(VoxelRec) == 32, "one voxel, one half cache line");
+
+struct VoxelTable {       // open addressing, linear probing, probe chains bounded by kMaxProbe
+  VoxelRec* rec;
   int* pend;                 // [slots][kPendCap] stack indices
   unsigned mask;             // slots - 1
   // occupancy index: one entry per 4 x 4 x 4 block of voxels of a cube -> 64-bit mask of the voxels that exist.
   // The 5-NN search probes ~27 blocks instead of ~343 mostly empty voxels.
   ulonglong2* blk;           // {key (0 = empty), mask}: one 16-byte load per probe
   unsigned bslots_mask;      // block slots - 1
+  int* stats;                // [4] keys in the table (live + purged) | entries purged since the last rebuild | block keys | spare
 };
+constexpr int kMaxProbe = 128;  // a longer chain means the table is overloaded: the lookup reports kErrMapFull instead of spinning
+constexpr int kCandChunk = 256; // candidates of the 5-NN search handled per pass (more are handled in further passes, exactly)
 
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
   unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
@@ -65,6 +75,7 @@ struct MapFrame {         // per-sweep device counters
   int rolled;
   int error;
   int n_factors[2][2];    // [outer][corner, surf] accepted factors
+  int max_candidates;     // largest 5-NN candidate list seen (diagnostic; lists beyond kCandChunk take extra passes)
 };
 
 struct MapContext {
@@ -82,7 +93,13 @@ struct MapContext {
   int* deferred[2] = {nullptr, nullptr};      // slots holding raw points outside the valid block
   FactorTable F[2];        // one per outer round (kept for the parity hooks)
   LMRecord* rec = nullptr; // [2]
-  int* nn = nullptr;       // [kMapFactorCap][5] hash slots of the 5 nearest map voxels of every stack point (-1: rejected)
+  float4* nbr = nullptr;   // [kMapFactorCap][5] the 5 nearest map points of every stack point (.w of the first: 1 = accepted, LM:479 / LM:547)
+  VoxelRec* rebuild_tmp = nullptr;  // live records while a table is being rebuilt (tombstone reclamation after grid rolls)
+  int rebuild_cap = 0;
+  int* rebuild_n = nullptr;
+  int* host_flags = nullptr;        // host-mapped: [kind] 1 = the table of that kind wants a rebuild (written by k_map_finalize)
+  int rebuild_cooldown[2] = {0, 0};
+  long long rebuilds = 0;
   float4* registered = nullptr;  // full-resolution cloud in the map frame, on request
   int max_points = 0;
   float inv_leaf[2] = {0, 0};
@@ -95,6 +112,10 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n);
 vloam_status map_error(MapContext* m, int* err_bits);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);
+// == /laser_cloud_map (laser_mapping.cpp:778-793): every cube's corner cloud then surf cloud, cube index ascending
+vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long cap, long long* n);
+vloam_status map_force_rebuild(MapContext* m, hipStream_t st);
+void map_destroy(MapContext* m);
 vloam_status map_counts(MapContext* m, long long c[16]);
 
 }  // namespace vloam

@@ -19,6 +19,7 @@
 #include <limits.h>
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include "lm_solve.h"
 #include "map_kernels.h"
 
@@ -49,6 +50,22 @@ __device__ __forceinline__ u64 pack_key(int Ai, int Aj, int Ak, int lx, int ly, 
 }
 __device__ __forceinline__ void unpack_cube(u64 k, int* Ai, int* Aj, int* Ak) {
   *Ai = (int)((k >> 50) & 0x3fff) - 8192; *Aj = (int)((k >> 36) & 0x3fff) - 8192; *Ak = (int)((k >> 24) & 0xfff) - 2048;
+}
+
+// A voxel record as two 16-byte loads of one 32-byte line
+struct RecVal { u64 key; float4 sum; int count, pend_cnt; };
+__device__ __forceinline__ RecVal rec_load(const VoxelRec* r) {
+  const uint4 a = reinterpret_cast<const uint4*>(r)[0], b = reinterpret_cast<const uint4*>(r)[1];
+  RecVal v;
+  v.key = (u64)a.x | ((u64)a.y << 32);
+  v.sum = make_float4(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+  v.count = (int)b.z; v.pend_cnt = (int)b.w;
+  return v;
+}
+// everything but the key (which only find-or-insert writes)
+__device__ __forceinline__ void rec_store_value(VoxelRec* r, float4 sum, int count, int pend_cnt) {
+  reinterpret_cast<float2*>(r)[1] = make_float2(sum.x, sum.y);
+  reinterpret_cast<uint4*>(r)[1] = make_uint4(__float_as_uint(sum.z), __float_as_uint(sum.w), (unsigned)count, (unsigned)pend_cnt);
 }
 
 // Eigen q * v (see lm_solve.hip / lo_kernels.hip) followed by + t, rounded to f32: pointAssociateToMap, LM:146-155
@@ -118,6 +135,10 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
       for (int k = 0; k < 2; k++) { fr->n_stack[k] = si->n_stack[k]; fr->n_touched[k] = 0; }
       ms->n_corner_stack = si->n_stack[0]; ms->n_surf_stack = si->n_stack[1];
       if (si->error) { atomicOr(&fr->error, si->error); si->error = 0; }
+      if (fr->error & kErrMapFull) {  // the map cannot take this sweep: no association, no insert; the pose stays the odometry guess (vloam_sync reports it)
+        fr->n_stack[0] = fr->n_stack[1] = 0;
+        ms->n_corner_stack = ms->n_surf_stack = 0;
+      }
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
     }
   }
@@ -165,14 +186,16 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
 // of a launch of its own in front of the association.
 __device__ void map_purge(const VoxelTable& T, const MapState* ms, int first, int stride) {
   const int cW = ms->cenW, cH = ms->cenH, cD = ms->cenD;
+  int dead = 0;
   for (unsigned s = (unsigned)first; s <= T.mask; s += (unsigned)stride) {
-    const u64 k = T.keys[s];
-    if (k == 0 || T.count[s] == 0) continue;
+    const RecVal v = rec_load(&T.rec[s]);
+    if (v.key == 0 || v.count == 0) continue;
     int Ai, Aj, Ak;
-    unpack_cube(k, &Ai, &Aj, &Ak);
+    unpack_cube(v.key, &Ai, &Aj, &Ak);
     const int i = Ai + cW, j = Aj + cH, kk = Ak + cD;
-    if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || kk < 0 || kk >= kCubeD) { T.count[s] = 0; T.sum[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || kk < 0 || kk >= kCubeD) { rec_store_value(&T.rec[s], make_float4(0.f, 0.f, 0.f, 0.f), 0, 0); dead++; }
   }
+  if (dead) atomicAdd(&T.stats[1], dead);  // tombstones: the key stays (probe chains run through it) until the table is rebuilt
 }
 
 // ---------------------------------------------------------------------------------------------- scan VoxelGrid
@@ -429,14 +452,14 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
 }
 
 __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
-                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms,
-                                                   int* __restrict__ nn) {
-  const int lane = threadIdx.x & 63;
+                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
+                                                   float4* __restrict__ nbr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // wave d of the launch takes the d-th stack point (corners, then surfs): the waves with work come first in dispatch order
   // instead of sitting behind the thousands of empty slots between the two parts of the table
-  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int d = blockIdx.x * 4 + wave;
   const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
-  if (d >= nc + nsf || !ms->do_optimize) return;  // (k_map_fit never looks at nn[] of a slot without a stack point)
+  if (d >= nc + nsf || !ms->do_optimize) return;  // (k_map_fit never looks at nbr[] of a slot without a stack point)
   const int kind = d < nc ? 0 : 1;
   const int i = kind ? d - nc : d;
   const int slot = kind ? kStackCapCorner + i : i;
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     // Per axis the voxel index range [lo, hi] is cut into (cube, 4-voxel block) pieces — a voxel that straddles a 50 m cube face
     // exists once per cube — each with the 4-bit mask of its voxels inside the range.  Phase 1: one lane per candidate block
     // fetches its occupancy mask.  Phase 2: the existing voxels of all blocks are flattened into an LDS work list so that
-    // phase 3 fetches one voxel per lane (all probes in flight together instead of a per-lane chain).
+    // phase 3 fetches one voxel RECORD (32 bytes, one line) per lane, all probes in flight together.
     const int cenv[3] = {ms->cenW, ms->cenH, ms->cenD};
     const int ctr[3] = {ms->centerCube[0] - cenv[0], ms->centerCube[1] - cenv[1], ms->centerCube[2] - cenv[2]};  // absolute centre cube
     const int halfw[3] = {2, 2, 1};   // valid block: 5 x 5 x 3 cubes (LM:404-420)
@@ -458,6 +481,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     const double leaf = 1.0 / (double)inv;
     constexpr int kMaxPieces = 8;
     int pa[3][kMaxPieces], pb[3][kMaxPieces], pm[3][kMaxPieces], np_[3];
+    bool overflow = false;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const int lo = (int)floorf((q3[a] - 1.001f) * inv), hi = (int)floorf((q3[a] + 1.001f) * inv);
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
         const int base = cube_voxel_base(A, inv);
         const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
         for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2) && ia <= ib; blk++) {
-          if (n >= kMaxPieces || (unsigned)blk > 63u) break;
+          if (n >= kMaxPieces || (unsigned)blk > 63u) { overflow = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
           int m4 = 0;
 #pragma unroll
           for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
@@ -482,118 +506,136 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       }
       np_[a] = __builtin_amdgcn_readfirstlane(n);
     }
-    __shared__ u64 s_cand[4][256];
-    __shared__ int s_slot[4][256];
-    __shared__ u64 s_best[4][8];
-    __shared__ int s_best_slot[4][8];
-    u64* my_cand = s_cand[threadIdx.x >> 6];
-    int* my_slot = s_slot[threadIdx.x >> 6];
+    __shared__ u64 s_cand[4][kCandChunk + 8];
+    __shared__ float4 s_pt[4][kCandChunk + 8];
+    __shared__ u64 s_best[4][2][8];
+    __shared__ float4 s_best_p[4][2][8];
+    u64* my_cand = s_cand[wave];
+    float4* my_pt = s_pt[wave];
     const int nblocks = np_[0] * np_[1] * np_[2];
-    int produced = 0;   // wave-uniform running size of the work list
-    for (int bb0 = 0; bb0 < nblocks; bb0 += 64) {
-      const int bb = bb0 + lane;
-      u64 occ = 0ull;
-      int Ai = 0, bx = 0, Aj = 0, by = 0, Ak = 0, bz = 0;
-      if (bb < nblocks) {
-        const int ex = bb % np_[0], ey = (bb / np_[0]) % np_[1], ez = bb / (np_[0] * np_[1]);
-        int mx = 0, my = 0, mz = 0;
+    bool chain_too_long = false;
+    int gen = 0, total = 0;
+    if (lane < 8) s_best[wave][0][lane] = ~0ull;
+    // Candidate lists longer than kCandChunk (a dense map at a fine leaf: up to 9^3 voxels in the box) are handled in several
+    // passes: every pass regenerates the work list, keeps ordinals [c0, c0 + kCandChunk), and merges with the best five so far.
+    for (int c0 = 0;; c0 += kCandChunk) {
+      int produced = 0;   // wave-uniform running size of the work list
+      for (int bb0 = 0; bb0 < nblocks; bb0 += 64) {
+        const int bb = bb0 + lane;
+        u64 occ = 0ull;
+        int Ai = 0, bx = 0, Aj = 0, by = 0, Ak = 0, bz = 0;
+        if (bb < nblocks) {
+          const int ex = bb % np_[0], ey = (bb / np_[0]) % np_[1], ez = bb / (np_[0] * np_[1]);
+          int mx = 0, my = 0, mz = 0;
 #pragma unroll
-        for (int e = 0; e < kMaxPieces; e++) {  // select this lane's pieces without dynamic register indexing
-          if (e == ex) { Ai = pa[0][e]; bx = pb[0][e]; mx = pm[0][e]; }
-          if (e == ey) { Aj = pa[1][e]; by = pb[1][e]; my = pm[1][e]; }
-          if (e == ez) { Ak = pa[2][e]; bz = pb[2][e]; mz = pm[2][e]; }
-        }
-        const u64 bkey = pack_key(Ai, Aj, Ak, bx, by, bz) | (1ull << 63);
-        unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
-        for (;;) {
-          const ulonglong2 e = T.blk[bs];
-          if (e.x == 0ull) break;
-          if (e.x == bkey) { occ = e.y; break; }
-          bs = (bs + 1) & T.bslots_mask;
-        }
-        // voxels of the block inside the search box: bit = z * 16 + y * 4 + x
-        const u64 ex4 = (u64)mx * 0x1111111111111111ull;
-        const u64 ey4 = ((u64)((my & 1) * 0xF) | ((u64)(((my >> 1) & 1) * 0xF) << 4) | ((u64)(((my >> 2) & 1) * 0xF) << 8) | ((u64)(((my >> 3) & 1) * 0xF) << 12)) * 0x0001000100010001ull;
-        const u64 ez4 = ((mz & 1) ? 0xFFFFull : 0ull) | ((mz & 2) ? 0xFFFFull << 16 : 0ull) | ((mz & 4) ? 0xFFFFull << 32 : 0ull) | ((mz & 8) ? 0xFFFFull << 48 : 0ull);
-        occ &= ex4 & ey4 & ez4;
-      }
-      // flatten: exclusive prefix of the per-lane voxel counts, then every lane appends its voxel keys
-      const int mine = __popcll(occ);
-      int inc = mine;
-      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-      int o = produced + inc - mine;
-      while (occ) {
-        const int bit = __ffsll((long long)occ) - 1;
-        occ &= occ - 1;
-        if (o < 256) my_cand[o] = pack_key(Ai, Aj, Ak, (bx << 2) | (bit & 3), (by << 2) | ((bit >> 2) & 3), (bz << 2) | (bit >> 4));
-        o++;
-      }
-      produced += __shfl(inc, 63);
-    }
-    lds_sync_wave();
-    const int ncand = min(produced, 256);
-    // phase 3: one voxel per lane and trip: probe, fetch the centroid, squared distance -> key back into the list.  Key =
-    // (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the valid cubes
-    // in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so equal
-    // distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
-    for (int w = lane; w < ncand; w += 64) {
-      const u64 key = my_cand[w];
-      unsigned s = (unsigned)mix64(key) & T.mask;
-      u64 out = ~0ull;
-      for (;;) {
-        const u64 k = T.keys[s];
-        if (k == 0ull) break;
-        if (k == key) {
-          const int n = T.count[s];
-          float4 p = T.sum[s];
-          if (n > 0) {
-            if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
-            const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
-            int Ai, Aj, Ak;
-            unpack_cube(key, &Ai, &Aj, &Ak);
-            const unsigned tie = ((unsigned)(Ai - ctr[0] + 2) << 29) | ((unsigned)(Aj - ctr[1] + 2) << 26) | ((unsigned)(Ak - ctr[2] + 1) << 24) |
-                                 ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
-            out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
-            my_slot[w] = (int)s;
+          for (int e = 0; e < kMaxPieces; e++) {  // select this lane's pieces without dynamic register indexing
+            if (e == ex) { Ai = pa[0][e]; bx = pb[0][e]; mx = pm[0][e]; }
+            if (e == ey) { Aj = pa[1][e]; by = pb[1][e]; my = pm[1][e]; }
+            if (e == ez) { Ak = pa[2][e]; bz = pb[2][e]; mz = pm[2][e]; }
           }
-          break;
+          const u64 bkey = pack_key(Ai, Aj, Ak, bx, by, bz) | (1ull << 63);
+          unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
+          int probe = 0;
+          for (; probe < kMaxProbe; probe++) {
+            const ulonglong2 e = T.blk[bs];
+            if (e.x == 0ull) break;
+            if (e.x == bkey) { occ = e.y; break; }
+            bs = (bs + 1) & T.bslots_mask;
+          }
+          if (probe == kMaxProbe) chain_too_long = true;
+          // voxels of the block inside the search box: bit = z * 16 + y * 4 + x
+          const u64 ex4 = (u64)mx * 0x1111111111111111ull;
+          const u64 ey4 = ((u64)((my & 1) * 0xF) | ((u64)(((my >> 1) & 1) * 0xF) << 4) | ((u64)(((my >> 2) & 1) * 0xF) << 8) | ((u64)(((my >> 3) & 1) * 0xF) << 12)) * 0x0001000100010001ull;
+          const u64 ez4 = ((mz & 1) ? 0xFFFFull : 0ull) | ((mz & 2) ? 0xFFFFull << 16 : 0ull) | ((mz & 4) ? 0xFFFFull << 32 : 0ull) | ((mz & 8) ? 0xFFFFull << 48 : 0ull);
+          occ &= ex4 & ey4 & ez4;
         }
-        s = (s + 1) & T.mask;
+        // flatten: exclusive prefix of the per-lane voxel counts, then every lane appends its voxel keys
+        const int mine = __popcll(occ);
+        int inc = mine;
+        for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+        int o = produced + inc - mine;
+        while (occ) {
+          const int bit = __ffsll((long long)occ) - 1;
+          occ &= occ - 1;
+          if (o >= c0 && o < c0 + kCandChunk)
+            my_cand[o - c0] = pack_key(Ai, Aj, Ak, (bx << 2) | (bit & 3), (by << 2) | ((bit >> 2) & 3), (bz << 2) | (bit >> 4));
+          o++;
+        }
+        produced += __shfl(inc, 63);
       }
-      my_cand[w] = out;
-    }
-    u64* my_best = s_best[threadIdx.x >> 6];
-    int* my_best_slot = s_best_slot[threadIdx.x >> 6];
-    if (lane < 8) { my_best[lane] = ~0ull; my_best_slot[lane] = -1; }
-    lds_sync_wave();
-    // phase 4: the five smallest keys by rank counting (keys are unique: distinct voxels); ~30 candidates on average
-    for (int w = lane; w < ncand; w += 64) {
-      const u64 mine = my_cand[w];
-      if (mine == ~0ull) continue;
-      int rank = 0;
-      for (int t = 0; t < ncand; t++) rank += my_cand[t] < mine;
-      if (rank < 5) { my_best[rank] = mine; my_best_slot[rank] = my_slot[w]; }
-    }
-    lds_sync_wave();
-    float nd[5];
-    int ns[5];
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-      nd[r] = __uint_as_float((unsigned)(my_best[r] >> 32));
-      ns[r] = my_best_slot[r];
+      total = produced;
+      lds_sync_wave();
+      const int ncand = min(total - c0, kCandChunk);
+      // phase 3: one voxel per lane and trip: probe, take the centroid out of the record, squared distance -> key back into the
+      // list.  Key = (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the
+      // valid cubes in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so
+      // equal distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
+      for (int w = lane; w < ncand; w += 64) {
+        const u64 key = my_cand[w];
+        unsigned s = (unsigned)mix64(key) & T.mask;
+        u64 out = ~0ull;
+        float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        int probe = 0;
+        for (; probe < kMaxProbe; probe++) {
+          const RecVal r = rec_load(&T.rec[s]);
+          if (r.key == 0ull) break;
+          if (r.key == key) {
+            const int n = r.count;
+            float4 p = r.sum;
+            if (n > 0) {
+              if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+              const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
+              int Ai, Aj, Ak;
+              unpack_cube(key, &Ai, &Aj, &Ak);
+              const unsigned tie = ((unsigned)(Ai - ctr[0] + 2) << 29) | ((unsigned)(Aj - ctr[1] + 2) << 26) | ((unsigned)(Ak - ctr[2] + 1) << 24) |
+                                   ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
+              out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+              pt = make_float4(p.x, p.y, p.z, 0.f);
+            }
+            break;
+          }
+          s = (s + 1) & T.mask;
+        }
+        if (probe == kMaxProbe) chain_too_long = true;
+        my_cand[w] = out;
+        my_pt[w] = pt;
+      }
+      // the best five of the earlier passes compete again
+      const int nlist = ncand + (c0 > 0 ? 5 : 0);
+      if (c0 > 0 && lane < 5) { my_cand[ncand + lane] = s_best[wave][gen][lane]; my_pt[ncand + lane] = s_best_p[wave][gen][lane]; }
+      u64* nb = s_best[wave][gen ^ 1];
+      float4* nbp = s_best_p[wave][gen ^ 1];
+      if (lane < 8) nb[lane] = ~0ull;
+      lds_sync_wave();
+      // phase 4: the five smallest keys by rank counting (keys are unique: distinct voxels); ~30 candidates on average
+      for (int w = lane; w < nlist; w += 64) {
+        const u64 mine = my_cand[w];
+        if (mine == ~0ull) continue;
+        int rank = 0;
+        for (int t = 0; t < nlist; t++) rank += my_cand[t] < mine;
+        if (rank < 5) { nb[rank] = mine; nbp[rank] = my_pt[w]; }
+      }
+      lds_sync_wave();
+      gen ^= 1;
+      if (c0 + kCandChunk >= total) break;
     }
     // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in
-    // registers and pure per-query math, so they should not hold 64 lanes and ~130 VGPRs hostage here)
-    if (lane == 0) {
-      const bool ok = ns[4] >= 0 && nd[4] < 1.0f;  // LM:479 / LM:547
-#pragma unroll
-      for (int j = 0; j < 5; j++) nn[slot * 5 + j] = ok ? ns[j] : -1;
+    // registers and pure per-query math, so they should not hold 64 lanes and ~130 VGPRs hostage here) — as points, so that the
+    // fit does not have to go back to the table
+    if (lane < 5) {
+      const u64 k4 = s_best[wave][gen][4];
+      const bool ok = k4 != ~0ull && __uint_as_float((unsigned)(k4 >> 32)) < 1.0f;  // LM:479 / LM:547
+      float4 p = s_best_p[wave][gen][lane];
+      p.w = ok ? 1.0f : 0.0f;
+      nbr[slot * 5 + lane] = p;
     }
+    if (lane == 0 && total > kCandChunk) atomicMax(&fr->max_candidates, total);
+    if (__ballot(chain_too_long || overflow) && lane == 0) atomicOr(&fr->error, kErrMapFull);
   }
 }
 
 __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
-                                                 VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr, const int* __restrict__ nn,
+                                                 VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr, const float4* __restrict__ nbr,
                                                  FactorTable F, int outer) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= kMapFactorCap) return;
@@ -601,16 +643,13 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
   const int i = kind ? slot - kStackCapCorner : slot;
   const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
   int type = 0;
-  if (ms->do_optimize && i < nst && nn[slot * 5] >= 0) {
-    const VoxelTable T = kind ? T1 : T0;
+  (void)T0; (void)T1;
+  if (ms->do_optimize && i < nst && nbr[slot * 5].w != 0.0f) {
     const float4 pointOri = kind ? stack1[i] : stack0[i];
     double P[5][3];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      const int s = nn[slot * 5 + j];
-      const int n = T.count[s];
-      float4 p = T.sum[s];
-      if (n > 1) { const float nnf = (float)n; p.x = p.x / nnf; p.y = p.y / nnf; p.z = p.z / nnf; }
+      const float4 p = nbr[slot * 5 + j];
       P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
     }
     double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
@@ -679,6 +718,21 @@ __device__ void map_update(MapState* ms, double* traj_row14) {
   if (traj_row14) for (int k = 0; k < 7; k++) traj_row14[7 + k] = ms->parameters[k];
 }
 
+// set the voxel's bit in its 4 x 4 x 4 block's occupancy mask (find-or-insert of the block entry)
+__device__ bool map_publish_block(const VoxelTable& T, int Ai, int Aj, int Ak, int lx, int ly, int lz) {
+  const u64 bkey = pack_key(Ai, Aj, Ak, lx >> 2, ly >> 2, lz >> 2) | (1ull << 63);
+  unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
+  for (int bp = 0; bp < kMaxProbe; bp++, bs = (bs + 1) & T.bslots_mask) {
+    const u64 bold = atomicCAS(&T.blk[bs].x, 0ull, bkey);
+    if (bold == 0ull || bold == bkey) {
+      if (bold == 0ull) atomicAdd(&T.stats[2], 1);
+      atomicOr(&T.blk[bs].y, 1ull << (((lz & 3) << 4) | ((ly & 3) << 2) | (lx & 3)));
+      return true;
+    }
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ stack0, const float4* __restrict__ stack1,
                                                     float4* __restrict__ smap0, float4* __restrict__ smap1, VoxelTable T0, VoxelTable T1,
                                                     float inv0, float inv1, MapState* ms, MapFrame* fr, int* __restrict__ touched0,
@@ -707,20 +761,14 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
     const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
     unsigned s = (unsigned)mix64(key) & T.mask;
     bool done = false;
-    for (unsigned probe = 0; probe <= T.mask && !done; probe++, s = (s + 1) & T.mask) {
-      const u64 old = atomicCAS(&T.keys[s], 0ull, key);
+    for (int probe = 0; probe < kMaxProbe && !done; probe++, s = (s + 1) & T.mask) {
+      const u64 old = atomicCAS(&T.rec[s].key, 0ull, key);
       if (old == 0ull || old == key) {
         if (old == 0ull) {  // new voxel: publish it in its block's occupancy mask
-          const u64 bkey = pack_key(Ai, Aj, Ak, lx >> 2, ly >> 2, lz >> 2) | (1ull << 63);
-          unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
-          bool bdone = false;
-          for (unsigned bp = 0; bp <= T.bslots_mask && !bdone; bp++, bs = (bs + 1) & T.bslots_mask) {
-            const u64 bold = atomicCAS(&T.blk[bs].x, 0ull, bkey);
-            if (bold == 0ull || bold == bkey) { atomicOr(&T.blk[bs].y, 1ull << (((lz & 3) << 4) | ((ly & 3) << 2) | (lx & 3))); bdone = true; }
-          }
-          if (!bdone) atomicOr(&fr->error, kErrMapFull);
+          atomicAdd(&T.stats[0], 1);
+          if (!map_publish_block(T, Ai, Aj, Ak, lx, ly, lz)) atomicOr(&fr->error, kErrMapFull);
         }
-        const int pos = atomicAdd(&T.pend_cnt[s], 1);
+        const int pos = atomicAdd(&T.rec[s].pend_cnt, 1);
         if (pos < kPendCap) T.pend[(size_t)s * kPendCap + pos] = i; else atomicOr(&fr->error, kErrMapFull);
         if (pos == 0) {
           const int tpos = atomicAdd(&fr->n_touched[kind], 1);
@@ -743,7 +791,8 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
 __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__ smap0, const float4* __restrict__ smap1, VoxelTable T0,
                                                       VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr,
                                                       const int* __restrict__ touched0, const int* __restrict__ touched1,
-                                                      int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ cube_cnt) {
+                                                      int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ cube_cnt,
+                                                      int* host_flags) {
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
   const float4* smap = kind ? smap1 : smap0;
@@ -755,7 +804,8 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
   if (t < nt) {
     const int s = touched[t];
     int idx[kPendCap];
-    const int np = min(T.pend_cnt[s], kPendCap);
+    const RecVal rv = rec_load(&T.rec[s]);
+    const int np = min(rv.pend_cnt, kPendCap);
     for (int a = 0; a < np; a++) idx[a] = T.pend[(size_t)s * kPendCap + a];
     for (int a = 1; a < np; a++) {  // stack order == the order the reference push_back()s into the cube cloud
       const int v = idx[a];
@@ -763,10 +813,10 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
       while (c >= 0 && idx[c] > v) { idx[c + 1] = idx[c]; c--; }
       idx[c + 1] = v;
     }
-    int n = T.count[s];
-    float4 acc = n > 0 ? T.sum[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int n = rv.count;
+    float4 acc = n > 0 ? rv.sum : make_float4(0.f, 0.f, 0.f, 0.f);
     int Ai, Aj, Ak;
-    unpack_cube(T.keys[s], &Ai, &Aj, &Ak);
+    unpack_cube(rv.key, &Ai, &Aj, &Ak);
     const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
     if (n == 0) atomicAdd(&cube_cnt[kind * kCubeNum + wi + kCubeW * wj + kCubeW * kCubeH * wk], 1);
     for (int a = 0; a < np; a++) { const float4 p = smap[idx[a]]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
@@ -777,7 +827,7 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
       acc.x = acc.x / nn; acc.y = acc.y / nn; acc.z = acc.z / nn; acc.w = acc.w / nn;
       n = 1;
     }
-    T.sum[s] = acc; T.count[s] = n; T.pend_cnt[s] = 0;
+    rec_store_value(&T.rec[s], acc, n, 0);
   }
   // raw voxels of earlier sweeps whose cube is valid now (rare; only with ranges beyond the 5x5x3 block)
   if (blockIdx.x == 0) {
@@ -786,17 +836,72 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
     for (int d = threadIdx.x; d < nd; d += 256) {
       const int s = deferred[d];
       if (s < 0) continue;
+      const RecVal dv = rec_load(&T.rec[s]);
       int Ai, Aj, Ak;
-      unpack_cube(T.keys[s], &Ai, &Aj, &Ak);
+      unpack_cube(dv.key, &Ai, &Aj, &Ak);
       const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
       if (abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1) {
-        const int n = T.count[s];
-        if (n > 1) { float4 a = T.sum[s]; const float nn = (float)n; a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn; T.sum[s] = a; T.count[s] = 1; }
+        const int n = dv.count;
+        if (n > 1) { float4 a = dv.sum; const float nn = (float)n; a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn; rec_store_value(&T.rec[s], a, 1, 0); }
         deferred[d] = -1;
       }
     }
   }
   if (fr->rolled) map_purge(T, ms, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+  // table health, once per sweep and kind: the error surfaces well before probe chains degrade, and the host learns (through a
+  // host-mapped word it polls without synchronising) when enough purged entries have piled up for a rebuild to pay
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long slots = (long long)T.mask + 1;
+    const int keys = T.stats[0], dead = T.stats[1];
+    if ((long long)(keys - dead) * 10 > slots * 6 || (long long)T.stats[2] * 10 > ((long long)T.bslots_mask + 1) * 6) atomicOr(&fr->error, kErrMapFull);
+    if (host_flags) {
+      const int want = ((long long)dead * 8 > slots || (long long)keys * 2 > slots) && dead > 0 ? 1 : 0;
+      __hip_atomic_store(&host_flags[kind], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- table rebuild (tombstone reclamation)
+// Purged entries keep their key so that probe chains stay intact; on a long drive they would fill the table.  When the host sees
+// the flag k_map_finalize raises, it enqueues — between two sweeps, on the mapping stream — gather (live records -> list), two
+// memsets, reinsert.  Voxel contents are untouched: only slot positions change (nothing keeps slot ids across sweeps except the
+// deferred list, which is rebuilt here).
+__global__ __launch_bounds__(256) void k_map_rebuild_gather(VoxelTable T, VoxelRec* __restrict__ tmp, int cap, int* n_tmp, MapFrame* fr, int kind) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_deferred[kind] = 0;
+  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
+    const RecVal v = rec_load(&T.rec[s]);
+    if (v.key == 0ull || v.count <= 0) continue;
+    const int o = atomicAdd(n_tmp, 1);
+    if (o < cap) { VoxelRec r; r.key = v.key; r.sx = v.sum.x; r.sy = v.sum.y; r.sz = v.sum.z; r.si = v.sum.w; r.count = v.count; r.pend_cnt = 0; tmp[o] = r; }
+    else atomicOr(&fr->error, kErrMapFull);
+  }
+}
+__global__ __launch_bounds__(256) void k_map_rebuild_insert(VoxelTable T, const VoxelRec* __restrict__ tmp, int cap, int* n_tmp, MapFrame* fr, int kind,
+                                                            int* __restrict__ deferred, int deferred_cap, float inv, int* host_flags) {
+  const int n = min(*n_tmp, cap);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const VoxelRec r = tmp[e];
+    unsigned s = (unsigned)mix64(r.key) & T.mask;
+    bool done = false;
+    for (int probe = 0; probe < kMaxProbe && !done; probe++, s = (s + 1) & T.mask) {
+      if (atomicCAS(&T.rec[s].key, 0ull, r.key) != 0ull) continue;   // keys are unique in the list
+      rec_store_value(&T.rec[s], make_float4(r.sx, r.sy, r.sz, r.si), r.count, 0);
+      int Ai, Aj, Ak;
+      unpack_cube(r.key, &Ai, &Aj, &Ak);
+      if (!map_publish_block(T, Ai, Aj, Ak, (int)((r.key >> 16) & 0xff), (int)((r.key >> 8) & 0xff), (int)(r.key & 0xff))) atomicOr(&fr->error, kErrMapFull);
+      if (r.count > 1) {  // raw points of a cube outside the valid block: still owed a centroid (see k_map_finalize)
+        const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
+        if (dpos < deferred_cap) deferred[dpos] = (int)s;
+      }
+      done = true;
+    }
+    if (!done) atomicOr(&fr->error, kErrMapFull);
+  }
+  (void)inv;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    T.stats[0] = n; T.stats[1] = 0;
+    if (host_flags) __hip_atomic_store(&host_flags[kind], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ void k_map_register(const float4* __restrict__ cloud, const FrameScalars* __restrict__ S, const MapState* __restrict__ ms,
@@ -826,8 +931,7 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
   const size_t slots = (size_t)1 << lg;
   for (int k = 0; k < 2 && ok; k++) {
     VoxelTable& T = m->tab[k];
-    ok = ok && dmalloc(allocs, st, &T.keys, slots) && dmalloc(allocs, st, &T.sum, slots) && dmalloc(allocs, st, &T.count, slots) &&
-         dmalloc(allocs, st, &T.pend_cnt, slots) && dmalloc(allocs, st, &T.pend, slots * kPendCap);
+    ok = ok && dmalloc(allocs, st, &T.rec, slots) && dmalloc(allocs, st, &T.pend, slots * kPendCap) && dmalloc(allocs, st, &T.stats, 4);
     T.mask = (unsigned)(slots - 1);
     const size_t bslots = slots / 2;
     ok = ok && dmalloc(allocs, st, &T.blk, bslots);
@@ -857,7 +961,11 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
   }
-  ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nn, 5 * (size_t)kMapFactorCap);
+  ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nbr, 5 * (size_t)kMapFactorCap);
+  m->rebuild_cap = (int)(slots / 2);
+  ok = ok && dmalloc(allocs, st, &m->rebuild_tmp, (size_t)m->rebuild_cap) && dmalloc(allocs, st, &m->rebuild_n, 1);
+  if (ok && hipHostMalloc((void**)&m->host_flags, 64, hipHostMallocMapped) != hipSuccess) { m->host_flags = nullptr; ok = false; }
+  if (ok) { m->host_flags[0] = m->host_flags[1] = 0; }
   ok = ok && dmalloc(allocs, st, &m->registered, (size_t)cfg.max_points);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
@@ -884,27 +992,116 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
+void map_destroy(MapContext* m) {
+  if (m->host_flags) { (void)hipHostFree(m->host_flags); m->host_flags = nullptr; }
+}
+
+// gather the live records, clear the table, reinsert (see k_map_rebuild_*); between two sweeps on the mapping stream
+static vloam_status map_rebuild_enqueue(MapContext* m, hipStream_t st, int kind) {
+  VoxelTable& T = m->tab[kind];
+  const size_t slots = (size_t)T.mask + 1, bslots = (size_t)T.bslots_mask + 1;
+  const int cap = kind ? kStackCapSurf : kStackCapCorner;
+  if (hipMemsetAsync(m->rebuild_n, 0, sizeof(int), st) != hipSuccess) return VLOAM_ERR_HIP;
+  hipLaunchKernelGGL(k_map_rebuild_gather, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind);
+  if (hipMemsetAsync(T.rec, 0, slots * sizeof(VoxelRec), st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemsetAsync(T.blk, 0, bslots * sizeof(ulonglong2), st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipMemsetAsync(T.stats, 0, 4 * sizeof(int), st) != hipSuccess) return VLOAM_ERR_HIP;
+  hipLaunchKernelGGL(k_map_rebuild_insert, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind,
+                     m->deferred[kind], cap, m->inv_leaf[kind], m->host_flags);
+  m->rebuilds++;
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+vloam_status map_force_rebuild(MapContext* m, hipStream_t st) {
+  for (int k = 0; k < 2; k++) { vloam_status s = map_rebuild_enqueue(m, st, k); if (s != VLOAM_OK) return s; }
+  return VLOAM_OK;
+}
+
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
                          bool skip_frame, int set, ProfHook* ph) {
   (void)cfg; (void)cur;
   MapState* ms = m->state;
   MapFrame* fr = m->frame;
   m->stack[0] = m->stack_sets[set][0]; m->stack[1] = m->stack_sets[set][1];
+  if (!skip_frame) {
+    // the flag is written by k_map_finalize of an EARLIER sweep (plain read of host-mapped memory, no synchronisation): a rebuild
+    // a few sweeps late is as good; the cool-down covers the sweeps already in flight that still report the old state
+    for (int k = 0; k < 2; k++) {
+      if (m->rebuild_cooldown[k] > 0) { m->rebuild_cooldown[k]--; continue; }
+      if (__atomic_load_n(&m->host_flags[k], __ATOMIC_RELAXED)) {
+        if (map_rebuild_enqueue(m, st, k) != VLOAM_OK) return VLOAM_ERR_HIP;
+        m->rebuild_cooldown[k] = 8;
+      }
+    }
+  }
   VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
                m->stack_info[set]);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
-                 m->inv_leaf[0], m->inv_leaf[1], ms, m->nn);
-    VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nn,
+                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr);
+    VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nbr,
                  m->F[outer], outer);
     lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
                m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14);
   VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
-               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt);
+               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------- map export
+// /laser_cloud_map (LM:778-793): for cube index 0..4850 the corner cloud then the surf cloud of the cube.  A cube cloud that has been
+// through its VoxelGrid re-filter (every cube that was ever valid) is ordered by voxel (iz, iy, ix); cubes that only ever received points
+// while outside the valid block hold raw points in the reference and (sum, count) accumulations here — emitted as their centroid
+// (see DESIGN.md "deferred"; unreachable for ranges <= 100 m).  The device compacts the live records with their order key; the
+// final ordering of this OUTPUT path is a host sort of the compacted list.
+struct ExportRow { u64 okey; float x, y, z, w; };
+__global__ __launch_bounds__(256) void k_map_export(VoxelTable T, const MapState* __restrict__ ms, int kind, ExportRow* __restrict__ out, long long cap,
+                                                    unsigned long long* n_out) {
+  const int cW = ms->cenW, cH = ms->cenH, cD = ms->cenD;
+  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
+    const RecVal v = rec_load(&T.rec[s]);
+    if (v.key == 0ull || v.count <= 0) continue;
+    int Ai, Aj, Ak;
+    unpack_cube(v.key, &Ai, &Aj, &Ak);
+    const int i = Ai + cW, j = Aj + cH, k = Ak + cD;
+    if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || k < 0 || k >= kCubeD) continue;
+    const u64 cube = (u64)(i + kCubeW * j + kCubeW * kCubeH * k);
+    const u64 lx = (v.key >> 16) & 0xff, ly = (v.key >> 8) & 0xff, lz = v.key & 0xff;
+    ExportRow r;
+    r.okey = (cube << 32) | ((u64)kind << 24) | (lz << 16) | (ly << 8) | lx;
+    const float nn = (float)v.count;
+    r.x = v.count > 1 ? v.sum.x / nn : v.sum.x; r.y = v.count > 1 ? v.sum.y / nn : v.sum.y; r.z = v.count > 1 ? v.sum.z / nn : v.sum.z;
+    r.w = v.count > 1 ? v.sum.w / nn : v.sum.w;
+    const unsigned long long o = atomicAdd(n_out, 1ull);
+    if ((long long)o < cap) out[o] = r;
+  }
+}
+
+vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long cap, long long* n) {
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  int stats[2][4];
+  for (int k = 0; k < 2; k++) if (hipMemcpy(stats[k], m->tab[k].stats, sizeof(stats[k]), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  const long long bound = (long long)stats[0][0] + stats[1][0] + 1;  // keys ever inserted >= live voxels
+  ExportRow* d_rows = nullptr;
+  unsigned long long* d_n = nullptr;
+  if (hipMalloc((void**)&d_rows, (size_t)bound * sizeof(ExportRow)) != hipSuccess || hipMalloc((void**)&d_n, sizeof(*d_n)) != hipSuccess) return VLOAM_ERR_HIP;
+  vloam_status rc = VLOAM_OK;
+  unsigned long long cnt = 0;
+  if (hipMemsetAsync(d_n, 0, sizeof(*d_n), st) != hipSuccess) rc = VLOAM_ERR_HIP;
+  for (int k = 0; k < 2 && rc == VLOAM_OK; k++) hipLaunchKernelGGL(k_map_export, dim3(1024), dim3(256), 0, st, m->tab[k], m->state, k, d_rows, bound, d_n);
+  if (rc == VLOAM_OK && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&cnt, d_n, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess)) rc = VLOAM_ERR_HIP;
+  std::vector<ExportRow> rows((size_t)((long long)cnt < bound ? (long long)cnt : bound));
+  if (rc == VLOAM_OK && !rows.empty() && hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(ExportRow), hipMemcpyDeviceToHost) != hipSuccess) rc = VLOAM_ERR_HIP;
+  (void)hipFree(d_rows); (void)hipFree(d_n);
+  if (rc != VLOAM_OK) return rc;
+  std::sort(rows.begin(), rows.end(), [](const ExportRow& a, const ExportRow& b) { return a.okey < b.okey; });
+  if (n) *n = (long long)rows.size();
+  const long long c = (long long)rows.size() < cap ? (long long)rows.size() : cap;
+  for (long long i = 0; xyzi4 && i < c; i++) { xyzi4[4 * i] = rows[(size_t)i].x; xyzi4[4 * i + 1] = rows[(size_t)i].y; xyzi4[4 * i + 2] = rows[(size_t)i].z; xyzi4[4 * i + 3] = rows[(size_t)i].w; }
+  return VLOAM_OK;
 }
 
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n) {
@@ -952,23 +1149,29 @@ vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, lo
   if (item == 67 || item == 68) {
     const VoxelTable& T = m->tab[item - 67];
     const size_t slots = (size_t)T.mask + 1;
-    std::vector<u64> keys(slots);
-    std::vector<int> cnt(slots);
-    std::vector<float4> sum(slots);
-    if (hipMemcpy(keys.data(), T.keys, slots * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    if (hipMemcpy(cnt.data(), T.count, slots * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    if (hipMemcpy(sum.data(), T.sum, slots * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    std::vector<VoxelRec> recs(slots);
+    if (hipMemcpy(recs.data(), T.rec, slots * sizeof(VoxelRec), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
     std::vector<unsigned> rows;
     for (size_t s = 0; s < slots; s++) {
-      if (keys[s] == 0 || cnt[s] == 0) continue;
+      if (recs[s].key == 0 || recs[s].count == 0) continue;
       unsigned r[7];
-      r[0] = (unsigned)(keys[s] & 0xffffffffu); r[1] = (unsigned)(keys[s] >> 32); r[2] = (unsigned)cnt[s];
-      memcpy(r + 3, &sum[s], 16);
+      r[0] = (unsigned)(recs[s].key & 0xffffffffu); r[1] = (unsigned)(recs[s].key >> 32); r[2] = (unsigned)recs[s].count;
+      memcpy(r + 3, &recs[s].sx, 16);
       rows.insert(rows.end(), r, r + 7);
     }
     if (n) *n = (long long)(rows.size() * 4);
     const size_t c = rows.size() * 4 < (size_t)cap ? rows.size() * 4 : (size_t)cap;
     if (buf && c) memcpy(buf, rows.data(), c);
+    return VLOAM_OK;
+  }
+  if (item == 69) {  // table health: {keys, purged, block keys, spare} x {corner, surf}, rebuilds, largest candidate list
+    int out[12] = {0};
+    for (int k = 0; k < 2; k++) if (hipMemcpy(out + 4 * k, m->tab[k].stats, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    MapFrame fr;
+    if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    out[8] = (int)m->rebuilds; out[9] = fr.max_candidates; out[10] = fr.n_deferred[0]; out[11] = fr.n_deferred[1];
+    if (n) *n = sizeof(out);
+    if (buf) memcpy(buf, out, (size_t)cap < sizeof(out) ? (size_t)cap : sizeof(out));
     return VLOAM_OK;
   }
   const int outer = item / 16, k = item % 16;
