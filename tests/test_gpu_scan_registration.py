@@ -117,3 +117,29 @@ def test_scan_registration_edge_cases(vl, orc, sweeps):
     with pytest.raises(vl.VloamError) as ei:
         vl.Handle(0, scan_line=48)
     assert ei.value.status == vl.ERR_INVALID
+
+
+def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
+    """vloam_process_scan bursts rotate four buffer sets and rewrite each set's error word every sweep: an empty sweep (all NaN) or a
+    dropped over-long ring in the MIDDLE of a burst must still be reported by the vloam_sync that ends it — once."""
+    good = [sweeps(64, 512, k) for k in range(10)]
+    h = vl.Handle(0, with_mapping=1)
+    for k in range(10):
+        h.process_scan(good[k] if k != 3 else np.full((4096, 4), np.nan, dtype=np.float32))
+    with pytest.raises(vl.VloamError) as ei:
+        h.sync()
+    assert ei.value.status == vl.ERR_EMPTY
+    h.sync()   # reported once
+    # one ring with more points than the LDS-resident ring buffer takes (kMaxRingLen = 4096): the ring is dropped, loudly
+    long_ring = np.zeros((6000, 4), dtype=np.float32)
+    az = -2 * np.pi * np.arange(6000) / 6000
+    el = np.deg2rad(-10.43)   # beam 35 of the HDL-64E table
+    long_ring[:, 0], long_ring[:, 1], long_ring[:, 2] = 20 * np.cos(el) * np.cos(az), 20 * np.cos(el) * np.sin(az), 20 * np.sin(el)
+    h2 = vl.Handle(0, with_mapping=0)
+    h2.process_scan(good[0]); h2.process_scan(long_ring)
+    for k in range(1, 6):
+        h2.process_scan(good[k])
+    with pytest.raises(vl.VloamError) as ei:
+        h2.sync()
+    assert ei.value.status == vl.ERR_CAPACITY
+    h2.sync()

@@ -233,6 +233,7 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       s = map_create(&h->map, h->cfg, h->stream, h->allocs);
       if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       h->lo_F.err = &h->map.frame->error;
+      for (int k = 0; k < vloam_handle::kSets; k++) h->sr[k].sticky_err = &h->map.frame->error;
       {
         // sync words of the three cooperative solves (odometry, mapping outer rounds): the fastest of 48 candidate lines
         constexpr int kCand = 48;
@@ -643,14 +644,13 @@ vloam_status vloam_sync(vloam_handle* h) {
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   if (h->frame > 0) {
-    // surface sticky device-side errors of the last sweep
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, &h->sr[set_of(h->frame - 1)].S->error, sizeof(int), hipMemcpyDeviceToHost));
-    if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
-    if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
+    // surface sticky device-side errors: scan-registration bits of ANY sweep since the last vloam_sync (k_sr_compact folds every
+    // sweep's word into the handle's sticky word; reported once, then cleared), map / solver bits for good
     int merr = 0;
-    vloam_status s = map_error(&h->map, &merr);
+    vloam_status s = map_error(&h->map, &merr, kErrEmpty | kErrRingTooLong);
     if (s != VLOAM_OK) return s;
+    if (merr & kErrEmpty) { set_err("no point survived NaN / minimum_range removal in at least one sweep since the last vloam_sync"); return VLOAM_ERR_EMPTY; }
+    if (merr & kErrRingTooLong) { set_err("a ring held more than %d points (dropped) in at least one sweep since the last vloam_sync", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }

@@ -326,6 +326,8 @@ struct LmShared {
   int n_edge;
   int go;              // 1: evaluate candidate next, 0: finished
   int n_valid;
+  int failed;          // cooperative solve: a workgroup gave up waiting at the grid barrier -> every workgroup abandons the solve
+  double x0[8];        // the parameters the solve started from (what an abandoned solve hands back)
 };
 
 // Factors owned by a lane stay in its registers across the evaluations of a solve (one workgroup = 256 lanes x 512 VGPRs):
@@ -565,10 +567,18 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)(eval_idx + 1) * (unsigned)NB;
       int spins = 0;
-      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      unsigned v;
+      // never hang the device: a workgroup that gives up sets the counter's top bit — every waiter (now or later) falls out of its
+      // loop on the value it polls anyway, the host is told through the sticky error word (vloam_sync), and the solve is abandoned
+      while ((v = __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) { if (F.err) atomicOr(F.err, kErrSolverSync); break; }  // never hang the device: flag (vloam_sync reports it) and fall through
+        if (++spins > (1 << 20)) {
+          v = __hip_atomic_fetch_or(bar, 0x80000000u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) | 0x80000000u;
+          if (F.err) atomicOr(F.err, kErrSolverSync);
+          break;
+        }
       }
+      if (v & 0x80000000u) sh.failed = 1;  // nobody continues with partial sums that may be incomplete
     }
     __syncthreads();
     if (tid < kAcc) {
@@ -697,8 +707,8 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     return;
   }
   constexpr int na = QUAT ? 7 : 6;
-  if (tid < na) sh.x[tid] = x_io[tid];
-  if (tid == 7) sh.x[7] = 0.0;
+  if (tid < na) { sh.x[tid] = x_io[tid]; sh.x0[tid] = sh.x[tid]; }
+  if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; }
 
   // ---- prologue: the factors were compacted by k_lm_compact; count them and release the row counters
   const long long t_start = clock64();
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.cur);
   if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
   __syncthreads();
+  const bool failed_at_start = NB > 1 && sh.failed;  // (uniform: written before the barrier that ends lm_evaluate)
   if (tid == 0) {
     x_cost = sh.cur[0];
     gmax = sh.gmax_c;
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   }
 
-  for (;;) {
+  for (; !failed_at_start;) {
     t_mark = clock64();
     if (tid == 0) {
       int go = -1;  // -1: invalid step, loop again inside thread 0; 0: stop; 1: evaluate the candidate
@@ -854,6 +865,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     t_mark = clock64();
     lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac, eval_idx++);
     cyc_eval += clock64() - t_mark;
+    if (NB > 1 && sh.failed) break;  // uniform across the workgroup; every workgroup sees the flag at this or its next barrier
     t_mark = clock64();
     // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
     if (tid == 64) sh.gmax_c = grad_max(sh.xc, sh.cand);
@@ -916,6 +928,11 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   }
   if (tid == 0 && lead) {
+    if (NB > 1 && sh.failed) {  // abandoned: the solve degrades to "no update" (x unchanged) instead of corrupting the state
+#pragma unroll
+      for (int i = 0; i < 7; i++) sh.best[i] = i < na ? sh.x0[i] : 0.0;
+      termination = 3;
+    }
 #pragma unroll
     for (int i = 0; i < na; i++) x_io[i] = sh.best[i];
 #pragma unroll

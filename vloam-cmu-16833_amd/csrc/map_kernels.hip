@@ -1125,10 +1125,13 @@ vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuf
   return VLOAM_OK;
 }
 
-vloam_status map_error(MapContext* m, int* e) {
-  MapFrame fr;
-  if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-  *e = fr.error;
+__global__ void k_map_error_fetch(MapFrame* fr, int clear_mask, int* out) { *out = atomicAnd(&fr->error, ~clear_mask); }
+
+// the sticky error word; the bits of clear_mask are reported once and cleared (transient per-sweep conditions)
+vloam_status map_error(MapContext* m, int* e, int clear_mask) {
+  int* d_out = m->rebuild_n;  // scratch int (no rebuild can be in flight: the caller has synchronised the streams)
+  hipLaunchKernelGGL(k_map_error_fetch, dim3(1), dim3(1), 0, 0, m->frame, clear_mask, d_out);
+  if (hipMemcpy(e, d_out, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
   return VLOAM_OK;
 }
 

@@ -7,6 +7,7 @@ namespace vloam {
 
 struct SRBuffers {
   FrameScalars* S;
+  int* sticky_err;      // handle-wide sticky error word: the per-sweep S->error (rewritten every sweep, per buffer set) is folded into it
   signed char* sid;     // [max_points] ring id or -1
   float* ori;           // [max_points] raw -atan2(y, x)
   int* blockhist;       // [nblk_max][kMaxRings]

@@ -704,10 +704,14 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
                                                     const int* __restrict__ less_sharp_idx, const int* __restrict__ flat_idx,
                                                     const float4* __restrict__ ring_ds, float4* __restrict__ sharp,
                                                     float4* __restrict__ less_sharp, float4* __restrict__ flat,
-                                                    float4* __restrict__ less_flat, int* __restrict__ dbg_feat_idx /* [3][kMaxLessSharp] */) {
+                                                    float4* __restrict__ less_flat, int* __restrict__ dbg_feat_idx /* [3][kMaxLessSharp] */,
+                                                    int* sticky_err) {
   __shared__ int base[4];
   __shared__ int soff[kSectors][3];
   const int r = blockIdx.x, tid = threadIdx.x;
+  // last launch of the sweep's scan registration: its error bits (S->error is per buffer set and rewritten every sweep) go into the
+  // handle's sticky word, so that a burst of vloam_process_scan calls cannot lose them
+  if (r == 0 && tid == 0 && sticky_err && S->error) atomicOr(sticky_err, S->error);
   {
     // 4 wavefronts: kinds 0..2 = sharp / lessSharp / flat picks per ring, kind 3 = per-ring VoxelGrid output size
     const int kind = tid >> 6, q = tid & 63;
@@ -781,7 +785,7 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                      debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr);
   VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
-                     b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr);
+                     b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr, b.sticky_err);
   return hipGetLastError();
 }
 
