@@ -69,6 +69,20 @@ const char* vloam_version(void);
 vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** out);
 vloam_status vloam_destroy(vloam_handle* h);
 
+/* ---- Batched execution: one handle, n_sessions independent sequences advanced in lock step.  Every kernel of the sweep chain is
+ * launched once per sweep for ALL sessions (session index in blockIdx.z), so n_sessions sequences cost one launch chain — the way to
+ * fill the chip with a path whose single-sequence form is a latency chain.  Each session owns an identical arena of
+ * device state; results are bit-identical to running the sequence alone.  vloam_create == vloam_create_batch(…, 1, …).
+ * vloam_batch_process_scan[_device]: session b gets sweep xyz_pad4[b] with n[b] points (arrays of n_sessions entries).
+ * vloam_select_session: which session the getters below (trajectory, features, counts, map, parity hooks) read; 0 after creation.
+ * The single-sequence entry points (vloam_scan_registration*, vloam_laser_*, vloam_process_scan*, vloam_process_frame*) return
+ * VLOAM_ERR_INVALID on a handle with more than one session. */
+vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessions, vloam_handle** out);
+vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions);
+vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n);
+vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_pad4, const int* n);
+vloam_status vloam_select_session(vloam_handle* h, int session);
+
 /* == LidarOdometryMapping::reset (lidar_odometry_mapping.cpp:65-71) */
 vloam_status vloam_reset_frame(vloam_handle* h);
 

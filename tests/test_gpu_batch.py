@@ -1,0 +1,79 @@
+"""-m gpu: batched execution — one handle, B independent sequences per launch chain (blockIdx.z = session).
+
+Every session must be bit-identical to the same sequence run alone on a single-session handle (trajectory, map, feature clouds):
+the sessions share the launch chain and nothing else.  The single-session path itself is checked against the CPU oracle everywhere
+else in tests/.  Reference for what one session computes: lidar_odometry_mapping.cpp:65-154."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def sequences(synth, B, n, shape=(64, 512)):
+    out = []
+    for b in range(B):
+        seq = synth.SynthSequence(n_rings=shape[0], n_azimuth=shape[1], n_sweeps=n + 1, seed_scene=1234 + 17 * b, seed_traj=42 + b,
+                                  seed_noise=5678 + 1000 * b)
+        out.append([seq.sweep(k) for k in range(n)])
+    return out
+
+
+@pytest.mark.parametrize("B,skip", [(4, 1), (3, 2)])
+def test_batched_sessions_equal_single_session_runs(vl, synth, B, skip):
+    n = 14
+    seqs = sequences(synth, B, n)
+    hb = vl.Handle(0, n_sessions=B, with_mapping=1, mapping_skip_frame=skip)
+    for k in range(n):
+        hb.batch_process_scan([seqs[b][k] for b in range(B)])
+    hb.sync()
+    trajs = []
+    for b in range(B):
+        hs = vl.Handle(0, with_mapping=1, mapping_skip_frame=skip)
+        for k in range(n):
+            hs.process_scan(seqs[b][k])
+        hs.sync()
+        hb.select(b)
+        tb, ts = hb.trajectory(), hs.trajectory()
+        assert tb.shape == (n, 14) and np.array_equal(tb, ts), "session %d trajectory" % b
+        mb, ms = hb.get_map(), hs.get_map()
+        assert mb.shape == ms.shape and mb.shape[0] > 1000 and np.array_equal(mb.view(np.uint32), ms.view(np.uint32)), "session %d map" % b
+        for which in (0, 2, 4, 7, 8):
+            fb, fs = hb.features(which), hs.features(which)
+            assert fb.shape == fs.shape and np.array_equal(fb.view(np.uint32), fs.view(np.uint32)), "session %d cloud %d" % (b, which)
+        assert hb.counts() == hs.counts()
+        trajs.append(tb)
+    for b in range(1, B):
+        assert not np.array_equal(trajs[0], trajs[b]), "the sessions are different sequences"
+
+
+def test_batched_sessions_with_different_sweep_sizes_and_device_input(vl, synth):
+    """Sessions may bring sweeps of different sizes (launch geometry follows the largest); device-resident inputs."""
+    import torch
+    n = 8
+    a = sequences(synth, 1, n, (64, 512))[0]
+    seq16 = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n + 1, seed_scene=99)
+    b_ = [seq16.sweep(k) for k in range(n)]
+    hb = vl.Handle(0, n_sessions=2, with_mapping=1)
+    keep = []
+    for k in range(n):
+        ta, tb = torch.from_numpy(a[k]).cuda(), torch.from_numpy(b_[k]).cuda()
+        keep += [ta, tb]
+        hb.batch_process_scan_device([ta.data_ptr(), tb.data_ptr()], [a[k].shape[0], b_[k].shape[0]])
+    hb.sync()
+    for b, clouds in enumerate((a, b_)):
+        hs = vl.Handle(0, with_mapping=1)
+        for c in clouds:
+            hs.process_scan(c)
+        hs.sync()
+        assert np.array_equal(hb.select(b).trajectory(), hs.trajectory()), b
+
+
+def test_single_sequence_entry_points_refuse_a_batched_handle(vl, sweeps):
+    hb = vl.Handle(0, n_sessions=2, with_mapping=0)
+    with pytest.raises(vl.VloamError) as e:
+        hb.process_scan(sweeps(64, 512, 0))
+    assert e.value.status == vl.ERR_INVALID
+    with pytest.raises(vl.VloamError):
+        hb.select(2)
+    with pytest.raises(vl.VloamError):
+        vl.Handle(0, n_sessions=0)

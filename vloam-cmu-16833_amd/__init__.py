@@ -92,11 +92,14 @@ def _fp(a):
 class Handle:
     """One sequence on one GPU (``vloam_handle``)."""
 
-    def __init__(self, device=0, **cfg):
+    def __init__(self, device=0, n_sessions=1, **cfg):
+        """n_sessions > 1: a batched handle — that many independent sequences advanced in lock step by batch_process_scan*;
+        select(b) chooses the session the getters read."""
         self.L = lib()
         self.cfg = default_config(**cfg)
         self.h = C.c_void_p()
-        self._chk(self.L.vloam_create(C.byref(self.cfg), int(device), C.byref(self.h)))
+        self.n_sessions = int(n_sessions)
+        self._chk(self.L.vloam_create_batch(C.byref(self.cfg), int(device), self.n_sessions, C.byref(self.h)))
 
     def _chk(self, st):
         if st != VLOAM_OK:
@@ -154,6 +157,24 @@ class Handle:
 
     def process_scan_device(self, dptr, n):
         self._chk(self.L.vloam_process_scan_device(self.h, C.c_void_p(dptr), int(n)))
+
+    # ---- batched execution (n_sessions sequences per launch chain)
+    def batch_process_scan(self, clouds):
+        clouds = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        assert len(clouds) == self.n_sessions
+        ptrs = (C.c_void_p * self.n_sessions)(*[c.ctypes.data for c in clouds])
+        ns = (C.c_int * self.n_sessions)(*[c.shape[0] for c in clouds])
+        self._chk(self.L.vloam_batch_process_scan(self.h, ptrs, ns))
+
+    def batch_process_scan_device(self, dptrs, ns):
+        assert len(dptrs) == self.n_sessions and len(ns) == self.n_sessions
+        ptrs = (C.c_void_p * self.n_sessions)(*[int(p) for p in dptrs])
+        nn = (C.c_int * self.n_sessions)(*[int(n) for n in ns])
+        self._chk(self.L.vloam_batch_process_scan_device(self.h, ptrs, nn))
+
+    def select(self, session):
+        self._chk(self.L.vloam_select_session(self.h, int(session)))
+        return self
 
     def sync(self):
         self._chk(self.L.vloam_sync(self.h))

@@ -54,7 +54,13 @@ struct vloam_handle {
   static constexpr int kSets = 4;   // 3 suffice for correctness; the 4th keeps the buffer-reuse wait off the critical cycle
   hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
   static_assert(kSets == MapContext::kSets, "the stack sets rotate with the SR buffer sets");
-  std::vector<void*> allocs;
+  // Device memory: B session arenas of identical layout, `se.ss` bytes apart, in ONE allocation; every device pointer below is
+  // session 0's (kernels add blockIdx.z * se.ss, host-side getters add sel * se.ss)
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  Sess se;
+  int sel = 0;          // session the getters read (vloam_select_session)
+  double* sync_pool = nullptr;
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
   int map_done = 0;     // sweeps whose laser mapping has been enqueued
@@ -89,36 +95,86 @@ struct vloam_handle {
   std::vector<int> prof_kids;
 };
 
-template <class T>
-static vloam_status dalloc(vloam_handle* h, T** p, size_t count) {
-  void* q = nullptr;
-  HIPCHK(hipMalloc(&q, count * sizeof(T) + 256));
-  HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T) + 256, h->stream));
-  h->allocs.push_back(q);
-  *p = (T*)q;
-  return VLOAM_OK;
-}
-#define ALLOC(p, n)                              \
-  do {                                           \
-    vloam_status s_ = dalloc(h, &(p), (n));      \
-    if (s_ != VLOAM_OK) return s_;               \
-  } while (0)
+#define TAKE(p, n) do { if (!A.take(&(p), (size_t)(n))) { set_err("session arena too small (internal)"); return VLOAM_ERR_HIP; } } while (0)
 
-static vloam_status alloc_factor_table(vloam_handle* h, FactorTable* F, int cap) {
+static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
   F->cap = cap;
-  ALLOC(F->type, cap);
-  ALLOC(F->p, 3 * (size_t)cap);
-  ALLOC(F->A, 3 * (size_t)cap);
-  ALLOC(F->B, 3 * (size_t)cap);
-  ALLOC(F->resid, 3 * (size_t)cap);
-  ALLOC(F->ctype, cap);
-  ALLOC(F->cslot, cap);
-  ALLOC(F->cpack, 11 * (size_t)cap);
-  ALLOC(F->rowcnt, (size_t)cap / 64 + 1);
+  TAKE(F->type, cap);
+  TAKE(F->p, 3 * (size_t)cap);
+  TAKE(F->A, 3 * (size_t)cap);
+  TAKE(F->B, 3 * (size_t)cap);
+  TAKE(F->resid, 3 * (size_t)cap);
+  TAKE(F->ctype, cap);
+  TAKE(F->cslot, cap);
+  TAKE(F->cpack, 11 * (size_t)cap);
+  TAKE(F->rowcnt, (size_t)cap / 64 + 1);
   F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated
   F->err = nullptr;    // set once the mapping context (owner of the sticky error word) exists
   return VLOAM_OK;
 }
+
+constexpr int kSyncCand = 48;          // candidate cache lines for the sync words of the cooperative solves
+constexpr size_t kSyncStride = 4352;   // 4 KB + 256 B: walks page and sub-page address bits; >= one slot
+static_assert(kSyncStride >= kLmSyncDoubles * sizeof(double), "slots must not overlap");
+
+// Carve one session's device state out of its arena.  Runs twice: dry (A.base == nullptr) to measure, then for real.
+static vloam_status handle_layout(vloam_handle* h, Arena& A) {
+  const vloam_config* cfg = &h->cfg;
+  const int P = cfg->max_points;
+  h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
+  TAKE(h->d_in, (size_t)P);
+  SRBuffers& a = h->sr[0];
+  TAKE(a.sid, (size_t)P);
+  TAKE(a.ori, (size_t)P);
+  TAKE(a.blockhist, (size_t)h->nblk_max * kMaxRings);
+  TAKE(a.blockoff, (size_t)h->nblk_max * kMaxRings);
+  TAKE(a.sharp_idx, kMaxSharp);
+  TAKE(a.less_sharp_idx, kMaxLessSharp);
+  TAKE(a.flat_idx, kMaxFlat);
+  TAKE(a.ring_ds, (size_t)kMaxRings * kMaxRingLen);
+  TAKE(a.dbg_curv, (size_t)P);
+  TAKE(a.dbg_sort, (size_t)P);
+  TAKE(a.dbg_picked, (size_t)P);
+  TAKE(a.dbg_label, (size_t)P);
+  TAKE(a.dbg_cyc, (size_t)kMaxRings * 8);
+  TAKE(a.dbg_feat_idx, 3 * kMaxLessSharp);
+  for (int k = 1; k < vloam_handle::kSets; k++) h->sr[k] = a;
+  for (int k = 0; k < vloam_handle::kSets; k++) {
+    TAKE(h->sr[k].S, 1);
+    TAKE(h->sr[k].cloud, (size_t)P);
+    TAKE(h->sr[k].sharp, kMaxSharp);
+    TAKE(h->sr[k].flat, kMaxFlat);
+    TAKE(h->sr[k].less_sharp, kMaxLessSharp);
+    TAKE(h->sr[k].less_flat, (size_t)P);
+  }
+  for (int k = 0; k < vloam_handle::kSets; k++) {
+    TAKE(h->grid[k].occ, 4 * kMaxRings);
+    TAKE(h->grid[k].stops, 4 * kStopLen);
+    for (int g = 0; g < 4; g++) {
+      h->grid[k].mask[g] = kGridBuckets[g] - 1;
+      TAKE(h->grid[k].cnt[g], kGridBuckets[g]);
+      TAKE(h->grid[k].start[g], kGridBuckets[g] + 2);
+      TAKE(h->grid[k].pts[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
+    }
+  }
+  TAKE(h->lo, 1);
+  vloam_status s = take_factor_table(A, &h->lo_F, kMaxLoFactors);
+  if (s != VLOAM_OK) return s;
+  for (int k = 0; k < 2; k++) { TAKE(h->lo_corr[k], kMaxLoFactors * 4); TAKE(h->lo_resid[k], 3 * kMaxLoFactors); if (h->cfg.debug) TAKE(h->lo_cyc[k], 4 * kMaxLoFactors); }
+  TAKE(h->lo_rec, 2);
+  TAKE(h->traj, (size_t)cfg->max_frames * 14);
+  TAKE(h->vo_traj, (size_t)cfg->max_frames * 7);
+  if (map_layout(&h->map, h->cfg, A) != VLOAM_OK) { set_err("map_layout failed"); return VLOAM_ERR_HIP; }
+  TAKE(h->sync_pool, kSyncCand * kSyncStride / sizeof(double));
+  if (vo_layout(&h->vo, h->cfg, A) != VLOAM_OK) { set_err("vo_layout failed"); return VLOAM_ERR_HIP; }
+  h->lo_F.err = &h->map.frame->error;
+  for (int k = 0; k < vloam_handle::kSets; k++) h->sr[k].sticky_err = &h->map.frame->error;
+  return VLOAM_OK;
+}
+
+// session-relative pointer for the host-side getters
+template <class T>
+static inline T* SEL(const vloam_handle* h, T* p) { return p ? (T*)((char*)p + (size_t)h->sel * h->se.ss) : p; }
 
 extern "C" {
 
@@ -143,8 +199,9 @@ void vloam_default_config(vloam_config* c) {
 const char* vloam_last_error(void) { return g_err.c_str(); }
 const char* vloam_version(void) { return "vloam_hip 0.1 (gfx950)"; }
 
-vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** out) {
+vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessions, vloam_handle** out) {
   if (!cfg || !out) { set_err("null argument"); return VLOAM_ERR_INVALID; }
+  if (n_sessions < 1 || n_sessions > kMaxBatch) { set_err("n_sessions must be 1..%d", kMaxBatch); return VLOAM_ERR_INVALID; }
   if (cfg->scan_line != 16 && cfg->scan_line != 32 && cfg->scan_line != 64) {
     set_err("only support velodyne with 16, 32 or 64 scan line!");  // scan_registration.cpp:54-58
     return VLOAM_ERR_INVALID;
@@ -173,83 +230,49 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
       set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
     }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
-    const int P = cfg->max_points;
-    h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
     auto body = [&]() -> vloam_status {
-      ALLOC(h->d_in, (size_t)P);
-      SRBuffers& a = h->sr[0];
-      ALLOC(a.sid, (size_t)P);
-      ALLOC(a.ori, (size_t)P);
-      ALLOC(a.blockhist, (size_t)h->nblk_max * kMaxRings);
-      ALLOC(a.blockoff, (size_t)h->nblk_max * kMaxRings);
-      ALLOC(a.sharp_idx, kMaxSharp);
-      ALLOC(a.less_sharp_idx, kMaxLessSharp);
-      ALLOC(a.flat_idx, kMaxFlat);
-      ALLOC(a.ring_ds, (size_t)kMaxRings * kMaxRingLen);
-      ALLOC(a.dbg_curv, (size_t)P);
-      ALLOC(a.dbg_sort, (size_t)P);
-      ALLOC(a.dbg_picked, (size_t)P);
-      ALLOC(a.dbg_label, (size_t)P);
-      ALLOC(a.dbg_cyc, (size_t)kMaxRings * 8);
-      ALLOC(a.dbg_feat_idx, 3 * kMaxLessSharp);
-      for (int k = 1; k < vloam_handle::kSets; k++) h->sr[k] = a;
-      for (int k = 0; k < vloam_handle::kSets; k++) {
-        ALLOC(h->sr[k].S, 1);
-        ALLOC(h->sr[k].cloud, (size_t)P);
-        ALLOC(h->sr[k].sharp, kMaxSharp);
-        ALLOC(h->sr[k].flat, kMaxFlat);
-        ALLOC(h->sr[k].less_sharp, kMaxLessSharp);
-        ALLOC(h->sr[k].less_flat, (size_t)P);
-      }
-      for (int k = 0; k < vloam_handle::kSets; k++) {
-        ALLOC(h->grid[k].occ, 4 * kMaxRings);
-        ALLOC(h->grid[k].stops, 4 * kStopLen);
-        {
-          int arm[4 * kMaxRings];
-          for (int q = 0; q < 4 * kMaxRings; q++) arm[q] = ((q / kMaxRings) & 1) ? -1 : INT_MAX;
-          HIPCHK(hipMemcpyAsync(h->grid[k].occ, arm, sizeof(arm), hipMemcpyHostToDevice, h->stream));
-          HIPCHK(hipStreamSynchronize(h->stream));
-        }
-        for (int g = 0; g < 4; g++) {
-          h->grid[k].mask[g] = kGridBuckets[g] - 1;
-          ALLOC(h->grid[k].cnt[g], kGridBuckets[g]);
-          ALLOC(h->grid[k].start[g], kGridBuckets[g] + 2);
-          ALLOC(h->grid[k].pts[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
-        }
-      }
-      ALLOC(h->lo, 1);
-      vloam_status s = alloc_factor_table(h, &h->lo_F, kMaxLoFactors);
+      // 1. measure one session, 2. one allocation for all sessions (zeroed), 3. lay session 0 out for real
+      Arena dry;
+      vloam_status s = handle_layout(h, dry);
       if (s != VLOAM_OK) return s;
-      for (int k = 0; k < 2; k++) { ALLOC(h->lo_corr[k], kMaxLoFactors * 4); ALLOC(h->lo_resid[k], 3 * kMaxLoFactors); if (h->cfg.debug) ALLOC(h->lo_cyc[k], 4 * kMaxLoFactors); }
-      ALLOC(h->lo_rec, 2);
-      ALLOC(h->traj, (size_t)cfg->max_frames * 14);
-      ALLOC(h->vo_traj, (size_t)cfg->max_frames * 7);
+      const size_t ss = (dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // 2 MB granules: every session sees the same address bits below
+      h->se.B = n_sessions;
+      h->se.ss = ss;
+      h->arena_bytes = ss * (size_t)n_sessions;
+      if (hipMalloc((void**)&h->arena, h->arena_bytes) != hipSuccess) {
+        set_err("hipMalloc of %zu MB for %d session(s) failed", h->arena_bytes >> 20, n_sessions); h->arena = nullptr; return VLOAM_ERR_HIP;
+      }
+      HIPCHK(hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
+      Arena A;
+      A.base = h->arena; A.cap = ss; A.dry = false;
+      s = handle_layout(h, A);
+      if (s != VLOAM_OK) return s;
+      h->map.se = h->se;
+      // ---- initial state of session 0
+      for (int k = 0; k < vloam_handle::kSets; k++) {
+        int arm[4 * kMaxRings];
+        for (int q = 0; q < 4 * kMaxRings; q++) arm[q] = ((q / kMaxRings) & 1) ? -1 : INT_MAX;
+        HIPCHK(hipMemcpyAsync(h->grid[k].occ, arm, sizeof(arm), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+      }
       LOState init;
       memset(&init, 0, sizeof(init));
       init.para_q[3] = 1.0; init.q_w_curr[3] = 1.0; init.prior_q[3] = 1.0;  // laser_odometry.cpp:80-90
       tf_identity(&init.tf.base_T_cam0); tf_identity(&init.tf.velo_T_cam0); tf_identity(&init.tf.cam0_curr_T_cam0_last);  // visual_odometry.cpp:73-74
       tf_identity(&init.tf.cam0_curr_LOT_cam0_prev); tf_identity(&init.tf.world_VOT_base_last);                            // vloam_tf.cpp:10-11
       HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-      s = map_create(&h->map, h->cfg, h->stream, h->allocs);
-      if (s != VLOAM_OK) { set_err("map_create failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
-      h->lo_F.err = &h->map.frame->error;
-      for (int k = 0; k < vloam_handle::kSets; k++) h->sr[k].sticky_err = &h->map.frame->error;
+      s = map_init(&h->map, h->stream);
+      if (s != VLOAM_OK) { set_err("map_init failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       {
-        // sync words of the three cooperative solves (odometry, mapping outer rounds): the fastest of 48 candidate lines
-        constexpr int kCand = 48;
-        constexpr size_t kStride = 4352;  // 4 KB + 256 B: walks page and sub-page address bits; >= one slot
-        static_assert(kStride >= kLmSyncDoubles * sizeof(double), "slots must not overlap");
-        double* pool = nullptr;
-        ALLOC(pool, kCand * kStride / sizeof(double));
-        int order[kCand];
-        if (lm_sync_calibrate(h->stream, pool, kCand, kStride, order) != 0) { set_err("lm_sync_calibrate failed"); return VLOAM_ERR_HIP; }
-        auto slot = [&](int r) { return reinterpret_cast<double*>(reinterpret_cast<char*>(pool) + kStride * (size_t)order[r]); };
+        // sync words of the three cooperative solves (odometry, mapping outer rounds): the fastest of 48 candidate lines, probed
+        // on session 0 (the other sessions' arenas start on 2 MB boundaries: same low address bits)
+        int order[kSyncCand];
+        if (lm_sync_calibrate(h->stream, h->sync_pool, kSyncCand - 1, kSyncStride, order) != 0) { set_err("lm_sync_calibrate failed"); return VLOAM_ERR_HIP; }
+        auto slot = [&](int r) { return reinterpret_cast<double*>(reinterpret_cast<char*>(h->sync_pool) + kSyncStride * (size_t)order[r]); };
         h->lo_F.gsync = slot(0);
         h->map.F[0].gsync = slot(1);
         h->map.F[1].gsync = slot(2);
       }
-      s = vo_create(&h->vo, h->cfg, h->stream, h->allocs);
-      if (s != VLOAM_OK) { set_err("vo_create failed"); return VLOAM_ERR_HIP; }
       for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&h->ev[k]));
       for (int k = 0; k < vloam_handle::kSets; k++) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_sr[k], hipEventDisableTiming));
@@ -258,6 +281,10 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
         HIPCHK(hipEventCreateWithFlags(&h->ev_stack[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_vo[k], hipEventDisableTiming));
       }
+      HIPCHK(hipStreamSynchronize(h->stream));
+      // ---- the other sessions start as byte-for-byte copies of session 0
+      for (int b = 1; b < n_sessions; b++)
+        HIPCHK(hipMemcpyAsync(h->arena + (size_t)b * ss, h->arena, dry.off, hipMemcpyDeviceToDevice, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       return VLOAM_OK;
     };
@@ -268,11 +295,27 @@ vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** ou
   return VLOAM_OK;
 }
 
+vloam_status vloam_create(const vloam_config* cfg, int device, vloam_handle** out) { return vloam_create_batch(cfg, device, 1, out); }
+
+vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions) {
+  if (!h || !n_sessions) return VLOAM_ERR_INVALID;
+  *n_sessions = h->se.B;
+  return VLOAM_OK;
+}
+
+// which session the getters (trajectory, features, counts, map, parity hooks) read; 0 after creation
+vloam_status vloam_select_session(vloam_handle* h, int session) {
+  if (!h || session < 0 || session >= h->se.B) return VLOAM_ERR_INVALID;
+  h->sel = session;
+  h->map.sel = session;
+  return VLOAM_OK;
+}
+
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
   (void)hipSetDevice(h->device);
   for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamSynchronize(st);
-  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->arena) (void)hipFree(h->arena);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
     for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k]}) if (e) (void)hipEventDestroy(e);
@@ -300,9 +343,21 @@ static vloam_status sync_all(vloam_handle* h) {
   return VLOAM_OK;
 }
 
-static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
-  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
-  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+static BatchIn one_sweep(const void* d_xyz_pad4, int n) {
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  bi.in[0] = (const float4*)d_xyz_pad4; bi.n[0] = n;
+  return bi;
+}
+
+static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
+  int n = 0;
+  for (int b = 0; b < h->se.B; b++) {
+    if (!bi.in[b]) { set_err("null sweep pointer for session %d", b); return VLOAM_ERR_INVALID; }
+    if (bi.n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+    if (bi.n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", bi.n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+    n = bi.n[b] > n ? bi.n[b] : n;
+  }
   if (h->frame >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
   const int k = h->frame, cur = set_of(k);
   // Set `cur` still holds sweep k - 3: read by odometry of sweeps k - 3 (current) and k - 2 (previous), mapping of sweep k - 3.
@@ -313,11 +368,11 @@ static vloam_status enqueue_sr(vloam_handle* h, const float4* d_in, int n) {
   if (k >= kS - 1) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - (kS - 1))]));
   if (k >= kS && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - kS)]));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  HIPCHK(sr_launch(h->stream, h->sr[cur], d_in, n, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof,
+  HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof,
                    h->ev_sr[cur]));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
-  lo_grid_build_launch(h->stream, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
+  lo_grid_build_launch(h->stream, h->se, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
   HIPCHK(hipGetLastError());
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   // the mapping stage's VoxelGrid of the scan features only needs this sweep's clouds: run it here, off the mapping stream
@@ -344,21 +399,21 @@ static vloam_status enqueue_lo(vloam_handle* h, int frame) {
       if (s != VLOAM_OK) { set_err("vo_solve_enqueue failed"); return s; }
     }
     // vloam_tf->VO2VeloAndBase(VO->cam0_curr_T_cam0_last) + (combined mode) the first outer round's para_q / para_t overwrite
-    lo_set_prior_launch(h->s_lo, h->lo, use_prior && frame > 0, h->vo.x, frame > 0, h->vo_traj + (size_t)frame * 7, &h->map.frame->error);
+    lo_set_prior_launch(h->s_lo, h->se, h->lo, use_prior && frame > 0, h->vo.x, frame > 0, h->vo_traj + (size_t)frame * 7, &h->map.frame->error);
   }
   if (frame > 0) {  // first sweep only initialises (laser_odometry.cpp:196-204)
     for (int outer = 0; outer < 2; outer++) {  // laser_odometry.cpp:211
-      if (use_prior && !(coupled && outer == 0)) lo_set_prior_launch(h->s_lo, h->lo);  // laser_odometry.cpp:223-236, both rounds (quirk A.8-4)
+      if (use_prior && !(coupled && outer == 0)) lo_set_prior_launch(h->s_lo, h->se, h->lo);  // laser_odometry.cpp:223-236, both rounds (quirk A.8-4)
       FactorTable F = h->lo_F;
       F.resid = h->lo_resid[outer];
-      lo_assoc_launch(h->s_lo, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
+      lo_assoc_launch(h->s_lo, h->se, h->sr[cur].sharp, h->sr[cur].flat, h->sr[cur].S, h->sr[prev].less_sharp, h->sr[prev].less_flat,
                       h->sr[prev].S, h->grid[prev], h->lo, F, h->lo_corr[outer], h->lo_cyc[outer], &h->prof);
       // the second solve also integrates the pose and writes the trajectory row (laser_odometry.cpp:530-531)
-      lm_launch(h->s_lo, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof, outer == 1 ? h->lo : nullptr,
+      lm_launch(h->s_lo, h->se, F, kMaxSharp, h->lo->para_q, h->lo_rec + outer, 4, 0.1, true, nullptr, &h->prof, outer == 1 ? h->lo : nullptr,
                 outer == 1 ? h->traj + (size_t)frame * 14 : nullptr, outer == 1 ? h->ev_lo[cur] : nullptr);
     }
   } else {
-    lo_finish_launch(h->s_lo, h->lo, h->traj + (size_t)frame * 14, false, &h->prof);
+    lo_finish_launch(h->s_lo, h->se, h->lo, h->traj + (size_t)frame * 14, false, &h->prof);
     HIPCHK(hipEventRecord(h->ev_lo[cur], h->s_lo));
   }
   HIPCHK(hipGetLastError());
@@ -417,12 +472,15 @@ static vloam_status finish_frame(vloam_handle* h) {
 }
 
 // ------------------------------------------------------------------ stage-wise API (façade order)
+#define SINGLE_SESSION_ONLY(h) do { if ((h)->se.B != 1) { set_err("this entry point drives one sequence: the handle has %d sessions (use the vloam_batch_* calls)", (h)->se.B); return VLOAM_ERR_INVALID; } } while (0)
+
 vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
   if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s = finish_frame(h); if (s != VLOAM_OK) return s; }  // previous sweep ended after LO (no mapping call)
   { vloam_status s = drain_deferred(h, 0, 0); if (s != VLOAM_OK) return s; }               // stages owed by earlier vloam_process_scan calls
-  return enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+  return enqueue_sr(h, one_sweep(d_xyz_pad4, n));
 }
 
 vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int n) {
@@ -437,7 +495,7 @@ vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int
 static vloam_status read_sr_error(vloam_handle* h, int cur) {
   int err = 0;
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
-  HIPCHK(hipMemcpy(&err, &h->sr[cur].S->error, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&err, &SEL(h, h->sr[cur].S)->error, sizeof(int), hipMemcpyDeviceToHost));
   if (err & kErrEmpty) { set_err("no point survived NaN / minimum_range removal"); return VLOAM_ERR_EMPTY; }
   if (err & kErrRingTooLong) { set_err("a ring holds more than %d points", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
   return VLOAM_OK;
@@ -450,17 +508,19 @@ vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int ca
   const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
   const int cur = set_of(f);
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  SRBuffers bsel = h->sr[cur];
+  bsel.rebase((size_t)h->sel * h->se.ss);
   FrameScalars S;
-  HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&S, bsel.S, sizeof(S), hipMemcpyDeviceToHost));
   const float4* src = nullptr;
   int cnt = 0;
   switch (which) {
-    case 0: src = h->sr[cur].cloud; cnt = S.N2; break;
-    case 1: src = h->sr[cur].sharp; cnt = S.n_sharp; break;
-    case 2: case 5: src = h->sr[cur].less_sharp; cnt = S.n_less_sharp; break;
-    case 3: src = h->sr[cur].flat; cnt = S.n_flat; break;
-    case 4: case 6: src = h->sr[cur].less_flat; cnt = S.n_less_flat; break;
-    default: return map_get_cloud(&h->map, h->stream, which, h->sr[cur], xyzi4, cap, n);
+    case 0: src = bsel.cloud; cnt = S.N2; break;
+    case 1: src = bsel.sharp; cnt = S.n_sharp; break;
+    case 2: case 5: src = bsel.less_sharp; cnt = S.n_less_sharp; break;
+    case 3: src = bsel.flat; cnt = S.n_flat; break;
+    case 4: case 6: src = bsel.less_flat; cnt = S.n_less_flat; break;
+    default: return map_get_cloud(&h->map, h->stream, which, bsel, xyzi4, cap, n);
   }
   *n = cnt;
   const int m = cnt < cap ? cnt : cap;
@@ -498,7 +558,7 @@ vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3],
   s = read_sr_error(h, set_of(h->frame));
   if (s != VLOAM_OK) return s;
   LOState lo;
-  HIPCHK(hipMemcpy(&lo, h->lo, sizeof(lo), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lo, SEL(h, h->lo), sizeof(lo), hipMemcpyDeviceToHost));
   if (q_w) memcpy(q_w, lo.q_w_curr, sizeof(double) * 4);
   if (t_w) memcpy(t_w, lo.t_w_curr, sizeof(double) * 3);
   if (q_lc) memcpy(q_lc, lo.para_q, sizeof(double) * 4);
@@ -519,7 +579,7 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
   // what LaserMapping::publish reports (laser_mapping.cpp:718-757): q_w_curr / t_w_curr after a mapped sweep, the
   // high-frequency pose q_wmap_wodom * q_wodom_curr after a skipped one — the map half of this sweep's trajectory row
   double row[14];
-  HIPCHK(hipMemcpy(row, h->traj + (size_t)h->frame * 14, sizeof(row), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(row, SEL(h, h->traj) + (size_t)h->frame * 14, sizeof(row), hipMemcpyDeviceToHost));
   if (q_map) memcpy(q_map, row + 7, sizeof(double) * 4);
   if (t_map) memcpy(t_map, row + 11, sizeof(double) * 3);
   return finish_frame(h);
@@ -530,11 +590,10 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
 // waits of enqueue_sr (odometry of sweep k - 3, mapping of sweep k - 4) stay behind what is enqueued here
 static constexpr int kLagLO = 1, kLagMap = 2;
 static_assert(kLagLO <= vloam_handle::kSets - 2 && kLagMap <= vloam_handle::kSets - 1, "deferred stages must be enqueued before enqueue_sr waits for them");
-vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
-  if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
+static vloam_status process_scan_batch(vloam_handle* h, const BatchIn& bi) {
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
-  vloam_status s = enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+  vloam_status s = enqueue_sr(h, bi);
   if (s != VLOAM_OK) return s;
   if (h->cfg.timing) {  // per-stage times: nothing deferred, the sweep is drained in finish_frame
     s = enqueue_lo(h, h->frame);
@@ -545,6 +604,39 @@ vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, 
   h->frame++;
   h->stage = 0;
   return drain_deferred(h, kLagLO, kLagMap);
+}
+
+vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
+  if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
+  return process_scan_batch(h, one_sweep(d_xyz_pad4, n));
+}
+
+// Batched execution: one call advances ALL sessions of the handle by one sweep (session b gets d_xyz_pad4[b], n[b] points); every kernel
+// of the sweep chain is launched ONCE with the session index in blockIdx.z.  The sessions are independent sequences that share nothing
+// but the launch chain; results per session through vloam_select_session + the getters.
+vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n) {
+  if (!h || !d_xyz_pad4 || !n) return VLOAM_ERR_INVALID;
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  for (int b = 0; b < h->se.B; b++) { bi.in[b] = (const float4*)d_xyz_pad4[b]; bi.n[b] = n[b]; }
+  return process_scan_batch(h, bi);
+}
+
+vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_pad4, const int* n) {
+  if (!h || !xyz_pad4 || !n) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  for (int b = 0; b < h->se.B; b++) {
+    if (!xyz_pad4[b]) return VLOAM_ERR_INVALID;
+    if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+    if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
+    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    bi.in[b] = dst; bi.n[b] = n[b];
+  }
+  return process_scan_batch(h, bi);
 }
 
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
@@ -581,11 +673,12 @@ vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16],
 // prev_uv / curr_uv: n_match integer pixel pairs in HOST memory (previous frame -> this frame; ignored for the first frame).
 vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
   if (!h || !d_xyz_pad4 || n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
   if (n_match > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match, kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
-  vloam_status s = enqueue_sr(h, (const float4*)d_xyz_pad4, n);
+  vloam_status s = enqueue_sr(h, one_sweep(d_xyz_pad4, n));
   if (s != VLOAM_OK) return s;
   const int k = h->frame, cur = set_of(k);
   // depth map + matches ride on the scan-registration stream (they only need the sweep); the solve itself belongs to the odometry stream
@@ -618,7 +711,7 @@ vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, doub
   if (!h || !poses7 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
-  if (count) HIPCHK(hipMemcpy(poses7, h->vo_traj + (size_t)first * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
+  if (count) HIPCHK(hipMemcpy(poses7, SEL(h, h->vo_traj) + (size_t)first * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
   return VLOAM_OK;
 }
 
@@ -632,7 +725,7 @@ vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t
   LOState lo;
   HIPCHK(hipMemcpy(x, h->vo.x, sizeof(x), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(cnt, h->vo.counters, sizeof(cnt), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&lo, h->lo, sizeof(lo), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lo, SEL(h, h->lo), sizeof(lo), hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; k++) { if (angle_axis) angle_axis[k] = x[k]; if (t) t[k] = x[3 + k]; if (prior_t) prior_t[k] = lo.prior_t[k]; }
   if (counters32_22) { counters32_22[0] = cnt[0]; counters32_22[1] = cnt[1]; }
   if (prior_q) for (int k = 0; k < 4; k++) prior_q[k] = lo.prior_q[k];
@@ -663,7 +756,7 @@ vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double*
   if (!h || !poses14 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
-  if (count) HIPCHK(hipMemcpy(poses14, h->traj + (size_t)first * 14, sizeof(double) * 14 * (size_t)count, hipMemcpyDeviceToHost));
+  if (count) HIPCHK(hipMemcpy(poses14, SEL(h, h->traj) + (size_t)first * 14, sizeof(double) * 14 * (size_t)count, hipMemcpyDeviceToHost));
   return VLOAM_OK;
 }
 vloam_status vloam_frame_count(vloam_handle* h, int* frames) {
@@ -673,7 +766,7 @@ vloam_status vloam_frame_count(vloam_handle* h, int* frames) {
 }
 vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long long* bytes) {
   if (!h || !d_ptr || !bytes) return VLOAM_ERR_INVALID;
-  *d_ptr = h->traj;
+  *d_ptr = SEL(h, h->traj);
   *bytes = (long long)h->cfg.max_frames * 14 * (long long)sizeof(double);
   return VLOAM_OK;
 }
@@ -714,9 +807,10 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
   const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
   const int cur = set_of(f);
   if (stage == 0) {
+    SRBuffers b = h->sr[cur];
+    b.rebase((size_t)h->sel * h->se.ss);
     FrameScalars S;
-    HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
-    const SRBuffers& b = h->sr[cur];
+    HIPCHK(hipMemcpy(&S, b.S, sizeof(S), hipMemcpyDeviceToHost));
     switch (item) {
       case 0: return copy_out(b.dbg_curv, sizeof(float) * S.N2, buf, cap, n);
       case 1: return copy_out(b.dbg_sort, sizeof(int) * S.N2, buf, cap, n);
@@ -742,12 +836,12 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
     const int outer = item / 16, k = item % 16;
     if (outer < 0 || outer > 1) return VLOAM_ERR_INVALID;
     switch (k) {
-      case 0: return copy_out(h->lo_corr[outer], sizeof(int) * 4 * kMaxSharp, buf, cap, n);
-      case 1: return copy_out(h->lo_corr[outer] + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
-      case 2: return copy_out(h->lo_rec + outer, sizeof(LMRecord), buf, cap, n);
-      case 3: return copy_out(h->lo_resid[outer], sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
+      case 0: return copy_out(SEL(h, h->lo_corr[outer]), sizeof(int) * 4 * kMaxSharp, buf, cap, n);
+      case 1: return copy_out(SEL(h, h->lo_corr[outer]) + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
+      case 2: return copy_out(SEL(h, h->lo_rec) + outer, sizeof(LMRecord), buf, cap, n);
+      case 3: return copy_out(SEL(h, h->lo_resid[outer]), sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
       case 4: if (!h->lo_cyc[outer]) return VLOAM_ERR_INVALID;
-              return copy_out(h->lo_cyc[outer], sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);
+              return copy_out(SEL(h, h->lo_cyc[outer]), sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);
     }
     return VLOAM_ERR_INVALID;
   }
@@ -834,16 +928,16 @@ vloam_status vloam_get_counts(vloam_handle* h, long long c[16]) {
   const int f = (h->stage == 0) ? h->frame - 1 : h->frame;
   const int cur = set_of(f), prev = set_of(f + vloam_handle::kSets - 1);
   FrameScalars S, Sp;
-  HIPCHK(hipMemcpy(&S, h->sr[cur].S, sizeof(S), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&Sp, h->sr[prev].S, sizeof(Sp), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&S, SEL(h, h->sr[cur].S), sizeof(S), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&Sp, SEL(h, h->sr[prev].S), sizeof(Sp), hipMemcpyDeviceToHost));
   LMRecord rec[2];
-  HIPCHK(hipMemcpy(rec, h->lo_rec, sizeof(rec), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rec, SEL(h, h->lo_rec), sizeof(rec), hipMemcpyDeviceToHost));
   c[0] = h->last_n_in; c[1] = S.N2; c[2] = S.n_sharp; c[3] = S.n_less_sharp; c[4] = S.n_flat; c[5] = S.n_less_flat;
   c[6] = Sp.n_less_sharp; c[7] = Sp.n_less_flat;
   if (f > 0) {
     // factor counts of the 2nd outer round; evaluations summed over both rounds
     int corr[4 * kMaxLoFactors];
-    HIPCHK(hipMemcpy(corr, h->lo_corr[1], sizeof(corr), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(corr, SEL(h, h->lo_corr[1]), sizeof(corr), hipMemcpyDeviceToHost));
     for (int k = 0; k < kMaxLoFactors; k++) if (corr[4 * k] >= 0) c[k < kMaxSharp ? 8 : 9]++;
     c[10] = (long long)(rec[0].n_evals + rec[1].n_evals);
   }

@@ -10,7 +10,7 @@ namespace vloam {
 // d_x: 7 doubles (q xyzw, t) when quat, else 6 (angle-axis, t); updated in place like ceres::Solve.
 // d_enable (optional): device int; 0 skips the solve entirely (mapping gate, laser_mapping.cpp:448).
 // n_edge_slots: slots [0, n_edge_slots) hold LidarEdgeFactors, the rest plane factors (multiple of 64; ignored when !quat).
-void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
+void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
                const int* d_enable, ProfHook* ph = nullptr, LOState* fin_lo = nullptr, double* fin_traj = nullptr,
                hipEvent_t done = nullptr);
 // fin_lo / fin_traj: when set, the solve's last act is LaserOdometry's pose integration + trajectory row (saves a launch)

@@ -698,7 +698,8 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
 
 template <bool QUAT, bool DIRECT, int NB>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
-                                                         double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj) {
+                                                         double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
+  VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
   const bool lead = NB == 1 || blockIdx.x == 0;  // the workgroup that owns every global side effect other than its factors' residuals
@@ -951,7 +952,8 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 // Deterministic stream compaction of the accepted factors (slot order): one wavefront per 64-slot row, many rows in flight
 // across the chip (a single workgroup would expose the full HBM latency of every row).  Edge factors get
 // v = (b - a) / |a - b| precomputed in place of b (lidarFactor.hpp:37-42 divides by de.norm()).
-__global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, const int* enable_flag) {
+__global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, const int* enable_flag, size_t ss) {
+  VL_SESSION(ss); F.rebase(so_); RB(enable_flag);
   if (enable_flag && *enable_flag == 0) return;
   const int r = blockIdx.x, lane = threadIdx.x;
   if (F.rowcnt[r] == 0) return;
@@ -1051,26 +1053,27 @@ int lm_sync_calibrate(hipStream_t st, double* pool, int n_cand, size_t stride_by
   return 0;
 }
 
-void lm_launch(hipStream_t st, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
+void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
+  const unsigned Z = (unsigned)se.B;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
-  if (!direct) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6), dim3(64), 0, st, F, quat ? 1 : 0, d_enable);
+  if (!direct) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
   if (direct && F.gsync)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj);
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj, se.ss);
   else if (direct)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
-                 fin_lo, fin_traj);
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
+                 fin_lo, fin_traj, se.ss);
   else if (quat && F.gsync)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoopMap>), dim3(kCoopMap), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
-                 huber_a, d_enable, fin_lo, fin_traj);
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoopMap>), dim3(kCoopMap, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
+                 huber_a, d_enable, fin_lo, fin_traj, se.ss);
   else if (quat)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj);
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj, se.ss);
   else
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false, 1>), dim3(1), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj);
+    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
+                 d_enable, fin_lo, fin_traj, se.ss);
 }
 
 }  // namespace vloam

@@ -19,17 +19,21 @@ struct LoGrid {
   int* occ;        // [2 kinds][first, last][kMaxRings] first / last index of every stored scan line (armed: INT_MAX / -1)
   int* stops;      // [2 kinds][2][kStopLen] where the reference's adjacent-line walks break (see k_lo_assoc)
   int mask[4];
+  __host__ __device__ void rebase(size_t off) {
+    for (int g = 0; g < 4; g++) { rbp(cnt[g], off); rbp(start[g], off); rbp(pts[g], off); }
+    rbp(occ, off); rbp(stops, off);
+  }
 };
-void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,
+void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,
                           ProfHook* ph = nullptr);
 
 // Slot layout of the LO factor table: [0, kMaxSharp) corner features, [kMaxSharp, kMaxLoFactors) plane features.
 // corr: [kMaxLoFactors][4] ints (feature index or -1, closest, 2nd, 3rd).
-void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
+void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
                      const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc, ProfHook* ph = nullptr);
 // copy_to_para: LO:223-236 (combined mode).  vo_row7 != nullptr: first publish this frame's visual odometry (see k_lo_set_prior).
-void lo_set_prior_launch(hipStream_t st, LOState* lo, bool copy_to_para = true, const double* vo_x = nullptr, bool vo_solved = false,
+void lo_set_prior_launch(hipStream_t st, Sess se, LOState* lo, bool copy_to_para = true, const double* vo_x = nullptr, bool vo_solved = false,
                          double* vo_row7 = nullptr, int* err = nullptr);
-void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph = nullptr);
+void lo_finish_launch(hipStream_t st, Sess se, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph = nullptr);
 
 }  // namespace vloam

@@ -69,7 +69,8 @@ __device__ __forceinline__ void wave_runs(unsigned b, int lane, int* head_lane, 
 }
 
 __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
-                                                       const FrameScalars* __restrict__ S, LoGrid G) {
+                                                       const FrameScalars* __restrict__ S, LoGrid G, size_t ss) {
+  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); G.rebase(so_);
   const int kind = blockIdx.y, lane = threadIdx.x & 63;
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
 // Exclusive scan of the bucket counters, one workgroup per grid.  Every thread owns `per` consecutive counters (whole 16-byte
 // vectors, registers only), wavefront scans + one LDS hop join them.  The counters themselves are left alone: the scatter
 // pass counts them back down to zero.
-__global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
+__global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
+  VL_SESSION(ss); G.rebase(so_);
   __shared__ int wsum[16];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = G.mask[g] + 1;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G) {
 }
 
 __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
-                                                         const FrameScalars* __restrict__ S, LoGrid G) {
+                                                         const FrameScalars* __restrict__ S, LoGrid G, size_t ss) {
+  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); G.rebase(so_);
   const int kind = blockIdx.y, lane = threadIdx.x & 63;
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
                                                   const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
                                                   const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
                                                   const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
-                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */) {
+                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */, size_t ss) {
+  VL_SESSION(ss); RB(sharp); RB(flat); RB(Sc); RB(CL); RB(SL); RB(Sp); G.rebase(so_); RB(lo); F.rebase(so_); RB(corr); RB(dbg_cyc);
   __shared__ int s_inc_all[4][512], s_rel_all[4][512];  // per-wavefront staging of cell prefix sums (for_each_candidate, KC > 2)
   const int lane = threadIdx.x & 63;
   int* s_inc = s_inc_all[threadIdx.x >> 6];
@@ -495,8 +499,9 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
 //   solveNlsAll's tail (VO:425-430): cam0_curr_T_cam0_last from (angle-axis, t) — only when a solve ran this frame (count > 0)
 //   VloamTF::VO2VeloAndBase (vloam_tf.cpp:59-75): velo_last_VOT_velo_curr -> prior_q / prior_t, world_VOT_base_last *= base_last_VOT_base_curr
 //   the VO row of the trajectory log: world_VOT_base_last as (q xyzw, t)
-__global__ void k_lo_set_prior(LOState* lo, int copy_to_para, const double* vo_x, int vo_solved, double* vo_row7, int* err) {
+__global__ void k_lo_set_prior(LOState* lo, int copy_to_para, const double* vo_x, int vo_solved, double* vo_row7, int* err, size_t ss) {
   if (threadIdx.x != 0) return;
+  VL_SESSION(ss); RB(lo); RB(vo_x); RB(vo_row7); RB(err);
   if (vo_row7) {
     VloamTfState& tf = lo->tf;
     if (vo_solved) {
@@ -532,8 +537,9 @@ __global__ void k_lo_set_prior(LOState* lo, int copy_to_para, const double* vo_x
 }
 
 // LO:477-478 pose integration (+ trajectory log row); q_w_curr is not renormalised, as in the reference.
-__global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
+__global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate, size_t ss) {
   if (threadIdx.x != 0) return;
+  VL_SESSION(ss); RB(lo); RB(traj_row14);
   if (integrate) {
     const double* q = lo->q_w_curr;
     const double* ql = lo->para_q;
@@ -561,22 +567,21 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate) {
   }
 }
 
-void lo_assoc_launch(hipStream_t st, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
+void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
                      const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc,
                      ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc);
+  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc, se.ss);
 }
-void lo_grid_build_launch(hipStream_t st, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
-  (void)ph;
-  VLOAM_LAUNCH(ph, kKLoGridCount, st, k_lo_grid_count, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
-  VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan, dim3(4), dim3(1024), 0, st, G);
-  VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2), dim3(256), 0, st, less_sharp, less_flat, S, G);
+void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoGridCount, st, k_lo_grid_count, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);
+  VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan, dim3(4, 1, se.B), dim3(1024), 0, st, G, se.ss);
+  VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);
 }
-void lo_set_prior_launch(hipStream_t st, LOState* lo, bool copy_to_para, const double* vo_x, bool vo_solved, double* vo_row7, int* err) {
-  hipLaunchKernelGGL(k_lo_set_prior, dim3(1), dim3(64), 0, st, lo, copy_to_para ? 1 : 0, vo_x, vo_solved ? 1 : 0, vo_row7, err);
+void lo_set_prior_launch(hipStream_t st, Sess se, LOState* lo, bool copy_to_para, const double* vo_x, bool vo_solved, double* vo_row7, int* err) {
+  hipLaunchKernelGGL(k_lo_set_prior, dim3(1, 1, se.B), dim3(64), 0, st, lo, copy_to_para ? 1 : 0, vo_x, vo_solved ? 1 : 0, vo_row7, err, se.ss);
 }
-void lo_finish_launch(hipStream_t st, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLoFinish, st, k_lo_finish, dim3(1), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0);
+void lo_finish_launch(hipStream_t st, Sess se, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {
+  VLOAM_LAUNCH(ph, kKLoFinish, st, k_lo_finish, dim3(1, 1, se.B), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0, se.ss);
 }
 
 }  // namespace vloam

@@ -41,6 +41,7 @@ struct VoxelTable {       // open addressing, linear probing, probe chains bound
   ulonglong2* blk;           // {key (0 = empty), mask}: one 16-byte load per probe
   unsigned bslots_mask;      // block slots - 1
   int* stats;                // [4] keys in the table (live + purged) | entries purged since the last rebuild | block keys | spare
+  __host__ __device__ void rebase(size_t off) { rbp(rec, off); rbp(pend, off); rbp(blk, off); rbp(stats, off); }
 };
 constexpr int kMaxProbe = 128;  // a longer chain means the table is overloaded: the lookup reports kErrMapFull instead of spinning
 constexpr int kCandChunk = 256; // candidates of the 5-NN search handled per pass (more are handled in further passes, exactly)
@@ -59,6 +60,10 @@ struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_map
   int* rank_slot;            // [stack_cap] hash slot of the t-th voxel in VoxelGrid output order
   int* rank_off;             // [stack_cap + 1] segment bounds in output order
   int hash_mask, stack_cap;
+  __host__ __device__ void rebase(size_t off) {
+    rbp(keys, off); rbp(cnt, off); rbp(fill, off); rbp(suidx, off); rbp(uniq, off); rbp(uslot, off); rbp(rank, off); rbp(this->off, off);
+    rbp(point_slot, off); rbp(seg, off); rbp(rank_slot, off); rbp(rank_off, off);
+  }
 };
 
 struct StackInfo {        // per stack set: counters of the scan-feature VoxelGrid (written on the scan-registration stream)
@@ -98,14 +103,30 @@ struct MapContext {
   int rebuild_cap = 0;
   int* rebuild_n = nullptr;
   int* host_flags = nullptr;        // host-mapped: [kind] 1 = the table of that kind wants a rebuild (written by k_map_finalize)
-  int rebuild_cooldown[2] = {0, 0};
+  int rebuild_cooldown[kMaxBatch][2] = {};
   long long rebuilds = 0;
+  Sess se;                 // sessions of the handle (launch geometry .z and arena stride)
+  int sel = 0;             // session the host-side getters read (vloam_select_session)
+  // a copy whose device pointers address session b (host-side getters, per-session rebuilds)
+  MapContext for_session(int b) const {
+    MapContext m = *this;
+    const size_t off = (size_t)b * se.ss;
+    rbp(m.state, off); rbp(m.frame, off); m.tab[0].rebase(off); m.tab[1].rebase(off); rbp(m.cube_cnt, off); m.ds[0].rebase(off); m.ds[1].rebase(off);
+    for (int c = 0; c < kSets; c++) { rbp(m.stack_sets[c][0], off); rbp(m.stack_sets[c][1], off); rbp(m.stack_info[c], off); }
+    for (int k = 0; k < 2; k++) { rbp(m.stack[k], off); rbp(m.stack_map[k], off); rbp(m.touched[k], off); rbp(m.deferred[k], off); m.F[k].rebase(off); }
+    rbp(m.rec, off); rbp(m.nbr, off); rbp(m.registered, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
+    if (m.host_flags) m.host_flags += 2 * b;
+    m.se.B = 1; m.sel = 0;
+    return m;
+  }
   float4* registered = nullptr;  // full-resolution cloud in the map frame, on request
   int max_points = 0;
   float inv_leaf[2] = {0, 0};
 };
 
-vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs);
+// layout: carve the session arena (called twice: dry to measure, then for real); init: the initial device state of session 0
+vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A);
+vloam_status map_init(MapContext* m, hipStream_t st);
 vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph);
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
                          bool skip_frame, int set, ProfHook* ph);
@@ -114,7 +135,7 @@ vloam_status map_error(MapContext* m, int* err_bits, int clear_mask = 0);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);
 // == /laser_cloud_map (laser_mapping.cpp:778-793): every cube's corner cloud then surf cloud, cube index ascending
 vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long cap, long long* n);
-vloam_status map_force_rebuild(MapContext* m, hipStream_t st);
+vloam_status map_force_rebuild(MapContext* m, hipStream_t st);  // every session
 void map_destroy(MapContext* m);
 vloam_status map_counts(MapContext* m, long long c[16]);
 

@@ -99,7 +99,8 @@ __device__ __forceinline__ void dquat_rot(const double* q, const double* v, doub
 
 // ---------------------------------------------------------------------------------------------- prepare
 __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr, const LOState* lo, int* cube_cnt, int skip_frame,
-                                                     double* traj_row14, StackInfo* si) {
+                                                     double* traj_row14, StackInfo* si, size_t ss) {
+  VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si);
   __shared__ int shift[3];
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -209,7 +210,8 @@ __device__ __forceinline__ u64 ds_key(float4 p, float inv) {
 // pass 1: voxel membership + per-voxel counts
 __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                       const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
-                                                      float inv1, StackInfo* fr) {
+                                                      float inv1, StackInfo* fr, size_t ss) {
+  VL_SESSION(ss); RB(corner_last); RB(surf_last); RB(S); D0.rebase(so_); D1.rebase(so_); RB(fr);
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const float inv = kind ? inv1 : inv0;
@@ -236,7 +238,8 @@ __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__
 // them by counting: tile (256 keys) x (512 entries), rank = #keys below mine, off = #points in voxels below mine (which is the
 // voxel's segment start, so no scan pass is needed).  Partial results are added up with integer atomics (order-free).
 constexpr int kRankKeys = 256, kRankChunk = 512;
-__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const StackInfo* __restrict__ fr) {
+__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const StackInfo* __restrict__ fr, size_t ss) {
+  VL_SESSION(ss); D0.rebase(so_); D1.rebase(so_); RB(fr);
   __shared__ __attribute__((aligned(16))) u64 s_key[kRankChunk];
   __shared__ __attribute__((aligned(16))) int s_cnt[kRankChunk];
   const int kind = blockIdx.y, tid = threadIdx.x;
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScrat
 }
 
 // pass 3: group the point indices by voxel (segment start = off of the voxel); the same launch publishes the output order
-__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, StackInfo* fr) {
+__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, StackInfo* fr, size_t ss) {
+  VL_SESSION(ss); RB(S); D0.rebase(so_); D1.rebase(so_); RB(fr);
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
@@ -295,7 +299,8 @@ __device__ __forceinline__ float rl(float v, int src) { return __int_as_float(__
 
 __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                        DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
-                                                       StackInfo* __restrict__ fr) {
+                                                       StackInfo* __restrict__ fr, size_t ss) {
+  VL_SESSION(ss); RB(corner_last); RB(surf_last); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
   __shared__ int s_idx[4][1024];
   __shared__ int s_sorted[4][1024];
   const int kind = blockIdx.y;
@@ -453,7 +458,8 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
 
 __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
                                                    VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
-                                                   float4* __restrict__ nbr) {
+                                                   float4* __restrict__ nbr, size_t ss) {
+  VL_SESSION(ss); RB(stack0); RB(stack1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(nbr);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // wave d of the launch takes the d-th stack point (corners, then surfs): the waves with work come first in dispatch order
   // instead of sitting behind the thousands of empty slots between the two parts of the table
@@ -636,7 +642,8 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
 
 __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
                                                  VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr, const float4* __restrict__ nbr,
-                                                 FactorTable F, int outer) {
+                                                 FactorTable F, int outer, size_t ss) {
+  VL_SESSION(ss); RB(stack0); RB(stack1); RB(ms); RB(fr); RB(nbr); F.rebase(so_);
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= kMapFactorCap) return;
   const int kind = slot < kStackCapCorner ? 0 : 1;
@@ -737,7 +744,9 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
                                                     float4* __restrict__ smap0, float4* __restrict__ smap1, VoxelTable T0, VoxelTable T1,
                                                     float inv0, float inv1, MapState* ms, MapFrame* fr, int* __restrict__ touched0,
                                                     int* __restrict__ touched1, int* __restrict__ deferred0, int* __restrict__ deferred1,
-                                                    double* traj_row14) {
+                                                    double* traj_row14, size_t ss) {
+  VL_SESSION(ss); RB(stack0); RB(stack1); RB(smap0); RB(smap1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(touched0); RB(touched1);
+  RB(deferred0); RB(deferred1); RB(traj_row14);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) map_update(ms, traj_row14);  // LM:636
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
@@ -792,7 +801,10 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
                                                       VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr,
                                                       const int* __restrict__ touched0, const int* __restrict__ touched1,
                                                       int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ cube_cnt,
-                                                      int* host_flags) {
+                                                      int* host_flags, size_t ss) {
+  VL_SESSION(ss); RB(smap0); RB(smap1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(touched0); RB(touched1); RB(deferred0); RB(deferred1);
+  RB(cube_cnt);
+  if (host_flags) host_flags += 2 * blockIdx.z;   // host-mapped, one pair per session (not part of the arenas)
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
   const float4* smap = kind ? smap1 : smap0;
@@ -912,65 +924,54 @@ __global__ void k_map_register(const float4* __restrict__ cloud, const FrameScal
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-template <class T>
-static bool dmalloc(std::vector<void*>& allocs, hipStream_t st, T** p, size_t count) {
-  void* q = nullptr;
-  if (hipMalloc(&q, count * sizeof(T) + 256) != hipSuccess) return false;
-  if (hipMemsetAsync(q, 0, count * sizeof(T) + 256, st) != hipSuccess) return false;
-  allocs.push_back(q);
-  *p = (T*)q;
-  return true;
-}
-
-vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs) {
+vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
   bool ok = true;
-  ok = ok && dmalloc(allocs, st, &m->state, 1);
-  ok = ok && dmalloc(allocs, st, &m->frame, 1);
-  ok = ok && dmalloc(allocs, st, &m->cube_cnt, 2 * (size_t)kCubeNum);
+  ok = ok && A.take(&m->state, 1) && A.take(&m->frame, 1) && A.take(&m->cube_cnt, 2 * (size_t)kCubeNum);
   const int lg = cfg.map_capacity_log2 < 10 ? 10 : (cfg.map_capacity_log2 > 28 ? 28 : cfg.map_capacity_log2);
   const size_t slots = (size_t)1 << lg;
   for (int k = 0; k < 2 && ok; k++) {
     VoxelTable& T = m->tab[k];
-    ok = ok && dmalloc(allocs, st, &T.rec, slots) && dmalloc(allocs, st, &T.pend, slots * kPendCap) && dmalloc(allocs, st, &T.stats, 4);
+    ok = ok && A.take(&T.rec, slots) && A.take(&T.pend, slots * kPendCap) && A.take(&T.stats, 4);
     T.mask = (unsigned)(slots - 1);
     const size_t bslots = slots / 2;
-    ok = ok && dmalloc(allocs, st, &T.blk, bslots);
+    ok = ok && A.take(&T.blk, bslots);
     T.bslots_mask = (unsigned)(bslots - 1);
     DsScratch& D = m->ds[k];
-    if (k == 0) for (int c = 0; c < MapContext::kSets; c++) ok = ok && dmalloc(allocs, st, &m->stack_info[c], 1);
+    if (k == 0) for (int c = 0; c < MapContext::kSets; c++) ok = ok && A.take(&m->stack_info[c], 1);
     D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
     const size_t hs = (size_t)D.hash_mask + 1;
-    ok = ok && dmalloc(allocs, st, &D.keys, hs) && dmalloc(allocs, st, &D.cnt, hs) && dmalloc(allocs, st, &D.fill, hs) && dmalloc(allocs, st, &D.suidx, hs) &&
-         dmalloc(allocs, st, &D.uslot, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.rank, (size_t)D.stack_cap) &&
-         dmalloc(allocs, st, &D.off, (size_t)D.stack_cap) &&
-         dmalloc(allocs, st, &D.uniq, (size_t)D.stack_cap) && dmalloc(allocs, st, &D.point_slot, (size_t)cfg.max_points) &&
-         dmalloc(allocs, st, &D.seg, (size_t)cfg.max_points) && dmalloc(allocs, st, &D.rank_slot, (size_t)D.stack_cap) &&
-         dmalloc(allocs, st, &D.rank_off, (size_t)D.stack_cap + 1);
-    for (int c = 0; c < MapContext::kSets; c++) ok = ok && dmalloc(allocs, st, &m->stack_sets[c][k], (size_t)D.stack_cap);
+    ok = ok && A.take(&D.keys, hs) && A.take(&D.cnt, hs) && A.take(&D.fill, hs) && A.take(&D.suidx, hs) &&
+         A.take(&D.uslot, (size_t)D.stack_cap) && A.take(&D.rank, (size_t)D.stack_cap) && A.take(&D.off, (size_t)D.stack_cap) &&
+         A.take(&D.uniq, (size_t)D.stack_cap) && A.take(&D.point_slot, (size_t)cfg.max_points) &&
+         A.take(&D.seg, (size_t)cfg.max_points) && A.take(&D.rank_slot, (size_t)D.stack_cap) && A.take(&D.rank_off, (size_t)D.stack_cap + 1);
+    for (int c = 0; c < MapContext::kSets; c++) ok = ok && A.take(&m->stack_sets[c][k], (size_t)D.stack_cap);
     m->stack[k] = m->stack_sets[0][k];
-    ok = ok && dmalloc(allocs, st, &m->stack_map[k], (size_t)D.stack_cap) &&
-         dmalloc(allocs, st, &m->touched[k], (size_t)D.stack_cap) && dmalloc(allocs, st, &m->deferred[k], (size_t)D.stack_cap);
+    ok = ok && A.take(&m->stack_map[k], (size_t)D.stack_cap) && A.take(&m->touched[k], (size_t)D.stack_cap) && A.take(&m->deferred[k], (size_t)D.stack_cap);
     FactorTable& F = m->F[k];
     F.cap = kMapFactorCap;
-    ok = ok && dmalloc(allocs, st, &F.type, (size_t)F.cap) && dmalloc(allocs, st, &F.p, 3 * (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.A, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.B, 3 * (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.resid, 3 * (size_t)F.cap) && dmalloc(allocs, st, &F.ctype, (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.cslot, (size_t)F.cap) && dmalloc(allocs, st, &F.cpack, 11 * (size_t)F.cap) &&
-         dmalloc(allocs, st, &F.rowcnt, (size_t)F.cap / 64 + 1);
+    ok = ok && A.take(&F.type, (size_t)F.cap) && A.take(&F.p, 3 * (size_t)F.cap) && A.take(&F.A, 3 * (size_t)F.cap) && A.take(&F.B, 3 * (size_t)F.cap) &&
+         A.take(&F.resid, 3 * (size_t)F.cap) && A.take(&F.ctype, (size_t)F.cap) && A.take(&F.cslot, (size_t)F.cap) && A.take(&F.cpack, 11 * (size_t)F.cap) &&
+         A.take(&F.rowcnt, (size_t)F.cap / 64 + 1);
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
   }
-  ok = ok && dmalloc(allocs, st, &m->rec, 2) && dmalloc(allocs, st, &m->nbr, 5 * (size_t)kMapFactorCap);
+  ok = ok && A.take(&m->rec, 2) && A.take(&m->nbr, 5 * (size_t)kMapFactorCap);
   m->rebuild_cap = (int)(slots / 2);
-  ok = ok && dmalloc(allocs, st, &m->rebuild_tmp, (size_t)m->rebuild_cap) && dmalloc(allocs, st, &m->rebuild_n, 1);
-  if (ok && hipHostMalloc((void**)&m->host_flags, 64, hipHostMallocMapped) != hipSuccess) { m->host_flags = nullptr; ok = false; }
-  if (ok) { m->host_flags[0] = m->host_flags[1] = 0; }
-  ok = ok && dmalloc(allocs, st, &m->registered, (size_t)cfg.max_points);
+  ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 1);
+  ok = ok && A.take(&m->registered, (size_t)cfg.max_points);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
   m->inv_leaf[0] = 1.0f / cfg.mapping_line_resolution;   // inverse_leaf_size_ of downSizeFilterCorner (LM:100)
   m->inv_leaf[1] = 1.0f / cfg.mapping_plane_resolution;  // downSizeFilterSurf (LM:101)
+  return VLOAM_OK;
+}
+
+vloam_status map_init(MapContext* m, hipStream_t st) {
+  if (!m->host_flags) {
+    if (hipHostMalloc((void**)&m->host_flags, sizeof(int) * 2 * kMaxBatch, hipHostMallocMapped) != hipSuccess) { m->host_flags = nullptr; return VLOAM_ERR_HIP; }
+    for (int k = 0; k < 2 * kMaxBatch; k++) m->host_flags[k] = 0;
+  }
   MapState init;
   memset(&init, 0, sizeof(init));
   init.parameters[3] = 1.0; init.q_wmap_wodom[3] = 1.0; init.q_wodom_curr[3] = 1.0;  // LM:74-91
@@ -983,12 +984,14 @@ vloam_status map_create(MapContext* m, const vloam_config& cfg, hipStream_t st, 
 // registration output, so it is enqueued on the scan-registration stream, ahead of the mapping stage that consumes it.
 vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph) {
   StackInfo* si = m->stack_info[set];
-  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
-               m->inv_leaf[0], m->inv_leaf[1], si);
-  VLOAM_LAUNCH(ph, kKMapDsRank, st, k_map_ds_rank, dim3(256, 2), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si);
-  VLOAM_LAUNCH(ph, kKMapDsScatter, st, k_map_ds_scatter, dim3(128, 2), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si);
-  VLOAM_LAUNCH(ph, kKMapDsReduce, st, k_map_ds_reduce, dim3(1024, 2), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
-               m->stack_sets[set][0], m->stack_sets[set][1], si);
+  const unsigned Z = (unsigned)m->se.B;
+  const size_t ss = m->se.ss;
+  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+               m->inv_leaf[0], m->inv_leaf[1], si, ss);
+  VLOAM_LAUNCH(ph, kKMapDsRank, st, k_map_ds_rank, dim3(256, 2, Z), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si, ss);
+  VLOAM_LAUNCH(ph, kKMapDsScatter, st, k_map_ds_scatter, dim3(128, 2, Z), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si, ss);
+  VLOAM_LAUNCH(ph, kKMapDsReduce, st, k_map_ds_reduce, dim3(1024, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+               m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -996,8 +999,10 @@ void map_destroy(MapContext* m) {
   if (m->host_flags) { (void)hipHostFree(m->host_flags); m->host_flags = nullptr; }
 }
 
-// gather the live records, clear the table, reinsert (see k_map_rebuild_*); between two sweeps on the mapping stream
-static vloam_status map_rebuild_enqueue(MapContext* m, hipStream_t st, int kind) {
+// gather the live records, clear the table, reinsert (see k_map_rebuild_*); between two sweeps on the mapping stream; one session
+static vloam_status map_rebuild_enqueue(MapContext* m0, hipStream_t st, int session, int kind) {
+  MapContext ms_ = m0->for_session(session);
+  MapContext* m = &ms_;
   VoxelTable& T = m->tab[kind];
   const size_t slots = (size_t)T.mask + 1, bslots = (size_t)T.bslots_mask + 1;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
@@ -1008,12 +1013,13 @@ static vloam_status map_rebuild_enqueue(MapContext* m, hipStream_t st, int kind)
   if (hipMemsetAsync(T.stats, 0, 4 * sizeof(int), st) != hipSuccess) return VLOAM_ERR_HIP;
   hipLaunchKernelGGL(k_map_rebuild_insert, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind,
                      m->deferred[kind], cap, m->inv_leaf[kind], m->host_flags);
-  m->rebuilds++;
+  m0->rebuilds++;
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
 vloam_status map_force_rebuild(MapContext* m, hipStream_t st) {
-  for (int k = 0; k < 2; k++) { vloam_status s = map_rebuild_enqueue(m, st, k); if (s != VLOAM_OK) return s; }
+  for (int b = 0; b < m->se.B; b++)
+    for (int k = 0; k < 2; k++) { vloam_status s = map_rebuild_enqueue(m, st, b, k); if (s != VLOAM_OK) return s; }
   return VLOAM_OK;
 }
 
@@ -1022,32 +1028,35 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   (void)cfg; (void)cur;
   MapState* ms = m->state;
   MapFrame* fr = m->frame;
+  const unsigned Z = (unsigned)m->se.B;
+  const size_t ss = m->se.ss;
   m->stack[0] = m->stack_sets[set][0]; m->stack[1] = m->stack_sets[set][1];
   if (!skip_frame) {
     // the flag is written by k_map_finalize of an EARLIER sweep (plain read of host-mapped memory, no synchronisation): a rebuild
     // a few sweeps late is as good; the cool-down covers the sweeps already in flight that still report the old state
-    for (int k = 0; k < 2; k++) {
-      if (m->rebuild_cooldown[k] > 0) { m->rebuild_cooldown[k]--; continue; }
-      if (__atomic_load_n(&m->host_flags[k], __ATOMIC_RELAXED)) {
-        if (map_rebuild_enqueue(m, st, k) != VLOAM_OK) return VLOAM_ERR_HIP;
-        m->rebuild_cooldown[k] = 8;
+    for (int b = 0; b < m->se.B; b++)
+      for (int k = 0; k < 2; k++) {
+        if (m->rebuild_cooldown[b][k] > 0) { m->rebuild_cooldown[b][k]--; continue; }
+        if (__atomic_load_n(&m->host_flags[2 * b + k], __ATOMIC_RELAXED)) {
+          if (map_rebuild_enqueue(m, st, b, k) != VLOAM_OK) return VLOAM_ERR_HIP;
+          m->rebuild_cooldown[b][k] = 8;
+        }
       }
-    }
   }
-  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
-               m->stack_info[set]);
+  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1, 1, Z), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
+               m->stack_info[set], ss);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
-    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
-                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr);
-    VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nbr,
-                 m->F[outer], outer);
-    lm_launch(st, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
+    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
+                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, ss);
+    VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nbr,
+                 m->F[outer], outer, ss);
+    lm_launch(st, m->se, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
   }
-  VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
-               m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14);
-  VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
-               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags);
+  VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
+               m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14, ss);
+  VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2, Z), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
+               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -1080,7 +1089,9 @@ __global__ __launch_bounds__(256) void k_map_export(VoxelTable T, const MapState
   }
 }
 
-vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long cap, long long* n) {
+vloam_status map_export(MapContext* m0, hipStream_t st, float* xyzi4, long long cap, long long* n) {
+  const MapContext msel = m0->for_session(m0->sel);
+  const MapContext* m = &msel;
   if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
   int stats[2][4];
   for (int k = 0; k < 2; k++) if (hipMemcpy(stats[k], m->tab[k].stats, sizeof(stats[k]), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
@@ -1104,7 +1115,10 @@ vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long c
   return VLOAM_OK;
 }
 
-vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n) {
+vloam_status map_get_cloud(MapContext* m0, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n) {
+  // `cur` is already the selected session's buffer set (the caller rebased it)
+  const MapContext msel = m0->for_session(m0->sel);
+  const MapContext* m = &msel;
   if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
   MapState ms;
   if (hipMemcpy(&ms, m->state, sizeof(ms), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
@@ -1127,11 +1141,17 @@ vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuf
 
 __global__ void k_map_error_fetch(MapFrame* fr, int clear_mask, int* out) { *out = atomicAnd(&fr->error, ~clear_mask); }
 
-// the sticky error word; the bits of clear_mask are reported once and cleared (transient per-sweep conditions)
+// the sticky error words of all sessions OR-ed; the bits of clear_mask are reported once and cleared (transient per-sweep conditions)
 vloam_status map_error(MapContext* m, int* e, int clear_mask) {
-  int* d_out = m->rebuild_n;  // scratch int (no rebuild can be in flight: the caller has synchronised the streams)
-  hipLaunchKernelGGL(k_map_error_fetch, dim3(1), dim3(1), 0, 0, m->frame, clear_mask, d_out);
-  if (hipMemcpy(e, d_out, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+  *e = 0;
+  for (int b = 0; b < m->se.B; b++) {
+    const MapContext mb = m->for_session(b);
+    int* d_out = mb.rebuild_n;  // scratch int (no rebuild can be in flight: the caller has synchronised the streams)
+    hipLaunchKernelGGL(k_map_error_fetch, dim3(1), dim3(1), 0, 0, mb.frame, clear_mask, d_out);
+    int v = 0;
+    if (hipMemcpy(&v, d_out, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    *e |= v;
+  }
   return VLOAM_OK;
 }
 
@@ -1145,7 +1165,9 @@ static vloam_status copy_dev(const void* src, size_t bytes, void* buf, long long
 // item = outer * 16 + k:  k = 0 factor types i32[kMapFactorCap], 1 A f64[3][cap], 2 B f64[3][cap], 3 LM record, 4 residuals f64[3][cap],
 //                         5 p f64[3][cap].  item 64: MapState.  item 65: MapFrame.  item 66: cube_cnt i32[2][4851].
 //                         item 67/68: dump of the corner / surf table as rows {key lo, key hi, count, x, y, z, w} (7 x 4 bytes) for live slots.
-vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n) {
+vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, long long* n) {
+  const MapContext msel = m0->for_session(m0->sel);
+  const MapContext* m = &msel;
   if (item == 64) return copy_dev(m->state, sizeof(MapState), buf, cap, n);
   if (item == 65) return copy_dev(m->frame, sizeof(MapFrame), buf, cap, n);
   if (item == 66) return copy_dev(m->cube_cnt, sizeof(int) * 2 * kCubeNum, buf, cap, n);
@@ -1172,7 +1194,7 @@ vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, lo
     for (int k = 0; k < 2; k++) if (hipMemcpy(out + 4 * k, m->tab[k].stats, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
     MapFrame fr;
     if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    out[8] = (int)m->rebuilds; out[9] = fr.max_candidates; out[10] = fr.n_deferred[0]; out[11] = fr.n_deferred[1];
+    out[8] = (int)m0->rebuilds; out[9] = fr.max_candidates; out[10] = fr.n_deferred[0]; out[11] = fr.n_deferred[1];
     if (n) *n = sizeof(out);
     if (buf) memcpy(buf, out, (size_t)cap < sizeof(out) ? (size_t)cap : sizeof(out));
     return VLOAM_OK;
@@ -1191,7 +1213,9 @@ vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, lo
   return VLOAM_ERR_INVALID;
 }
 
-vloam_status map_counts(MapContext* m, long long c[16]) {
+vloam_status map_counts(MapContext* m0, long long c[16]) {
+  const MapContext msel = m0->for_session(m0->sel);
+  const MapContext* m = &msel;
   MapState ms;
   MapFrame fr;
   LMRecord rec[2];

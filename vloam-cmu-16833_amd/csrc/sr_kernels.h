@@ -26,10 +26,17 @@ struct SRBuffers {
   int *dbg_sort, *dbg_picked, *dbg_label;
   long long* dbg_cyc;   // [kMaxRings][8] shader-clock cycles of k_sr_ring's phases (debug)
   int* dbg_feat_idx;    // [3][kMaxLessSharp]
+  __host__ __device__ void rebase(size_t off) {
+    rbp(S, off); rbp(sticky_err, off); rbp(sid, off); rbp(ori, off); rbp(blockhist, off); rbp(blockoff, off); rbp(cloud, off);
+    rbp(sharp_idx, off); rbp(less_sharp_idx, off); rbp(flat_idx, off); rbp(ring_ds, off); rbp(sharp, off); rbp(less_sharp, off);
+    rbp(flat, off); rbp(less_flat, off); rbp(dbg_curv, off); rbp(dbg_sort, off); rbp(dbg_picked, off); rbp(dbg_label, off);
+    rbp(dbg_cyc, off); rbp(dbg_feat_idx, off);
+  }
 };
 
 hipError_t sr_init();
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph = nullptr,
-                     hipEvent_t done = nullptr);  // `done`: recorded when the feature clouds are complete
+// bi: the sweeps of the B sessions (device pointers + point counts); `done`: recorded when the feature clouds are complete
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, bool debug, ProfHook* ph = nullptr,
+                     hipEvent_t done = nullptr);
 
 }  // namespace vloam

@@ -92,7 +92,10 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 // 256-lane workgroups: small enough to slip onto CUs whose register file is mostly taken by the previous sweep's odometry
 // kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
 constexpr int kFLThreads = 256;
-__global__ __launch_bounds__(kFLThreads) void k_sr_first_last(const float4* __restrict__ in, int n, float thres, int2* __restrict__ slice) {
+__global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float thres, int2* __restrict__ slice, size_t ss) {
+  VL_SESSION(ss); RB(slice);
+  const float4* __restrict__ in = bi.in[blockIdx.z];
+  const int n = bi.n[blockIdx.z];
   __shared__ int s_first, s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
@@ -112,10 +115,13 @@ __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(const float4* __re
 // ------------------------------------------------------------------------------------------------
 // blk: per-workgroup results for k_sr_scatter — [0, nblk): candidate pivot (SR:246-249) or INT_MAX, [nblk, 2 nblk): points
 // surviving S1.  Plain stores, no counters to re-arm between sweeps.
-__global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restrict__ in, int n, float thres, int N_SCANS,
+__global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thres, int N_SCANS,
                                                           FrameScalars* S, signed char* __restrict__ sid,
                                                           float* __restrict__ ori_raw, int* __restrict__ blockhist,
-                                                          const int2* __restrict__ slice, int nslice, int* __restrict__ blk) {
+                                                          const int2* __restrict__ slice, int nslice, int* __restrict__ blk, size_t ss) {
+  VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(slice); RB(blk);
+  const float4* __restrict__ in = bi.in[blockIdx.z];
+  const int n = bi.n[blockIdx.z];
   __shared__ int hist[kMaxRings];
   __shared__ int s_istar, s_cnt, s_first, s_last;
   __shared__ float s_start;
@@ -178,10 +184,13 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(const float4* __restri
 // Stable scatter into the ring-major cloud.  Every workgroup first derives, from the per-WG ring histograms of k_sr_label,
 // the ring offsets (SR:276-281) and its own base inside every ring — 32 KB of L2 reads per WG instead of a separate
 // single-workgroup scan kernel on the critical path.
-__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(const float4* __restrict__ in, int n, FrameScalars* S,
+__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(BatchIn bi, FrameScalars* S,
                                                             const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
                                                             const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud,
-                                                            const int* __restrict__ blk) {
+                                                            const int* __restrict__ blk, size_t ss) {
+  VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(cloud); RB(blk);
+  const float4* __restrict__ in = bi.in[blockIdx.z];
+  const int n = bi.n[blockIdx.z];
   __shared__ int wcnt[kLabelBlock / 64][kMaxRings];
   __shared__ int s_istar, s_nvalid;
   __shared__ int part_before[kLabelBlock / 64][kMaxRings], part_all[kLabelBlock / 64][kMaxRings];
@@ -337,7 +346,9 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
                                                           int* __restrict__ less_sharp_idx, int* __restrict__ flat_idx,
                                                           float4* __restrict__ ring_ds, float* __restrict__ dbg_curv,
                                                           int* __restrict__ dbg_sort, int* __restrict__ dbg_picked,
-                                                          int* __restrict__ dbg_label, long long* __restrict__ dbg_cyc /* [rings][8] */) {
+                                                          int* __restrict__ dbg_label, long long* __restrict__ dbg_cyc /* [rings][8] */, size_t ss) {
+  VL_SESSION(ss); RB(cloud); RB(S); RB(sharp_idx); RB(less_sharp_idx); RB(flat_idx); RB(ring_ds); RB(dbg_curv); RB(dbg_sort); RB(dbg_picked);
+  RB(dbg_label); RB(dbg_cyc);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* px = (float*)smem;                          // [kMaxRingLen]
   float* py = px + kMaxRingLen;
@@ -705,7 +716,9 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
                                                     const float4* __restrict__ ring_ds, float4* __restrict__ sharp,
                                                     float4* __restrict__ less_sharp, float4* __restrict__ flat,
                                                     float4* __restrict__ less_flat, int* __restrict__ dbg_feat_idx /* [3][kMaxLessSharp] */,
-                                                    int* sticky_err) {
+                                                    int* sticky_err, size_t ss) {
+  VL_SESSION(ss); RB(cloud); RB(S); RB(sharp_idx); RB(less_sharp_idx); RB(flat_idx); RB(ring_ds); RB(sharp); RB(less_sharp); RB(flat); RB(less_flat);
+  RB(dbg_feat_idx); RB(sticky_err);
   __shared__ int base[4];
   __shared__ int soff[kSectors][3];
   const int r = blockIdx.x, tid = threadIdx.x;
@@ -772,20 +785,23 @@ hipError_t sr_init() {
   return hipFuncSetAttribute((const void*)k_sr_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_ring_smem_bytes());
 }
 
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const float4* d_in, int n, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done) {
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done) {
+  int n = 0;
+  for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
+  const unsigned Z = (unsigned)se.B;
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
   const int nslice = (n + kFLThreads - 1) / kFLThreads;
   int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
   int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
-  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice), dim3(kFLThreads), 0, st, d_in, n, min_range, slice);
-  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
-               slice, nslice, blk);
-  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk), dim3(kLabelBlock), 0, st, d_in, n, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk);
-  VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
+  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice, 1, Z), dim3(kFLThreads), 0, st, bi, min_range, slice, se.ss);
+  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
+               slice, nslice, blk, se.ss);
+  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings, 1, Z), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                      b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-                     debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr);
-  VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
-                     b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr, b.sticky_err);
+                     debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, se.ss);
+  VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings, 1, Z), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
+                     b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr, b.sticky_err, se.ss);
   return hipGetLastError();
 }
 

@@ -9,6 +9,34 @@
 
 namespace vloam {
 
+// ---------------------------------------------------------------- sessions of a handle (batched execution)
+// One handle drives B independent sequences in lock step: every launch of the sweep chain carries a session index in blockIdx.z.
+// All device state of a session lives in ONE arena; session b's arena is the byte-for-byte layout of session 0's, `ss` bytes
+// further on.  Hosts and kernels therefore hold session 0's pointers only and kernels rebase them by blockIdx.z * ss on entry —
+// one extra kernel argument instead of B copies of every argument.
+constexpr int kMaxBatch = 16;
+struct Sess { int B = 1; size_t ss = 0; };
+struct BatchIn { const float4* in[kMaxBatch]; int n[kMaxBatch]; };   // the one thing that is not in the arenas: the callers' sweeps
+template <class T>
+__host__ __device__ inline void rbp(T*& p, size_t off) { if (p) p = (T*)((unsigned long long)p + off); }
+#define VL_SESSION(ss) const size_t so_ = (size_t)blockIdx.z * (size_t)(ss)
+#define RB(p) ((p) = (p) ? (decltype(p))((unsigned long long)(p) + so_) : (p))   // works on __restrict__-qualified kernel parameters too
+
+// Bump allocator over a session arena.  dry = true only measures (pointers are offsets, never dereferenced).
+struct Arena {
+  char* base = nullptr;
+  size_t off = 256, cap = 0;
+  bool dry = true;
+  template <class T>
+  bool take(T** p, size_t count) {
+    const size_t bytes = (count * sizeof(T) + 256 + 255) & ~(size_t)255;  // 256 B of slack behind every buffer (vector loads may run over)
+    if (!dry && off + bytes > cap) return false;
+    *p = (T*)(base + off);
+    off += bytes;
+    return true;
+  }
+};
+
 constexpr int kMaxRings = 64;        // N_SCANS upper bound (scan_registration.cpp:195-226)
 constexpr int kSectors = 6;          // scan_registration.cpp:317
 constexpr int kMaxRingLen = 4096;    // points of one ring kept in LDS by k_sr_ring (HDL-64E: <= ~2100)
@@ -124,6 +152,10 @@ struct FactorTable {
   int cap;
   double* gsync;  // optional [kLmSyncDoubles]: barrier counters + per-workgroup partial sums of the multi-workgroup solve (null: one workgroup)
   int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
+  __host__ __device__ void rebase(size_t off) {
+    rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off);
+    rbp(rowcnt, off); rbp(gsync, off); rbp(err, off);
+  }
 };
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
 constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 32;  // 2 counters (+ flags) | [parity][workgroup][32] partial accumulators

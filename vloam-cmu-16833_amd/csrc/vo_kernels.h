@@ -44,7 +44,7 @@ struct VOContext {
   int max_points = 0;
 };
 
-vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs);
+vloam_status vo_layout(VOContext* v, const vloam_config& cfg, Arena& A);  // the VO stack belongs to session 0 (the coupled frame loop is single-session)
 vloam_status vo_set_calib(VOContext* v, hipStream_t st, const vloam_calib* c);
 vloam_status vo_process_point_cloud(VOContext* v, hipStream_t st, const float4* d_in, int n);
 vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, const int* prev_uv, const int* curr_uv, int n_match,

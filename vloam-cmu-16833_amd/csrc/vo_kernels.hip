@@ -259,35 +259,25 @@ __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_u
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-template <class T>
-static bool dmalloc(std::vector<void*>& allocs, hipStream_t st, T** p, size_t count) {
-  void* q = nullptr;
-  if (hipMalloc(&q, count * sizeof(T) + 256) != hipSuccess) return false;
-  if (hipMemsetAsync(q, 0, count * sizeof(T) + 256, st) != hipSuccess) return false;
-  allocs.push_back(q);
-  *p = (T*)q;
-  return true;
-}
-
-vloam_status vo_create(VOContext* v, const vloam_config& cfg, hipStream_t st, std::vector<void*>& allocs) {
-  bool ok = dmalloc(allocs, st, &v->d_calib, 1);
+// carve the VO buffers out of the session arena (dry run to measure, then for real); everything starts zeroed with the arena
+vloam_status vo_layout(VOContext* v, const vloam_config& cfg, Arena& A) {
+  bool ok = A.take(&v->d_calib, 1);
   for (int k = 0; k < VOContext::kSets && ok; k++)
-    ok = dmalloc(allocs, st, &v->d_prev_set[k], 2 * kVoMaxMatches) && dmalloc(allocs, st, &v->d_curr_set[k], 2 * kVoMaxMatches) &&
-         dmalloc(allocs, st, &v->maps[k].bx, kBuckets) && dmalloc(allocs, st, &v->maps[k].by, kBuckets) &&
-         dmalloc(allocs, st, &v->maps[k].bd, kBuckets) && dmalloc(allocs, st, &v->maps[k].bc, kBuckets);
-  ok = ok && dmalloc(allocs, st, &v->uvd, (size_t)cfg.max_points) && dmalloc(allocs, st, &v->bcount, kBuckets + 1) &&
-       dmalloc(allocs, st, &v->bfill, kBuckets) && dmalloc(allocs, st, &v->seg, (size_t)cfg.max_points) &&
-       dmalloc(allocs, st, &v->d_prev, 2 * kVoMaxMatches) && dmalloc(allocs, st, &v->d_curr, 2 * kVoMaxMatches);
+    ok = A.take(&v->d_prev_set[k], 2 * kVoMaxMatches) && A.take(&v->d_curr_set[k], 2 * kVoMaxMatches) &&
+         A.take(&v->maps[k].bx, kBuckets) && A.take(&v->maps[k].by, kBuckets) &&
+         A.take(&v->maps[k].bd, kBuckets) && A.take(&v->maps[k].bc, kBuckets);
+  ok = ok && A.take(&v->uvd, (size_t)cfg.max_points) && A.take(&v->bcount, kBuckets + 1) &&
+       A.take(&v->bfill, kBuckets) && A.take(&v->seg, (size_t)cfg.max_points) &&
+       A.take(&v->d_prev, 2 * kVoMaxMatches) && A.take(&v->d_curr, 2 * kVoMaxMatches);
   v->F.cap = kVoMaxMatches;
-  ok = ok && dmalloc(allocs, st, &v->F.type, kVoMaxMatches) && dmalloc(allocs, st, &v->F.p, 3 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.A, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.B, 3 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.resid, 3 * kVoMaxMatches) && dmalloc(allocs, st, &v->F.ctype, kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.cslot, kVoMaxMatches) && dmalloc(allocs, st, &v->F.cpack, 11 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->F.rowcnt, kVoMaxMatches / 64 + 1);
+  ok = ok && A.take(&v->F.type, kVoMaxMatches) && A.take(&v->F.p, 3 * kVoMaxMatches) &&
+       A.take(&v->F.A, 3 * kVoMaxMatches) && A.take(&v->F.B, 3 * kVoMaxMatches) &&
+       A.take(&v->F.resid, 3 * kVoMaxMatches) && A.take(&v->F.ctype, kVoMaxMatches) &&
+       A.take(&v->F.cslot, kVoMaxMatches) && A.take(&v->F.cpack, 11 * kVoMaxMatches) &&
+       A.take(&v->F.rowcnt, kVoMaxMatches / 64 + 1);
   v->F.gsync = nullptr;
   v->F.err = nullptr;
-  ok = ok && dmalloc(allocs, st, &v->rec, 1) && dmalloc(allocs, st, &v->x, 8) && dmalloc(allocs, st, &v->match_dbg, 7 * kVoMaxMatches) &&
-       dmalloc(allocs, st, &v->counters, 4);
+  ok = ok && A.take(&v->rec, 1) && A.take(&v->x, 8) && A.take(&v->match_dbg, 7 * kVoMaxMatches) && A.take(&v->counters, 4);
   v->max_points = cfg.max_points;
   return ok ? VLOAM_OK : VLOAM_ERR_HIP;
 }
@@ -336,7 +326,7 @@ vloam_status vo_solve_enqueue(VOContext* v, const vloam_config& cfg, hipStream_t
   if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
   VLOAM_LAUNCH(ph, kKVoMatch, st, k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev_set[set], v->d_curr_set[set], v->n_match_set[set],
                v->d_calib, v->maps[prev], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters, lo, v->x, cfg.reset_VO_to_identity);
-  lm_launch(st, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr, ph);
+  lm_launch(st, Sess(), v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr, ph);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -353,7 +343,7 @@ vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, con
   hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib,
                      v->maps[(v->i + VOContext::kSets - 1) % VOContext::kSets], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters,
                      (const LOState*)nullptr, (double*)nullptr, 0);
-  lm_launch(st, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
+  lm_launch(st, Sess(), v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
   if (hipMemcpyAsync(x, v->x, sizeof(x), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
   int cnt[2];
   if (hipMemcpyAsync(cnt, v->counters, sizeof(cnt), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
