@@ -26,9 +26,7 @@ import os
 import sys
 import time
 
-# Several pipelined sessions own 3 HIP streams each; with the runtime's default of 4 hardware queues their stage streams share
-# queues and serialise behind each other.  Must be set before the HIP runtime loads; the single-session headline value does
-# not depend on it.
+# the three stage streams of a handle (+ torch's) should not share hardware queues; must be set before the HIP runtime loads
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -202,8 +200,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the HIP-event replay (per-kernel table + roofline kernel; for profiler runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (latency, configs[1], multi-session, VO stage)")
     ap.add_argument("--vo-frames", type=int, default=20, help="extra leg: frames of the coupled VLOAM loop (configs[3] analogue) to time (0 = skip)")
-    ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "2")),
-                    help="extra leg: this many independent sequences driven concurrently on ONE GPU (own handle + streams each); 0 = skip")
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
+                    help="extra leg: batched execution, this many independent sequences per launch chain on ONE GPU (vloam_create_batch); 0 = skip")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
     args = ap.parse_args()
 
@@ -332,35 +330,43 @@ def main():
         configs1 = {"workload": WORKLOADS["lo"], "value": K / (a1 - a0), "unit": "scans/s", "ms_per_step": 1e3 * (a1 - a0) / K}
         h1.close()
 
-    # ---- extra leg (never the headline): multi-session throughput of one GPU.  A single sequence is a chain of dependent
-    # launches (latency bound); independent sessions on separate streams overlap those latencies.
-    multi_session = None
+    # ---- extra leg (never the headline): BATCHED execution — B independent sequences advanced by ONE launch chain per sweep (session index
+    # in blockIdx.z, vloam_create_batch).  A single sequence is a chain of dependent, mostly latency-bound launches; the batch fills the
+    # chip with B of them.  Every session replays this rank's sweeps here (own arena of device state each), so each session's trajectory
+    # must equal the single-sequence run bit for bit.
+    batched = None
     if extras and args.sessions > 1:
-        import threading
         B = args.sessions
-        hs = [new_handle() for _ in range(B)]
+        hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8)
 
-        def drive(hh, lo, hi):
-            stream(hh, lo, hi)
-            hh.sync()
+        def bstream(lo, hi):
+            for kk in range(lo, hi):
+                hb.batch_process_scan_device([base_ptr + kk * stride] * B, [n_pts] * B)
 
-        ths = [threading.Thread(target=drive, args=(hh, 0, M0 + W)) for hh in hs]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
+        bstream(0, M0 + W)
+        hb.sync()
         torch.cuda.synchronize()
         m0 = time.perf_counter()
-        ths = [threading.Thread(target=drive, args=(hh, M0 + W, T)) for hh in hs]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
+        bstream(M0 + W, T)
+        hb.sync()
         torch.cuda.synchronize()
         m1 = time.perf_counter()
-        same = all(np.array_equal(hh.trajectory(), traj) for hh in hs)
-        multi_session = {"sessions": B, "value": B * K / (m1 - m0), "unit": "scans/s", "ms_per_step_all_sessions": 1e3 * (m1 - m0) / K,
-                         "trajectories_identical_to_single_session": bool(same),
-                         "note": "B independent handles (3 streams each, one host thread each) on one GPU replaying the same sweeps; "
-                                 "GPU_MAX_HW_QUEUES=" + os.environ.get("GPU_MAX_HW_QUEUES", "") + "; not the headline value"}
-        for hh in hs:
-            hh.close()
+        same = all(np.array_equal(hb.select(b).trajectory(), traj) for b in range(B))
+        hb.close()
+        bk = {}
+        if not args.no_kernel_timer:   # per-kernel durations of the batched launches (separate replay, like the single-sequence table)
+            hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8)
+            bstream(0, M0 + W)
+            hb.sync()
+            hb.profile_kernel("*", 48 * K + 64)
+            bstream(M0 + W, T)
+            hb.sync()
+            bk = hb.profile_table()
+            hb.close()
+        batched = {"sessions": B, "value": B * K / (m1 - m0), "unit": "scans/s", "ms_per_batch_step": 1e3 * (m1 - m0) / K,
+                   "speedup_vs_single_sequence": (B * K / (m1 - m0)) / (K / (t1 - t0)),
+                   "trajectories_identical_to_single_sequence": bool(same), "kernel_table": bk,
+                   "note": "one vloam_batch_process_scan_device per sweep for all B sessions; not the headline value (BASELINE.json's metric is one sequence per GPU)"}
 
     # ---- extra: latency of ONE sweep (enqueue + drain, nothing in flight).  The headline value streams the sequence: the three
     # stage streams overlap consecutive sweeps, so 1 / value is a throughput period, not a latency.
@@ -449,8 +455,19 @@ def main():
             out["configs1"] = configs1
         if vo_stage:
             out["configs3"] = vo_stage
-        if multi_session:
-            out["multi_session"] = multi_session
+        if batched:
+            bt = batched.pop("kernel_table")
+            if bt:   # roofline of the same kernel when B sessions share its launches: B x the algorithmic bytes per launch
+                btot = sum(v[0] for v in bt.values()) or 1.0
+                batched["kernels"] = {name: {"avg_us": round(1e3 * ms / n, 2), "share_of_gpu_time": round(ms / btot, 4),
+                                             "achieved_GBs": round(batched["sessions"] * algorithmic_bytes(name, counts) / (1e3 * ms / n * 1e-6) / 1e9, 2)}
+                                      for name, (ms, n) in sorted(bt.items(), key=lambda kv: -kv[1][0])}
+                if kernel in bt:
+                    a = batched["sessions"] * kb / (bt[kernel][0] / bt[kernel][1] * 1e-3) / 1e9
+                    batched["roofline"] = {"kernel": kernel, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                                           "avg_launch_us": 1e3 * bt[kernel][0] / bt[kernel][1]}
+                batched["end_to_end_frac"] = (b_sr + b_lo + b_map) * batched["value"] / 1e9 / HBM_PEAK_GBS
+            out["batched"] = batched
         if world == 1 and not args.no_cpu_baseline:
             # ONE pass of the CPU oracle over the very same T sweeps (it has to start at sweep 0: the map is part of the state):
             # cpu_baseline = its rate over the sweeps the GPU's warm-up + timed region covered (same map state), and the per-frame

@@ -20,8 +20,13 @@ struct LoGrid {
   int* stops;      // [2 kinds][2][kStopLen] where the reference's adjacent-line walks break (see k_lo_assoc)
   int mask[4];
   __host__ __device__ void rebase(size_t off) {
-    for (int g = 0; g < 4; g++) { rbp(cnt[g], off); rbp(start[g], off); rbp(pts[g], off); }
-    rbp(occ, off); rbp(stops, off);
+    // (never null: no select against nullptr here — it would cost the kernels the global-address-space inference for these
+    // dynamically indexed members and turn their accesses into FLAT instructions)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      cnt[g] = (int*)((char*)cnt[g] + off); start[g] = (int*)((char*)start[g] + off); pts[g] = (float4*)((char*)pts[g] + off);
+    }
+    occ = (int*)((char*)occ + off); stops = (int*)((char*)stops + off);
   }
 };
 void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G,

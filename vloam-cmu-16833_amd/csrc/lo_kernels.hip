@@ -70,8 +70,11 @@ __device__ __forceinline__ void wave_runs(unsigned b, int lane, int* head_lane, 
 
 __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                        const FrameScalars* __restrict__ S, LoGrid G, size_t ss) {
-  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); G.rebase(so_);
   const int kind = blockIdx.y, lane = threadIdx.x & 63;
+  // pick the pointers out of the kernel-argument struct FIRST, then rebase them: a dynamically indexed, modified copy of the struct
+  // would cost the compiler the global-address-space inference (FLAT instead of GLOBAL memory instructions)
+  int* cnt_f = G.cnt[kind]; int* cnt_c = G.cnt[kind + 2]; int* occ_ = G.occ;
+  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); RB(cnt_f); RB(cnt_c); RB(occ_);
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
   for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
@@ -86,14 +89,14 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
     }
     int hl, off, len;
     wave_runs(bf, lane, &hl, &off, &len);
-    if (off == 0 && i < n) atomicAdd(&G.cnt[kind][bf], len);
+    if (off == 0 && i < n) atomicAdd(&cnt_f[bf], len);
     wave_runs(bc, lane, &hl, &off, &len);
-    if (off == 0 && i < n) atomicAdd(&G.cnt[kind + 2][bc], len);
+    if (off == 0 && i < n) atomicAdd(&cnt_c[bc], len);
     // first / last index of every stored scan line (one atomic per run of equal lines)
     wave_runs((unsigned)line, lane, &hl, &off, &len);
     if (i < n && line >= 0 && line < kMaxRings) {
-      if (off == 0) atomicMin(&G.occ[(kind * 2 + 0) * kMaxRings + line], i);
-      if (off == len - 1) atomicMax(&G.occ[(kind * 2 + 1) * kMaxRings + line], i);
+      if (off == 0) atomicMin(&occ_[(kind * 2 + 0) * kMaxRings + line], i);
+      if (off == len - 1) atomicMax(&occ_[(kind * 2 + 1) * kMaxRings + line], i);
     }
   }
 }
@@ -102,12 +105,13 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
 // vectors, registers only), wavefront scans + one LDS hop join them.  The counters themselves are left alone: the scatter
 // pass counts them back down to zero.
 __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
-  VL_SESSION(ss); G.rebase(so_);
   __shared__ int wsum[16];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* cnt_g = G.cnt[g]; int* start_g = G.start[g]; int* occ_ = G.occ; int* stops_ = G.stops;   // select, then rebase (see k_lo_grid_count)
+  VL_SESSION(ss); RB(cnt_g); RB(start_g); RB(occ_); RB(stops_);
   const int nb = G.mask[g] + 1;
   const int per = nb / 1024;  // 4, 8 or 32 (kGridBuckets)
-  const int4* src = (const int4*)(G.cnt[g] + tid * per);
+  const int4* src = (const int4*)(cnt_g + tid * per);
   int4 v[8];
   int s = 0;
 #pragma unroll
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
   __syncthreads();
   int run = inc - s;
   for (int w = 0; w < wave; w++) run += wsum[w];
-  int4* dst = (int4*)(G.start[g] + tid * per);
+  int4* dst = (int4*)(start_g + tid * per);
 #pragma unroll
   for (int q = 0; q < 8; q++)
     if (q * 4 < per) {
@@ -130,12 +134,12 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
       o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
       dst[q] = o;
     }
-  if (tid == 1023) G.start[g][nb] = run;
+  if (tid == 1023) start_g[nb] = run;
   // walk stops of the corner (g == 0) / surf (g == 1) cloud: stops[v] = first index with line >= v (v = 0 .. kStopLen - 1),
   // stops[kStopLen + v] = last index with line <= v - 3; then the occurrence table is re-armed for the next sweep
   if (g < 2 && wave == 0) {
-    int* first = G.occ + (g * 2 + 0) * kMaxRings;
-    int* last = G.occ + (g * 2 + 1) * kMaxRings;
+    int* first = occ_ + (g * 2 + 0) * kMaxRings;
+    int* last = occ_ + (g * 2 + 1) * kMaxRings;
     int f = first[lane], l = last[lane];  // kMaxRings == 64 lanes
     first[lane] = INT_MAX; last[lane] = -1;
     for (int d = 1; d < 64; d <<= 1) {  // suffix min of f, prefix max of l
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
       if (lane + d < 64) f = min(f, of);
       if (lane >= d) l = max(l, ol);
     }
-    int* stops = G.stops + g * 2 * kStopLen;
+    int* stops = stops_ + g * 2 * kStopLen;
     stops[lane] = f;
     stops[kStopLen + 3 + lane] = l;
     if (lane < kStopLen - 64) stops[64 + lane] = INT_MAX;
@@ -153,8 +157,10 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
 
 __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat,
                                                          const FrameScalars* __restrict__ S, LoGrid G, size_t ss) {
-  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); G.rebase(so_);
   const int kind = blockIdx.y, lane = threadIdx.x & 63;
+  int* cnt_f = G.cnt[kind]; int* cnt_c = G.cnt[kind + 2]; int* start_f = G.start[kind]; int* start_c = G.start[kind + 2];
+  float4* pts_f = G.pts[kind]; float4* pts_c = G.pts[kind + 2];   // select, then rebase (see k_lo_grid_count)
+  VL_SESSION(ss); RB(less_sharp); RB(less_flat); RB(S); RB(cnt_f); RB(cnt_c); RB(start_f); RB(start_c); RB(pts_f); RB(pts_c);
   const float4* pts = kind ? less_flat : less_sharp;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
   for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
@@ -169,13 +175,13 @@ __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restric
     }
     int hl, off, len, pos = 0;
     wave_runs(bf, lane, &hl, &off, &len);
-    if (off == 0 && i < n) pos = G.start[kind][bf] + atomicSub(&G.cnt[kind][bf], len) - len;
+    if (off == 0 && i < n) pos = start_f[bf] + atomicSub(&cnt_f[bf], len) - len;
     pos = __shfl(pos, hl);
-    if (i < n) G.pts[kind][pos + off] = packed;
+    if (i < n) pts_f[pos + off] = packed;
     wave_runs(bc, lane, &hl, &off, &len);
-    if (off == 0 && i < n) pos = G.start[kind + 2][bc] + atomicSub(&G.cnt[kind + 2][bc], len) - len;
+    if (off == 0 && i < n) pos = start_c[bc] + atomicSub(&cnt_c[bc], len) - len;
     pos = __shfl(pos, hl);
-    if (i < n) G.pts[kind + 2][pos + off] = packed;
+    if (i < n) pts_c[pos + off] = packed;
   }
 }
 

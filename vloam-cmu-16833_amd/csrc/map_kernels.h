@@ -99,6 +99,8 @@ struct MapContext {
   FactorTable F[2];        // one per outer round (kept for the parity hooks)
   LMRecord* rec = nullptr; // [2]
   float4* nbr = nullptr;   // [kMapFactorCap][5] the 5 nearest map points of every stack point (.w of the first: 1 = accepted, LM:479 / LM:547)
+  int4* cbox = nullptr;    // [kMapFactorCap][2] voxel-index search box + candidate count of the first outer round's 5-NN search
+  float4* ccand = nullptr; // [kMapFactorCap][kCandChunk] its candidates (centroid, tie rank): the second round re-ranks them without a hash probe
   VoxelRec* rebuild_tmp = nullptr;  // live records while a table is being rebuilt (tombstone reclamation after grid rolls)
   int rebuild_cap = 0;
   int* rebuild_n = nullptr;
@@ -114,7 +116,7 @@ struct MapContext {
     rbp(m.state, off); rbp(m.frame, off); m.tab[0].rebase(off); m.tab[1].rebase(off); rbp(m.cube_cnt, off); m.ds[0].rebase(off); m.ds[1].rebase(off);
     for (int c = 0; c < kSets; c++) { rbp(m.stack_sets[c][0], off); rbp(m.stack_sets[c][1], off); rbp(m.stack_info[c], off); }
     for (int k = 0; k < 2; k++) { rbp(m.stack[k], off); rbp(m.stack_map[k], off); rbp(m.touched[k], off); rbp(m.deferred[k], off); m.F[k].rebase(off); }
-    rbp(m.rec, off); rbp(m.nbr, off); rbp(m.registered, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
+    rbp(m.rec, off); rbp(m.nbr, off); rbp(m.cbox, off); rbp(m.ccand, off); rbp(m.registered, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
     if (m.host_flags) m.host_flags += 2 * b;
     m.se.B = 1; m.sel = 0;
     return m;

@@ -18,9 +18,11 @@ constexpr int kMaxBatch = 16;
 struct Sess { int B = 1; size_t ss = 0; };
 struct BatchIn { const float4* in[kMaxBatch]; int n[kMaxBatch]; };   // the one thing that is not in the arenas: the callers' sweeps
 template <class T>
-__host__ __device__ inline void rbp(T*& p, size_t off) { if (p) p = (T*)((unsigned long long)p + off); }
+__host__ __device__ inline void rbp(T*& p, size_t off) { if (p) p = (T*)((char*)p + off); }   // pointer arithmetic, NOT an integer round trip:
+// the compiler must keep seeing a kernel-argument-derived (global address space) pointer, or every access turns into a FLAT instruction
+// (measured: flat atomics made the atomic-heavy kernels 7-9x slower)
 #define VL_SESSION(ss) const size_t so_ = (size_t)blockIdx.z * (size_t)(ss)
-#define RB(p) ((p) = (p) ? (decltype(p))((unsigned long long)(p) + so_) : (p))   // works on __restrict__-qualified kernel parameters too
+#define RB(p) ((p) = (p) ? (decltype(p))((char*)(p) + so_) : (p))   // works on __restrict__-qualified kernel parameters too
 
 // Bump allocator over a session arena.  dry = true only measures (pointers are offsets, never dereferenced).
 struct Arena {
