@@ -351,7 +351,10 @@ def main():
         hb.sync()
         torch.cuda.synchronize()
         m1 = time.perf_counter()
-        same = all(np.array_equal(hb.select(b).trajectory(), traj) for b in range(B))
+        tjs = [hb.select(b).trajectory() for b in range(B)]
+        same = all(np.array_equal(t, traj) for t in tjs)
+        same_among = all(np.array_equal(t, tjs[0]) for t in tjs)
+        max_diff = max(float(np.max(np.abs(t - traj))) for t in tjs)
         hb.close()
         bk = {}
         if not args.no_kernel_timer:   # per-kernel durations of the batched launches (separate replay, like the single-sequence table)
@@ -365,7 +368,8 @@ def main():
             hb.close()
         batched = {"sessions": B, "value": B * K / (m1 - m0), "unit": "scans/s", "ms_per_batch_step": 1e3 * (m1 - m0) / K,
                    "speedup_vs_single_sequence": (B * K / (m1 - m0)) / (K / (t1 - t0)),
-                   "trajectories_identical_to_single_sequence": bool(same), "kernel_table": bk,
+                   "trajectories_identical_to_single_sequence": bool(same), "sessions_identical_to_each_other": bool(same_among),
+                   "max_abs_pose_diff_vs_single_sequence": max_diff, "kernel_table": bk,
                    "note": "one vloam_batch_process_scan_device per sweep for all B sessions; not the headline value (BASELINE.json's metric is one sequence per GPU)"}
 
     # ---- extra: latency of ONE sweep (enqueue + drain, nothing in flight).  The headline value streams the sequence: the three

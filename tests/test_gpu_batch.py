@@ -34,9 +34,11 @@ def test_batched_sessions_equal_single_session_runs(vl, synth, B, skip):
         hs.sync()
         hb.select(b)
         tb, ts = hb.trajectory(), hs.trajectory()
-        assert tb.shape == (n, 14) and np.array_equal(tb, ts), "session %d trajectory" % b
         mb, ms = hb.get_map(), hs.get_map()
-        assert mb.shape == ms.shape and mb.shape[0] > 1000 and np.array_equal(mb.view(np.uint32), ms.view(np.uint32)), "session %d map" % b
+        assert tb.shape == (n, 14) and mb.shape == ms.shape and mb.shape[0] > 1000
+        # same kernels, same reduction trees, own arena: bit for bit
+        assert np.array_equal(tb, ts), "session %d trajectory" % b
+        assert np.array_equal(mb.view(np.uint32), ms.view(np.uint32)), "session %d map" % b
         for which in (0, 2, 4, 7, 8):
             fb, fs = hb.features(which), hs.features(which)
             assert fb.shape == fs.shape and np.array_equal(fb.view(np.uint32), fs.view(np.uint32)), "session %d cloud %d" % (b, which)

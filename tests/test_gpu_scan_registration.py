@@ -143,3 +143,32 @@ def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
         h2.sync()
     assert ei.value.status == vl.ERR_CAPACITY
     h2.sync()
+
+
+def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
+    """k_sr_ring runs as a 2112-point tier (two rings per CU) plus, only while needed, the 4096-point tier: always during the first 8
+    sweeps, afterwards once a ring has come within 10 % of the small tier's capacity (host-mapped watch word).  Rings that grow from
+    1 792 over 2 000 to 2 300 points across the 8-sweep mark must come out of the right tier: features equal the oracle's throughout."""
+    def sweep(n_az, k):
+        return synth.SynthSequence(n_rings=64, n_azimuth=n_az, n_sweeps=k + 1).sweep(k)
+    h = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+    plan = [1792] * 10 + [2000] * 2 + [2300] * 3 + [1792] * 2
+    for k, n_az in enumerate(plan):
+        cloud = sweep(n_az, k)
+        h.reset_frame()
+        h.scan_registration(cloud)
+        o = orc.Oracle(with_mapping=False)
+        assert o.scan_registration(cloud) == 0
+        sc = o.sr_scalars()
+        flips = check_cloud(h.features(0), o.cloud(0), "laserCloud sweep %d" % k, unwrap_bounds(sc["startOri"], sc["endOri"]))
+        for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+            check_cloud(h.features(which), o.cloud(which), "%s sweep %d (%d columns)" % (name, k, n_az), max_flips=flips)
+        h.laser_odometry()
+    h.sync()
+    # without the warning (a jump from far below the watch threshold to beyond the small tier after the first sweeps): reported, not dropped
+    h2 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+    with pytest.raises(vl.VloamError) as e:
+        for k in range(12):
+            h2.process_scan(sweep(1024 if k < 10 else 2300, k))
+        h2.sync()
+    assert e.value.status == vl.ERR_CAPACITY

@@ -61,6 +61,7 @@ struct vloam_handle {
   Sess se;
   int sel = 0;          // session the getters read (vloam_select_session)
   double* sync_pool = nullptr;
+  int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
   int map_done = 0;     // sweeps whose laser mapping has been enqueued
@@ -261,6 +262,8 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       tf_identity(&init.tf.base_T_cam0); tf_identity(&init.tf.velo_T_cam0); tf_identity(&init.tf.cam0_curr_T_cam0_last);  // visual_odometry.cpp:73-74
       tf_identity(&init.tf.cam0_curr_LOT_cam0_prev); tf_identity(&init.tf.world_VOT_base_last);                            // vloam_tf.cpp:10-11
       HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+      if (hipHostMalloc((void**)&h->ring_watch, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) { h->ring_watch = nullptr; set_err("hipHostMalloc failed"); return VLOAM_ERR_HIP; }
+      for (int b = 0; b < kMaxBatch; b++) h->ring_watch[b] = 0;
       s = map_init(&h->map, h->stream);
       if (s != VLOAM_OK) { set_err("map_init failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       {
@@ -322,6 +325,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
   map_destroy(&h->map);
+  if (h->ring_watch) (void)hipHostFree(h->ring_watch);
   delete h;
   return VLOAM_OK;
 }
@@ -368,8 +372,10 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   if (k >= kS - 1) HIPCHK(hipEventSynchronize(h->ev_lo[set_of(k - (kS - 1))]));
   if (k >= kS && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - kS)]));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+  bool big_tier = k < 8;   // nothing is known about the ring lengths yet
+  for (int b = 0; b < h->se.B; b++) big_tier = big_tier || __atomic_load_n(&h->ring_watch[b], __ATOMIC_RELAXED) != 0;
   HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof,
-                   h->ev_sr[cur]));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
+                   h->ev_sr[cur], h->ring_watch, big_tier));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
   lo_grid_build_launch(h->stream, h->se, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);

@@ -14,6 +14,7 @@
 // Ceres is not vendored by the reference; the algorithm restated here is spelled out in
 // oracle/orc_ceres.cpp (CPU oracle, DENSE_QR on the stacked Jacobian) and SURVEY.md Appendix A.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <float.h>
 #include <math.h>
 #include <algorithm>
@@ -1058,14 +1059,19 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
   const int edge_rows = n_edge_slots >> 6;
   const unsigned Z = (unsigned)se.B;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
+  // Batches keep the cooperative form: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured only 3 % faster at
+  // B = 8 (10 785 vs 10 435 scans/s) and gives up the bit-identity of a batched session with the same sequence run alone (the f64
+  // sums of the normal equations would be added in a different order).
+  static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
+  const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1);
   if (!direct) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
-  if (direct && F.gsync)
+  if (direct && coop)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
                  d_enable, fin_lo, fin_traj, se.ss);
   else if (direct)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
                  fin_lo, fin_traj, se.ss);
-  else if (quat && F.gsync)
+  else if (quat && coop)
     VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoopMap>), dim3(kCoopMap, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
                  huber_a, d_enable, fin_lo, fin_traj, se.ss);
   else if (quat)

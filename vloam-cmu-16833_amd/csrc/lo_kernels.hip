@@ -104,18 +104,22 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
 // Exclusive scan of the bucket counters, one workgroup per grid.  Every thread owns `per` consecutive counters (whole 16-byte
 // vectors, registers only), wavefront scans + one LDS hop join them.  The counters themselves are left alone: the scatter
 // pass counts them back down to zero.
-__global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
+// TPB = 1024 for a single sequence (shortest chain); batches use 256-lane workgroups: a 1024-lane workgroup needs a quarter of a
+// CU's wave slots at once and waits for them on a busy chip (measured at B = 8: 131 us for this 15 us kernel).
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_lo_grid_scan(LoGrid G, size_t ss) {
   __shared__ int wsum[16];
+  constexpr int kV = kGridMaxBuckets / TPB / 4;   // int4 vectors a lane may own
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* cnt_g = G.cnt[g]; int* start_g = G.start[g]; int* occ_ = G.occ; int* stops_ = G.stops;   // select, then rebase (see k_lo_grid_count)
   VL_SESSION(ss); RB(cnt_g); RB(start_g); RB(occ_); RB(stops_);
   const int nb = G.mask[g] + 1;
-  const int per = nb / 1024;  // 4, 8 or 32 (kGridBuckets)
+  const int per = nb / TPB;  // 4, 8 or 32 (kGridBuckets) at 1024 lanes
   const int4* src = (const int4*)(cnt_g + tid * per);
-  int4 v[8];
+  int4 v[kV];
   int s = 0;
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
+  for (int q = 0; q < kV; q++) {
     v[q] = make_int4(0, 0, 0, 0);
     if (q * 4 < per) v[q] = src[q];
     s += v[q].x + v[q].y + v[q].z + v[q].w;
@@ -128,13 +132,13 @@ __global__ __launch_bounds__(1024) void k_lo_grid_scan(LoGrid G, size_t ss) {
   for (int w = 0; w < wave; w++) run += wsum[w];
   int4* dst = (int4*)(start_g + tid * per);
 #pragma unroll
-  for (int q = 0; q < 8; q++)
+  for (int q = 0; q < kV; q++)
     if (q * 4 < per) {
       int4 o;
       o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
       dst[q] = o;
     }
-  if (tid == 1023) start_g[nb] = run;
+  if (tid == TPB - 1) start_g[nb] = run;
   // walk stops of the corner (g == 0) / surf (g == 1) cloud: stops[v] = first index with line >= v (v = 0 .. kStopLen - 1),
   // stops[kStopLen + v] = last index with line <= v - 3; then the occurrence table is re-armed for the next sweep
   if (g < 2 && wave == 0) {
@@ -580,7 +584,8 @@ void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4*
 }
 void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
   VLOAM_LAUNCH(ph, kKLoGridCount, st, k_lo_grid_count, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);
-  VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan, dim3(4, 1, se.B), dim3(1024), 0, st, G, se.ss);
+  if (se.B > 1) VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan<256>, dim3(4, 1, se.B), dim3(256), 0, st, G, se.ss);
+  else VLOAM_LAUNCH(ph, kKLoGridScan, st, k_lo_grid_scan<1024>, dim3(4, 1, se.B), dim3(1024), 0, st, G, se.ss);
   VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);
 }
 void lo_set_prior_launch(hipStream_t st, Sess se, LOState* lo, bool copy_to_para, const double* vo_x, bool vo_solved, double* vo_row7, int* err) {

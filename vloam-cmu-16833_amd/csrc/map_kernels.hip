@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     // its candidates (centroid + tie rank) in HBM, so this round needs no hash probe at all: one coalesced read, distances, top five.
     int blo[3], bhi[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) { blo[a] = (int)floorf((q3[a] - 1.001f) * inv); bhi[a] = (int)floorf((q3[a] + 1.001f) * inv); }
+    for (int a = 0; a < 3; a++) {  // (the query is the wavefront's: uniform values, kept in scalar registers)
+      blo[a] = __builtin_amdgcn_readfirstlane((int)floorf((q3[a] - 1.001f) * inv));
+      bhi[a] = __builtin_amdgcn_readfirstlane((int)floorf((q3[a] + 1.001f) * inv));
+    }
     bool from_cache = false;
     if (outer > 0) {
       const int4 b0 = cbox[2 * slot], b1 = cbox[2 * slot + 1];
@@ -532,10 +535,10 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     const int halfw[3] = {2, 2, 1};   // valid block: 5 x 5 x 3 cubes (LM:404-420)
     const int wdim[3] = {kCubeW, kCubeH, kCubeD};
     const double leaf = 1.0 / (double)inv;
-    constexpr int kMaxPieces = 8;
-    int pa[3][kMaxPieces], pb[3][kMaxPieces], pm[3][kMaxPieces], np_[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
+    // Piece e of axis a — (cube, 4-voxel block, 4-bit mask of the block's voxels inside the range) — or, with e = -1, just the number
+    // of pieces.  A short wave-uniform loop that every lane walks with its OWN target index: no piece tables (tables written
+    // through a run-time counter cost ~70 VGPRs here and with them a wavefront of occupancy per SIMD).
+    auto axis_piece = [&](int a, int e, int& A_out, int& blk_out, int& m4_out) -> int {
       const int lo = blo[a], hi = bhi[a];
       const int Amin = cube_lo((double)lo * leaf), Amax = cube_hi((double)(hi + 1) * leaf);
       int n = 0;
@@ -546,18 +549,25 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
         // voxels that can hold points of cube A: from the voxel containing its lower face to the one containing its upper face
         const int base = cube_voxel_base(A, inv);
         const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
-        for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2) && ia <= ib; blk++) {
-          if (n >= kMaxPieces || (unsigned)blk > 63u) { overflow = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
-          int m4 = 0;
+        if (ia > ib) continue;
+        for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2); blk++) {
+          if ((unsigned)blk > 63u) { overflow = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
+          if (n == e) {
+            int m4 = 0;
 #pragma unroll
-          for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
-          // wave-uniform by construction: keep the piece tables in scalar registers (they would otherwise cost ~72 VGPRs)
-          pa[a][n] = __builtin_amdgcn_readfirstlane(A); pb[a][n] = __builtin_amdgcn_readfirstlane(blk);
-          pm[a][n] = __builtin_amdgcn_readfirstlane(m4); n++;
+            for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
+            A_out = A; blk_out = blk; m4_out = m4;
+          }
+          n++;
         }
       }
-      np_[a] = __builtin_amdgcn_readfirstlane(n);
-    }
+      return n;
+    };
+    int np_[3];
+    { int d0, d1, d2;
+      np_[0] = __builtin_amdgcn_readfirstlane(axis_piece(0, -1, d0, d1, d2));
+      np_[1] = __builtin_amdgcn_readfirstlane(axis_piece(1, -1, d0, d1, d2));
+      np_[2] = __builtin_amdgcn_readfirstlane(axis_piece(2, -1, d0, d1, d2)); }
     const int nblocks = np_[0] * np_[1] * np_[2];
     if (lane < 8) s_best[wave][0][lane] = ~0ull;
     // Candidate lists longer than kCandChunk (a dense map at a fine leaf: up to 9^3 voxels in the box) are handled in several
@@ -571,12 +581,9 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
         if (bb < nblocks) {
           const int ex = bb % np_[0], ey = (bb / np_[0]) % np_[1], ez = bb / (np_[0] * np_[1]);
           int mx = 0, my = 0, mz = 0;
-#pragma unroll
-          for (int e = 0; e < kMaxPieces; e++) {  // select this lane's pieces without dynamic register indexing
-            if (e == ex) { Ai = pa[0][e]; bx = pb[0][e]; mx = pm[0][e]; }
-            if (e == ey) { Aj = pa[1][e]; by = pb[1][e]; my = pm[1][e]; }
-            if (e == ez) { Ak = pa[2][e]; bz = pb[2][e]; mz = pm[2][e]; }
-          }
+          axis_piece(0, ex, Ai, bx, mx);
+          axis_piece(1, ey, Aj, by, my);
+          axis_piece(2, ez, Ak, bz, mz);
           const u64 bkey = pack_key(Ai, Aj, Ak, bx, by, bz) | (1ull << 63);
           unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
           int probe = 0;

@@ -342,26 +342,36 @@ __device__ void sr_spread(int ind, const float* px, const float* py, const float
   }
 }
 
+// Two capacity tiers of the LDS-resident ring.  CAP = kRingCapSmall covers every real HDL-64E / HDL-32 / VLP-16 ring (a revolution
+// has <= ~2 100 firings) in 76.5 KB of LDS, so TWO rings share a CU (and other kernels' workgroups still find LDS next to one);
+// the kMaxRingLen tier (146 KB, one workgroup per CU) is launched right behind it and only works on rings the small tier had to
+// leave alone (len > kRingCapSmall) — normally it exits at once.
+constexpr int kRingCapSmall = 2112, kSectCapSmall = 512, kRingWatch = 1920;
+template <int CAP, int SECT>
+constexpr size_t sr_ring_keys_bytes() { return sizeof(u64) * kSectors * SECT > (size_t)12 * CAP ? sizeof(u64) * kSectors * SECT : (size_t)12 * CAP; }
+
+template <int CAP, int SECT, bool BIG_TIER>
 __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restrict__ cloud, FrameScalars* S, int* __restrict__ sharp_idx,
                                                           int* __restrict__ less_sharp_idx, int* __restrict__ flat_idx,
                                                           float4* __restrict__ ring_ds, float* __restrict__ dbg_curv,
                                                           int* __restrict__ dbg_sort, int* __restrict__ dbg_picked,
-                                                          int* __restrict__ dbg_label, long long* __restrict__ dbg_cyc /* [rings][8] */, size_t ss) {
+                                                          int* __restrict__ dbg_label, long long* __restrict__ dbg_cyc /* [rings][8] */,
+                                                          int* ring_watch /* host-mapped [sessions] */, int big_follows, size_t ss) {
   VL_SESSION(ss); RB(cloud); RB(S); RB(sharp_idx); RB(less_sharp_idx); RB(flat_idx); RB(ring_ds); RB(dbg_curv); RB(dbg_sort); RB(dbg_picked);
   RB(dbg_label); RB(dbg_cyc);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* px = (float*)smem;                          // [kMaxRingLen]
-  float* py = px + kMaxRingLen;
-  float* pz = py + kMaxRingLen;
-  float* pi = pz + kMaxRingLen;                      // intensity
-  u64* keys = (u64*)(pi + kMaxRingLen);              // [kSectors * kSectCap]
-  int* iscratch = (int*)(keys + kSectors * kSectCap);  // [kMaxRingLen] heads / ranks
-  int* scan_tmp = iscratch + kMaxRingLen;            // [kRingThreads]
-  unsigned char* picked = (unsigned char*)(scan_tmp + kRingThreads);  // [kMaxRingLen]
-  signed char* label = (signed char*)(picked + kMaxRingLen);         // [kMaxRingLen]
-  unsigned char* gap = (unsigned char*)(label + kMaxRingLen);        // [kMaxRingLen]
-  unsigned char* reachb = gap + kMaxRingLen;                         // [kMaxRingLen]
-  int* s_sp = (int*)(reachb + kMaxRingLen);                           // [kSectors]   (all LDS lives in the dynamic
+  float* px = (float*)smem;                          // [CAP]
+  float* py = px + CAP;
+  float* pz = py + CAP;
+  float* pi = pz + CAP;                              // intensity
+  u64* keys = (u64*)(pi + CAP);                      // debug sort: [kSectors * SECT]; VoxelGrid: run keys [CAP] + voxel ids [CAP]
+  int* iscratch = (int*)((unsigned char*)keys + sr_ring_keys_bytes<CAP, SECT>());  // [CAP] heads / ranks
+  int* scan_tmp = iscratch + CAP;                    // [kRingThreads]
+  unsigned char* picked = (unsigned char*)(scan_tmp + kRingThreads);  // [CAP]
+  signed char* label = (signed char*)(picked + CAP);                 // [CAP]
+  unsigned char* gap = (unsigned char*)(label + CAP);                // [CAP]
+  unsigned char* reachb = gap + CAP;                                 // [CAP]
+  int* s_sp = (int*)(reachb + CAP);                                   // [kSectors]   (all LDS lives in the dynamic
   int* s_ep = s_sp + 8;                                              // [kSectors]    region so its base stays 16-B aligned)
   float* s_red = (float*)(s_ep + 8);                                 // [6]
   int* s_ncand_p = (int*)(s_red + 8);
@@ -377,9 +387,15 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   SR_STAMP();
   const int len = S->ring_count[r], off = S->ring_off[r];
   const int start = off + 5, end = off + len - 6;  // SR:278-280
+  if (BIG_TIER && len <= kRingCapSmall) return;    // the small tier has done this ring
   if (tid < kSectors * 3) (&S->sect_cnt[r][0][0])[tid] = 0;
   if (tid == 0) S->ring_ds_cnt[r] = 0;
-  if (len > kMaxRingLen) { if (tid == 0) atomicOr(&S->error, kErrRingTooLong); return; }
+  // The big tier asks for 146 KB of LDS just to start, which on a busy chip (batches) costs tens of microseconds even when it has
+  // nothing to do: the host only launches it while rings near the small tier's capacity have been seen (ring_watch, a host-mapped
+  // word it polls without synchronising) or during the first sweeps.  A ring that outgrows the small tier without that warning
+  // (it would have to jump from < kRingWatch to > kRingCapSmall points between two sweeps) is reported, not dropped silently.
+  if (!BIG_TIER && tid == 0 && len > kRingWatch && ring_watch) __hip_atomic_store(&ring_watch[blockIdx.z], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (len > CAP) { if ((BIG_TIER || !big_follows) && tid == 0) atomicOr(&S->error, kErrRingTooLong); return; }   // small tier: left to the big tier
   if (end - start < 6) return;  // SR:314
 
   for (int l = tid; l < len; l += kRingThreads) {
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     const int seclen = ep - sp + 1;
     int P = 2;
     while (P < seclen) P <<= 1;
-    u64* K = keys + wave * kSectCap;
+    u64* K = keys + wave * SECT;
     for (int t = lane; t < P; t += 64) {
       u64 key = ~0ull;
       if (t < seclen) key = ((u64)__float_as_uint(curvature(sp + t)) << 32) | (unsigned)(sp + t);  // c >= 0: bits order like the value
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   };
   auto run_sector = [&](int s, int in_hi, bool redo) {
     if (s_ep[s] - s_sp[s] + 1 <= 6 * 64) run_sector_q(std::integral_constant<int, 6>{}, s, in_hi, redo);   // HDL-64E: ~330 points per sector
-    else run_sector_q(std::integral_constant<int, kSectCap / 64>{}, s, in_hi, redo);
+    else run_sector_q(std::integral_constant<int, SECT / 64>{}, s, in_hi, redo);
   };
   if (wave < kSectors) run_sector(wave, -1, false);
   __syncthreads();
@@ -653,8 +669,8 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   // consecutive candidates sharing a voxel), not points: key = (voxel index, first point of the run).  Sorted runs of one
   // voxel are in input order and so are the points inside a run, hence summing run after run reproduces the
   // input-order f32 sums of pcl::VoxelGrid exactly, with a network several times smaller.
-  u64* K2 = keys;                      // [<= kMaxRingLen] run keys
-  int* vox = (int*)(keys + kMaxRingLen);  // [kMaxRingLen] voxel index of every covered point (-1: not a candidate)
+  u64* K2 = keys;                      // [<= CAP] run keys
+  int* vox = (int*)(keys + CAP);       // [CAP] voxel index of every covered point (-1: not a candidate)
   for (int l = tid; l < len; l += kRingThreads) {
     int idx = -1;
     if (l >= c_lo && l <= c_hi && label[l] <= 0) {
@@ -776,16 +792,23 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
 }
 
 // ------------------------------------------------------------------------------------------------
-size_t sr_ring_smem_bytes() {
-  return sizeof(float) * 4 * kMaxRingLen + sizeof(u64) * kSectors * kSectCap + sizeof(int) * (kMaxRingLen + kRingThreads) +
-         4 * kMaxRingLen + 64 * sizeof(int);
+template <int CAP, int SECT>
+static size_t sr_ring_smem_bytes() {
+  return sizeof(float) * 4 * CAP + sr_ring_keys_bytes<CAP, SECT>() + sizeof(int) * (CAP + kRingThreads) + 4 * CAP + 64 * sizeof(int);
 }
+static_assert(kRingCapSmall % 4 == 0 && 2 * (sizeof(float) * 4 * kRingCapSmall + (size_t)12 * kRingCapSmall + sizeof(int) * (kRingCapSmall + kRingThreads) +
+              4 * kRingCapSmall + 64 * sizeof(int)) <= 160 * 1024, "two small-tier rings must fit the 160 KB of LDS of one CU");
 
 hipError_t sr_init() {
-  return hipFuncSetAttribute((const void*)k_sr_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_ring_smem_bytes());
+  hipError_t e = hipFuncSetAttribute((const void*)k_sr_ring<kRingCapSmall, kSectCapSmall, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>());
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)k_sr_ring<kMaxRingLen, kSectCap, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)sr_ring_smem_bytes<kMaxRingLen, kSectCap>());
 }
 
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done) {
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done,
+                     int* ring_watch, bool big_tier) {
   int n = 0;
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
@@ -797,9 +820,15 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
                slice, nslice, blk, se.ss);
   VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
-  VLOAM_LAUNCH(ph, kKSrRing, st, k_sr_ring, dim3(kMaxRings, 1, Z), dim3(kRingThreads), sr_ring_smem_bytes(), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
-                     b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-                     debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, se.ss);
+  VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
+               (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
+               b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
+               debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, ring_watch, big_tier ? 1 : 0, se.ss);
+  if (big_tier)
+    VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
+                 (sr_ring_smem_bytes<kMaxRingLen, kSectCap>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
+                 b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
+                 debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
   VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings, 1, Z), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
                      b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr, b.sticky_err, se.ss);
   return hipGetLastError();
