@@ -9,6 +9,14 @@
 // VLOAM_HIP_WITH_PCL (and have PCL on the include path) to get overloads taking pcl::PointCloud — that adapter is
 // compile-guarded and untested here because PCL / ROS are absent from this image.  Errors: the reference aborts
 // (ROS_BREAK) or returns void; here a failing ABI call throws std::runtime_error carrying vloam_last_error().
+//
+// What stays in HBM: the reference hands clouds from stage to stage by value (LaserOdometry::input deep-copies the five
+// scan-registration clouds, laser_odometry.cpp:141-145; LaserMapping::input copies three more, laser_mapping.cpp:167-181).
+// Here the stages read each other's results on the device, so input(...) does not upload anything — but it CHECKS that the
+// clouds it is given are the ones the previous stage produced (size + first / last point) and throws std::invalid_argument
+// otherwise: a caller that edits or substitutes clouds between the stages is told so instead of being silently ignored.
+// init(std::shared_ptr<TF>&) accepts (and ignores) the reference's vloam_tf blackboard: the pose hand-overs it carries are
+// device-resident (vloam_set_lo_prior / vloam_process_frame are the VO coupling points).
 #pragma once
 #include <array>
 #include <memory>
@@ -36,13 +44,21 @@ inline void check(vloam_status s) {
   if (s != VLOAM_OK) throw std::runtime_error(std::string("vloam_hip: ") + vloam_last_error());
 }
 
+inline bool same_cloud(const Cloud& a, const Cloud& b) {  // cheap identity check: size, first and last point bit for bit
+  if (a.size() != b.size()) return false;
+  if (a.empty()) return true;
+  auto eq = [](const PointXYZI& p, const PointXYZI& q) { return p.x == q.x && p.y == q.y && p.z == q.z; };
+  return eq(a.front(), b.front()) && eq(a.back(), b.back());
+}
+
 class Session {  // one vloam_handle == one sequence on one GPU; shared by the three stage objects
  public:
   explicit Session(int device = 0, const vloam_config* cfg = nullptr) {
-    vloam_config c;
-    if (cfg) c = *cfg; else vloam_default_config(&c);
-    check(vloam_create(&c, device, &h_));
+    if (cfg) config = *cfg; else vloam_default_config(&config);
+    check(vloam_create(&config, device, &h_));
   }
+  vloam_config config;
+  int frames_done = 0;   // sweeps whose laser odometry has run == LaserOdometry::frameCount
   ~Session() { vloam_destroy(h_); }
   Session(const Session&) = delete;
   Session& operator=(const Session&) = delete;
@@ -63,6 +79,7 @@ class ScanRegistration {
  public:
   explicit ScanRegistration(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}                                   // parameters were bound at vloam_create
+  template <class TF> void init(std::shared_ptr<TF>&) {}
   void reset() { check(vloam_reset_frame(s_->get())); }
   void input(const Cloud& laserCloudIn) { check(vloam_scan_registration(s_->get(), laserCloudIn.empty() ? nullptr : &laserCloudIn[0].x, (int)laserCloudIn.size())); }
 #ifdef VLOAM_HIP_WITH_PCL
@@ -84,16 +101,27 @@ class LaserOdometry {
  public:
   explicit LaserOdometry(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}
-  // the five clouds stay resident in HBM; the reference deep-copies them here (laser_odometry.cpp:141-145)
-  void input(const Cloud&, const Cloud&, const Cloud&, const Cloud&, const Cloud&) {}
+  template <class TF> void init(std::shared_ptr<TF>&) {}   // laser_odometry.h:70 takes the vloam_tf blackboard
+  // laser_odometry.cpp:135-146.  The five clouds are already resident in HBM: nothing is uploaded, but foreign clouds are refused.
+  void input(const Cloud& laserCloud, const Cloud& cornerPointsSharp, const Cloud& cornerPointsLessSharp, const Cloud& surfPointsFlat,
+             const Cloud& surfPointsLessFlat) {
+    const Cloud* given[5] = {&laserCloud, &cornerPointsSharp, &cornerPointsLessSharp, &surfPointsFlat, &surfPointsLessFlat};
+    for (int k = 0; k < 5; k++)
+      if (!same_cloud(*given[k], s_->features(k)))
+        throw std::invalid_argument("vloam_hip: LaserOdometry::input was given a cloud that is not ScanRegistration::output's (the stages exchange "
+                                    "clouds on the device; substituted clouds are not uploaded)");
+  }
   void input() {}
   void setVOPrior(const Quaterniond& q, const Vector3d& t) { check(vloam_set_lo_prior(s_->get(), q.data(), t.data())); }  // vloam_tf->velo_last_VOT_velo_curr
-  void solveLO() { check(vloam_laser_odometry(s_->get(), q_w_curr.data(), t_w_curr.data(), q_last_curr.data(), t_last_curr.data())); }
+  void solveLO() {
+    check(vloam_laser_odometry(s_->get(), q_w_curr.data(), t_w_curr.data(), q_last_curr.data(), t_last_curr.data()));
+    s_->frames_done++;   // laser_odometry.cpp:535 frameCount++
+  }
   void publish() {}
   void output(Quaterniond& q_w_curr_, Vector3d& t_w_curr_, Cloud& laserCloudCornerLast, Cloud& laserCloudSurfLast, Cloud& laserCloudFullRes, bool& skip_frame) {
     q_w_curr_ = q_w_curr; t_w_curr_ = t_w_curr;
     laserCloudCornerLast = s_->features(5); laserCloudSurfLast = s_->features(6); laserCloudFullRes = s_->features(0);
-    skip_frame = false;  // mapping_skip_frame handling lives inside vloam_laser_mapping
+    skip_frame = (s_->frames_done % s_->config.mapping_skip_frame) != 0;  // laser_odometry.cpp:618 (vloam_laser_mapping applies the same rule)
   }
   Quaterniond q_w_curr{{0, 0, 0, 1}}, q_last_curr{{0, 0, 0, 1}};
   Vector3d t_w_curr{{0, 0, 0}}, t_last_curr{{0, 0, 0}};
@@ -106,10 +134,25 @@ class LaserMapping {
  public:
   explicit LaserMapping(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}
+  template <class TF> void init(std::shared_ptr<TF>&) {}   // laser_mapping.h:85
   void reset() {}
-  void input(const Cloud&, const Cloud&, const Cloud&, const Quaterniond&, const Vector3d&, const bool&) {}
+  // laser_mapping.cpp:167-196: clouds and odometry pose are read on the device; what is passed in must be LaserOdometry::output's
+  void input(const Cloud& laserCloudCornerLast, const Cloud& laserCloudSurfLast, const Cloud& laserCloudFullRes, const Quaterniond&, const Vector3d&,
+             const bool& skip_frame) {
+    if (!same_cloud(laserCloudCornerLast, s_->features(5)) || !same_cloud(laserCloudSurfLast, s_->features(6)) || !same_cloud(laserCloudFullRes, s_->features(0)))
+      throw std::invalid_argument("vloam_hip: LaserMapping::input was given a cloud that is not LaserOdometry::output's");
+    if (skip_frame != ((s_->frames_done % s_->config.mapping_skip_frame) != 0))
+      throw std::invalid_argument("vloam_hip: LaserMapping::input: skip_frame differs from frameCount % mapping_skip_frame (laser_odometry.cpp:618)");
+  }
   void input() {}
   void solveMapping() { check(vloam_laser_mapping(s_->get(), q_w_curr.data(), t_w_curr.data())); }
+  Cloud map() {   // /laser_cloud_map (laser_mapping.cpp:778-793)
+    long long n = 0;
+    check(vloam_get_map(s_->get(), nullptr, 0, &n));
+    Cloud c(static_cast<size_t>(n));
+    if (n) check(vloam_get_map(s_->get(), &c[0].x, n, &n));
+    return c;
+  }
   void publish() {}
   Cloud registeredCloud() { return s_->features(11); }  // /velodyne_cloud_registered (laser_mapping.cpp:795-805)
   Quaterniond q_w_curr{{0, 0, 0, 1}};
@@ -124,8 +167,12 @@ class LidarOdometryMapping {
   explicit LidarOdometryMapping(int device = 0, const vloam_config* cfg = nullptr)
       : session(std::make_shared<Session>(device, cfg)), scan_registration(session), laser_odometry(session), laser_mapping(session) {}
   void init() {}
+  template <class TF> void init(std::shared_ptr<TF>&) {}   // lidar_odometry_mapping.h: init(std::shared_ptr<VloamTF>&)
   void reset() { scan_registration.reset(); laser_mapping.reset(); }
   void scanRegistrationIO(const Cloud& laserCloudIn) { scan_registration.input(laserCloudIn); }
+#ifdef VLOAM_HIP_WITH_PCL
+  void scanRegistrationIO(const pcl::PointCloud<pcl::PointXYZ>& laserCloudIn) { scan_registration.input(laserCloudIn); }  // lidar_odometry_mapping.cpp:73
+#endif
   void laserOdometryIO() { laser_odometry.input(); laser_odometry.solveLO(); laser_odometry.publish(); }
   void laserMappingIO() { laser_mapping.input(); laser_mapping.solveMapping(); laser_mapping.publish(); }
   std::shared_ptr<Session> session;

@@ -6,8 +6,11 @@
 // self-contained vector algebra (no Eigen), so a user who HAS Ceres can still do
 //   new ceres::AutoDiffCostFunction<vloam::factors::LidarEdgeFactor, 3, 4, 3>(new vloam::factors::LidarEdgeFactor(...))
 // while the GPU path evaluates the same residuals with closed-form Jacobians (csrc/lm_solve.hip).
-// T must support + - * / < >, sqrt, sin, cos (found by ADL, as for ceres::Jet).  s == 1 (DISTORTION == false,
-// laser_odometry.h:90): Identity.slerp(1, q) == q, so the slerp of the reference is the identity here.
+// T must support + - * / < >, sqrt, sin, cos, acos, abs (found by ADL, as for ceres::Jet).  The interpolation ratio s is honoured
+// exactly like the reference (lidarFactor.hpp:26-33: q_last_curr = Identity.slerp(s, q), t_last_curr = s * t); the GPU path runs with
+// s == 1 (DISTORTION == false, laser_odometry.h:90), where the slerp returns q itself.
+// Not provided: the static Create(...) factories (lidarFactor.hpp:47-52, 94-101, 132-134) — they return ceres::CostFunction*, i.e. need
+// Ceres; with Ceres at hand they are the one-liners quoted above.
 #pragma once
 #include <cmath>
 #include <limits>
@@ -20,7 +23,7 @@ template <class T> inline V3<T> sub(const V3<T>& a, const V3<T>& b) { return {a.
 template <class T> inline V3<T> cross(const V3<T>& a, const V3<T>& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 template <class T> inline T dot(const V3<T>& a, const V3<T>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // q = (x, y, z, w); v + w (2 u x v) + u x (2 u x v)   (Eigen's QuaternionBase::_transformVector)
-template <class T> inline V3<T> rotate(const T* q, const V3<T>& v) {
+template <class T, class Q> inline V3<T> rotate(const Q* q, const V3<T>& v) {
   V3<T> u{q[0], q[1], q[2]};
   V3<T> uv = cross(u, v);
   uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
@@ -28,12 +31,32 @@ template <class T> inline V3<T> rotate(const T* q, const V3<T>& v) {
   return {v.x + q[3] * uv.x + c.x, v.y + q[3] * uv.y + c.y, v.z + q[3] * uv.z + c.z};
 }
 
+// Eigen::Quaternion::slerp from the identity (Eigen/src/Geometry/Quaternion.h): d = Identity . q = q.w; near-parallel -> linear weights,
+// otherwise sin((1 - s) theta) / sin(theta) and sin(s theta) / sin(theta), the second negated when d < 0.
+template <class T> inline void slerp_from_identity(const T& s, const T* q, T* out) {
+  using std::acos; using std::sin; using std::abs;
+  const T one = T(1.0) - T(std::numeric_limits<double>::epsilon());
+  const T d = q[3];
+  const T absD = abs(d);
+  T scale0, scale1;
+  if (absD >= one) { scale0 = T(1.0) - s; scale1 = s; }
+  else {
+    const T theta = acos(absD), sinTheta = sin(theta);
+    scale0 = sin((T(1.0) - s) * theta) / sinTheta;
+    scale1 = sin(s * theta) / sinTheta;
+  }
+  if (d < T(0.0)) scale1 = -scale1;
+  out[0] = scale1 * q[0]; out[1] = scale1 * q[1]; out[2] = scale1 * q[2]; out[3] = scale0 + scale1 * q[3];
+}
+
 struct LidarEdgeFactor {
   LidarEdgeFactor(const double c[3], const double a[3], const double b[3], double s_) : s(s_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; lpa[i] = a[i]; lpb[i] = b[i]; } }
   template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
     using std::sqrt;
     V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, a{T(lpa[0]), T(lpa[1]), T(lpa[2])}, b{T(lpb[0]), T(lpb[1]), T(lpb[2])};
-    V3<T> r = rotate(q, p);
+    T qs[4];
+    slerp_from_identity(T(s), q, qs);   // lidarFactor.hpp:29-33
+    V3<T> r = rotate(qs, p);
     V3<T> lp{r.x + T(s) * t[0], r.y + T(s) * t[1], r.z + T(s) * t[2]};
     V3<T> nu = cross(sub(lp, a), sub(lp, b));
     V3<T> de = sub(a, b);
@@ -54,7 +77,9 @@ struct LidarPlaneFactor {
   }
   template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
     V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, j{T(lpj[0]), T(lpj[1]), T(lpj[2])}, n{T(ljm[0]), T(ljm[1]), T(ljm[2])};
-    V3<T> r = rotate(q, p);
+    T qs[4];
+    slerp_from_identity(T(s), q, qs);   // lidarFactor.hpp:84-88
+    V3<T> r = rotate(qs, p);
     V3<T> lp{r.x + T(s) * t[0], r.y + T(s) * t[1], r.z + T(s) * t[2]};
     residual[0] = dot(sub(lp, j), n);
     return true;

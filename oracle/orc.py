@@ -200,11 +200,12 @@ def knn(pts, queries, k, use_tree=True):
     return idx, d2
 
 
-def eval_lidar_factor(ftype, curr, geom, q, t):
+def eval_lidar_factor(ftype, curr, geom, q, t, s=1.0):
+    """Residual + tangent-space Jacobian of one LiDAR factor; s = the functors' interpolation ratio (lidarFactor.hpp:26-33)."""
     L = lib()
     curr, geom, q, t = [np.ascontiguousarray(a, dtype=np.float64) for a in (curr, geom, q, t)]
     r, J = np.zeros(3), np.zeros((3, 6))
-    n = L.orc_eval_lidar_factor(ftype, _p(curr, D), _p(geom, D), _p(q, D), _p(t, D), _p(r, D), _p(J, D))
+    n = L.orc_eval_lidar_factor_s(ftype, _p(curr, D), _p(geom, D), _p(q, D), _p(t, D), D(s), _p(r, D), _p(J, D))
     return r[:n], J[:n]
 
 

@@ -225,12 +225,19 @@ void orc_knn(const float* xyzi, int n, const float* queries_xyz, int nq, int k, 
 // type: 0 LidarEdgeFactor (geom = a[3], b[3]), 1 LidarPlaneFactor (geom = j,l,m [9]), 2 LidarPlaneNormFactor (geom = n[3], d).
 // Returns nres; residual[nres]; jac_local = nres x 6 row-major in the tangent space of (q ⊞ δ, t + δt)
 // exactly as Ceres assembles it (autodiff global Jacobian x EigenQuaternionParameterization Jacobian); no loss applied.
+int orc_eval_lidar_factor_s(int type, const double* curr3, const double* geom, const double* q4, const double* t3, double s_ratio, double* residual,
+                            double* jac_local);
 int orc_eval_lidar_factor(int type, const double* curr3, const double* geom, const double* q4, const double* t3, double* residual,
                           double* jac_local) {
+  return orc_eval_lidar_factor_s(type, curr3, geom, q4, t3, 1.0, residual, jac_local);
+}
+// s_ratio: the functors' interpolation ratio s (lidarFactor.hpp:26-33: q slerped from identity by s, t scaled by s); 1.0 when DISTORTION == false
+int orc_eval_lidar_factor_s(int type, const double* curr3, const double* geom, const double* q4, const double* t3, double s_ratio, double* residual,
+                            double* jac_local) {
   std::unique_ptr<CostFunction> f;
   Vec3d c(curr3[0], curr3[1], curr3[2]);
-  if (type == 0) f.reset(new AutoDiffCost<LidarEdgeFactor, 3, 4>(LidarEdgeFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), 1.0)));
-  else if (type == 1) f.reset(new AutoDiffCost<LidarPlaneFactor, 1, 4>(LidarPlaneFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), Vec3d(geom[6], geom[7], geom[8]), 1.0)));
+  if (type == 0) f.reset(new AutoDiffCost<LidarEdgeFactor, 3, 4>(LidarEdgeFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), s_ratio)));
+  else if (type == 1) f.reset(new AutoDiffCost<LidarPlaneFactor, 1, 4>(LidarPlaneFactor(c, Vec3d(geom[0], geom[1], geom[2]), Vec3d(geom[3], geom[4], geom[5]), Vec3d(geom[6], geom[7], geom[8]), s_ratio)));
   else if (type == 2) f.reset(new AutoDiffCost<LidarPlaneNormFactor, 1, 4>(LidarPlaneNormFactor(c, Vec3d(geom[0], geom[1], geom[2]), geom[3])));
   else return -1;
   double j0[12], j1[9];

@@ -21,6 +21,11 @@ int main() {
   vloam::factors::LidarPlaneNormFactor pn(c, n, 0.25); pn(q, t, r); std::printf("%.17g\n", r[0]);
   vloam_config cfg; vloam_default_config(&cfg);
   std::printf("%d %s\n", cfg.scan_line, vloam_version());
+  // interpolation ratio s != 1 (DISTORTION == true in the reference): q slerped from the identity, t scaled (lidarFactor.hpp:26-33)
+  vloam::factors::LidarEdgeFactor e2(c, a, b, 0.4); e2(q, t, r); std::printf("%.17g %.17g %.17g\n", r[0], r[1], r[2]);
+  vloam::factors::LidarPlaneFactor p2(c, a, b, m, 0.4); p2(q, t, r); std::printf("%.17g\n", r[0]);
+  double qn[4] = {-0.3, 0.2, -0.1, -0.9273618495495703};   // w < 0: the sign branch of Eigen's slerp
+  vloam::factors::LidarEdgeFactor e3(c, a, b, 0.7); e3(qn, t, r); std::printf("%.17g %.17g %.17g\n", r[0], r[1], r[2]);
   return 0;
 }
 '''
@@ -43,6 +48,14 @@ def test_headers_compile_and_functors_match_oracle(tmp_path, orc, vl):
     assert np.allclose(e, r0, rtol=1e-13, atol=1e-14)
     assert abs(float(out[1]) - r1[0]) < 1e-13 and abs(float(out[2]) - r2[0]) < 1e-13
     assert out[3].startswith("64 vloam_hip")
+    e2 = np.array([float(x) for x in out[4].split()])
+    r3, _ = orc.eval_lidar_factor(0, curr, a + b, q, t, s=0.4)
+    r4, _ = orc.eval_lidar_factor(1, curr, a + b + m, q, t, s=0.4)
+    assert np.allclose(e2, r3, rtol=1e-13, atol=1e-14) and abs(float(out[5]) - r4[0]) < 1e-13
+    assert np.linalg.norm(e2 - e) > 1e-3, "s must matter"
+    e3 = np.array([float(x) for x in out[6].split()])
+    r5, _ = orc.eval_lidar_factor(0, curr, a + b, [-0.3, 0.2, -0.1, -0.9273618495495703], t, s=0.7)
+    assert np.allclose(e3, r5, rtol=1e-13, atol=1e-14)
     # c_api.h is plain C
     csrc = tmp_path / "c.c"
     csrc.write_text('#include "vloam_hip/c_api.h"\nint main(void) { vloam_config c; vloam_default_config(&c); return c.scan_line != 64; }\n')

@@ -1,0 +1,95 @@
+"""-m gpu: the C++ class surface (include/vloam_hip/compat.hpp) executed on the GPU.
+
+A C++ program written against vloam::LidarOdometryMapping / ScanRegistration / LaserOdometry / LaserMapping exactly the way the
+reference's façade drives them (lidar_odometry_mapping.cpp:65-154: reset -> scanRegistrationIO -> laserOdometryIO -> laserMappingIO,
+with the explicit output() / input() hand-overs of scan_registration.h:71-77, laser_odometry.h:70-84, laser_mapping.h:85-94) is
+compiled with g++ against libvloam_hip.so, fed synthetic sweeps from a file, and its poses / feature counts / skip flags are
+compared with the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PROBE = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+#include "vloam_hip/compat.hpp"
+struct FakeTF {};   // stands in for vloam::VloamTF: init(std::shared_ptr<VloamTF>&) must accept it
+int main(int argc, char** argv) {
+  const int n_sweeps = std::atoi(argv[2]), n_pts = std::atoi(argv[3]), skip = std::atoi(argv[4]);
+  std::FILE* f = std::fopen(argv[1], "rb");
+  vloam_config cfg; vloam_default_config(&cfg); cfg.mapping_skip_frame = skip;
+  vloam::LidarOdometryMapping LOAM(0, &cfg);
+  auto tf = std::make_shared<FakeTF>();
+  LOAM.init(tf);
+  for (int k = 0; k < n_sweeps; k++) {
+    vloam::Cloud in((size_t)n_pts);
+    if (std::fread(in.data(), sizeof(vloam::PointXYZI), (size_t)n_pts, f) != (size_t)n_pts) return 2;
+    LOAM.reset();
+    // the reference's laserOdometryIO / laserMappingIO spelled out (lidar_odometry_mapping.cpp:84-154)
+    LOAM.scanRegistrationIO(in);
+    vloam::Cloud full, sharp, lessSharp, flat, lessFlat;
+    LOAM.scan_registration.output(full, sharp, lessSharp, flat, lessFlat);
+    LOAM.laser_odometry.input(full, sharp, lessSharp, flat, lessFlat);
+    LOAM.laser_odometry.solveLO();
+    vloam::Quaterniond q; vloam::Vector3d t; vloam::Cloud cornerLast, surfLast, fullRes; bool skip_frame = false;
+    LOAM.laser_odometry.output(q, t, cornerLast, surfLast, fullRes, skip_frame);
+    LOAM.laser_mapping.input(cornerLast, surfLast, fullRes, q, t, skip_frame);
+    LOAM.laser_mapping.solveMapping();
+    std::printf("%d %zu %zu %zu %zu %zu %d", k, full.size(), sharp.size(), lessSharp.size(), flat.size(), lessFlat.size(), (int)skip_frame);
+    for (int i = 0; i < 4; i++) std::printf(" %.17g", q[i]);
+    for (int i = 0; i < 3; i++) std::printf(" %.17g", t[i]);
+    for (int i = 0; i < 4; i++) std::printf(" %.17g", LOAM.laser_mapping.q_w_curr[i]);
+    for (int i = 0; i < 3; i++) std::printf(" %.17g", LOAM.laser_mapping.t_w_curr[i]);
+    std::printf("\n");
+    if (k == 1) {   // a substituted cloud must be refused, not silently ignored
+      vloam::Cloud bogus = sharp; bogus.pop_back();
+      bool threw = false;
+      try { LOAM.laser_odometry.input(full, bogus, lessSharp, flat, lessFlat); } catch (const std::invalid_argument&) { threw = true; }
+      if (!threw) return 3;
+    }
+  }
+  std::printf("map %zu registered %zu\n", LOAM.laser_mapping.map().size(), LOAM.laser_mapping.registeredCloud().size());
+  return 0;
+}
+'''
+
+
+def qdist(a, b):
+    return min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+
+
+@pytest.mark.parametrize("skip", [1, 2])
+def test_cpp_facade_runs_on_the_gpu_and_matches_the_oracle(tmp_path, orc, sweeps, vl, skip):
+    n, shape = 5, (64, 512)
+    clouds = [sweeps(shape[0], shape[1], k) for k in range(n)]
+    data = tmp_path / "sweeps.bin"
+    np.stack(clouds).astype(np.float32).tofile(data)
+    src, exe = tmp_path / "probe.cpp", tmp_path / "probe"
+    src.write_text(PROBE)
+    libdir = os.path.join(ROOT, "vloam-cmu-16833_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lvloam_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(data), str(n), str(clouds[0].shape[0]), str(skip)]).decode().strip().split("\n")
+    assert len(out) == n + 1
+    o = orc.Oracle(with_mapping=True, mapping_skip_frame=skip)
+    for k in range(n):
+        f = out[k].split()
+        o.process(clouds[k])
+        counts = [int(v) for v in f[1:6]]
+        assert counts == [o.cloud(w).shape[0] for w in range(5)], "frame %d feature counts" % k
+        assert int(f[6]) == (1 if ((k + 1) % skip) != 0 else 0), "skip_frame of LaserOdometry::output (laser_odometry.cpp:618)"
+        v = np.array([float(x) for x in f[7:]])
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert qdist(v[0:4], qw) < 1e-8 and np.linalg.norm(v[4:7] - tw) < 1e-8, "frame %d odometry pose" % k
+        assert qdist(v[7:11], qm) < 1e-8 and np.linalg.norm(v[11:14] - tm) < 1e-8, "frame %d mapping pose" % k
+    last = out[n].split()
+    info = o.map_info()
+    assert int(last[1]) == info["total_corner"] + info["total_surf"] and int(last[3]) == o.cloud(0).shape[0]

@@ -315,3 +315,32 @@ def test_long_run_with_grid_roll(vl, orc, synth):
         assert pts.shape == ref.shape
         a, b = lexsort_rows(pts), lexsort_rows(ref)
         assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+
+
+def test_full_size_steady_state_run(vl, orc, synth):
+    """configs[2] at full size: 110 sweeps of 64 x 2048 streamed through vloam_process_scan — the local map grows to its steady state
+    (~10^5 points in the valid block) — every laser-odometry and mapping pose against the sweep-by-sweep oracle, and the whole map
+    (every voxel centroid, in /laser_cloud_map order) bit for bit at the end."""
+    n = 110
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=n + 1)
+    h = vl.Handle(0, with_mapping=1, max_points=131072)
+    o = orc.Oracle(with_mapping=True)
+    ref = []
+    for k in range(n):
+        c = seq.sweep(k)
+        h.process_scan(c)
+        o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        ref.append(np.concatenate([qw, tw, qm, tm]))
+    h.sync()
+    tj = h.trajectory()
+    ref = np.array(ref)
+    for k in range(n):
+        assert qdist(tj[k, 0:4], ref[k, 0:4]) < POSE_TOL * 10 and np.linalg.norm(tj[k, 4:7] - ref[k, 4:7]) < POSE_TOL * 10, k
+        assert qdist(tj[k, 7:11], ref[k, 7:11]) < POSE_TOL * 10 and np.linalg.norm(tj[k, 11:14] - ref[k, 11:14]) < POSE_TOL * 10, k
+    got, want = h.get_map(), oracle_published_map(o)
+    assert got.shape == want.shape and got.shape[0] > 100000
+    assert same_cloud(got, want)
+    st = h.map_state()
+    assert st["deferred"] == 0 and st["n_map_corner"] + st["n_map_surf"] > 80000

@@ -146,13 +146,13 @@ def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
 
 
 def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
-    """k_sr_ring runs as a 2112-point tier (two rings per CU) plus, only while needed, the 4096-point tier: always during the first 8
-    sweeps, afterwards once a ring has come within 10 % of the small tier's capacity (host-mapped watch word).  Rings that grow from
-    1 792 over 2 000 to 2 300 points across the 8-sweep mark must come out of the right tier: features equal the oracle's throughout."""
+    """k_sr_ring runs as a 2176-point tier (two rings per CU) plus, only while needed, the 4096-point tier: always during the first 8
+    sweeps, afterwards once a ring has come within 32 points of the small tier's capacity (host-mapped watch word).  Rings that grow
+    from 1 792 over 2 160 to 2 300 points across the 8-sweep mark must come out of the right tier: features equal the oracle's."""
     def sweep(n_az, k):
         return synth.SynthSequence(n_rings=64, n_azimuth=n_az, n_sweeps=k + 1).sweep(k)
     h = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
-    plan = [1792] * 10 + [2000] * 2 + [2300] * 3 + [1792] * 2
+    plan = [1792] * 10 + [2160] * 2 + [2300] * 3 + [1792] * 2
     for k, n_az in enumerate(plan):
         cloud = sweep(n_az, k)
         h.reset_frame()

@@ -343,10 +343,10 @@ __device__ void sr_spread(int ind, const float* px, const float* py, const float
 }
 
 // Two capacity tiers of the LDS-resident ring.  CAP = kRingCapSmall covers every real HDL-64E / HDL-32 / VLP-16 ring (a revolution
-// has <= ~2 100 firings) in 76.5 KB of LDS, so TWO rings share a CU (and other kernels' workgroups still find LDS next to one);
+// has <= ~2 100 firings) in 78.75 KB of LDS, so TWO rings share a CU (and other kernels' workgroups still find LDS next to one);
 // the kMaxRingLen tier (146 KB, one workgroup per CU) is launched right behind it and only works on rings the small tier had to
-// leave alone (len > kRingCapSmall) — normally it exits at once.
-constexpr int kRingCapSmall = 2112, kSectCapSmall = 512, kRingWatch = 1920;
+// leave alone (len > kRingCapSmall).
+constexpr int kRingCapSmall = 2176, kSectCapSmall = 512, kRingWatch = 2144;   // an HDL-64E revolution at 10 Hz has <= 2 083 firings per laser
 template <int CAP, int SECT>
 constexpr size_t sr_ring_keys_bytes() { return sizeof(u64) * kSectors * SECT > (size_t)12 * CAP ? sizeof(u64) * kSectors * SECT : (size_t)12 * CAP; }
 
