@@ -11,7 +11,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $O
 timeout 600 python bench.py > $OUT/bench_map.json 2> $OUT/bench_map.err; cut -c1-400 $OUT/bench_map.json
 export TMPDIR=/tmp
 for W in map lo; do
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$W -- python $GRAFT_REPO_ROOT/bench.py --workload $W --no-cpu-baseline --no-kernel-timer --no-extras > $OUT/prof_$W.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$W -- python $GRAFT_REPO_ROOT/bench.py --workload $W --synth-procs 1 --no-cpu-baseline --no-kernel-timer --no-extras > $OUT/prof_$W.log 2>&1)
   DB=$(find $OUT/prof_$W -name '*.db' | head -1)
   python tools/rocprof_summary.py $DB $OUT/kernel_stats_$W.txt "bench.py --workload $W ($TAG)" | head -34
   python tools/timeline.py $OUT/prof_$W > $OUT/timeline_$W.txt 2>&1; head -60 $OUT/timeline_$W.txt
@@ -19,7 +19,8 @@ done
 if [ -n "$PMC" ] && [ "$PMC" != "-" ]; then
   for W in map; do
     for CTR in FETCH_SIZE WRITE_SIZE; do
-      (cd /tmp && timeout 600 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${W}_$CTR -- python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timer --no-extras > $OUT/pmc_${W}_$CTR.log 2>&1)
+      # counter collection serialises every dispatch: a short run (30-sweep map warm-up, 30 timed sweeps), no worker processes
+      (cd /tmp && timeout 420 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${W}_$CTR -- python $GRAFT_REPO_ROOT/bench.py --workload $W --map-warmup 30 --steps 30 --warmup 5 --synth-procs 1 --no-cpu-baseline --no-kernel-timer --no-extras > $OUT/pmc_${W}_$CTR.log 2>&1)
     done
     F=$(find $OUT/pmc_${W}_FETCH_SIZE -name '*counter_collection.csv' | head -1); Wf=$(find $OUT/pmc_${W}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
     python tools/pmc_summary.py $F $Wf $OUT/hbm_traffic_$W.txt | head -30
