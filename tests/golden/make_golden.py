@@ -60,7 +60,41 @@ def run_case(n_rings, n_az, n_frames, store_inputs):
     return out
 
 
+def run_vloam_case(n_rings, n_az, n_frames):
+    """The coupled per-frame loop (MAIN/src/vloam_main_node.cpp:125-180) in combined mode: inputs (sweeps + pixel matches) and the
+    oracle's per-frame VO estimate, VO -> LO prior, LO / mapping / VO world poses."""
+    import orc_vloam
+    synth = conftest.load_synth()
+    seq = synth.SynthSequence(n_rings=n_rings, n_azimuth=n_az, n_sweeps=n_frames + 1)
+    cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
+    base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
+    o = orc_vloam.VloamOracle(cam_T_velo, rect0_T_cam, P, base_T_cam0, velo_T_cam0, detach_VO_LO=False, scan_line=n_rings, with_mapping=True)
+    out = {"cam_T_velo": cam_T_velo, "rect0_T_cam": rect0_T_cam, "P_rect0": P, "base_T_cam0": base_T_cam0, "velo_T_cam0": velo_T_cam0}
+    for k in range(n_frames):
+        cloud = seq.sweep(k)
+        out["in_%d" % k] = cloud[:, :3].copy()
+        m = synth.synth_matches(seq, k) if k > 0 else (np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32))
+        out["prev_uv_%d" % k], out["curr_uv_%d" % k] = m
+        assert o.process(cloud, m[0] if k else None, m[1] if k else None) == 0
+        pre = "f%d_" % k
+        if o.vo_result is not None:
+            out[pre + "vo"] = np.concatenate([o.vo_result["angles"], o.vo_result["t"], [o.vo_result["counter32"], o.vo_result["counter22"]]])
+        pq, pt = o.lo_prior()
+        out[pre + "prior"] = np.concatenate([pq, pt])
+        qw, tw, ql, tl = o.lidar.lo_pose()
+        qm, tm = o.lidar.map_published_pose()
+        vq, vt = o.vo_world_pose()
+        out[pre + "poses"] = np.concatenate([qw, tw, qm, tm, vq, vt])
+        for outer in range(o.lidar.lo_num_outer()):
+            c, p = o.lidar.lo_corr(outer)
+            out[pre + "lo%d_corner" % outer] = c
+            out[pre + "lo%d_plane" % outer] = p
+    return out
+
+
 if __name__ == "__main__":
+    vl4 = run_vloam_case(64, 256, 5)
+    np.savez_compressed(os.path.join(HERE, "vloam_64x256_5frames.npz"), **vl4)
     small = run_case(64, 256, 3, store_inputs=True)
     np.savez_compressed(os.path.join(HERE, "loam_64x256_3frames.npz"), **small)
     big = run_case(64, 2048, 3, store_inputs=False)  # inputs regenerated from the seeds (SURVEY.md §8c)

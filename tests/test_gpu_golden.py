@@ -61,3 +61,37 @@ def test_golden_small(vl):
 def test_golden_full_size(vl, sweeps):
     g = np.load(os.path.join(HERE, "golden", "loam_64x2048_3frames.npz"))
     run(vl, g, [sweeps(64, 2048, k, n_sweeps=3) for k in range(3)])
+
+
+def test_golden_coupled_vloam_frames(vl):
+    """The coupled VO + LiDAR frame loop (vloam_process_frame, detach_VO_LO = 0) against tests/golden/vloam_64x256_5frames.npz."""
+    g = np.load(os.path.join(HERE, "golden", "vloam_64x256_5frames.npz"))
+    h = vl.Handle(0, debug=1, with_mapping=1, detach_VO_LO=0)
+    h.vo_set_calib(g["cam_T_velo"], g["rect0_T_cam"], g["P_rect0"])
+    h.set_extrinsics(g["base_T_cam0"], g["velo_T_cam0"])
+    for k in range(5):
+        c = np.zeros((g["in_%d" % k].shape[0], 4), dtype=np.float32)
+        c[:, :3] = g["in_%d" % k]
+        if k:
+            h.process_frame(c, g["prev_uv_%d" % k], g["curr_uv_%d" % k])
+        else:
+            h.process_frame(c)
+        pre = "f%d_" % k
+        tol = 1e-6 if k == 1 else 1e-8   # frame 1: the VO starts from 2 acos(1 - ulp) (tests/test_oracle_vloam.py)
+        r = h.vo_result()
+        if k:
+            gv = g[pre + "vo"]
+            assert (r["counter32"], r["counter22"]) == (int(gv[6]), int(gv[7]))
+            assert np.linalg.norm(r["angles"] - gv[0:3]) < tol and np.linalg.norm(r["t"] - gv[3:6]) < tol
+            if k > 1:
+                for outer in range(2):
+                    lo = h.lo_debug(outer)
+                    assert np.array_equal(lo["corner"], g[pre + "lo%d_corner" % outer]) and np.array_equal(lo["plane"], g[pre + "lo%d_plane" % outer])
+                    assert np.array_equal(lo["rec"]["x_in"][:4], r["prior_q"]) and np.array_equal(lo["rec"]["x_in"][4:], r["prior_t"])
+        gp = g[pre + "prior"]
+        assert qdist(r["prior_q"], gp[0:4]) < tol and np.linalg.norm(r["prior_t"] - gp[4:7]) < tol
+        tj, vj, gq = h.trajectory()[k], h.vo_trajectory()[k], g[pre + "poses"]
+        tolp = 1e-6 if k >= 1 else 1e-8
+        assert qdist(tj[0:4], gq[0:4]) < tolp and np.linalg.norm(tj[4:7] - gq[4:7]) < tolp
+        assert qdist(tj[7:11], gq[7:11]) < tolp and np.linalg.norm(tj[11:14] - gq[11:14]) < tolp
+        assert qdist(vj[0:4], gq[14:18]) < tolp and np.linalg.norm(vj[4:7] - gq[18:21]) < tolp

@@ -104,3 +104,21 @@ def test_coupling_carries_the_motion_both_ways(coupled_run):
     # up to the static extrinsics used here)
     q, t = o.vo_world_pose()
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(t)) and np.linalg.norm(t) > 2.0
+
+
+def test_oracle_reproduces_the_coupled_loop_fixture():
+    """tests/golden/vloam_64x256_5frames.npz (written by make_golden.py; inputs stored in the fixture) is still what the oracle computes."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vloam_64x256_5frames.npz"))
+    o = ov.VloamOracle(g["cam_T_velo"], g["rect0_T_cam"], g["P_rect0"], g["base_T_cam0"], g["velo_T_cam0"], detach_VO_LO=False, with_mapping=True)
+    for k in range(5):
+        c = np.zeros((g["in_%d" % k].shape[0], 4), dtype=np.float32)
+        c[:, :3] = g["in_%d" % k]
+        assert o.process(c, g["prev_uv_%d" % k] if k else None, g["curr_uv_%d" % k] if k else None) == 0
+        qw, tw, _, _ = o.lidar.lo_pose()
+        qm, tm = o.lidar.map_published_pose()
+        vq, vt = o.vo_world_pose()
+        assert np.allclose(np.concatenate([qw, tw, qm, tm, vq, vt]), g["f%d_poses" % k], rtol=0, atol=1e-12)
+        if k:
+            assert np.allclose(np.concatenate([o.vo_result["angles"], o.vo_result["t"]]), g["f%d_vo" % k][:6], rtol=0, atol=1e-12)
+            assert [o.vo_result["counter32"], o.vo_result["counter22"]] == list(g["f%d_vo" % k][6:].astype(int))
