@@ -51,6 +51,7 @@ struct vloam_handle {
   hipStream_t stream = nullptr;   // scan registration (+ NN grid build); also creation / VO work
   hipStream_t s_lo = nullptr;     // laser odometry
   hipStream_t s_map = nullptr;    // laser mapping
+  hipStream_t s_ds = nullptr;     // VoxelGrid of the scan features for mapping (needs the sweep's feature clouds only: off the SR stream's chain)
   static constexpr int kSets = 4;   // 3 suffice for correctness; the 4th keeps the buffer-reuse wait off the critical cycle
   hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
   static_assert(kSets == MapContext::kSets, "the stack sets rotate with the SR buffer sets");
@@ -227,7 +228,8 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   vloam_status st = VLOAM_OK;
   do {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s_lo, hipStreamNonBlocking) != hipSuccess ||
-        (cfg->with_mapping && hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess)) {  // no mapping: no third hardware queue
+        (cfg->with_mapping && (hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess ||
+                               hipStreamCreateWithFlags(&h->s_ds, hipStreamNonBlocking) != hipSuccess))) {  // no mapping: no further hardware queues
       set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
     }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
@@ -317,13 +319,13 @@ vloam_status vloam_select_session(vloam_handle* h, int session) {
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
   (void)hipSetDevice(h->device);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds}) if (st) (void)hipStreamSynchronize(st);
   if (h->arena) (void)hipFree(h->arena);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
     for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map}) if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds}) if (st) (void)hipStreamDestroy(st);
   map_destroy(&h->map);
   if (h->ring_watch) (void)hipHostFree(h->ring_watch);
   delete h;
@@ -343,6 +345,7 @@ static vloam_status sync_all(vloam_handle* h) {
   { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->s_lo));
+  if (h->s_ds) HIPCHK(hipStreamSynchronize(h->s_ds));
   if (h->s_map) HIPCHK(hipStreamSynchronize(h->s_map));
   return VLOAM_OK;
 }
@@ -383,8 +386,8 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   // the mapping stage's VoxelGrid of the scan features only needs this sweep's clouds: run it here, off the mapping stream
   if (h->cfg.with_mapping && ((k + 1) % h->cfg.mapping_skip_frame) == 0) {
-    if (map_stack_enqueue(&h->map, h->stream, h->sr[cur], cur, &h->prof) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }
-    HIPCHK(hipEventRecord(h->ev_stack[cur], h->stream));
+    HIPCHK(hipStreamWaitEvent(h->s_ds, h->ev_sr[cur], 0));   // the feature clouds (ev_sr is bound to k_sr_compact); a live wait, on a stream that has the time
+    if (map_stack_enqueue(&h->map, h->s_ds, h->sr[cur], cur, &h->prof, h->ev_stack[cur]) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }
   }
   h->last_n_in = n;
   h->stage = 1;
@@ -434,10 +437,9 @@ static vloam_status enqueue_map(vloam_handle* h, int frame) {
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[4], h->s_map));
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
   const bool skip = ((frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)frame * 14, skip, cur, &h->prof);
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)frame * 14, skip, cur, &h->prof, h->ev_map[cur]);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[5], h->s_map));
-  HIPCHK(hipEventRecord(h->ev_map[cur], h->s_map));
   return VLOAM_OK;
 }
 

@@ -129,9 +129,9 @@ struct MapContext {
 // layout: carve the session arena (called twice: dry to measure, then for real); init: the initial device state of session 0
 vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A);
 vloam_status map_init(MapContext* m, hipStream_t st);
-vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph);
+vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph, hipEvent_t done = nullptr);
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
-                         bool skip_frame, int set, ProfHook* ph);
+                         bool skip_frame, int set, ProfHook* ph, hipEvent_t done = nullptr);
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n);
 vloam_status map_error(MapContext* m, int* err_bits, int clear_mask = 0);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
           atomicOr(&fr->error, kErrMapDeferred);
           atomicAdd(&ms->deferred, 1);
           const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
-          if (dpos < cap) deferred[dpos] = (int)s;
+          if (dpos < cap) deferred[dpos] = (int)s; else atomicOr(&fr->error, kErrMapFull);   // the list of raw voxels is full: say so
         }
         done = true;
       }
@@ -893,23 +893,47 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
     }
     rec_store_value(&T.rec[s], acc, n, 0);
   }
-  // raw voxels of earlier sweeps whose cube is valid now (rare; only with ranges beyond the 5x5x3 block)
+  // Raw voxels of earlier sweeps whose cube is valid now (only with ranges beyond the 5x5x3 block): the reference's re-filter of the
+  // valid cubes (LM:689-702) merges them in the first sweep their cube is valid, touched or not.  One workgroup walks the list,
+  // resolves what became valid and COMPACTS the rest in place (chunks of 256, left to right: an entry only ever moves left), so the
+  // list holds the currently-raw voxels only.  A slot that also received points this sweep (pend_cnt > 0, or already count == 1)
+  // is finalised by its own thread above — with the validity rule applied to the whole sum — and only leaves the list here.
   if (blockIdx.x == 0) {
+    __shared__ int s_wcnt[4], s_out;
     int* deferred = kind ? deferred1 : deferred0;
     const int nd = min(fr->n_deferred[kind], cap);
-    for (int d = threadIdx.x; d < nd; d += 256) {
-      const int s = deferred[d];
-      if (s < 0) continue;
-      const RecVal dv = rec_load(&T.rec[s]);
-      int Ai, Aj, Ak;
-      unpack_cube(dv.key, &Ai, &Aj, &Ak);
-      const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
-      if (abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1) {
-        const int n = dv.count;
-        if (n > 1) { float4 a = dv.sum; const float nn = (float)n; a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn; rec_store_value(&T.rec[s], a, 1, 0); }
-        deferred[d] = -1;
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    for (int base = 0; base < nd; base += 256) {
+      const int d = base + threadIdx.x;
+      int s = d < nd ? deferred[d] : -1;
+      if (s >= 0) {
+        const RecVal dv = rec_load(&T.rec[s]);
+        int Ai, Aj, Ak;
+        unpack_cube(dv.key, &Ai, &Aj, &Ak);
+        const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
+        const bool in_window = wi >= 0 && wi < kCubeW && wj >= 0 && wj < kCubeH && wk >= 0 && wk < kCubeD;
+        if (!in_window || dv.count <= 0) s = -1;   // purged with its cube
+        else if (abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1) {
+          if (dv.pend_cnt == 0 && dv.count > 1) {
+            float4 a = dv.sum; const float nn = (float)dv.count;
+            a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn;
+            rec_store_value(&T.rec[s], a, 1, 0);
+          }
+          s = -1;
+        }
       }
+      const unsigned long long keep = __ballot(s >= 0);
+      if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = __popcll(keep);
+      __syncthreads();   // every entry of the chunk has been read
+      int o = s_out;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); w++) o += s_wcnt[w];
+      if (s >= 0) deferred[o + __popcll(keep & ((1ull << (threadIdx.x & 63)) - 1ull))] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) s_out += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      __syncthreads();
     }
+    if (threadIdx.x == 0) fr->n_deferred[kind] = s_out;
   }
   if (fr->rolled) map_purge(T, ms, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
   // table health, once per sweep and kind: the error surfaces well before probe chains degrade, and the host learns (through a
@@ -1035,7 +1059,7 @@ vloam_status map_init(MapContext* m, hipStream_t st) {
 
 // pcl::VoxelGrid of this sweep's lessSharp / lessFlat clouds (LM:432-440) -> stack set `set`.  Needs nothing but the scan
 // registration output, so it is enqueued on the scan-registration stream, ahead of the mapping stage that consumes it.
-vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph) {
+vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& cur, int set, ProfHook* ph, hipEvent_t done) {
   StackInfo* si = m->stack_info[set];
   const unsigned Z = (unsigned)m->se.B;
   const size_t ss = m->se.ss;
@@ -1043,8 +1067,9 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
                m->inv_leaf[0], m->inv_leaf[1], si, ss);
   VLOAM_LAUNCH(ph, kKMapDsRank, st, k_map_ds_rank, dim3(256, 2, Z), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si, ss);
   VLOAM_LAUNCH(ph, kKMapDsScatter, st, k_map_ds_scatter, dim3(128, 2, Z), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si, ss);
-  VLOAM_LAUNCH(ph, kKMapDsReduce, st, k_map_ds_reduce, dim3(1024, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
-               m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
+  // `done` (the stack of this sweep is complete) is bound to the last dispatch instead of a marker packet behind it
+  VLOAM_LAUNCH_EV(ph, kKMapDsReduce, st, done, k_map_ds_reduce, dim3(1024, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
+                  m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -1077,7 +1102,7 @@ vloam_status map_force_rebuild(MapContext* m, hipStream_t st) {
 }
 
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
-                         bool skip_frame, int set, ProfHook* ph) {
+                         bool skip_frame, int set, ProfHook* ph, hipEvent_t done) {
   (void)cfg; (void)cur;
   MapState* ms = m->state;
   MapFrame* fr = m->frame;
@@ -1096,8 +1121,9 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
         }
       }
   }
-  VLOAM_LAUNCH(ph, kKMapPrepare, st, k_map_prepare, dim3(1, 1, Z), dim3(256), 0, st, ms, fr, lo, m->cube_cnt, skip_frame ? 1 : 0, traj_row14,
-               m->stack_info[set], ss);
+  // `done` (mapping of this sweep finished) rides on the sweep's last dispatch: a marker packet behind it costs ~5 us of idle stream
+  VLOAM_LAUNCH_EV(ph, kKMapPrepare, st, skip_frame ? done : nullptr, k_map_prepare, dim3(1, 1, Z), dim3(256), 0, st, ms, fr, lo, m->cube_cnt,
+                  skip_frame ? 1 : 0, traj_row14, m->stack_info[set], ss);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
@@ -1108,8 +1134,8 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   }
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
                m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14, ss);
-  VLOAM_LAUNCH(ph, kKMapFinalize, st, k_map_finalize, dim3(kStackCapSurf / 256, 2, Z), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
-               m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags, ss);
+  VLOAM_LAUNCH_EV(ph, kKMapFinalize, st, done, k_map_finalize, dim3(kStackCapSurf / 256, 2, Z), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
+                  m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
