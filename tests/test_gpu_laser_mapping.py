@@ -376,3 +376,30 @@ def test_returns_beyond_the_valid_block(vl, orc, synth, monkeypatch):
     got, ref = h.get_map(), oracle_published_map(o)
     # the oracle's map still holds the raw points of never-valid cubes one by one; the device holds one voxel each
     assert got.shape[0] <= ref.shape[0] and got.shape[0] > 0.9 * ref.shape[0]
+
+
+def test_long_drive_purges_and_rebuilds_the_tables(vl, orc, synth):
+    """1.7 km drive (560 sweeps, 3 m apart): the 21 x 21 x 11 cube window (1 050 m) rolls many times, the voxels of the
+    cubes that fell out are purged to tombstones, and once enough have piled up k_map_finalize's host-mapped flag makes the host
+    rebuild the tables between two sweeps — the production path of the tombstone reclamation (a KITTI-length drive
+    must not fill or hang the table).  Poses along the way and the final map against the oracle."""
+    n = 560
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n, speed=30.0)
+    h = vl.Handle(0, with_mapping=1, map_capacity_log2=20, max_frames=n + 8)
+    o = orc.Oracle(with_mapping=True)
+    for k in range(n):
+        c = seq.sweep(k)
+        h.process_scan(c)
+        o.process(c)
+        if k % 100 == 99:
+            tj = h.trajectory()[k]
+            qm, tm = o.map_published_pose()
+            assert qdist(tj[7:11], qm) < 1e-6 and np.linalg.norm(tj[11:14] - tm) < 1e-6, k
+    h.sync()
+    hl = h.map_health()
+    assert hl["rebuilds"] >= 2, hl            # both tables went through at least one rebuild
+    st = h.map_state()
+    assert np.array_equal(st["cen"], o.map_info()["cen"]) and abs(int(st["cen"][0]) - 10) + abs(int(st["cen"][1]) - 10) >= 15, st["cen"]
+    got, ref = h.get_map(), oracle_published_map(o)
+    assert got.shape == ref.shape and same_cloud(got, ref)
+    assert hl["keys"][0] + hl["keys"][1] < 2.5 * got.shape[0], hl   # the tables hold the live map plus a bounded number of tombstones
