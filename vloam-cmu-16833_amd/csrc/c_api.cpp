@@ -174,6 +174,8 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   return VLOAM_OK;
 }
 
+#define SINGLE_SESSION_ONLY(h) do { if ((h)->se.B != 1) { set_err("this entry point drives one sequence: the handle has %d sessions (use the vloam_batch_* calls)", (h)->se.B); return VLOAM_ERR_INVALID; } } while (0)
+
 // session-relative pointer for the host-side getters
 template <class T>
 static inline T* SEL(const vloam_handle* h, T* p) { return p ? (T*)((char*)p + (size_t)h->sel * h->se.ss) : p; }
@@ -480,8 +482,6 @@ static vloam_status finish_frame(vloam_handle* h) {
 }
 
 // ------------------------------------------------------------------ stage-wise API (façade order)
-#define SINGLE_SESSION_ONLY(h) do { if ((h)->se.B != 1) { set_err("this entry point drives one sequence: the handle has %d sessions (use the vloam_batch_* calls)", (h)->se.B); return VLOAM_ERR_INVALID; } } while (0)
-
 vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
   if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
   SINGLE_SESSION_ONLY(h);
@@ -547,6 +547,7 @@ vloam_status vloam_get_map(vloam_handle* h, float* xyzi4, long long cap, long lo
 
 vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double t[3]) {
   if (!h || !q || !t) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }  // the prior belongs to the NEXT sweep's odometry
   double buf[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
@@ -660,6 +661,7 @@ vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
 // == vloam_tf->processStaticTransform()'s products base_T_cam0 / velo_T_cam0 (vloam_tf.cpp:55-56), row-major 4x4
 vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16], const double velo_T_cam0[16]) {
   if (!h || !base_T_cam0 || !velo_T_cam0) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   VloamTfState tf;
@@ -782,11 +784,13 @@ vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long lon
 // ------------------------------------------------------------------ VO
 vloam_status vloam_vo_set_calib(vloam_handle* h, const vloam_calib* c) {
   if (!h || !c) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   return vo_set_calib(&h->vo, h->stream, c) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4, int n) {
   if (!h || !xyz_pad4 || n <= 0) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   if (n > h->cfg.max_points) return VLOAM_ERR_CAPACITY;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
@@ -794,6 +798,7 @@ vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4
 }
 vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr_uv, int n_match, double aa[3], double t[3], int counters[2]) {
   if (!h || !prev_uv || !curr_uv || !aa || !t || n_match < 0) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   vloam_status s = vo_solve(&h->vo, h->cfg, h->stream, prev_uv, curr_uv, n_match, aa, t, counters);
   if (s != VLOAM_OK) set_err("vo_solve failed: %s", hipGetErrorString(hipGetLastError()));
