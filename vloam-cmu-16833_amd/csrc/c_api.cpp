@@ -1,5 +1,6 @@
 // Host side of libvloam_hip.so: the C ABI declared in include/vloam_hip/c_api.h.
-// One handle = one sequence = one HIP device + one in-order stream per façade stage (scan registration, odometry, mapping);
+// One handle = one HIP device, B sequences advanced in lock step (B = 1 unless vloam_create_batch), one in-order stream per façade stage
+// (scan registration, odometry, mapping) plus one for the mapping stage's scan-feature VoxelGrid;
 // every per-frame count stays in HBM, so a sweep is a fixed chain of kernel launches with no host synchronisation until
 // the caller asks for results (the only host waits are the back-pressure on buffer sets that are still being read).
 // There is NO CPU fallback: without a usable HIP device vloam_create fails.
