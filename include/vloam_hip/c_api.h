@@ -11,8 +11,8 @@
  * binding a maintainer of the reference would add.
  *
  * Conventions: plain C, opaque handle, caller-owned buffers, int status (0 = OK, < 0 = error), no
- * exceptions across the boundary.  One handle = one sequence (one HIP device + one stream).  A handle
- * is not thread-safe; distinct handles are independent.  Quaternions are (x, y, z, w) — the layout of
+ * exceptions across the boundary.  One handle = one sequence on one HIP device (or n_sessions sequences advanced in lock
+ * step, vloam_create_batch), with its own HIP streams.  A handle is not thread-safe; distinct handles are independent.  Quaternions are (x, y, z, w) — the layout of
  * the reference's para_q / parameters arrays (laser_odometry.h:126-130, laser_mapping.h:141-143).
  * Clouds are packed float4: (x, y, z, pad) on input == pcl::PointXYZ, (x, y, z, intensity) on
  * output == the payload of pcl::PointXYZI (common.h:42).

@@ -1,19 +1,25 @@
 // laserMapping on gfx950: scan-to-map ICP against a persistent voxel hash.
 // Restates LaserMapping::input / solveMapping, /root/reference/src/lidar_odometry_mapping/src/laser_mapping.cpp:167-708
 // ("LM:<line>").  One sweep = 13 launches + 2 x (compaction + Levenberg–Marquardt), no host synchronisation; the four
-// k_map_ds_* launches only need the sweep's feature clouds and are enqueued on the scan-registration stream:
-//   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448)
+// k_map_ds_* launches only need the sweep's feature clouds and run on a stream of their own.  Every kernel carries the session
+// index of a batched handle in blockIdx.z and rebases its pointer arguments by blockIdx.z * ss (vloam_device.h).
+//   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448); stops taking sweeps
+//                             when the voxel table is full
 //   k_map_ds_count  grid      pcl::VoxelGrid of the scan features (LM:432-440), pass 1: hash sweep points to voxels, count
 //   k_map_ds_rank   grid      pass 2: output rank + segment start of every occupied voxel by whole-chip counting
 //   k_map_ds_scatter grid     pass 3: group point indices by voxel
 //   k_map_ds_reduce grid      pass 4: per voxel, input-ordered f32 centroid
-//   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN through the block-occupancy index of the voxel hash  x2
+//   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN through the block-occupancy index of the voxel hash (one 32-byte
+//                             record per candidate); the second outer round re-ranks the first round's candidates             x2
 //   k_map_fit       1 thread/pt 3x3 eigen / 5x3 least squares, emission of LidarEdgeFactor / LidarPlaneNormFactor (LM:472-581) x2
 //   (k_lm_solve)                                                                                                x2
 //   k_map_insert    grid      transformUpdate (LM:140-144,636) + trajectory row; scan voxels -> map frame -> cube -> hash
 //                             find-or-insert, queue on the voxel (LM:639-683)
 //   k_map_finalize  grid      per touched voxel: stack-ordered f32 accumulation == per-cube VoxelGrid re-filter (LM:689-702);
-//                             after a grid roll also drops the voxels whose cube left the 21x21x11 window
+//                             raw voxels of cubes that became valid; after a grid roll drops the voxels whose cube left the
+//                             21x21x11 window (tombstones); table health -> host-mapped rebuild flag
+//   k_map_rebuild_* grid      (rare, between sweeps) gather live records, clear, reinsert: tombstone reclamation
+//   k_map_export    grid      /laser_cloud_map (LM:778-793) for vloam_get_map
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <limits.h>

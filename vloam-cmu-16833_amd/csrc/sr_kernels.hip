@@ -10,6 +10,7 @@
 //   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, sort-free picks (wavefront arg-max rounds, six sectors
 //                                at once + boundary fixed point), lessFlat + VoxelGrid(0.2) over voxel runs  SR:288-439
+//                                (two capacity tiers: 2 176 points in 78.75 KB of LDS = two rings per CU; 4 096 points only while needed)
 //   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
 #include <hip/hip_runtime.h>
 #include <limits.h>
