@@ -360,7 +360,13 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   const int lane = threadIdx.x & 63;
   int* s_inc = s_inc_all[threadIdx.x >> 6];
   int* s_rel = s_rel_all[threadIdx.x >> 6];
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-aware remap (workgroup b runs on XCD b % 8, each with its own L2): the features are ring / sector ordered, so neighbouring
+  // slots scan overlapping grid blocks — one XCD takes a contiguous eighth of the corner slots and a contiguous eighth of the plane
+  // slots (both kinds everywhere: a plane query costs more than a corner query) instead of every eighth workgroup
+  constexpr int kWc = kMaxSharp / 4 / 8, kWp = kMaxFlat / 4 / 8;   // corner / plane workgroups per XCD
+  static_assert(kMaxSharp % 32 == 0 && kMaxFlat % 32 == 0 && (kMaxLoFactors + 3) / 4 == 8 * (kWc + kWp), "bijective remap");
+  const int bq_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);
+  const int slot = (bq_ < kWc ? (xcd_ * kWc + bq_) * 4 : kMaxSharp + (xcd_ * kWp + (bq_ - kWc)) * 4) + (int)(threadIdx.x >> 6);
   if (slot >= kMaxLoFactors) return;
   const bool is_corner = slot < kMaxSharp;
   const int i = is_corner ? slot : slot - kMaxSharp;

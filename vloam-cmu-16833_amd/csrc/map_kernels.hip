@@ -467,11 +467,18 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
                                                    float4* __restrict__ nbr, int outer, int4* __restrict__ cbox, float4* __restrict__ ccand, size_t ss) {
   VL_SESSION(ss); RB(stack0); RB(stack1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(nbr); RB(cbox); RB(ccand);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // wave d of the launch takes the d-th stack point (corners, then surfs): the waves with work come first in dispatch order
-  // instead of sitting behind the thousands of empty slots between the two parts of the table
-  const int d = blockIdx.x * 4 + wave;
   const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
-  if (d >= nc + nsf || !ms->do_optimize) return;  // (k_map_fit never looks at nbr[] of a slot without a stack point)
+  // Wave d takes the d-th stack point (corners, then surfs).  The stack clouds are VoxelGrid output, i.e. spatially sorted, so
+  // neighbouring d search overlapping boxes — and workgroup b is dispatched to XCD b % 8, each XCD with an L2 of its own: the
+  // workgroups of one XCD are given a CONTIGUOUS eighth of the corner points and a contiguous eighth of the surf points (XCD-aware
+  // remap over the workgroups that have work; both kinds on every XCD, because a corner query at leaf 0.4 costs more than a surf
+  // query at leaf 0.8), so that overlapping boxes meet in one L2 instead of being fetched from HBM by up to eight.
+  const int wc = (nc + 3) >> 2, ws = (nsf + 3) >> 2, cpc = (wc + 7) >> 3, cps = (ws + 7) >> 3;
+  const int bq = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+  if (bq >= cpc + cps || !ms->do_optimize) return;
+  int d;
+  if (bq < cpc) { const int i0 = (xcd * cpc + bq) * 4 + wave; if (i0 >= nc) return; d = i0; }
+  else { const int i0 = (xcd * cps + (bq - cpc)) * 4 + wave; if (i0 >= nsf) return; d = nc + i0; }
   const int kind = d < nc ? 0 : 1;
   const int i = kind ? d - nc : d;
   const int slot = kind ? kStackCapCorner + i : i;
