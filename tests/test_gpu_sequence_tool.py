@@ -42,3 +42,28 @@ def test_run_sequence_rows_match_oracle(vl, orc, sweeps, tmp_path):
         # "%f" keeps 6 decimals: rows agree to the printed precision (poses agree to ~1e-9)
         assert np.allclose(lo[k, :3], row_lo[:3], atol=2e-6), k
         assert np.allclose(mo[k, :3], row_mo[:3], atol=2e-6), k
+
+
+@pytest.mark.gpu
+def test_run_sequence_coupled_frames_and_metrics(tmp_path):
+    """--vloam: the coupled VO + LiDAR frame loop over a synthetic sequence, VO0 / LO0 / MO0 rows + one JSON line of metrics per frame."""
+    import json
+    out = tmp_path / "res"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_sequence.py"), "--synthetic", "6", "--azimuth", "512", "--vloam",
+                        "--metrics", str(tmp_path / "frames.jsonl"), "--out", str(out), "--mapping-skip-frame", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kio = importlib.import_module("vloam_amd.kitti_io")
+    vo, lo, mo = [kio.read_trajectory(out / ("%s0.txt" % k)) for k in ("VO", "LO", "MO")]
+    assert vo.shape == lo.shape == mo.shape == (6, 4, 4)
+    assert np.allclose(vo[0], np.eye(4)) and np.allclose(lo[0], np.eye(4))          # rows are relative to the start frame
+    d = np.linalg.norm(vo[5, :3, 3] - lo[5, :3, 3])
+    assert np.linalg.norm(lo[5, :3, 3]) > 3.0 and d < 0.5, (vo[5, :3, 3], lo[5, :3, 3])  # 5 m of travel, VO and LO chains agree to decimetres
+    rows = [json.loads(l) for l in open(tmp_path / "frames.jsonl")]
+    assert len(rows) == 6 and rows[3]["vo"]["counter32"] > 100 and rows[3]["lo_round1"]["iterations"] >= 2
+    assert rows[3]["counts"]["K_m"] > 100 and rows[3]["map_round1"]["residual_blocks"] == rows[3]["counts"]["K_m"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_sequence.py"), "--synthetic", "3", "--azimuth", "512",
+                         "--metrics", str(tmp_path / "f2.jsonl"), "--out", str(tmp_path / "res2")], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    rows2 = [json.loads(l) for l in open(tmp_path / "f2.jsonl")]
+    assert len(rows2) == 3 and rows2[2]["stage_ms"]["laserOdometry"] > 0

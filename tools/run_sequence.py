@@ -5,10 +5,17 @@ LO0.txt / MO0.txt in the reference's results format — the part of vloam_main_n
 
   python tools/run_sequence.py --velodyne /data/2011_09_26_drive_0001_sync/velodyne_points/data --out results/
   python tools/run_sequence.py --synthetic 50 --out /tmp/res        # needs an MI355X either way
+  python tools/run_sequence.py --synthetic 50 --vloam --metrics /tmp/res/frames.jsonl --out /tmp/res
+      --vloam:   the coupled per-frame loop (vloam_process_frame: VO solve -> LO prior -> SR -> LO -> VO prior -> mapping, combined mode)
+                 on synthetic pixel matches (the image front-end is out of scope), also writes VO0.txt
+      --metrics: one JSON object per frame — the reference prints these through ROS_INFO / TicToc: feature counts
+                 (scan_registration.cpp), correspondences and solver iterations (laser_odometry.cpp:453-465, laser_mapping.cpp:606-618),
+                 per-stage milliseconds
 """
 import argparse
 import glob
 import importlib.util
+import json
 import os
 import sys
 
@@ -29,10 +36,13 @@ def load_pkg():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--velodyne", help="directory of KITTI raw velodyne .bin sweeps")
-    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 64x2048 sweeps instead")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 64 x --azimuth sweeps instead")
+    ap.add_argument("--azimuth", type=int, default=2048)
     ap.add_argument("--out", required=True)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--mapping-skip-frame", type=int, default=2)
+    ap.add_argument("--vloam", action="store_true", help="coupled VO + LiDAR frames (synthetic sequences only: synthetic pixel matches)")
+    ap.add_argument("--metrics", help="write per-frame metrics as JSON lines to this file")
     ap.add_argument("--imu-T-velo", help="16 numbers, row major (default: KITTI 2011_09_26 extrinsics, approx.)")
     ap.add_argument("--imu-T-cam0", help="16 numbers, row major")
     a = ap.parse_args()
@@ -46,7 +56,7 @@ def main():
         n = len(files)
     else:
         synth = importlib.import_module("vloam_amd.synth")
-        seq = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=max(a.synthetic, 2))
+        seq = synth.SynthSequence(n_rings=64, n_azimuth=a.azimuth, n_sweeps=max(a.synthetic, 2) + 1)
         clouds = (seq.sweep(k) for k in range(a.synthetic))
         n = a.synthetic
     if n == 0:
@@ -59,21 +69,63 @@ def main():
     imu_T_cam0 = mat(a.imu_T_cam0, kio.make_T([0.5, -0.5, 0.5, -0.5], [1.08, -0.32, 0.72]))
     tf = kio.VloamTF(imu_T_velo, imu_T_cam0)
 
-    loam = vl.LidarOdometryMapping(device=a.device, mapping_skip_frame=a.mapping_skip_frame, detach_VO_LO=1)
+    if a.vloam and a.velodyne:
+        sys.exit("--vloam needs pixel matches: only available for --synthetic sequences (the image front-end is out of scope)")
+    loam = vl.LidarOdometryMapping(device=a.device, mapping_skip_frame=a.mapping_skip_frame, detach_VO_LO=0 if a.vloam else 1,
+                                   timing=1 if (a.metrics and not a.vloam) else 0)
+    hd = loam.hd
+    if a.vloam:
+        hd.vo_set_calib(*synth.kitti_like_calib())
+        hd.set_extrinsics(tf.base_T_cam0, tf.velo_T_cam0)
     os.makedirs(a.out, exist_ok=True)
-    lo_rows, mo_rows = [], []
+    lo_rows, mo_rows, vo_rows = [], [], []
+    mf = open(a.metrics, "w") if a.metrics else None
+    ms_prev = np.zeros(4)
     for count, cloud in enumerate(clouds):
-        loam.reset()
-        loam.scanRegistrationIO(cloud)
-        loam.laserOdometryIO()
-        loam.laserMappingIO()
-        lo, lm = loam.laser_odometry, loam.laser_mapping
-        tf.LO2CamPrior(lo.q_last_curr, lo.t_last_curr)
-        lo_rows.append(tf.LO2Cam0StartFrame(lo.q_w_curr, lo.t_w_curr, count))
-        mo_rows.append(tf.MO2Cam0StartFrame(lm.q_w_curr, lm.t_w_curr, count))
+        if a.vloam:
+            m = synth.synth_matches(seq, count) if count > 0 else (None, None)
+            hd.process_frame(cloud, m[0], m[1])
+            row = hd.trajectory(count, 1)[0]
+            q_lo, t_lo, q_mo, t_mo = row[0:4], row[4:7], row[7:11], row[11:14]
+            v = hd.vo_trajectory(count, 1)[0]
+            tf.world_VOT_base_last = kio.make_T(v[0:4], v[4:7])
+            vo_rows.append(tf.VO2Cam0StartFrame(count))
+        else:
+            loam.reset()
+            loam.scanRegistrationIO(cloud)
+            loam.laserOdometryIO()
+            loam.laserMappingIO()
+            lo, lm = loam.laser_odometry, loam.laser_mapping
+            tf.LO2CamPrior(lo.q_last_curr, lo.t_last_curr)
+            q_lo, t_lo, q_mo, t_mo = lo.q_w_curr, lo.t_w_curr, lm.q_w_curr, lm.t_w_curr
+        lo_rows.append(tf.LO2Cam0StartFrame(q_lo, t_lo, count))
+        mo_rows.append(tf.MO2Cam0StartFrame(q_mo, t_mo, count))
+        if mf:
+            c = hd.counts()
+            rec = {"frame": count, "points_in": int(cloud.shape[0]), "counts": c, "lo_pose": [float(x) for x in list(q_lo) + list(t_lo)],
+                   "map_pose": [float(x) for x in list(q_mo) + list(t_mo)]}
+            if count > 0:
+                for name, st, item in (("lo_round0", 1, 2), ("lo_round1", 1, 18), ("map_round0", 2, 3), ("map_round1", 2, 19)):
+                    r = hd.debug_lm_record(st, item)
+                    rec[name] = {"residual_blocks": r["n_factors"], "iterations": int(r["trace"].shape[0]), "evaluations": r["n_evals"],
+                                 "initial_cost": r["initial_cost"], "final_cost": r["final_cost"], "termination": r["termination"]}
+            if a.vloam and count > 0:
+                rv = hd.vo_result()
+                rec["vo"] = {"counter32": rv["counter32"], "counter22": rv["counter22"], "angles_0to1": [float(x) for x in rv["angles"]],
+                             "t_0to1": [float(x) for x in rv["t"]]}
+            if not a.vloam:
+                ms, _ = hd.stage_ms()
+                rec["stage_ms"] = {"scanRegistration": float(ms[0] - ms_prev[0]), "laserOdometry": float(ms[1] - ms_prev[1]),
+                                   "laserMapping": float(ms[2] - ms_prev[2])}
+                ms_prev = ms.copy()
+            mf.write(json.dumps(rec) + "\n")
+    if mf:
+        mf.close()
     kio.write_trajectory(os.path.join(a.out, "LO0.txt"), lo_rows)
     kio.write_trajectory(os.path.join(a.out, "MO0.txt"), mo_rows)
-    print("wrote %d rows to %s/{LO0,MO0}.txt" % (n, a.out))
+    if vo_rows:
+        kio.write_trajectory(os.path.join(a.out, "VO0.txt"), vo_rows)
+    print("wrote %d rows to %s/{LO0,MO0%s}.txt" % (n, a.out, ",VO0" if vo_rows else ""))
 
 
 if __name__ == "__main__":
