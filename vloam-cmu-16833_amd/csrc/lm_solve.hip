@@ -1035,7 +1035,7 @@ int lm_sync_calibrate(hipStream_t st, double* pool, int n_cand, size_t stride_by
     for (int c = 0; c < n_cand && ok; c++) {
       double* slot = reinterpret_cast<double*>(reinterpret_cast<char*>(pool) + stride_bytes * (size_t)c);
       ok = hipEventRecord(e0, st) == hipSuccess;
-      hipLaunchKernelGGL(k_lm_sync_probe, dim3(kCoop), dim3(kLmThreads), 0, st, slot, pass ? 192 : 8, sink);
+      VL_RAW_LAUNCH(k_lm_sync_probe, dim3(kCoop), dim3(kLmThreads), 0, st, slot, pass ? 192 : 8, sink);
       ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
       float ms = 0.f;
       ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;

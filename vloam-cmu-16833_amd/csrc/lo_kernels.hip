@@ -595,7 +595,7 @@ void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, con
   VLOAM_LAUNCH(ph, kKLoGridScatter, st, k_lo_grid_scatter, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);
 }
 void lo_set_prior_launch(hipStream_t st, Sess se, LOState* lo, bool copy_to_para, const double* vo_x, bool vo_solved, double* vo_row7, int* err) {
-  hipLaunchKernelGGL(k_lo_set_prior, dim3(1, 1, se.B), dim3(64), 0, st, lo, copy_to_para ? 1 : 0, vo_x, vo_solved ? 1 : 0, vo_row7, err, se.ss);
+  VL_RAW_LAUNCH(k_lo_set_prior, dim3(1, 1, se.B), dim3(64), 0, st, lo, copy_to_para ? 1 : 0, vo_x, vo_solved ? 1 : 0, vo_row7, err, se.ss);
 }
 void lo_finish_launch(hipStream_t st, Sess se, LOState* lo, double* traj_row14, bool integrate, ProfHook* ph) {
   VLOAM_LAUNCH(ph, kKLoFinish, st, k_lo_finish, dim3(1, 1, se.B), dim3(64), 0, st, lo, traj_row14, integrate ? 1 : 0, se.ss);

@@ -1098,11 +1098,11 @@ static vloam_status map_rebuild_enqueue(MapContext* m0, hipStream_t st, int sess
   const size_t slots = (size_t)T.mask + 1, bslots = (size_t)T.bslots_mask + 1;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
   if (hipMemsetAsync(m->rebuild_n, 0, sizeof(int), st) != hipSuccess) return VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_map_rebuild_gather, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind);
+  VL_RAW_LAUNCH(k_map_rebuild_gather, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind);
   if (hipMemsetAsync(T.rec, 0, slots * sizeof(VoxelRec), st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemsetAsync(T.blk, 0, bslots * sizeof(ulonglong2), st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemsetAsync(T.stats, 0, 4 * sizeof(int), st) != hipSuccess) return VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_map_rebuild_insert, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind,
+  VL_RAW_LAUNCH(k_map_rebuild_insert, dim3(1024), dim3(256), 0, st, T, m->rebuild_tmp, m->rebuild_cap, m->rebuild_n, m->frame, kind,
                      m->deferred[kind], cap, m->inv_leaf[kind], m->host_flags);
   m0->rebuilds++;
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
@@ -1194,7 +1194,7 @@ vloam_status map_export(MapContext* m0, hipStream_t st, float* xyzi4, long long 
   vloam_status rc = VLOAM_OK;
   unsigned long long cnt = 0;
   if (hipMemsetAsync(d_n, 0, sizeof(*d_n), st) != hipSuccess) rc = VLOAM_ERR_HIP;
-  for (int k = 0; k < 2 && rc == VLOAM_OK; k++) hipLaunchKernelGGL(k_map_export, dim3(1024), dim3(256), 0, st, m->tab[k], m->state, k, d_rows, bound, d_n);
+  for (int k = 0; k < 2 && rc == VLOAM_OK; k++) VL_RAW_LAUNCH(k_map_export, dim3(1024), dim3(256), 0, st, m->tab[k], m->state, k, d_rows, bound, d_n);
   if (rc == VLOAM_OK && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&cnt, d_n, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess)) rc = VLOAM_ERR_HIP;
   std::vector<ExportRow> rows((size_t)((long long)cnt < bound ? (long long)cnt : bound));
   if (rc == VLOAM_OK && !rows.empty() && hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(ExportRow), hipMemcpyDeviceToHost) != hipSuccess) rc = VLOAM_ERR_HIP;
@@ -1221,7 +1221,7 @@ vloam_status map_get_cloud(MapContext* m0, hipStream_t st, int which, const SRBu
   else if (which == 11) {
     FrameScalars S;
     if (hipMemcpy(&S, cur.S, sizeof(S), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    hipLaunchKernelGGL(k_map_register, dim3(256), dim3(256), 0, st, cur.cloud, cur.S, m->state, m->registered);
+    VL_RAW_LAUNCH(k_map_register, dim3(256), dim3(256), 0, st, cur.cloud, cur.S, m->state, m->registered);
     if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
     src = m->registered; cnt = S.N2;
   } else return VLOAM_ERR_INVALID;
@@ -1239,7 +1239,7 @@ vloam_status map_error(MapContext* m, int* e, int clear_mask) {
   for (int b = 0; b < m->se.B; b++) {
     const MapContext mb = m->for_session(b);
     int* d_out = mb.rebuild_n;  // scratch int (no rebuild can be in flight: the caller has synchronised the streams)
-    hipLaunchKernelGGL(k_map_error_fetch, dim3(1), dim3(1), 0, 0, mb.frame, clear_mask, d_out);
+    VL_RAW_LAUNCH(k_map_error_fetch, dim3(1), dim3(1), 0, 0, mb.frame, clear_mask, d_out);
     int v = 0;
     if (hipMemcpy(&v, d_out, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
     *e |= v;

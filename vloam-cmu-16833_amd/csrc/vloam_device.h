@@ -76,11 +76,26 @@ struct ProfHook {
   }
   inline void end(hipStream_t st) { (void)hipEventRecord(ev[2 * used + 1], st); used++; }
 };
-#define VLOAM_LAUNCH(ph, kid, st, ...)                     \
-  do {                                                     \
-    bool prof_ = (ph) && (ph)->begin((kid), (st));         \
-    hipLaunchKernelGGL(__VA_ARGS__);                       \
-    if (prof_) (ph)->end((st));                            \
+// ---- session-major launch geometry.  Every kernel is WRITTEN against a logical grid (x, y, z = session) but LAUNCHED as the hardware
+// grid (session, x, y): the dispatcher hands workgroups to the 8 XCDs in linear order (block b -> XCD b % 8, x fastest), so with the
+// session in the fastest dimension all workgroups of session s of a batch of 8 run on XCD s (B = 16: two sessions per XCD; B = 2 / 4:
+// a session owns every 2nd / 4th XCD; B = 1: the plain round robin).  A session's working set — its NN grids, the hot part of its voxel
+// map, its solver's barrier words — then lives in ONE 4 MB L2 instead of competing with seven other sessions in every L2.  Inside the
+// kernels `blockIdx` / `gridDim` are redirected to the logical coordinates (the two accessors below are defined BEFORE the macros, so
+// they read the hardware values); host code passes logical grids to the launch macros, which transpose them.
+struct VlDim3 { unsigned x, y, z; };
+__device__ __forceinline__ VlDim3 vl_block_idx() { VlDim3 r; r.x = blockIdx.y; r.y = blockIdx.z; r.z = blockIdx.x; return r; }
+__device__ __forceinline__ VlDim3 vl_grid_dim() { VlDim3 r; r.x = gridDim.y; r.y = gridDim.z; r.z = gridDim.x; return r; }
+inline dim3 vl_hw_grid(dim3 g) { return dim3(g.z, g.x, g.y); }
+#define blockIdx (::vloam::vl_block_idx())
+#define gridDim (::vloam::vl_grid_dim())
+#define VL_RAW_LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), __VA_ARGS__)
+
+#define VLOAM_LAUNCH(ph, kid, st, kern, grid, ...)                            \
+  do {                                                                        \
+    bool prof_ = (ph) && (ph)->begin((kid), (st));                            \
+    hipLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), __VA_ARGS__);         \
+    if (prof_) (ph)->end((st));                                               \
   } while (0)
 
 // Same, with the stage's "finished" event bound to the dispatch itself (its completion signal) instead of a marker packet
@@ -88,8 +103,8 @@ struct ProfHook {
 #define VLOAM_LAUNCH_EV(ph, kid, st, stop_ev, kern, grid, block, shmem, stream, ...)                        \
   do {                                                                                                      \
     bool prof_ = (ph) && (ph)->begin((kid), (st));                                                          \
-    if (stop_ev) hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, nullptr, (stop_ev), 0, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                                 \
+    if (stop_ev) hipExtLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), block, shmem, stream, nullptr, (stop_ev), 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), block, shmem, stream, __VA_ARGS__);            \
     if (prof_) (ph)->end((st));                                                                             \
   } while (0)
 

@@ -292,8 +292,8 @@ vloam_status vo_set_calib(VOContext* v, hipStream_t st, const vloam_calib* c) {
 static vloam_status vo_depth_launch(VOContext* v, hipStream_t st, const float4* d_in, int n, int set, ProfHook* ph) {
   if (hipMemsetAsync(v->bcount, 0, sizeof(int) * (kBuckets + 1), st) != hipSuccess) return VLOAM_ERR_HIP;
   VLOAM_LAUNCH(ph, kKVoProject, st, k_vo_project, dim3(256), dim3(256), 0, st, d_in, n, v->d_calib, v->uvd, v->bcount);
-  hipLaunchKernelGGL(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
-  hipLaunchKernelGGL(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
+  VL_RAW_LAUNCH(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
+  VL_RAW_LAUNCH(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
   VLOAM_LAUNCH(ph, kKVoFold, st, k_vo_fold, dim3((kBuckets + 255) / 256), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[set]);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
@@ -340,7 +340,7 @@ vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, con
   if (hipMemcpyAsync(v->d_curr, curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemcpyAsync(v->x, x, sizeof(x), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
-  hipLaunchKernelGGL(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib,
+  VL_RAW_LAUNCH(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib,
                      v->maps[(v->i + VOContext::kSets - 1) % VOContext::kSets], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters,
                      (const LOState*)nullptr, (double*)nullptr, 0);
   lm_launch(st, Sess(), v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
