@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""In-kernel cycle counters of the two kernels with the largest per-sweep chip cost (debug = 1 builds the stamps in):
+k_sr_ring's phases per scan line and k_lo_assoc's per-query cost (closest point / second+third point / stages / candidates).
+Needs an MI355X.   python tools/kernel_cycles.py [--sweeps 8] [--azimuth 2048]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import conftest  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sweeps", type=int, default=8)
+ap.add_argument("--azimuth", type=int, default=2048)
+a = ap.parse_args()
+vl = conftest.load_pkg()
+synth = conftest.load_synth()
+seq = synth.SynthSequence(n_rings=64, n_azimuth=a.azimuth, n_sweeps=a.sweeps + 1)
+h = vl.Handle(0, debug=1, with_mapping=1, max_frames=a.sweeps + 8)
+for k in range(a.sweeps):
+    h.process_scan(seq.sweep(k))
+h.sync()
+
+
+def pct(x, name, unit="cycles"):
+    x = np.asarray(x, dtype=np.float64)
+    if x.size == 0:
+        print("  %-34s (none)" % name)
+        return
+    print("  %-34s n %5d  mean %9.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f %s" %
+          (name, x.size, x.mean(), np.percentile(x, 10), np.percentile(x, 50), np.percentile(x, 90), x.max(), unit))
+
+
+cyc = h.debug_raw(0, 11, np.int64).reshape(-1, 8)[:64]
+names = ["load ring -> LDS", "gaps / reach (+ debug sort)", "greedy picks (6 wavefronts)", "bbox, voxel ids, run keys", "bitonic sort of runs",
+         "voxel heads + centroids"]
+print("k_sr_ring: cycles per phase over the %d scan lines of the last sweep (debug build: includes the reference-order debug sort)" % cyc.shape[0])
+for q, n in enumerate(names):
+    pct(cyc[:, q], n)
+pct(cyc[:, :6].sum(axis=1), "whole workgroup")
+
+for outer in (0, 1):
+    raw = h.debug_raw(1, outer * 16 + 4, np.int64).reshape(-1, 4)
+    st = raw[:, 3]
+    used = (raw[:, 0] != 0) | (raw[:, 1] != 0)
+    print("k_lo_assoc, outer round %d: %d queries" % (outer, int(used.sum())))
+    for kind, sl in (("corner", slice(0, vl.K_MAX_SHARP)), ("plane", slice(vl.K_MAX_SHARP, None))):
+        r, u = raw[sl], used[sl]
+        r = r[u]
+        if r.shape[0] == 0:
+            continue
+        e = (r[:, 3] & 0xff).astype(np.int8)
+        s2 = ((r[:, 3] >> 8) & 0xff).astype(np.int8)
+        cand = r[:, 3] >> 16
+        print(" %s queries" % kind)
+        pct(r[:, 0], "closest point")
+        pct(r[:, 1], "second / third point")
+        pct(cand, "candidates visited (2nd pass)", "points")
+        print("  closest-point stage reached:     ", {int(v): int((e == v).sum()) for v in np.unique(e)})
+        print("  second/third stage reached:      ", {int(v): int((s2 == v).sum()) for v in np.unique(s2)})
+h.close()

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Where a k_lm_solve launch spends its shader cycles (LMRecord.cyc: factor loops / evaluations incl. reductions and grid barriers /
+serial trust-region bookkeeping / whole kernel), for the four solves of a steady-state sweep.  Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import conftest  # noqa: E402
+
+vl = conftest.load_pkg()
+synth = conftest.load_synth()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seq = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=n + 1)
+h = vl.Handle(0, with_mapping=1, max_frames=n + 8)
+for k in range(n):
+    h.process_scan(seq.sweep(k))
+h.sync()
+for name, st, item in (("LO round 0", 1, 2), ("LO round 1", 1, 18), ("map round 0", 2, 3), ("map round 1", 2, 19)):
+    r = h.debug_lm_record(st, item)
+    c = r["cyc"]
+    print("%-12s factors %5d  iterations %d  evaluations %d  | cycles: factor loops %7.0f  evaluations %7.0f  serial %7.0f  whole solve %7.0f  (other %7.0f)" %
+          (name, r["n_factors"], int(r["trace"].shape[0]), r["n_evals"], c[0], c[1], c[2], c[3], c[3] - c[1] - c[2]))
+h.close()

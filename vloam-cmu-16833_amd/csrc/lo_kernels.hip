@@ -316,13 +316,57 @@ __device__ __forceinline__ V for_each_candidate(const int* __restrict__ gstart, 
   return v;
 }
 
+// The radius-1 block of the 1 m level around (cx, cy, cz), fetched ONCE for both searches of a query: one trip for the 27 bucket
+// ranges, one for up to 4 x 64 points, which then stay in registers (c[u], valid when t[u] >= 0) — the closest-point pass and
+// the second / third point pass of the common query both run over them without touching memory again.  Returns false (nothing
+// fetched) when the block holds more than 256 points; the caller then goes through for_each_candidate.
+__device__ __forceinline__ bool fetch_block1(const int* __restrict__ gstart, const float4* __restrict__ gpts, unsigned gmask, int cx, int cy,
+                                             int cz, int lane, float4 (&c)[4], int (&t)[4]) {
+  int bs = 0, cnt = 0;
+  if (lane < 27) {
+    const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
+    const unsigned b = grid_hash(cx + ox, cy + oy, cz + oz) & gmask;
+    bs = gstart[b];
+    cnt = gstart[b + 1] - bs;
+  }
+  int inc = cnt;
+  for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }   // lanes >= 27 add nothing
+  const int total = __shfl(inc, 31);
+  const int exc = inc - cnt;
+  if (total > 256) return false;
+  int lo[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) lo[u] = 0;  // number of lanes whose inclusive sum is <= i == the lane owning item i (< 27)
+#pragma unroll
+  for (int step = 16; step > 0; step >>= 1) {
+    int vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) vv[u] = __shfl(inc, lo[u] + step - 1);
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (vv[u] <= u * 64 + lane) lo[u] += step;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = u * 64 + lane;
+    const int r = i - __shfl(exc, lo[u]), b0 = __shfl(bs, lo[u]);
+    t[u] = i < total ? b0 + r : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) c[u] = gpts[t[u] >= 0 ? t[u] : 0];  // unconditional: the four loads go out back to back
+  return true;
+}
+
 struct VisitNearest {  // LO:269 / LO:356: nearest candidate, ties to the lowest index
   float3 sel;
   u64 loc;
+  int ring;   // stored scan line of the best candidate so far (== int(intensity) of that point)
   __device__ __forceinline__ void visit(float4 c) {
     const float d = sqdist(c, sel);
-    const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)tag_index(__float_as_uint(c.w));
-    loc = key < loc ? key : loc;
+    const unsigned tag = __float_as_uint(c.w);
+    const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)tag_index(tag);
+    const bool better = key < loc;
+    loc = better ? key : loc;
+    ring = better ? tag_ring(tag) : ring;
   }
 };
 struct VisitAdjacent {  // LO:279-324 / LO:368-417 as a class filter (see k_lo_assoc)
@@ -408,10 +452,49 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     constexpr int kSparseUB = 8;
     constexpr int kGroups = kMaxRings >> kRingGroupShift;
     auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 2 ? 4.0f * 0.999999f : (stage == 3 ? 9.0f * 0.999999f : 3.0e38f)); };
+    // walk stops of this kind's cloud, one table entry per lane (ringA indexes them through a cross-lane read below)
+    const int* stops = is_corner ? G.stops : G.stops + 2 * kStopLen;
+    const int sf_l = stops[lane + 3], sb_l = stops[kStopLen + lane];  // first index with line >= lane + 3, last with line <= lane - 3
     u64 best = ~0ull;
-    for (int stage = 0; stage < 5 && n > 0; stage++) {
+    int ringA = -1;
+    // FAST PATH (most queries): the radius-1 block answers the closest point; its candidates stay in registers for the second /
+    // third point
+    float4 c0[4];
+    int t0[4];
+    bool fast = false, adj_done = false;
+    int stop_f = 0, stop_b = 0;
+    u64 b2 = ~0ull, b3 = ~0ull;
+    const bool kept = n > 0 && fetch_block1(fstart, fpts, fmask, fcx, fcy, fcz, lane, c0, t0);
+    if (kept) {
       VisitNearest vn;
-      vn.sel = sel; vn.loc = ~0ull;
+      vn.sel = sel; vn.loc = ~0ull; vn.ring = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (t0[u] >= 0) vn.visit(c0[u]);
+      best = wave_min_u64(vn.loc);
+      if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= stage_bound(0)) {
+        fast = true;
+        exact_dbg = 0;
+        ringA = __shfl(vn.ring, __ffsll((long long)__ballot(vn.loc == best)) - 1);
+        stop_f = __shfl(sf_l, ringA); stop_b = __shfl(sb_l, ringA);
+        // stage 0 of the second / third point plan (see below) on the same registers; c0 is not needed after this block
+        VisitAdjacent va;
+        va.sel = sel; va.idx = (int)(best & 0xffffffffu); va.ringA = ringA; va.stop_f = stop_f; va.stop_b = stop_b; va.is_corner = is_corner;
+        va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (t0[u] >= 0) va.visit(c0[u]);
+        cand_dbg += va.visited;
+        b2 = wave_min_u64(va.l2);
+        if (!is_corner) b3 = wave_min_u64(va.l3);
+        const bool done2 = b2 != ~0ull && __uint_as_float((unsigned)(b2 >> 32)) <= stage_bound(0);
+        const bool done3 = is_corner || (b3 != ~0ull && __uint_as_float((unsigned)(b3 >> 32)) <= stage_bound(0));
+        stage2_dbg = 0;
+        adj_done = done2 && done3;
+      }
+    }
+    if (!fast)
+    for (int stage = kept ? 1 : 0; stage < 5 && n > 0; stage++) {
+      VisitNearest vn;
+      vn.sel = sel; vn.loc = ~0ull; vn.ring = 0;
       bool skipped = false;
       if (stage == 0) vn = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
       else if (stage == 1) {
@@ -431,21 +514,20 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     if (dbg_cyc) t1 = clock64();
     if (best != ~0ull && dmin < 25.0f) {  // DISTANCE_SQ_THRESHOLD, LO:272 / LO:359
       const int idx = (int)(best & 0xffffffffu);
-      const int ringA = (int)cand[idx].w;  // closestPointScanID
+      if (!fast) ringA = (int)cand[idx].w;  // closestPointScanID (the fast path read it off the winning candidate's tag)
       // ---- second (and third) point: the reference walks the ring-sorted cloud upwards from idx + 1 until the scan line
       // exceeds ringA + NEARBY_SCAN and downwards from idx - 1 until it drops below ringA - NEARBY_SCAN, keeping the nearest
       // point with d2 < 25 per class, first strictly smaller wins (LO:279-324 / LO:368-417).  On a ring-sorted cloud that is
       // the minimum of (d2, visiting order) over the index interval between the two break points, split into classes by
       // (j > idx, ring_j), so it is answered by the same expanding grid search with the class filter applied to every candidate.
-      u64 b2 = ~0ull, b3 = ~0ull;
       // Where the walks break.  The stored scan line int(intensity) of a point of scan line r is r or r - 1 (the fractional part
       // 0.1 * relTime lies in (-0.05, 0.15): SR:237-265), so the clouds are only ALMOST sorted by it: the upward walk breaks at
       // the first point anywhere with a line > ringA + NEARBY_SCAN, the downward walk at the last one with a line below
       // ringA - NEARBY_SCAN, and points beyond a break are never looked at even if their own line is in range.
-      const int* stops = is_corner ? G.stops : G.stops + 2 * kStopLen;
-      const int stop_f = stops[ringA + 3], stop_b = stops[kStopLen + ringA];  // first index with line >= ringA + 3, last with line <= ringA - 3
+      if (!fast) { stop_f = __shfl(sf_l, ringA); stop_b = __shfl(sb_l, ringA); }  // first index with line >= ringA + 3, last with line <= ringA - 3
       const int glo = max(ringA - 2, 0) >> kRingGroupShift, ghi = min(ringA + 2, kMaxRings - 1) >> kRingGroupShift;
-      for (int stage = 0; stage < 5; stage++) {
+      if (!adj_done)
+      for (int stage = fast ? 1 : 0; stage < 5; stage++) {
         VisitAdjacent va;
         va.sel = sel; va.idx = idx; va.ringA = ringA; va.stop_f = stop_f; va.stop_b = stop_b; va.is_corner = is_corner;
         va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
