@@ -54,6 +54,8 @@ typedef struct vloam_config {
   int map_capacity_log2;           /* voxel-hash slots = 2^n per feature kind        (22)   */
   int debug;                       /* 1: keep parity-hook arrays (curvature, sort order, …) */
   int timing;                      /* 1: HIP-event per-stage timing (synchronises every sweep)   */
+  int image_width;                 /* capacity of the image front-end (KITTI: 1242 x 375); 0 = none (0) */
+  int image_height;
 } vloam_config;
 
 typedef struct vloam_calib {  /* row-major f32, as PointCloudUtil holds them (point_cloud_util.h:43-46) */
@@ -160,6 +162,30 @@ vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, 
 vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, double* poses7);
 /* last frame: VO estimate (angles_0to1, t_0to1), counter32 / counter22, and velo_last_VOT_velo_curr derived from it (any may be NULL) */
 vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t[3], int counters32_22[2], double prior_q[4], double prior_t[3]);
+
+/* ---- Image front-end of the visual odometry, optical-flow configuration (vloam_main.launch: optical_flow_match = true); needs
+ * cfg.image_width / image_height > 0.  Replaces, on the device:
+ *   ImageUtil::detKeypoints (ShiTomasi)   src/visual_odometry/src/image_util.cpp:13-36    cv::goodFeaturesToTrack(img, 1024, 0.03, 7.5, 5)
+ *   ImageUtil::calculateOpticalFlow       src/visual_odometry/src/image_util.cpp:351-372  cv::calcOpticalFlowPyrLK(15 x 15, 2 levels, 10 / 0.03)
+ *   VisualOdometry::processImage          src/visual_odometry/src/visual_odometry.cpp:91-132 (the NEW image's corners are tracked from the
+ *                                         previous image into the new one, :121-122)
+ * vloam_vo_process_image[_device]: one 8-bit grey image (row stride in bytes); every image of a sequence has the same size.
+ * vloam_vo_get_keypoints: the corners of the last image, (x, y) pairs in goodFeaturesToTrack's order.
+ * vloam_vo_get_flow: for the last image, per corner: where it sits in the previous image (= the corner itself), where it was tracked to
+ *   in the new image, and calcOpticalFlowPyrLK's status byte (n = 0 after the first image).
+ * vloam_vo_get_flow_matches: the match loop's integer pixel pairs of the tracked corners (visual_odometry.cpp:296-308), ready for
+ *   vloam_vo_solve / vloam_process_frame.
+ * vloam_process_frame_image[_device]: vloam_process_frame with the matches taken from the image instead of from the caller — cloud and
+ *   image of one frame in, nothing comes back to the host (the image work rides on a stream of its own next to scan registration).
+ * The ORB + brute-force Hamming configuration (optical_flow_match = false) is not provided: OpenCV's learned ORB sampling table
+ * cannot be restated without the library. */
+vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride);
+vloam_status vloam_vo_process_image_device(vloam_handle* h, const void* d_gray, int width, int height, int stride);
+vloam_status vloam_vo_get_keypoints(vloam_handle* h, float* xy, int cap, int* n);
+vloam_status vloam_vo_get_flow(vloam_handle* h, float* prev_xy, float* curr_xy, unsigned char* status, int cap, int* n);
+vloam_status vloam_vo_get_flow_matches(vloam_handle* h, int* prev_uv, int* curr_uv, int cap, int* n);
+vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride);
+vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride);
 
 /* Parity hooks (tests only; need cfg.debug = 1 for the per-point arrays).  Copies up to cap elements of
  * the named array into buf (element type given per item) and returns the element count in *n.

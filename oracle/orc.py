@@ -227,6 +227,61 @@ def solve(factors, p0, p1, quaternion=True, huber_a=0.1, max_iters=4):
                 final_cost=costs[1])
 
 
+# ---- image front-end (orc_img.h): cv::goodFeaturesToTrack / cv::calcOpticalFlowPyrLK restated, reference parameters as defaults
+U8 = C.c_ubyte
+
+
+def good_features(img, max_corners=1024, quality=0.03, min_distance=7.5, block_size=5, want_eig=False):
+    """image_util.cpp:13-36 — corners [n, 2] f32 (x, y) in acceptance order (and the min-eigenvalue map)."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = max(max_corners, 1) if max_corners > 0 else w * h
+    xy = np.zeros((cap, 2), dtype=np.float32)
+    eig = np.zeros((h, w), dtype=np.float32) if want_eig else None
+    n = L.orc_good_features(_p(img, U8), w, h, max_corners, D(quality), D(min_distance), block_size, _p(xy, F), cap,
+                            _p(eig, F) if want_eig else None)
+    return (xy[:n], eig) if want_eig else xy[:n]
+
+
+def pyramid_levels(img, win=15, max_level=2):
+    """[(level image u8 [h, w], Scharr derivative int16 [h, w, 2])] of cv::buildOpticalFlowPyramid + calcSharrDeriv."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    nl = L.orc_pyramid_level(_p(img, U8), w, h, win, max_level, -1, None, None, None)
+    out = []
+    for lv in range(nl):
+        im = np.zeros(h * w, dtype=np.uint8)
+        de = np.zeros(h * w * 2, dtype=np.int16)
+        wh = np.zeros(2, dtype=np.int32)
+        L.orc_pyramid_level(_p(img, U8), w, h, win, max_level, lv, _p(im, U8), _p(de, C.c_short), _p(wh, I))
+        lw, lh = int(wh[0]), int(wh[1])
+        out.append((im[:lw * lh].reshape(lh, lw).copy(), de[:2 * lw * lh].reshape(lh, lw, 2).copy()))
+    return out
+
+
+def pyr_lk(prev, nxt, pts, win=15, max_level=2, max_count=10, epsilon=0.03):
+    """image_util.cpp:351-372 — (next_pts [n, 2] f32, status [n] u8)."""
+    L = lib()
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
+    assert prev.shape == nxt.shape
+    h, w = prev.shape
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    st = np.zeros(max(pts.shape[0], 1), dtype=np.uint8)
+    L.orc_pyr_lk(_p(prev, U8), _p(nxt, U8), w, h, _p(pts, F), pts.shape[0], _p(out, F), _p(st, U8), win, max_level, max_count, D(epsilon))
+    return out, st[:pts.shape[0]]
+
+
+def flow_matches(corners, tracked, status):
+    """visual_odometry.cpp:296-308 with optical_flow_match: (prev_uv, curr_uv) int32 [m, 2] of the tracked corners, float -> int
+    truncation; prev = the corner (detected in the current image, used as a point of the previous one), curr = where it went."""
+    ok = np.asarray(status) == 1
+    return np.asarray(corners)[ok].astype(np.int32), np.asarray(tracked)[ok].astype(np.int32)
+
+
 class VOOracle:
     def __init__(self, cam_T_velo, rect0_T_cam, P_rect0, remove_outlier=100):
         self.L = lib()

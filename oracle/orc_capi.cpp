@@ -2,6 +2,8 @@
 // Plain-C entry points so tests/ and bench.py's cpu_baseline leg can drive the oracle via ctypes.
 #include <cstring>
 #include "orc_loam.h"
+#include "orc_img.h"
+#include <algorithm>
 
 using namespace orc;
 
@@ -289,6 +291,40 @@ int orc_solve(const double* factors, int nf, int quaternion, double huber_a, int
   SolveSummary s;
   prob.Solve(opt, p0, p1, &s);
   pack_summary(s, trace, cap_iters, n_iters, H0, g0, termination, costs2);
+  return 0;
+}
+
+// ---- image front-end (orc_img.h)
+int orc_good_features(const unsigned char* img, int w, int h, int max_corners, double quality, double min_distance, int block_size, float* xy_out,
+                      int cap, float* eig_out) {
+  std::vector<float> eig;
+  std::vector<ImgCorner> c = good_features_to_track(img, w, h, max_corners, quality, min_distance, block_size, eig_out ? &eig : nullptr);
+  if (eig_out) std::copy(eig.begin(), eig.end(), eig_out);
+  const int n = (int)c.size();
+  for (int i = 0; i < n && i < cap; i++) { xy_out[2 * i] = c[i].x; xy_out[2 * i + 1] = c[i].y; }
+  return n;
+}
+// level < 0: only the number of levels.  img_out [w_l * h_l], deriv_out [2 * w_l * h_l], wh [2]
+int orc_pyramid_level(const unsigned char* img, int w, int h, int win, int max_level, int level, unsigned char* img_out, short* deriv_out, int* wh) {
+  Pyramid P;
+  P.build(img, w, h, win, max_level);
+  if (level < 0) return P.levels();
+  if (level >= P.levels()) return -1;
+  std::copy(P.img[level].begin(), P.img[level].end(), img_out);
+  std::copy(P.deriv[level].begin(), P.deriv[level].end(), deriv_out);
+  wh[0] = P.w[level]; wh[1] = P.h[level];
+  return P.levels();
+}
+int orc_pyr_lk(const unsigned char* prev, const unsigned char* next, int w, int h, const float* pts, int n, float* next_pts, unsigned char* status, int win,
+               int max_level, int max_count, double epsilon) {
+  Pyramid P, N;
+  P.build(prev, w, h, win, max_level);
+  N.build(next, w, h, win, max_level);
+  std::vector<ImgCorner> a((size_t)n), b;
+  for (int i = 0; i < n; i++) a[i] = ImgCorner{pts[2 * i], pts[2 * i + 1]};
+  std::vector<uint8_t> st;
+  calc_optical_flow_pyr_lk(P, N, a, &b, &st, win, max_count, epsilon);
+  for (int i = 0; i < n; i++) { next_pts[2 * i] = b[i].x; next_pts[2 * i + 1] = b[i].y; status[i] = st[i]; }
   return 0;
 }
 

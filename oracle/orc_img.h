@@ -1,0 +1,51 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  PARITY UNPINNED.
+//
+// CPU restatement of the image front-end of the visual odometry in its optical-flow configuration
+// (vloam_main.launch:10 optical_flow_match = true):
+//   ImageUtil::detKeypoints, DetectorType::ShiTomasi   src/visual_odometry/src/image_util.cpp:13-36
+//        cv::goodFeaturesToTrack(img, corners, 1024, 0.03, 7.5, Mat(), 5, false, 0.04)
+//   ImageUtil::calculateOpticalFlow                    src/visual_odometry/src/image_util.cpp:351-372
+//        cv::calcOpticalFlowPyrLK(image0, image1, pts0, pts1, status, err, Size(15, 15), 2, TermCriteria(COUNT + EPS, 10, 0.03))
+//   VisualOdometry::processImage                       src/visual_odometry/src/visual_odometry.cpp:91-132
+//        (the corners detected in the CURRENT image are handed to calcOpticalFlowPyrLK as points of the PREVIOUS image, :121-122)
+//   the match loop's float -> int truncation           src/visual_odometry/src/visual_odometry.cpp:296-308
+//
+// The two algorithms live in a third-party dependency that is absent from the reference tree and from this image: OpenCV 4
+// (the reference includes <opencv4/opencv2/opencv.hpp>; Ubuntu 20.04 / ROS Noetic ships 4.2.0).  They are restated here from
+// OpenCV's published algorithm (modules/imgproc/src/featureselect.cpp + corner.cpp, modules/video/src/lkpyramid.cpp,
+// modules/imgproc/src/pyramids.cpp), anchored on the reference's call sites and parameters above.  No OpenCV output is
+// available to check against: PARITY UNPINNED.  Where OpenCV's result depends on the build (SIMD paths add floats in a
+// different order than the scalar path) the restatement takes an order-independent definition, stated at each place:
+//   * cornerMinEigenVal: the structure tensor is summed EXACTLY in integers (Sobel responses of an 8-bit image are integers)
+//     and the smaller eigenvalue is evaluated once in f64 and rounded to f32 — within a few f32 ulps of any OpenCV build's
+//     f32 running sums (boxFilter's RowSum / ColumnSum), identical on every machine;
+//   * Lucas-Kanade: the 2x2 gradient matrix and the mismatch vector are sums of integer products (OpenCV's fixed-point
+//     window, W_BITS = 14); they are summed exactly and rounded to f32 once (OpenCV: f32 accumulation, order build-dependent).
+// The ORB descriptor / brute-force Hamming configuration (optical_flow_match = false) needs OpenCV's learned 256-pair sampling
+// table (orb.cpp, bit_pattern_31_), which cannot be restated without the library: not covered.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace orc {
+
+struct ImgCorner { float x, y; };
+
+// cv::goodFeaturesToTrack on an 8-bit image (row stride = width).  eig_out (optional): the min-eigenvalue map (f32, w*h).
+std::vector<ImgCorner> good_features_to_track(const uint8_t* img, int w, int h, int max_corners, double quality_level, double min_distance,
+                                              int block_size, std::vector<float>* eig_out = nullptr);
+
+struct Pyramid {                      // cv::buildOpticalFlowPyramid without the padded borders (border pixels are computed on access)
+  std::vector<std::vector<uint8_t>> img;
+  std::vector<std::vector<int16_t>> deriv;   // [level][2 * (y * w + x)]: Scharr Ix, Iy (calcSharrDeriv); zero outside the image
+  std::vector<int> w, h;
+  void build(const uint8_t* src, int width, int height, int win, int max_level);
+  int levels() const { return (int)img.size(); }
+};
+
+// cv::calcOpticalFlowPyrLK(prev, next, prev_pts -> next_pts, status), winSize win x win, maxLevel from the pyramids, criteria
+// (COUNT + EPS, max_count, epsilon), flags = 0, minEigThreshold = 1e-4, err requested (its bounds check clears status too).
+void calc_optical_flow_pyr_lk(const Pyramid& prev, const Pyramid& next, const std::vector<ImgCorner>& prev_pts, std::vector<ImgCorner>* next_pts,
+                              std::vector<uint8_t>* status, int win, int max_count, double epsilon);
+
+}  // namespace orc

@@ -20,6 +20,7 @@ VLOAM_OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY, ERR_NO_DEVICE, ERR_ORDE
 K_MAX_RINGS, K_SECTORS = 64, 6
 K_MAX_SHARP, K_MAX_LESS_SHARP, K_MAX_FLAT = 768, 7680, 1536
 K_MAX_LO_FACTORS = K_MAX_SHARP + K_MAX_FLAT
+K_IMG_MAX_CORNERS = 1024   # image_util.cpp:23 maxCorners
 K_LM_MAX_TRACE = 104
 K_STACK_CAP_CORNER, K_STACK_CAP_SURF = 8192, 16384
 K_MAP_FACTOR_CAP = K_STACK_CAP_CORNER + K_STACK_CAP_SURF
@@ -36,7 +37,7 @@ class Config(C.Structure):
                 ("mapping_line_resolution", C.c_float), ("mapping_plane_resolution", C.c_float), ("detach_VO_LO", C.c_int),
                 ("reset_VO_to_identity", C.c_int), ("remove_VO_outlier", C.c_int), ("with_mapping", C.c_int),
                 ("max_points", C.c_int), ("max_frames", C.c_int), ("map_capacity_log2", C.c_int), ("debug", C.c_int),
-                ("timing", C.c_int)]
+                ("timing", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int)]
 
 
 class Calib(C.Structure):
@@ -281,6 +282,61 @@ class Handle:
         aa, t, cnt, pq, pt = np.zeros(3), np.zeros(3), np.zeros(2, dtype=np.int32), np.zeros(4), np.zeros(3)
         self._chk(self.L.vloam_get_vo_result(self.h, _fp(aa), _fp(t), _fp(cnt), _fp(pq), _fp(pt)))
         return dict(angles=aa, t=t, counter32=int(cnt[0]), counter22=int(cnt[1]), prior_q=pq, prior_t=pt)
+
+    # ---- image front-end (optical-flow configuration; needs image_width / image_height in the config)
+    def vo_process_image(self, gray):
+        """VisualOdometry::processImage (visual_odometry.cpp:91-132, optical_flow_match = true): uint8 [h, w]."""
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        self._chk(self.L.vloam_vo_process_image(self.h, _fp(g), g.shape[1], g.shape[0], g.shape[1]))
+
+    def vo_process_image_device(self, dptr, width, height, stride=None):
+        self._chk(self.L.vloam_vo_process_image_device(self.h, C.c_void_p(dptr), int(width), int(height), int(stride or width)))
+
+    def vo_keypoints(self):
+        n = C.c_int(0)
+        out = np.zeros((K_IMG_MAX_CORNERS, 2), dtype=np.float32)
+        self._chk(self.L.vloam_vo_get_keypoints(self.h, _fp(out), K_IMG_MAX_CORNERS, C.byref(n)))
+        return out[:n.value]
+
+    def vo_flow(self):
+        """(corner in the previous image, tracked position in the new image, status) per corner of the last image."""
+        n = C.c_int(0)
+        a = np.zeros((K_IMG_MAX_CORNERS, 2), dtype=np.float32)
+        b = np.zeros((K_IMG_MAX_CORNERS, 2), dtype=np.float32)
+        st = np.zeros(K_IMG_MAX_CORNERS, dtype=np.uint8)
+        self._chk(self.L.vloam_vo_get_flow(self.h, _fp(a), _fp(b), _fp(st), K_IMG_MAX_CORNERS, C.byref(n)))
+        return a[:n.value], b[:n.value], st[:n.value]
+
+    def vo_flow_matches(self):
+        n = C.c_int(0)
+        a = np.zeros((K_IMG_MAX_CORNERS, 2), dtype=np.int32)
+        b = np.zeros((K_IMG_MAX_CORNERS, 2), dtype=np.int32)
+        self._chk(self.L.vloam_vo_get_flow_matches(self.h, _fp(a), _fp(b), K_IMG_MAX_CORNERS, C.byref(n)))
+        return a[:n.value], b[:n.value]
+
+    def process_frame_image(self, cloud, gray):
+        """One frame of the coupled loop from raw inputs: sweep + grey image (matches come from the image front-end)."""
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        self._chk(self.L.vloam_process_frame_image(self.h, _fp(cloud), cloud.shape[0], _fp(g), g.shape[1], g.shape[0], g.shape[1]))
+
+    def process_frame_image_device(self, dptr, n_pts, gptr, width, height, stride=None):
+        self._chk(self.L.vloam_process_frame_image_device(self.h, C.c_void_p(dptr), int(n_pts), C.c_void_p(gptr), int(width), int(height),
+                                                          int(stride or width)))
+
+    def img_debug(self, width, height):
+        """eig map f32 [h, w] and the pyramid of the last image: [(u8 [h_l, w_l], int16 [h_l, w_l, 2])]."""
+        eig = self.debug_raw(4, 0, np.float32).reshape(height, width)
+        lv = []
+        w, h = width, height
+        for l in range(3):
+            try:
+                im = self.debug_raw(4, 1 + l, np.uint8)
+            except VloamError:
+                break
+            lv.append((im.reshape(h, w).copy(), self.debug_raw(4, 4 + l, np.int16).reshape(h, w, 2).copy()))
+            w, h = (w + 1) // 2, (h + 1) // 2
+        return eig, lv
 
     # ---- parity hooks
     def debug_raw(self, stage, item, dtype, max_bytes=1 << 26):

@@ -21,6 +21,7 @@
 #include "sr_kernels.h"
 #include "vloam_device.h"
 #include "vo_kernels.h"
+#include "img_kernels.h"
 
 using namespace vloam;
 
@@ -52,6 +53,7 @@ struct vloam_handle {
   hipStream_t stream = nullptr;   // scan registration (+ NN grid build); also creation / VO work
   hipStream_t s_lo = nullptr;     // laser odometry
   hipStream_t s_map = nullptr;    // laser mapping
+  hipStream_t s_img = nullptr;    // image front-end of the coupled frame loop (needs the image only: next to the scan-registration stream)
   hipStream_t s_ds = nullptr;     // VoxelGrid of the scan features for mapping (needs the sweep's feature clouds only: off the SR stream's chain)
   static constexpr int kSets = 4;   // 3 suffice for correctness; the 4th keeps the buffer-reuse wait off the critical cycle
   hipEvent_t ev_sr[kSets] = {}, ev_lo[kSets] = {}, ev_map[kSets] = {}, ev_stack[kSets] = {};  // "stage finished for the sweep in set c"
@@ -84,6 +86,9 @@ struct vloam_handle {
   hipEvent_t ev_vo[kSets] = {};     // depth map + matches of the frame in set c are in HBM
   bool vo_frame[kSets] = {};        // the sweep in set c came through vloam_process_frame (its odometry is preceded by the VO solve)
   bool have_extrinsics = false;
+  ImgContext img;
+  hipEvent_t ev_img[kSets] = {};    // the image-derived matches of the frame in set c are in HBM
+  bool img_frame[kSets] = {};
   LoGrid grid[kSets];          // per set: NN grid over that sweep's lessSharp / lessFlat
   // mapping + vo
   MapContext map;
@@ -170,6 +175,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   if (map_layout(&h->map, h->cfg, A) != VLOAM_OK) { set_err("map_layout failed"); return VLOAM_ERR_HIP; }
   TAKE(h->sync_pool, kSyncCand * kSyncStride / sizeof(double));
   if (vo_layout(&h->vo, h->cfg, A) != VLOAM_OK) { set_err("vo_layout failed"); return VLOAM_ERR_HIP; }
+  if (img_layout(&h->img, h->cfg, A) != VLOAM_OK) { set_err("img_layout failed"); return VLOAM_ERR_HIP; }
   h->lo_F.err = &h->map.frame->error;
   for (int k = 0; k < vloam_handle::kSets; k++) h->sr[k].sticky_err = &h->map.frame->error;
   return VLOAM_OK;
@@ -199,6 +205,8 @@ void vloam_default_config(vloam_config* c) {
   c->map_capacity_log2 = 22;
   c->debug = 0;
   c->timing = 0;
+  c->image_width = 0;
+  c->image_height = 0;
 }
 
 const char* vloam_last_error(void) { return g_err.c_str(); }
@@ -216,6 +224,10 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   }
   if (!(cfg->mapping_line_resolution >= 0.25f) || !(cfg->mapping_plane_resolution >= 0.25f)) {  // 8-bit voxel index inside a 50 m cube, <= 8 pieces per axis
     set_err("mapping resolutions below 0.25 m are not supported"); return VLOAM_ERR_INVALID;
+  }
+  if (cfg->image_width < 0 || cfg->image_height < 0 || (long long)cfg->image_width * cfg->image_height > (1ll << 24) ||
+      ((cfg->image_width > 0) != (cfg->image_height > 0)) || (cfg->image_width > 0 && (cfg->image_width < 2 * kImgWin || cfg->image_height < 2 * kImgWin))) {
+    set_err("image_width x image_height must be 0 x 0 (no image front-end) or between %d x %d and 2^24 pixels", 2 * kImgWin, 2 * kImgWin); return VLOAM_ERR_INVALID;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -235,6 +247,7 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
                                hipStreamCreateWithFlags(&h->s_ds, hipStreamNonBlocking) != hipSuccess))) {  // no mapping: no further hardware queues
       set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
     }
+    if (cfg->image_width > 0 && hipStreamCreateWithFlags(&h->s_img, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
     auto body = [&]() -> vloam_status {
       // 1. measure one session, 2. one allocation for all sessions (zeroed), 3. lay session 0 out for real
@@ -288,6 +301,7 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
         HIPCHK(hipEventCreateWithFlags(&h->ev_map[k], hipEventDisableTiming | hipEventBlockingSync));
         HIPCHK(hipEventCreateWithFlags(&h->ev_stack[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_vo[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_img[k], hipEventDisableTiming));
       }
       HIPCHK(hipStreamSynchronize(h->stream));
       // ---- the other sessions start as byte-for-byte copies of session 0
@@ -322,13 +336,13 @@ vloam_status vloam_select_session(vloam_handle* h, int session) {
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
   (void)hipSetDevice(h->device);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds}) if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamSynchronize(st);
   if (h->arena) (void)hipFree(h->arena);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
-    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k], h->ev_img[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds}) if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamDestroy(st);
   map_destroy(&h->map);
   if (h->ring_watch) (void)hipHostFree(h->ring_watch);
   delete h;
@@ -350,6 +364,7 @@ static vloam_status sync_all(vloam_handle* h) {
   HIPCHK(hipStreamSynchronize(h->s_lo));
   if (h->s_ds) HIPCHK(hipStreamSynchronize(h->s_ds));
   if (h->s_map) HIPCHK(hipStreamSynchronize(h->s_map));
+  if (h->s_img) HIPCHK(hipStreamSynchronize(h->s_img));
   return VLOAM_OK;
 }
 
@@ -395,6 +410,7 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   h->last_n_in = n;
   h->stage = 1;
   h->vo_frame[cur] = false;
+  h->img_frame[cur] = false;
   return VLOAM_OK;
 }
 
@@ -406,6 +422,7 @@ static vloam_status enqueue_lo(vloam_handle* h, int frame) {
   const bool use_prior = !h->cfg.detach_VO_LO;
   if (coupled) {
     HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_vo[cur], 0));
+    if (h->img_frame[cur]) HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_img[cur], 0));
     if (frame > 0) {  // Section 4: if (count > 0) VO->solveNlsAll()
       vloam_status s = vo_solve_enqueue(&h->vo, h->cfg, h->s_lo, frame, h->lo, &h->prof);
       if (s != VLOAM_OK) { set_err("vo_solve_enqueue failed"); return s; }
@@ -682,21 +699,32 @@ vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16],
 // cam0_curr_LOT_cam0_prev, on the device), VO2VeloAndBase (-> velo_last_VOT_velo_curr, read by solveLO when detach_VO_LO == 0),
 // scanRegistrationIO, laserOdometryIO (publish() refreshes cam0_curr_LOT_cam0_prev), laserMappingIO.
 // prev_uv / curr_uv: n_match integer pixel pairs in HOST memory (previous frame -> this frame; ignored for the first frame).
-vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
-  if (!h || !d_xyz_pad4 || n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match,
+                                         const unsigned char* d_gray, int width, int height, int stride) {
   SINGLE_SESSION_ONLY(h);
   if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
   if (n_match > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match, kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
+  if (d_gray && h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
   vloam_status s = enqueue_sr(h, one_sweep(d_xyz_pad4, n));
   if (s != VLOAM_OK) return s;
   const int k = h->frame, cur = set_of(k);
   // depth map + matches ride on the scan-registration stream (they only need the sweep); the solve itself belongs to the odometry stream
-  s = vo_depth_enqueue(&h->vo, h->stream, (const float4*)d_xyz_pad4, n, k, prev_uv, curr_uv, n_match, &h->prof);
+  s = vo_depth_enqueue(&h->vo, h->stream, (const float4*)d_xyz_pad4, n, k, prev_uv, curr_uv, d_gray ? 0 : n_match, &h->prof);
   if (s != VLOAM_OK) { set_err("vo_depth_enqueue failed"); return s; }
   HIPCHK(hipEventRecord(h->ev_vo[cur], h->stream));
   h->vo_frame[cur] = true;
+  if (d_gray) {
+    // processImage on its own stream: corners + flow straight into this frame's match arrays (one entry per corner slot, untracked
+    // slots marked), consumed by the VO solve in front of this frame's laser odometry
+    const int vset = k % VOContext::kSets;
+    s = img_process(&h->img, h->s_img, d_gray, width, height, stride, h->vo.d_prev_set[vset], h->vo.d_curr_set[vset], &h->prof);
+    if (s != VLOAM_OK) { set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h); return s; }
+    h->vo.n_match_set[vset] = k > 0 ? kImgMaxCorners : 0;
+    HIPCHK(hipEventRecord(h->ev_img[cur], h->s_img));
+    h->img_frame[cur] = true;
+  }
   if (h->cfg.timing) {
     s = enqueue_lo(h, h->frame);
     if (s != VLOAM_OK) return s;
@@ -708,6 +736,11 @@ vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4,
   return drain_deferred(h, kLagLO, kLagMap);
 }
 
+vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
+  if (!h || !d_xyz_pad4 || n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+  return process_frame_common(h, d_xyz_pad4, n, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
+}
+
 vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
   if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
@@ -715,6 +748,113 @@ vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, 
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   return vloam_process_frame_device(h, h->d_in, n, prev_uv, curr_uv, n_match);
+}
+
+vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride) {
+  if (!h || !d_xyz_pad4 || !d_gray) return VLOAM_ERR_INVALID;
+  return process_frame_common(h, d_xyz_pad4, n, nullptr, nullptr, 0, (const unsigned char*)d_gray, width, height, stride);
+}
+
+vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride) {
+  if (!h || !xyz_pad4 || !gray) return VLOAM_ERR_INVALID;
+  if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+  if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpy2DAsync(h->img.staging, (size_t)width, gray, (size_t)stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, h->s_img));
+  return process_frame_common(h, h->d_in, n, nullptr, nullptr, 0, h->img.staging, width, height, width);
+}
+
+// ---- the image front-end on its own (VisualOdometry::processImage, optical_flow_match = true)
+vloam_status vloam_vo_process_image_device(vloam_handle* h, const void* d_gray, int width, int height, int stride) {
+  if (!h || !d_gray) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  HIPCHK(hipSetDevice(h->device));
+  vloam_status s = img_process(&h->img, h->s_img, (const unsigned char*)d_gray, width, height, stride, h->vo.d_prev, h->vo.d_curr, &h->prof);
+  if (s != VLOAM_OK) set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h);
+  return s;
+}
+
+vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride) {
+  if (!h || !gray) return VLOAM_ERR_INVALID;
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy2DAsync(h->img.staging, (size_t)width, gray, (size_t)stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, h->s_img));
+  return vloam_vo_process_image_device(h, h->img.staging, width, height, width);
+}
+
+static vloam_status img_results(vloam_handle* h, std::vector<float2>* corners, std::vector<float2>* tracked, std::vector<unsigned char>* status, int* n_corners,
+                                bool* have_flow) {
+  if (h->img.max_w == 0 || h->img.count < 0) { set_err("no image processed yet"); return VLOAM_ERR_ORDER; }
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  int ierr = 0;
+  HIPCHK(hipMemcpy(&ierr, h->img.error, sizeof(int), hipMemcpyDeviceToHost));
+  if (ierr) { set_err("image front-end capacity exceeded (bits %d: 1 candidates > %d, 2 neighbours > %d, 4 corners > %d)", ierr, kImgCandCap, kImgNbrCap, kImgAccCap); return VLOAM_ERR_CAPACITY; }
+  const int cur = h->img.count % 2;
+  HIPCHK(hipMemcpy(n_corners, h->img.n_corners[cur], sizeof(int), hipMemcpyDeviceToHost));
+  corners->resize((size_t)*n_corners + 1);
+  if (*n_corners) HIPCHK(hipMemcpy(corners->data(), h->img.corners[cur], sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
+  *have_flow = h->img.count > 0;
+  if (tracked && *have_flow && *n_corners) {
+    tracked->resize((size_t)*n_corners); status->resize((size_t)*n_corners);
+    HIPCHK(hipMemcpy(tracked->data(), h->img.tracked, sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status->data(), h->img.status, (size_t)*n_corners, hipMemcpyDeviceToHost));
+  }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_vo_get_keypoints(vloam_handle* h, float* xy, int cap, int* n) {
+  if (!h || !n || cap < 0 || (cap > 0 && !xy)) return VLOAM_ERR_INVALID;
+  std::vector<float2> c;
+  int nc = 0;
+  bool flow = false;
+  vloam_status s = img_results(h, &c, nullptr, nullptr, &nc, &flow);
+  if (s != VLOAM_OK) return s;
+  *n = nc;
+  for (int k = 0; k < nc && k < cap; k++) { xy[2 * k] = c[(size_t)k].x; xy[2 * k + 1] = c[(size_t)k].y; }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_vo_get_flow(vloam_handle* h, float* prev_xy, float* curr_xy, unsigned char* status, int cap, int* n) {
+  if (!h || !n || cap < 0 || (cap > 0 && (!prev_xy || !curr_xy || !status))) return VLOAM_ERR_INVALID;
+  std::vector<float2> c, t;
+  std::vector<unsigned char> st;
+  int nc = 0;
+  bool flow = false;
+  vloam_status s = img_results(h, &c, &t, &st, &nc, &flow);
+  if (s != VLOAM_OK) return s;
+  *n = flow ? nc : 0;
+  for (int k = 0; k < *n && k < cap; k++) {
+    prev_xy[2 * k] = c[(size_t)k].x; prev_xy[2 * k + 1] = c[(size_t)k].y;
+    curr_xy[2 * k] = t[(size_t)k].x; curr_xy[2 * k + 1] = t[(size_t)k].y;
+    status[k] = st[(size_t)k];
+  }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_vo_get_flow_matches(vloam_handle* h, int* prev_uv, int* curr_uv, int cap, int* n) {
+  if (!h || !n || cap < 0 || (cap > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+  std::vector<float2> c, t;
+  std::vector<unsigned char> st;
+  int nc = 0, m = 0;
+  bool flow = false;
+  vloam_status s = img_results(h, &c, &t, &st, &nc, &flow);
+  if (s != VLOAM_OK) return s;
+  for (int k = 0; flow && k < nc; k++) {
+    if (st[(size_t)k] != 1) continue;   // visual_odometry.cpp:298-308
+    if (m < cap) {
+      prev_uv[2 * m] = (int)c[(size_t)k].x; prev_uv[2 * m + 1] = (int)c[(size_t)k].y;
+      curr_uv[2 * m] = (int)t[(size_t)k].x; curr_uv[2 * m + 1] = (int)t[(size_t)k].y;
+    }
+    m++;
+  }
+  *n = m;
+  return VLOAM_OK;
 }
 
 // world_VOT_base_last of frames first..first+count-1 as {q xyzw, t} (what VO2Cam0StartFrame turns into VO rows, vloam_tf.cpp:77-101)
@@ -865,6 +1005,7 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
   }
   if (stage == 2) return map_debug_get(&h->map, item, buf, cap, n);
   if (stage == 3) return vo_debug_get(&h->vo, item, buf, cap, n);
+  if (stage == 4) return img_debug_get(&h->img, item, buf, cap, n);
   return VLOAM_ERR_INVALID;
 }
 

@@ -1,0 +1,66 @@
+// Image front-end of the visual odometry on gfx950 — host-visible interface (img_kernels.hip).
+// Restates VisualOdometry::processImage in its optical-flow configuration (optical_flow_match = true):
+//   ImageUtil::detKeypoints, ShiTomasi   /root/reference/src/visual_odometry/src/image_util.cpp:13-36   cv::goodFeaturesToTrack
+//   ImageUtil::calculateOpticalFlow      /root/reference/src/visual_odometry/src/image_util.cpp:351-372 cv::calcOpticalFlowPyrLK
+//   VisualOdometry::processImage         /root/reference/src/visual_odometry/src/visual_odometry.cpp:91-132
+//   the match loop's float -> int reads  /root/reference/src/visual_odometry/src/visual_odometry.cpp:296-308
+// OpenCV 4 itself is not part of the reference tree: the two algorithms follow its published sources (featureselect.cpp, corner.cpp,
+// lkpyramid.cpp, pyramids.cpp) with the order-independent sums stated in oracle/orc_img.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/vloam_hip/c_api.h"
+#include "vloam_device.h"
+
+namespace vloam {
+
+constexpr int kImgMaxCorners = 1024;   // image_util.cpp:23   maxCorners
+constexpr int kImgBlock = 5;           // image_util.cpp:17   block_size
+constexpr int kImgWin = 15;            // image_util.cpp:364  winSize
+constexpr int kImgMaxLevel = 2;        // image_util.cpp:364  maxLevel
+constexpr int kImgLkIters = 10;        // image_util.cpp:362  TermCriteria count
+constexpr int kImgLevels = kImgMaxLevel + 1;
+constexpr int kImgCandCap = 65536;     // local maxima above the quality threshold (one status byte each in the selection kernel's LDS)
+constexpr int kImgNbrCap = 64;         // stronger candidates within minDistance of a candidate (3x3 local maxima are >= 2 px apart)
+constexpr int kImgAccCap = 16384;      // corners before the maxCorners cut (a 1242 x 375 image holds < 10 600 at minDistance 7.5)
+constexpr int kImgMaxRadius = 8;       // floor(minDistance) the neighbourhood scan supports
+
+struct ImgPyrDev {
+  unsigned char* img[kImgLevels];
+  short2* deriv[kImgLevels];   // Scharr (Ix, Iy), calcSharrDeriv
+  int w[kImgLevels], h[kImgLevels];
+  int levels;
+};
+
+struct ImgContext {
+  int max_w = 0, max_h = 0;    // 0: no image front-end in this handle
+  int w = 0, h = 0;            // size of the images seen so far (all images of a sequence share it)
+  int count = -1;              // VisualOdometry::reset(): ++count; i = count % 2
+  ImgPyrDev pyr[2];
+  short2* sobel = nullptr;     // [w * h] Sobel (dx, dy)
+  float* eig = nullptr;        // [w * h] cornerMinEigenVal
+  unsigned* maxbits = nullptr; // [1] bits of the largest eigenvalue
+  int* cmap = nullptr;         // [w * h] candidate index of a pixel or -1
+  int* clist = nullptr;        // [kImgCandCap] pixel address of candidate c
+  int* n_cand = nullptr;       // [1]
+  int* nbr = nullptr;          // [kImgCandCap][kImgNbrCap] stronger candidates closer than minDistance
+  unsigned char* nbr_cnt = nullptr;
+  unsigned long long* acc = nullptr;  // [kImgAccCap] accepted corners, (eig bits, address) keys
+  float2* corners[2] = {nullptr, nullptr};   // [kImgMaxCorners] per image, acceptance order
+  int* n_corners[2] = {nullptr, nullptr};
+  float2* tracked = nullptr;   // [kImgMaxCorners] calcOpticalFlowPyrLK's nextPts
+  unsigned char* status = nullptr;
+  int* error = nullptr;        // sticky capacity bits
+  unsigned char* staging = nullptr;   // [max_w * max_h] upload buffer of the host-pointer entry
+};
+
+constexpr int kErrImgCandidates = 1, kErrImgNeighbours = 2, kErrImgAccepted = 4;
+
+vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // session 0 only (the frame loop is single-session)
+// processImage for the image in d_gray (device, row stride in bytes): pyramid + derivatives, corners, and — from the second image
+// on — the flow of the new corners from the previous image into this one.  prev_uv / curr_uv (device, [kImgMaxCorners][2] ints, may be
+// null): the match loop's integer pixel pairs, x = INT_MIN in entries without a tracked corner.
+vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
+                         ProfHook* ph);
+vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n);
+
+}  // namespace vloam

@@ -1,0 +1,485 @@
+// Image front-end of the visual odometry (optical-flow configuration) as hand-written HIP for gfx950.  See img_kernels.h for the
+// reference call sites; the arithmetic follows oracle/orc_img.h's statement of cv::goodFeaturesToTrack / cv::calcOpticalFlowPyrLK
+// (integer-exact structure tensor and Lucas-Kanade sums, everything else in OpenCV's own f32 / fixed-point order).
+//
+//   k_img_sobel       1 thread / pixel     Sobel 3x3 (ints) of the 8-bit image + contiguous copy = pyramid level 0
+//   k_img_eig         32 x 8 tiles         5 x 5 box sums of the gradient products through LDS, min eigenvalue (f64 -> f32), global max
+//   k_img_localmax    1 thread / pixel     quality threshold + 3 x 3 non-maximum suppression -> candidate list + pixel -> candidate map
+//   k_img_neighbours  1 thread / candidate the stronger candidates closer than minDistance (what the greedy pass can be blocked by)
+//   k_img_select      1 workgroup          the greedy minDistance pass as a fixed point over "blocked by an accepted stronger
+//                                          neighbour" (order-free: the result equals the sorted sequential pass), then the
+//                                          (strength, address)-sorted cut at maxCorners through an LDS bitonic network
+//   k_img_pyrdown     1 thread / pixel     cv::pyrDown
+//   k_img_scharr      1 thread / pixel     calcSharrDeriv
+//   k_img_lk          1 wavefront / corner pyramidal Lucas-Kanade, all levels in one launch; the 15 x 15 window lives in registers
+//                                          (4 pixels per lane), the 2 x 2 system in exact integer sums
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <float.h>
+#include <math.h>
+#include "img_kernels.h"
+
+namespace vloam {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ int reflect101(int i, int n) {  // cv::borderInterpolate(i, n, BORDER_REFLECT_101)
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void k_img_sobel(const unsigned char* __restrict__ img, int w, int h, int stride, short2* __restrict__ out,
+                                                   unsigned char* __restrict__ level0, unsigned* maxbits, int* n_cand) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) { *maxbits = 0u; *n_cand = 0; }
+  if (idx >= w * h) return;
+  const int y = idx / w, x = idx - y * w;
+  const unsigned char* r0 = img + (size_t)reflect101(y - 1, h) * stride;
+  const unsigned char* r1 = img + (size_t)y * stride;
+  const unsigned char* r2 = img + (size_t)reflect101(y + 1, h) * stride;
+  const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+  const int dx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+  const int dy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
+  out[idx] = make_short2((short)dx, (short)dy);
+  level0[idx] = r1[x];
+}
+
+constexpr int kTileW = 32, kTileH = 8, kHalo = kImgBlock / 2;
+__global__ __launch_bounds__(kTileW * kTileH) void k_img_eig(const short2* __restrict__ D, int w, int h, double hs2, float* __restrict__ eig,
+                                                             unsigned* maxbits) {
+  __shared__ short2 tile[kTileH + 2 * kHalo][kTileW + 2 * kHalo + 1];
+  __shared__ unsigned wmax[kTileW * kTileH / 64];
+  const int tid = threadIdx.x, tx = tid % kTileW, ty = tid / kTileW;
+  const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+  constexpr int TW = kTileW + 2 * kHalo, TH = kTileH + 2 * kHalo;
+  for (int e = tid; e < TW * TH; e += kTileW * kTileH) {
+    const int ly = e / TW, lx = e - ly * TW;
+    // the box filter reflects the PRODUCT images (BORDER_REFLECT_101 on the filter's own input), i.e. the gradient of the reflected pixel
+    const int gx = reflect101(x0 + lx - kHalo, w), gy = reflect101(y0 + ly - kHalo, h);
+    tile[ly][lx] = D[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  const int x = x0 + tx, y = y0 + ty;
+  float e = 0.f;
+  if (x < w && y < h) {
+    int sxx = 0, sxy = 0, syy = 0;  // <= 25 * 1020^2: exact in 32 bits
+#pragma unroll
+    for (int j = 0; j < kImgBlock; j++)
+#pragma unroll
+      for (int i = 0; i < kImgBlock; i++) {
+        const short2 g = tile[ty + j][tx + i];
+        sxx += (int)g.x * g.x; sxy += (int)g.x * g.y; syy += (int)g.y * g.y;
+      }
+    const long long d = (long long)sxx - syy;
+    const double root = sqrt((double)(d * d + 4ll * sxy * sxy));   // < 2^53: the radicand is exact
+    e = (float)(((double)(sxx + syy) - root) * hs2);
+    eig[(size_t)y * w + x] = e;
+  }
+  unsigned b = e > 0.f ? __float_as_uint(e) : 0u;  // positive floats order like their bit patterns
+  for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(b, d); b = o > b ? o : b; }
+  if ((tid & 63) == 0) wmax[tid >> 6] = b;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned m = 0;
+    for (int k = 0; k < kTileW * kTileH / 64; k++) m = wmax[k] > m ? wmax[k] : m;
+    if (m) atomicMax(maxbits, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_img_localmax(const float* __restrict__ eig, int w, int h, const unsigned* __restrict__ maxbits,
+                                                      double quality, int* __restrict__ cmap, int* __restrict__ clist, int* n_cand, int* err) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * h) return;
+  const int y = idx / w, x = idx - y * w;
+  int c = -1;
+  if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+    const float thr = (float)((double)__uint_as_float(*maxbits) * quality);   // threshold(eig, maxVal * qualityLevel, THRESH_TOZERO)
+    const float v = eig[idx];
+    if (v > thr) {
+      // v == dilate3x3(thresholded)  <=>  no neighbour is larger (thr >= 0: a neighbour the threshold zeroed is below v anyway)
+      bool is_max = true;
+#pragma unroll
+      for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) is_max = is_max && !(eig[idx + j * w + i] > v);
+      if (is_max) {
+        c = atomicAdd(n_cand, 1);
+        if (c < kImgCandCap) clist[c] = idx;
+        else { c = -1; atomicOr(err, kErrImgCandidates); }
+      }
+    }
+  }
+  cmap[idx] = c;
+}
+
+__global__ __launch_bounds__(256) void k_img_neighbours(const float* __restrict__ eig, int w, int h, const int* __restrict__ cmap,
+                                                        const int* __restrict__ clist, const int* __restrict__ n_cand, float md2, int R,
+                                                        int* __restrict__ nbr, unsigned char* __restrict__ nbr_cnt, int* err) {
+  const int n = min(*n_cand, kImgCandCap);
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+    const int p = clist[c];
+    const int y = p / w, x = p - y * w;
+    const float v = eig[p];
+    int cnt = 0;
+    for (int dy = -R; dy <= R; dy++) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= h) continue;
+      for (int dx = -R; dx <= R; dx++) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+        if (!((float)(dx * dx + dy * dy) < md2)) continue;        // featureselect.cpp: dx*dx + dy*dy < minDistance^2
+        const int q = yy * w + xx;
+        const int cq = cmap[q];
+        if (cq < 0) continue;
+        const float vq = eig[q];
+        if (vq > v || (vq == v && q > p)) {   // sorted ahead of this candidate (greaterThanPtr: value, then the larger address)
+          if (cnt < kImgNbrCap) nbr[(size_t)c * kImgNbrCap + cnt] = cq;
+          cnt++;
+        }
+      }
+    }
+    if (cnt > kImgNbrCap) { atomicOr(err, kErrImgNeighbours); cnt = kImgNbrCap; }
+    nbr_cnt[c] = (unsigned char)cnt;
+  }
+}
+
+constexpr int kSelThreads = 1024;
+__global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restrict__ eig, int w, const int* __restrict__ clist,
+                                                            const int* __restrict__ n_cand, const int* __restrict__ nbr,
+                                                            const unsigned char* __restrict__ nbr_cnt, u64* acc, int max_corners,
+                                                            float2* __restrict__ corners, int* n_corners, int* err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* status = smem;          // [kImgCandCap]: 0 undecided, 1 accepted, 2 dropped;   later reused as u64 keys[kImgAccCap]
+  __shared__ int s_changed, s_nacc;
+  const int tid = threadIdx.x;
+  const int n = min(*n_cand, kImgCandCap);
+  for (int c = tid; c < n; c += kSelThreads) status[c] = 0;
+  if (tid == 0) s_nacc = 0;
+  __syncthreads();
+  // The sequential pass accepts a candidate iff no ACCEPTED candidate sorted ahead of it lies closer than minDistance.  A candidate is
+  // therefore decided as soon as one such neighbour is accepted (dropped) or all of them are dropped (accepted): decisions never
+  // change, every sweep decides at least the strongest undecided candidate, and any update order reaches the same fixed point.
+  for (int sweep = 0; sweep <= n; sweep++) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    bool changed = false;
+    for (int c = tid; c < n; c += kSelThreads) {
+      if (status[c] != 0) continue;
+      const int cnt = nbr_cnt[c];
+      bool any_acc = false, all_drop = true;
+      for (int k = 0; k < cnt; k++) {
+        const int s = status[nbr[(size_t)c * kImgNbrCap + k]];
+        any_acc = any_acc || s == 1;
+        all_drop = all_drop && s == 2;
+      }
+      if (any_acc) { status[c] = 2; changed = true; }
+      else if (all_drop) { status[c] = 1; changed = true; }
+    }
+    if (changed) s_changed = 1;
+    __syncthreads();
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  for (int c = tid; c < n; c += kSelThreads)
+    if (status[c] == 1) {
+      const int k = atomicAdd(&s_nacc, 1);
+      const int p = clist[c];
+      if (k < kImgAccCap) acc[k] = ((u64)__float_as_uint(eig[p]) << 32) | (unsigned)p;
+    }
+  __syncthreads();
+  int nacc = s_nacc;
+  if (nacc > kImgAccCap) { if (tid == 0) atomicOr(err, kErrImgAccepted); nacc = kImgAccCap; }
+  // corners come out in sorted order (descending strength, ties: larger address first), cut at maxCorners
+  u64* keys = reinterpret_cast<u64*>(smem);
+  int P = 2;
+  while (P < nacc) P <<= 1;
+  __syncthreads();  // everyone is done with `status`
+  for (int t = tid; t < P; t += kSelThreads) keys[t] = t < nacc ? acc[t] : 0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P; t += kSelThreads) {
+        const int l = t ^ j;
+        if (l > t) {
+          const u64 a = keys[t], b = keys[l];
+          const bool desc = (t & k) == 0;   // descending blocks first: the whole array ends up descending
+          if (desc ? a < b : a > b) { keys[t] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const int nout = max_corners > 0 ? min(nacc, max_corners) : nacc;
+  for (int t = tid; t < nout && t < kImgMaxCorners; t += kSelThreads) {
+    const int p = (int)(keys[t] & 0xffffffffu);
+    const int y = p / w, x = p - y * w;
+    corners[t] = make_float2((float)x, (float)y);
+  }
+  if (tid == 0) *n_corners = min(nout, kImgMaxCorners);
+}
+
+__global__ __launch_bounds__(256) void k_img_pyrdown(const unsigned char* __restrict__ src, int sw, int sh, unsigned char* __restrict__ dst, int dw,
+                                                     int dh) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= dw * dh) return;
+  const int y = idx / dw, x = idx - y * dw;
+  int xs[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) xs[i] = reflect101(2 * x + i - 2, sw);
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const unsigned char* row = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
+    const int rs = (int)row[xs[0]] + 4 * (int)row[xs[1]] + 6 * (int)row[xs[2]] + 4 * (int)row[xs[3]] + (int)row[xs[4]];
+    s += (j == 0 || j == 4) ? rs : ((j == 2) ? 6 * rs : 4 * rs);
+  }
+  dst[idx] = (unsigned char)((s + 128) >> 8);
+}
+
+__global__ __launch_bounds__(256) void k_img_scharr(const unsigned char* __restrict__ img, int w, int h, short2* __restrict__ deriv) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * h) return;
+  const int y = idx / w, x = idx - y * w;
+  const unsigned char* s0 = img + (size_t)reflect101(y - 1, h) * w;
+  const unsigned char* s1 = img + (size_t)y * w;
+  const unsigned char* s2 = img + (size_t)reflect101(y + 1, h) * w;
+  const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+  const int t0m = ((int)s0[xm] + (int)s2[xm]) * 3 + (int)s1[xm] * 10, t0p = ((int)s0[xp] + (int)s2[xp]) * 3 + (int)s1[xp] * 10;
+  const int t1m = (int)s2[xm] - (int)s0[xm], t1c = (int)s2[x] - (int)s0[x], t1p = (int)s2[xp] - (int)s0[xp];
+  deriv[idx] = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {  // exact integers below 2^53: the order of the adds does not matter
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }   // CV_DESCALE
+
+// LKTrackerInvoker::operator() for one point, levels from the top (lkpyramid.cpp).  Pyramid levels: REFLECT_101 border, derivative
+// images: zero border.  Every lane runs the same scalar control flow on wavefront-uniform values; the window sums are the only
+// cross-lane step.
+__global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const float2* __restrict__ pts, const int* __restrict__ n_pts,
+                                                float2* __restrict__ out, unsigned char* __restrict__ status, int* __restrict__ prev_uv,
+                                                int* __restrict__ curr_uv, double eps2) {
+  const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= kImgMaxCorners) return;
+  if (p >= *n_pts) {
+    if (lane == 0) {
+      status[p] = 0;
+      out[p] = make_float2(0.f, 0.f);
+      if (prev_uv) { prev_uv[2 * p] = INT_MIN; prev_uv[2 * p + 1] = 0; curr_uv[2 * p] = INT_MIN; curr_uv[2 * p + 1] = 0; }
+    }
+    return;
+  }
+  constexpr int win = kImgWin, W_BITS = 14, kQ = (win * win + 63) / 64;
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const float half = (win - 1) * 0.5f;
+  const float2 pt = pts[p];
+  float ox = 0.f, oy = 0.f;  // nextPts[ptidx]
+  bool st = true;
+  const int top = min(P.levels, N.levels) - 1;
+  for (int level = top; level >= 0; level--) {
+    const int cw = P.w[level], ch = P.h[level];
+    const unsigned char* I = P.img[level];
+    const unsigned char* J = N.img[level];
+    const short2* dI = P.deriv[level];
+    float px = pt.x * (float)(1. / (1 << level)), py = pt.y * (float)(1. / (1 << level));
+    float nx, ny;
+    if (level == top) { nx = px; ny = py; }
+    else { nx = ox * 2.f; ny = oy * 2.f; }
+    ox = nx; oy = ny;
+    px -= half; py -= half;
+    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    if (ipx < -win || ipx >= cw || ipy < -win || ipy >= ch) {
+      if (level == 0) st = false;
+      continue;
+    }
+    float a = px - ipx, b = py - ipy;
+    int iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << W_BITS));
+    int iw01 = (int)rintf(a * (1.f - b) * (1 << W_BITS));
+    int iw10 = (int)rintf((1.f - a) * b * (1 << W_BITS));
+    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    int Iw[kQ], Ix[kQ], Iy[kQ];
+    double sA11 = 0.0, sA12 = 0.0, sA22 = 0.0;
+#pragma unroll
+    for (int q = 0; q < kQ; q++) {
+      const int wi = q * 64 + lane;
+      Iw[q] = 0; Ix[q] = 0; Iy[q] = 0;
+      if (wi < win * win) {
+        const int wy = wi / win, wx = wi - wy * win;
+        const int X = ipx + wx, Y = ipy + wy;
+        const int x0 = reflect101(X, cw), x1 = reflect101(X + 1, cw), y0 = reflect101(Y, ch), y1 = reflect101(Y + 1, ch);
+        Iw[q] = descale((int)I[(size_t)y0 * cw + x0] * iw00 + (int)I[(size_t)y0 * cw + x1] * iw01 + (int)I[(size_t)y1 * cw + x0] * iw10 +
+                        (int)I[(size_t)y1 * cw + x1] * iw11, W_BITS - 5);
+        const bool bx0 = X >= 0 && X < cw, bx1 = X + 1 >= 0 && X + 1 < cw, by0 = Y >= 0 && Y < ch, by1 = Y + 1 >= 0 && Y + 1 < ch;
+        const short2 z = make_short2(0, 0);
+        const short2 d00 = (bx0 && by0) ? dI[(size_t)Y * cw + X] : z, d01 = (bx1 && by0) ? dI[(size_t)Y * cw + X + 1] : z;
+        const short2 d10 = (bx0 && by1) ? dI[(size_t)(Y + 1) * cw + X] : z, d11 = (bx1 && by1) ? dI[(size_t)(Y + 1) * cw + X + 1] : z;
+        Ix[q] = descale((int)d00.x * iw00 + (int)d01.x * iw01 + (int)d10.x * iw10 + (int)d11.x * iw11, W_BITS);
+        Iy[q] = descale((int)d00.y * iw00 + (int)d01.y * iw01 + (int)d10.y * iw10 + (int)d11.y * iw11, W_BITS);
+        sA11 += (double)Ix[q] * (double)Ix[q]; sA12 += (double)Ix[q] * (double)Iy[q]; sA22 += (double)Iy[q] * (double)Iy[q];
+      }
+    }
+    sA11 = wave_sum_f64(sA11); sA12 = wave_sum_f64(sA12); sA22 = wave_sum_f64(sA22);
+    const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if ((double)min_eig < 1e-4 || D < FLT_EPSILON) {   // minEigThreshold
+      if (level == 0) st = false;
+      continue;
+    }
+    D = 1.f / D;
+    nx -= half; ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    for (int j = 0; j < kImgLkIters; j++) {
+      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      if (inx < -win || inx >= cw || iny < -win || iny >= ch) {
+        if (level == 0) st = false;
+        break;
+      }
+      a = nx - inx; b = ny - iny;
+      iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << W_BITS));
+      iw01 = (int)rintf(a * (1.f - b) * (1 << W_BITS));
+      iw10 = (int)rintf((1.f - a) * b * (1 << W_BITS));
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      double sb1 = 0.0, sb2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < kQ; q++) {
+        const int wi = q * 64 + lane;
+        if (wi < win * win) {
+          const int wy = wi / win, wx = wi - wy * win;
+          const int x0 = reflect101(inx + wx, cw), x1 = reflect101(inx + wx + 1, cw), y0 = reflect101(iny + wy, ch), y1 = reflect101(iny + wy + 1, ch);
+          const int diff = descale((int)J[(size_t)y0 * cw + x0] * iw00 + (int)J[(size_t)y0 * cw + x1] * iw01 + (int)J[(size_t)y1 * cw + x0] * iw10 +
+                                   (int)J[(size_t)y1 * cw + x1] * iw11, W_BITS - 5) - Iw[q];
+          sb1 += (double)diff * (double)Ix[q];
+          sb2 += (double)diff * (double)Iy[q];
+        }
+      }
+      sb1 = wave_sum_f64(sb1); sb2 = wave_sum_f64(sb2);
+      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      const float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
+      nx += ddx; ny += ddy;
+      ox = nx + half; oy = ny + half;
+      if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= eps2) break;
+      if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
+        ox -= ddx * 0.5f;
+        oy -= ddy * 0.5f;
+        break;
+      }
+      pdx = ddx; pdy = ddy;
+    }
+    if (st && level == 0) {  // the error measure's window check (the reference asks for `err`)
+      const int ix = (int)floorf(ox - half), iy = (int)floorf(oy - half);
+      if (ix < -win || ix >= cw || iy < -win || iy >= ch) st = false;
+    }
+  }
+  if (lane == 0) {
+    out[p] = make_float2(ox, oy);
+    status[p] = st ? 1 : 0;
+    if (prev_uv) {  // visual_odometry.cpp:303-306: int = float (truncation); untracked corners are skipped by the match loop (:308)
+      prev_uv[2 * p] = st ? (int)pt.x : INT_MIN; prev_uv[2 * p + 1] = (int)pt.y;
+      curr_uv[2 * p] = st ? (int)ox : INT_MIN; curr_uv[2 * p + 1] = st ? (int)oy : 0;
+    }
+  }
+}
+
+__global__ void k_img_no_matches(int* prev_uv, int* curr_uv) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < kImgMaxCorners) { prev_uv[2 * p] = INT_MIN; prev_uv[2 * p + 1] = 0; curr_uv[2 * p] = INT_MIN; curr_uv[2 * p + 1] = 0; }
+}
+
+// ---- host side
+static void pyr_dims(int w, int h, ImgPyrDev* P) {   // buildOpticalFlowPyramid's early stop: the next level must be larger than the window
+  P->w[0] = w; P->h[0] = h; P->levels = 1;
+  for (int l = 0; l < kImgMaxLevel; l++) {
+    const int nw = (P->w[l] + 1) / 2, nh = (P->h[l] + 1) / 2;
+    if (nw <= kImgWin || nh <= kImgWin) break;
+    P->w[l + 1] = nw; P->h[l + 1] = nh; P->levels = l + 2;
+  }
+}
+
+vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
+  c->max_w = cfg.image_width; c->max_h = cfg.image_height;
+  if (c->max_w <= 0 || c->max_h <= 0) { c->max_w = c->max_h = 0; return VLOAM_OK; }
+  const size_t npx = (size_t)c->max_w * c->max_h;
+  bool ok = true;
+  for (int s = 0; s < 2; s++) {
+    ImgPyrDev tmp;
+    pyr_dims(c->max_w, c->max_h, &tmp);
+    for (int l = 0; l < kImgLevels; l++) {
+      const size_t n = l < tmp.levels ? (size_t)tmp.w[l] * tmp.h[l] : 1;
+      ok = ok && A.take(&c->pyr[s].img[l], n) && A.take(&c->pyr[s].deriv[l], n);
+    }
+    ok = ok && A.take(&c->corners[s], kImgMaxCorners) && A.take(&c->n_corners[s], 1);
+  }
+  ok = ok && A.take(&c->sobel, npx) && A.take(&c->eig, npx) && A.take(&c->maxbits, 1) && A.take(&c->cmap, npx) && A.take(&c->clist, kImgCandCap) &&
+       A.take(&c->n_cand, 1) && A.take(&c->nbr, (size_t)kImgCandCap * kImgNbrCap) && A.take(&c->nbr_cnt, kImgCandCap) && A.take(&c->acc, kImgAccCap) &&
+       A.take(&c->tracked, kImgMaxCorners) && A.take(&c->status, kImgMaxCorners) && A.take(&c->error, 1) && A.take(&c->staging, npx);
+  return ok ? VLOAM_OK : VLOAM_ERR_CAPACITY;
+}
+
+vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
+                         ProfHook* ph) {
+  if (c->max_w == 0) return VLOAM_ERR_ORDER;
+  if (width < 2 * kImgWin || height < 2 * kImgWin || (size_t)width * height > (size_t)c->max_w * c->max_h || stride < width) return VLOAM_ERR_INVALID;
+  if (c->count >= 0 && (width != c->w || height != c->h)) return VLOAM_ERR_INVALID;   // one image size per sequence
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_img_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(u64) * kImgAccCap)) != hipSuccess)
+      return VLOAM_ERR_HIP;
+    attr_set = true;
+  }
+  c->w = width; c->h = height;
+  c->count++;
+  const int cur = c->count % 2;
+  ImgPyrDev& P = c->pyr[cur];
+  pyr_dims(width, height, &P);
+  const int npx = width * height, gpx = (npx + 255) / 256;
+  // image_util.cpp:17-31: block_size 5, min_distance 7.5, maxCorners 1024, quality_level 0.03
+  const double quality = 0.03, min_distance = kImgBlock * 1.5;
+  const double scale = 1.0 / (4.0 * (double)kImgBlock * 255.0);
+  const double hs2 = 0.5 * scale * scale;
+  VLOAM_LAUNCH(ph, kKImgSobel, st, k_img_sobel, dim3(gpx), dim3(256), 0, st, d_gray, width, height, stride, c->sobel, P.img[0], c->maxbits, c->n_cand);
+  VLOAM_LAUNCH(ph, kKImgEig, st, k_img_eig, dim3((width + kTileW - 1) / kTileW, (height + kTileH - 1) / kTileH), dim3(kTileW * kTileH), 0, st, c->sobel, width,
+               height, hs2, c->eig, c->maxbits);
+  VLOAM_LAUNCH(ph, kKImgLocalMax, st, k_img_localmax, dim3(gpx), dim3(256), 0, st, c->eig, width, height, c->maxbits, quality, c->cmap, c->clist, c->n_cand,
+               c->error);
+  VLOAM_LAUNCH(ph, kKImgNeighbours, st, k_img_neighbours, dim3(kImgCandCap / 256 / 4), dim3(256), 0, st, c->eig, width, height, c->cmap, c->clist, c->n_cand,
+               (float)(min_distance * min_distance), (int)min_distance, c->nbr, c->nbr_cnt, c->error);
+  VLOAM_LAUNCH(ph, kKImgSelect, st, k_img_select, dim3(1), dim3(kSelThreads), sizeof(u64) * kImgAccCap, st, c->eig, width, c->clist, c->n_cand, c->nbr,
+               c->nbr_cnt, c->acc, kImgMaxCorners, c->corners[cur], c->n_corners[cur], c->error);
+  for (int l = 1; l < P.levels; l++)
+    VLOAM_LAUNCH(ph, kKImgPyrDown, st, k_img_pyrdown, dim3((P.w[l] * P.h[l] + 255) / 256), dim3(256), 0, st, P.img[l - 1], P.w[l - 1], P.h[l - 1], P.img[l],
+                 P.w[l], P.h[l]);
+  for (int l = 0; l < P.levels; l++)
+    VLOAM_LAUNCH(ph, kKImgScharr, st, k_img_scharr, dim3((P.w[l] * P.h[l] + 255) / 256), dim3(256), 0, st, P.img[l], P.w[l], P.h[l], P.deriv[l]);
+  if (c->count > 0) {
+    const double eps = 0.03;   // image_util.cpp:362 TermCriteria(COUNT + EPS, 10, 0.03); calcOpticalFlowPyrLK squares epsilon
+    VLOAM_LAUNCH(ph, kKImgLk, st, k_img_lk, dim3(kImgMaxCorners / 4), dim3(256), 0, st, c->pyr[1 - cur], P, c->corners[cur], c->n_corners[cur], c->tracked,
+                 c->status, prev_uv, curr_uv, eps * eps);
+  } else if (prev_uv) {
+    VL_RAW_LAUNCH(k_img_no_matches, dim3(kImgMaxCorners / 256), dim3(256), 0, st, prev_uv, curr_uv);
+  }
+  return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+static vloam_status img_copy_out(const void* d, size_t bytes, void* buf, long long cap, long long* n) {
+  if (n) *n = (long long)bytes;
+  if (!buf) return VLOAM_OK;
+  const size_t m = (size_t)cap < bytes ? (size_t)cap : bytes;
+  return hipMemcpy(buf, d, m, hipMemcpyDeviceToHost) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+// items: 0 eig map, 1 + l pyramid level l of the last image, 4 + l its derivative level l, 8 candidate count, 9 error bits
+vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n) {
+  if (c->max_w == 0 || c->count < 0) return VLOAM_ERR_ORDER;
+  const ImgPyrDev& P = c->pyr[c->count % 2];
+  if (item == 0) return img_copy_out(c->eig, sizeof(float) * (size_t)c->w * c->h, buf, cap, n);
+  if (item >= 1 && item <= 3) { const int l = item - 1; if (l >= P.levels) return VLOAM_ERR_INVALID; return img_copy_out(P.img[l], (size_t)P.w[l] * P.h[l], buf, cap, n); }
+  if (item >= 4 && item <= 6) { const int l = item - 4; if (l >= P.levels) return VLOAM_ERR_INVALID; return img_copy_out(P.deriv[l], sizeof(short2) * (size_t)P.w[l] * P.h[l], buf, cap, n); }
+  if (item == 8) return img_copy_out(c->n_cand, sizeof(int), buf, cap, n);
+  if (item == 9) return img_copy_out(c->error, sizeof(int), buf, cap, n);
+  return VLOAM_ERR_INVALID;
+}
+
+}  // namespace vloam

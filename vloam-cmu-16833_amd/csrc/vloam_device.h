@@ -54,12 +54,14 @@ constexpr int kMaxLoFactors = kMaxSharp + kMaxFlat;                         // 2
 enum KernelId : int {
   kKNone = 0, kKSrFirstLast, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
   kKMapPrepare, kKMapStack, kKMapAssoc, kKMapInsert, kKMapFinalize, kKVoProject, kKVoMatch,
-  kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsRank, kKMapDsScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig, kKCount
+  kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsRank, kKMapDsScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig,
+  kKImgSobel, kKImgEig, kKImgLocalMax, kKImgNeighbours, kKImgSelect, kKImgPyrDown, kKImgScharr, kKImgLk, kKCount
 };
 static const char* const kKernelNames[kKCount] = {"", "k_sr_first_last", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
   "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_ds_count", "k_map_assoc", "k_map_insert",
   "k_map_finalize", "k_vo_project", "k_vo_match", "k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter", "k_map_ds_rank",
-  "k_map_ds_scatter", "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier"};
+  "k_map_ds_scatter", "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier",
+  "k_img_sobel", "k_img_eig", "k_img_localmax", "k_img_neighbours", "k_img_select", "k_img_pyrdown", "k_img_scharr", "k_img_lk"};
 constexpr int kKAll = -1;  // ProfHook::id: bracket every launch, whichever kernel
 
 // Records a HIP-event pair around every launch of one selected kernel (or of all kernels), on the stream it is launched on.

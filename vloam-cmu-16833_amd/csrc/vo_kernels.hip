@@ -8,6 +8,7 @@
 //   (k_lm_solve)         Huber(0.1), DENSE_QR-equivalent LM, <= 100 iterations on (angle-axis, t) (VO:67-68,423)
 // "PCU" = /root/reference/src/visual_odometry/src/point_cloud_util.cpp, "VO" = .../visual_odometry.cpp.
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 #include "lm_solve.h"
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_u
   if (j < n_match) {
     const int px = prev_uv[2 * j], py = prev_uv[2 * j + 1], cx = curr_uv[2 * j], cy = curr_uv[2 * j + 1];
     const long long d2 = (long long)(px - cx) * (px - cx) + (long long)(py - cy) * (py - cy);
-    if (!(remove_outlier > 0 && d2 > (long long)remove_outlier * remove_outlier)) {  // VO:309-314
+    // px == INT_MIN: an entry of the image front-end without a tracked corner (optical_flow_status != 1: `continue`, VO:308)
+    if (px != INT_MIN && !(remove_outlier > 0 && d2 > (long long)remove_outlier * remove_outlier)) {  // VO:309-314
       float K[9];
       for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) K[r * 3 + q] = c->P_rect0[r * 4 + q];
       depth0 = query_depth(Mprev, (float)px, (float)py);  // VO:316 (depth1 is computed but unused in the reference)

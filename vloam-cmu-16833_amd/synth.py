@@ -290,3 +290,54 @@ def synth_matches(seq, k, n_match=1400, pixel_noise=0.5, seed=99):
     a = uv0[idx] + rng.normal(0, pixel_noise, (idx.size, 2))
     b = uv1[idx] + rng.normal(0, pixel_noise, (idx.size, 2))
     return a.astype(np.float32).astype(np.int32), b.astype(np.float32).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------------- images (config 4 front-end)
+def synth_texture(w, h, seed=7, octaves=(96, 48, 24, 12, 6)):
+    """Smooth random texture, float64 [h, w] in [0, 255]: multi-octave value noise (bilinear) plus a few hard-edged rectangles —
+    smooth enough for Lucas-Kanade, cornered enough for Shi-Tomasi."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64)
+    img = np.zeros((h, w))
+    amp = 1.0
+    for cs in octaves:
+        g = rng.random((h // cs + 3, w // cs + 3))
+        fy, fx = ys / cs, xs / cs
+        iy, ix = fy.astype(int), fx.astype(int)
+        ty, tx = (fy - iy)[:, None], (fx - ix)[None, :]
+        a = g[iy][:, ix]; b = g[iy][:, ix + 1]; c = g[iy + 1][:, ix]; d = g[iy + 1][:, ix + 1]
+        img += amp * ((a * (1 - tx) + b * tx) * (1 - ty) + (c * (1 - tx) + d * tx) * ty)
+        amp *= 0.6
+    for _ in range(max(8, w * h // 700)):
+        x0, y0 = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8))
+        ww, hh = int(rng.integers(5, 28)), int(rng.integers(5, 22))
+        img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(0.25, 0.5) * (1 if rng.random() < 0.5 else -1)
+    img -= img.min()
+    return img * (255.0 / img.max())
+
+
+def warp_image(canvas, w, h, A, t):
+    """uint8 [h, w] view of a float canvas: pixel (x, y) shows canvas at A @ (x, y) + t (bilinear), i.e. content moves by the inverse."""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    sx = A[0, 0] * xs + A[0, 1] * ys + t[0]
+    sy = A[1, 0] * xs + A[1, 1] * ys + t[1]
+    sx = np.clip(sx, 0, canvas.shape[1] - 1.001); sy = np.clip(sy, 0, canvas.shape[0] - 1.001)
+    ix, iy = sx.astype(int), sy.astype(int)
+    tx, ty = sx - ix, sy - iy
+    v = (canvas[iy, ix] * (1 - tx) + canvas[iy, ix + 1] * tx) * (1 - ty) + (canvas[iy + 1, ix] * (1 - tx) + canvas[iy + 1, ix + 1] * tx) * ty
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def synth_image_pair(w=1242, h=375, seed=7, shift=(3.6, -1.3), rot=0.004, scale=1.003):
+    """(prev, next, flow function): two uint8 views of one texture; a point at (x, y) in prev appears at flow(x, y) in next."""
+    m = 64
+    canvas = synth_texture(w + 2 * m, h + 2 * m, seed)
+    I2 = np.eye(2)
+    prev = warp_image(canvas, w, h, I2, (m, m))
+    c, s = np.cos(rot) * scale, np.sin(rot) * scale
+    B = np.array([[c, -s], [s, c]])                     # next(x) = canvas(B x + tb)  ->  prev point p shows at B^-1 (p + m - tb)
+    tb = np.array([m - shift[0], m - shift[1]]) - (B - I2) @ np.array([w / 2, h / 2])
+    nxt = warp_image(canvas, w, h, B, tb)
+    Binv = np.linalg.inv(B)
+    flow = lambda p: (np.asarray(p, dtype=np.float64) + m - tb) @ Binv.T   # noqa: E731
+    return prev, nxt, flow
