@@ -157,6 +157,21 @@ class VloamOracle:
         self.count += 1
         return rc
 
+    def process_image(self, cloud, gray):
+        """One callback() from raw inputs with optical_flow_match = true: VisualOdometry::processImage (visual_odometry.cpp:91-132) —
+        corners of the new image, tracked from the previous image into the new one — then the match loop's integer pairs."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        corners = orc.good_features(gray)                                  # image_util.cpp:13-36
+        prev_uv = curr_uv = None
+        self.flow = None
+        if self.count > 0:
+            tracked, status = orc.pyr_lk(self.prev_image, gray, corners)   # image_util.cpp:351-372 (prev image, new image, NEW corners)
+            prev_uv, curr_uv = orc.flow_matches(corners, tracked, status)   # visual_odometry.cpp:296-308
+            self.flow = (corners, tracked, status)
+        self.prev_image = gray
+        self.keypoints = corners
+        return self.process(cloud, prev_uv, curr_uv)
+
     def VO2VeloAndBase(self, cam0_curr_VOT_cam0_last):     # vloam_tf.cpp:59-75
         inv = cam0_curr_VOT_cam0_last.inverse()
         self.velo_last_VOT_velo_curr = self.velo_T_cam0 * inv * self.velo_T_cam0.inverse()

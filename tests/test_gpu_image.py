@@ -67,3 +67,49 @@ def test_image_frontend_edge_cases(vl, orc):
         h3.vo_process_image(flat)
     assert e.value.status == vl.ERR_ORDER
     h3.close()
+
+
+@pytest.mark.gpu
+def test_coupled_frame_loop_from_raw_images(vl, synth):
+    """configs[3] from raw inputs: every frame hands a sweep AND a grey image to vloam_process_frame_image; corners, flow, depth map,
+    VO solve, VO -> LO prior, scan registration, odometry, LO -> VO prior and mapping all stay on the device.  Same frames through
+    the oracle (image restatement + coupled pipeline): matches identical, poses <= 1e-8."""
+    from test_gpu_laser_odometry import qdist
+    from test_gpu_vloam import make
+    nframes, W, H = 7, 1242, 375
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=1024, n_sweeps=nframes + 1)
+    h, o = make(vl, synth, detach=False, with_mapping=1, image_width=W, image_height=H)
+    frames = [(seq.sweep(k), synth.render_image(seq, k, W, H)) for k in range(nframes)]
+    for k in range(nframes):
+        cloud, img = frames[k]
+        h.process_frame_image(cloud, img)
+        assert o.process_image(cloud, img) == 0
+        assert np.array_equal(h.vo_keypoints(), o.keypoints)
+        if k > 0:
+            a, b, st = h.vo_flow()
+            assert np.array_equal(a, o.flow[0]) and np.array_equal(b, o.flow[1]) and np.array_equal(st, o.flow[2])
+            r, v = h.vo_result(), o.vo_result
+            assert (r["counter32"], r["counter22"]) == (v["counter32"], v["counter22"]) and r["counter32"] + r["counter22"] > 100
+            tol = 2e-7 if k == 1 else 1e-8
+            assert np.linalg.norm(r["angles"] - v["angles"]) < tol and np.linalg.norm(r["t"] - v["t"]) < tol, "VO estimate, frame %d" % k
+        tol = 1e-6 if k == 1 else 1e-8 * (k + 1)
+        tj = h.trajectory()[k]
+        qw, tw, _, _ = o.lidar.lo_pose()
+        qm, tm = o.lidar.map_published_pose()
+        assert qdist(tj[0:4], qw) < tol and np.linalg.norm(tj[4:7] - tw) < tol, "LO world pose, frame %d" % k
+        assert qdist(tj[7:11], qm) < tol and np.linalg.norm(tj[11:14] - tm) < tol, "map pose, frame %d" % k
+        vq, vt = o.vo_world_pose()
+        vj = h.vo_trajectory()[k]
+        assert qdist(vj[0:4], vq) < tol and np.linalg.norm(vj[4:7] - vt) < tol, "world_VOT_base_last, frame %d" % k
+    # the VO chain built from tracked image corners follows the LiDAR chain (geometry-consistent images)
+    assert np.linalg.norm(h.vo_trajectory()[nframes - 1][4:7] - h.trajectory()[nframes - 1][4:7]) < 0.6
+    # the same frames streamed without reading anything back in between give the same trajectory
+    h2, _ = make(vl, synth, detach=False, with_mapping=1, image_width=W, image_height=H)
+    for k in range(nframes):
+        cloud, img = frames[k][0].copy(), np.pad(frames[k][1], ((0, 0), (0, 38)))   # padded rows (stride != width); buffers die right after the call
+        h2.L.vloam_process_frame_image(h2.h, cloud.ctypes.data_as(vl.C.c_void_p), cloud.shape[0], img.ctypes.data_as(vl.C.c_void_p), W, H, img.shape[1])
+        cloud[:] = 0; img[:] = 0
+        del cloud, img
+    h2.sync()
+    assert np.array_equal(h2.trajectory(), h.trajectory()) and np.array_equal(h2.vo_trajectory(), h.vo_trajectory())
+    h.close(); h2.close()

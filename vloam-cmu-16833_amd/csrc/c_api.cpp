@@ -87,6 +87,7 @@ struct vloam_handle {
   bool vo_frame[kSets] = {};        // the sweep in set c came through vloam_process_frame (its odometry is preceded by the VO solve)
   bool have_extrinsics = false;
   ImgContext img;
+  std::vector<unsigned char> img_pack;   // host scratch: a padded image packed to width-stride rows
   hipEvent_t ev_img[kSets] = {};    // the image-derived matches of the frame in set c are in HBM
   bool img_frame[kSets] = {};
   LoGrid grid[kSets];          // per set: NN grid over that sweep's lessSharp / lessFlat
@@ -699,6 +700,20 @@ vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16],
 // cam0_curr_LOT_cam0_prev, on the device), VO2VeloAndBase (-> velo_last_VOT_velo_curr, read by solveLO when detach_VO_LO == 0),
 // scanRegistrationIO, laserOdometryIO (publish() refreshes cam0_curr_LOT_cam0_prev), laserMappingIO.
 // prev_uv / curr_uv: n_match integer pixel pairs in HOST memory (previous frame -> this frame; ignored for the first frame).
+// Host image -> the device staging buffer, on the image stream.  hipMemcpyAsync from pageable memory has taken its copy of the source when
+// it returns; hipMemcpy2DAsync has NOT (measured: tools/microbench/pageable_async_copy.py) — so a padded image is packed on the host
+// first, and the caller may reuse its buffer as soon as the call is back either way.
+static vloam_status upload_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride) {
+  const unsigned char* src = gray;
+  if (stride != width) {
+    h->img_pack.resize((size_t)width * height);
+    for (int y = 0; y < height; y++) memcpy(h->img_pack.data() + (size_t)y * width, gray + (size_t)y * stride, (size_t)width);
+    src = h->img_pack.data();
+  }
+  HIPCHK(hipMemcpyAsync(h->img.staging, src, (size_t)width * height, hipMemcpyHostToDevice, h->s_img));
+  return VLOAM_OK;
+}
+
 static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match,
                                          const unsigned char* d_gray, int width, int height, int stride) {
   SINGLE_SESSION_ONLY(h);
@@ -763,7 +778,7 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpy2DAsync(h->img.staging, (size_t)width, gray, (size_t)stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, h->s_img));
+  { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
   return process_frame_common(h, h->d_in, n, nullptr, nullptr, 0, h->img.staging, width, height, width);
 }
 
@@ -783,7 +798,7 @@ vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, 
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpy2DAsync(h->img.staging, (size_t)width, gray, (size_t)stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, h->s_img));
+  { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
   return vloam_vo_process_image_device(h, h->img.staging, width, height, width);
 }
 

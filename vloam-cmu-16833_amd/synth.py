@@ -265,6 +265,121 @@ def kitti_like_extrinsics():
     return base_T_imu @ imu_T_cam0, np.linalg.inv(imu_T_velo) @ imu_T_cam0
 
 
+def _hash01(ix, iy, seed):
+    """Integer lattice -> [0, 1): a fixed 64-bit mix (the same values on every machine)."""
+    h = (ix.astype(np.int64).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (iy.astype(np.int64).astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ \
+        np.uint64((seed * 0x165667B19E3779F9) & 0xFFFFFFFFFFFFFFFF)
+    h ^= h >> np.uint64(29); h *= np.uint64(0xBF58476D1CE4E5B9); h ^= h >> np.uint64(32)
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def _value_noise(u, v, cell, seed):
+    fu, fv = u / cell, v / cell
+    iu, iv = np.floor(fu), np.floor(fv)
+    tu, tv = fu - iu, fv - iv
+    tu, tv = tu * tu * (3 - 2 * tu), tv * tv * (3 - 2 * tv)
+    iu, iv = iu.astype(np.int64), iv.astype(np.int64)
+    a, b = _hash01(iu, iv, seed), _hash01(iu + 1, iv, seed)
+    c, d = _hash01(iu, iv + 1, seed), _hash01(iu + 1, iv + 1, seed)
+    return (a * (1 - tu) + b * tu) * (1 - tv) + (c * (1 - tu) + d * tu) * tv
+
+
+def render_image(seq, k, width=1242, height=375):
+    """uint8 [height, width] grey image of sweep k's scene through the camera of kitti_like_calib(): the same ground / boxes / cylinders the
+    LiDAR sees, with a procedural surface texture (value noise in surface coordinates, octaves faded out below the pixel footprint) —
+    so that corners tracked between two frames move the way the geometry says."""
+    cam_T_velo, _, P = kitti_like_calib()
+    K = P[:, :3].astype(np.float64)
+    Tcv = cam_T_velo.astype(np.float64)
+    Rcv, tcv = Tcv[:3, :3], Tcv[:3, 3]
+    R, o = seq.pose(k)
+    us, vs = np.meshgrid(np.arange(width, dtype=np.float64) * (1242.0 / width) + 0.5 * (1242.0 / width - 1), np.arange(height, dtype=np.float64) * (375.0 / height) + 0.5 * (375.0 / height - 1))
+    dc = np.stack([(us - K[0, 2]) / K[0, 0], (vs - K[1, 2]) / K[1, 1], np.ones_like(us)], -1).reshape(-1, 3)
+    dc /= np.linalg.norm(dc, axis=1, keepdims=True)
+    dw = (dc @ Rcv) @ R.T                      # cam -> velo (Rcv^T d) -> world (R d)
+    ow = o + R @ (-Rcv.T @ tcv)
+    n = dw.shape[0]
+    best = np.full(n, np.inf)
+    tu, tv = np.zeros(n), np.zeros(n)          # texture coordinates of the hit
+    shade = np.zeros(n)
+    sid = np.zeros(n, dtype=np.int64)          # texture seed per surface
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dw
+        tg = (GROUND_Z - ow[2]) / dw[:, 2]
+    hit = (dw[:, 2] < 0) & (tg > 0) & (tg < 2.0 * MAX_RANGE)
+    best = np.where(hit, tg, best)
+    pg = ow[None, :] + tg[:, None] * dw
+    tu, tv = np.where(hit, pg[:, 0], tu), np.where(hit, pg[:, 1], tv)
+    shade = np.where(hit, 0.55, shade)
+    bx = seq.boxes
+    cen = 0.5 * (bx[:, :2] + bx[:, 3:5])
+    fwd = (R @ np.array([1.0, 0, 0]))[:2]
+    rel = cen - ow[None, :2]
+    near = (np.linalg.norm(rel, axis=1) < MAX_RANGE + 10.0) & (rel @ fwd > -12.0)
+    for bi in np.nonzero(near)[0]:
+        b = bx[bi]
+        t1 = (b[None, 0:3] - ow[None, :]) * inv
+        t2 = (b[None, 3:6] - ow[None, :]) * inv
+        tlo = np.minimum(t1, t2)
+        tmin = np.nanmax(tlo, axis=1)
+        tmax = np.nanmin(np.maximum(t1, t2), axis=1)
+        h = (tmax >= tmin) & (tmin > 0) & (tmin < best)
+        if not h.any():
+            continue
+        ax = np.nanargmax(tlo[h], axis=1)       # entry face
+        ph = ow[None, :] + tmin[h, None] * dw[h]
+        best[h] = tmin[h]
+        tu[h] = np.where(ax == 0, ph[:, 1], ph[:, 0])
+        tv[h] = np.where(ax == 2, ph[:, 1], ph[:, 2])
+        shade[h] = np.where(ax == 0, 0.85, np.where(ax == 1, 0.7, 1.0))
+        sid[h] = 1 + 3 * bi + ax
+    cy = seq.cyls
+    rel = cy[:, :2] - ow[None, :2]
+    near = (np.linalg.norm(rel, axis=1) < 60.0) & (rel @ fwd > -3.0)
+    for ci in np.nonzero(near)[0]:
+        c = cy[ci]
+        ox, oy = ow[0] - c[0], ow[1] - c[1]
+        a = dw[:, 0] ** 2 + dw[:, 1] ** 2
+        bq = 2 * (ox * dw[:, 0] + oy * dw[:, 1])
+        cq = ox * ox + oy * oy - c[2] ** 2
+        disc = bq * bq - 4 * a * cq
+        with np.errstate(invalid="ignore", divide="ignore"):
+            tc = (-bq - np.sqrt(disc)) / (2 * a)
+        zc = ow[2] + tc * dw[:, 2]
+        h = (disc > 0) & (tc > 0) & (zc >= c[3]) & (zc <= c[4]) & (tc < best)
+        if not h.any():
+            continue
+        ph = ow[None, :] + tc[h, None] * dw[h]
+        best[h] = tc[h]
+        tu[h] = np.arctan2(ph[:, 1] - c[1], ph[:, 0] - c[0]) * c[2]
+        tv[h] = ph[:, 2]
+        shade[h] = 0.9
+        sid[h] = 100000 + ci
+    ok = np.isfinite(best)
+    foot = np.where(ok, best, 1.0) / K[0, 0] * (1242.0 / width)     # metres per pixel at the hit
+    val = np.zeros(n)
+    wsum = np.zeros(n)
+    amp = 1.0
+    for cell in (3.0, 1.1, 0.4, 0.15):
+        wgt = amp * np.clip((cell / np.maximum(foot, 1e-9) - 3.0) / 3.0, 0.0, 1.0)   # an octave needs >= 3 pixels per cell, full weight from 6
+        if wgt.max() > 0:
+            val += wgt * _value_noise(tu, tv, cell, 17)
+            wsum += wgt
+        amp *= 0.7
+    tex = np.where(wsum > 0, val / np.maximum(wsum, 1e-9), 0.5)
+    # hard-edged tiles (constant per cell): their junctions are the corners Shi-Tomasi finds; faded out like the noise octaves
+    for cell, a_t in ((1.3, 0.5), (0.45, 0.35)):
+        wgt = np.clip((cell / np.maximum(foot, 1e-9) - 4.0) / 4.0, 0.0, 1.0)
+        tile = _hash01(np.floor(tu / cell), np.floor(tv / cell), 23)
+        tex = tex + a_t * wgt * (tile - 0.5)
+    # per-surface brightness offset: edges between faces / objects are corners too
+    base = 0.25 + 0.5 * _hash01(sid, sid * 0 + 3, 5)
+    g = np.where(ok, shade * (0.45 * base + 0.75 * tex), 0.0)
+    sky = 0.75 + 0.2 * (vs.reshape(-1) / 375.0)
+    g = np.where(ok, g, sky)
+    return np.clip(np.rint(255.0 * g / 1.3), 0, 255).astype(np.uint8).reshape(height, width)
+
+
 def synth_matches(seq, k, n_match=1400, pixel_noise=0.5, seed=99):
     """Pixel pairs (prev frame k-1 -> current frame k) of scene points visible in both images, standing in for the
     OpenCV front-end (out of scope): integer (truncated) pixel coordinates like visual_odometry.cpp:283-294."""
