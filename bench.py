@@ -141,6 +141,23 @@ def _sweep_worker(k):
     return _SEQ.sweep(k)
 
 
+_SYNTH = None
+
+
+def _image_worker(k):
+    return _SYNTH.render_image(_SEQ, k)
+
+
+def make_images(synth, frames, procs):
+    """Grey camera images of the given sweeps of the sequence make_sweeps built (same worker-process rule: before HIP loads)."""
+    global _SYNTH
+    _SYNTH = synth
+    if procs > 1 and len(frames) > 1:
+        with mp.get_context("fork").Pool(min(procs, len(frames))) as pool:
+            return np.stack(pool.map(_image_worker, list(frames), chunksize=1))
+    return np.stack([_image_worker(k) for k in frames])
+
+
 def make_sweeps(synth, n_total, rings, azimuth, seeds, procs):
     """The synthetic sequence's first n_total sweeps, ray-cast in parallel worker processes (forked BEFORE the HIP runtime loads)."""
     global _SEQ
@@ -200,6 +217,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the HIP-event replay (per-kernel table + roofline kernel; for profiler runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (latency, configs[1], multi-session, VO stage)")
     ap.add_argument("--vo-frames", type=int, default=20, help="extra leg: frames of the coupled VLOAM loop (configs[3] analogue) to time (0 = skip)")
+    ap.add_argument("--image-frames", type=int, default=24, help="extra leg: frames of the coupled loop driven from raw images (rendered on the host before the GPU work starts; 0 = skip)")
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
                     help="extra leg: batched execution, this many independent sequences per launch chain on ONE GPU (vloam_create_batch); 0 = skip")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
@@ -223,6 +241,8 @@ def main():
     procs = args.synth_procs or max(1, min(cores // max(world, 1), 16))
     g0 = time.perf_counter()
     seq, host = make_sweeps(synth, T, args.rings, args.azimuth, multi.rank_sequence_seeds(rank), procs)
+    n_img = 0 if (args.no_extras or args.rings != 64 or world != 1) else min(max(args.image_frames, 0), T - 1)
+    images = make_images(synth, range(T - n_img, T), procs) if n_img >= 2 else None
     synth_s = time.perf_counter() - g0
     n_pts = host.shape[1]
 
@@ -415,6 +435,63 @@ def main():
                     "note": "the VO solve of frame k needs the LiDAR odometry of frame k-1 and feeds the one of frame k: VO and LO are one serial chain per frame (mapping still overlaps)"}
         hv.close()
 
+
+    # ---- extra: the same coupled loop from RAW inputs — every frame hands over the sweep and a grey camera image; corners
+    # (Shi-Tomasi) and their pyramidal Lucas-Kanade flow are computed on the device and feed the VO solve directly
+    # (vloam_process_frame_image_device; the reference's optical_flow_match = true configuration, visual_odometry.cpp:91-132)
+    img_stage = None
+    if extras and images is not None:
+        import orc as _orc
+        ni, IH, IW = images.shape
+        d_img = torch.from_numpy(images).cuda()
+        hi = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8, detach_VO_LO=0,
+                       image_width=IW, image_height=IH)
+        hi.vo_set_calib(*synth.kitti_like_calib())
+        hi.set_extrinsics(*synth.kitti_like_extrinsics())
+        f0 = T - ni
+        stream(hi, 0, f0)                           # LiDAR-only up to the map's steady state ...
+        hi.process_frame_image_device(base_ptr + f0 * stride, n_pts, d_img.data_ptr(), IW, IH)   # ... the first image only primes corners / pyramid / depth map
+        hi.sync()
+        i0 = time.perf_counter()
+        for j in range(1, ni):
+            hi.process_frame_image_device(base_ptr + (f0 + j) * stride, n_pts, d_img.data_ptr() + j * IW * IH, IW, IH)
+        hi.sync()
+        i1 = time.perf_counter()
+        r = hi.vo_result()
+        ncorn = int(hi.vo_keypoints().shape[0])
+        hi.close()
+        # the image front-end alone, images resident in HBM, and its per-kernel table
+        hf = vl.Handle(local_rank, with_mapping=0, image_width=IW, image_height=IH)
+        for j in range(2 * ni):
+            hf.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
+        hf.sync()
+        reps = 25 * ni
+        a0 = time.perf_counter()
+        for j in range(reps):
+            hf.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
+        hf.sync()
+        a1 = time.perf_counter()
+        hf.profile_kernel("*", 16384)
+        for j in range(4 * ni):
+            hf.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
+        itab = hf.profile_table()
+        hf.close()
+        # CPU restatement beside it (oracle: cv::goodFeaturesToTrack + cv::calcOpticalFlowPyrLK restated, single thread)
+        c0 = time.perf_counter()
+        for j in range(1, min(ni, 4)):
+            cc = _orc.good_features(images[j])
+            _orc.pyr_lk(images[j - 1], images[j], cc)
+        c1 = time.perf_counter()
+        img_stage = {"workload": "configs[3] analogue from raw inputs: vloam_process_frame_image_device (sweep + %d x %d grey image per frame; corners + pyramidal LK flow + "
+                                 "depth-enhanced VO + LiDAR odometry + mapping, all on the device)" % (IW, IH),
+                     "value": (ni - 1) / (i1 - i0), "unit": "frames/s", "ms_per_frame": 1e3 * (i1 - i0) / (ni - 1), "frames": ni - 1, "corners_last": ncorn,
+                     "counter32_last": r["counter32"], "counter22_last": r["counter22"],
+                     "image_front_end_alone": {"value": reps / (a1 - a0), "unit": "images/s", "us_per_image": 1e6 * (a1 - a0) / reps,
+                                               "kernels_us": {k: round(1e3 * ms / n, 2) for k, (ms, n) in sorted(itab.items(), key=lambda kv: -kv[1][0])},
+                                               "algorithmic_bytes_per_image": int(IW * IH * (1 + 1.33 + 4 * 1.33) + 2 * 1024 * 8),
+                                               "cpu_oracle_ms_per_image": 1e3 * (c1 - c0) / max(min(ni, 4) - 1, 1)},
+                     "note": "images are synthetic renders of the LiDAR scene (synth.render_image); ORB + brute-force matching (optical_flow_match = false) is not provided"}
+
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)
         assert len(trajectories) == world and all(t.shape == (T, 14) for t in trajectories)
@@ -459,6 +536,8 @@ def main():
             out["configs1"] = configs1
         if vo_stage:
             out["configs3"] = vo_stage
+        if img_stage:
+            out["configs3_from_images"] = img_stage
         if batched:
             bt = batched.pop("kernel_table")
             if bt:   # roofline of the same kernel when B sessions share its launches: B x the algorithmic bytes per launch

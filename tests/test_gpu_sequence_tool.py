@@ -67,3 +67,21 @@ def test_run_sequence_coupled_frames_and_metrics(tmp_path):
     assert r2.returncode == 0, r2.stdout + r2.stderr
     rows2 = [json.loads(l) for l in open(tmp_path / "f2.jsonl")]
     assert len(rows2) == 3 and rows2[2]["stage_ms"]["laserOdometry"] > 0
+
+
+@pytest.mark.gpu
+def test_run_sequence_from_rendered_images(tmp_path):
+    """--vloam --images: every frame's pixel matches come from a rendered grey image through the device image front-end."""
+    import json
+    out = tmp_path / "res"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_sequence.py"), "--synthetic", "4", "--azimuth", "512", "--vloam", "--images",
+                        "--metrics", str(tmp_path / "frames.jsonl"), "--out", str(out), "--mapping-skip-frame", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kio = importlib.import_module("vloam_amd.kitti_io")
+    vo, lo = [kio.read_trajectory(out / ("%s0.txt" % k)) for k in ("VO", "LO")]
+    assert vo.shape == lo.shape == (4, 4, 4)
+    rows = [json.loads(l) for l in open(tmp_path / "frames.jsonl")]
+    assert rows[0]["image"]["keypoints"] > 100 and rows[0]["image"]["tracked"] == 0
+    assert rows[3]["image"]["tracked"] > 0.8 * rows[3]["image"]["keypoints"] and rows[3]["vo"]["counter32"] + rows[3]["vo"]["counter22"] > 100
+    assert np.linalg.norm(lo[3, :3, 3]) > 2.0 and np.linalg.norm(vo[3, :3, 3] - lo[3, :3, 3]) < 0.5   # 3 m of travel; VO (from image flow) follows LO

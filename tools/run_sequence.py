@@ -7,7 +7,10 @@ LO0.txt / MO0.txt in the reference's results format — the part of vloam_main_n
   python tools/run_sequence.py --synthetic 50 --out /tmp/res        # needs an MI355X either way
   python tools/run_sequence.py --synthetic 50 --vloam --metrics /tmp/res/frames.jsonl --out /tmp/res
       --vloam:   the coupled per-frame loop (vloam_process_frame: VO solve -> LO prior -> SR -> LO -> VO prior -> mapping, combined mode)
-                 on synthetic pixel matches (the image front-end is out of scope), also writes VO0.txt
+                 on synthetic pixel matches, also writes VO0.txt
+      --images:  with --vloam: the matches come from grey camera images instead (vloam_process_frame_image: Shi-Tomasi corners +
+                 pyramidal Lucas-Kanade on the device, the reference's optical_flow_match = true); the synthetic sequence's images are
+                 rendered from the same scene (synth.render_image)
       --metrics: one JSON object per frame — the reference prints these through ROS_INFO / TicToc: feature counts
                  (scan_registration.cpp), correspondences and solver iterations (laser_odometry.cpp:453-465, laser_mapping.cpp:606-618),
                  per-stage milliseconds
@@ -42,6 +45,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--mapping-skip-frame", type=int, default=2)
     ap.add_argument("--vloam", action="store_true", help="coupled VO + LiDAR frames (synthetic sequences only: synthetic pixel matches)")
+    ap.add_argument("--images", action="store_true", help="with --vloam: take the pixel matches from grey images (device image front-end)")
     ap.add_argument("--metrics", help="write per-frame metrics as JSON lines to this file")
     ap.add_argument("--imu-T-velo", help="16 numbers, row major (default: KITTI 2011_09_26 extrinsics, approx.)")
     ap.add_argument("--imu-T-cam0", help="16 numbers, row major")
@@ -71,8 +75,10 @@ def main():
 
     if a.vloam and a.velodyne:
         sys.exit("--vloam needs pixel matches: only available for --synthetic sequences (the image front-end is out of scope)")
+    if a.images and not a.vloam:
+        sys.exit("--images belongs to the coupled loop: add --vloam")
     loam = vl.LidarOdometryMapping(device=a.device, mapping_skip_frame=a.mapping_skip_frame, detach_VO_LO=0 if a.vloam else 1,
-                                   timing=1 if (a.metrics and not a.vloam) else 0)
+                                   timing=1 if (a.metrics and not a.vloam) else 0, **(dict(image_width=1242, image_height=375) if a.images else {}))
     hd = loam.hd
     if a.vloam:
         hd.vo_set_calib(*synth.kitti_like_calib())
@@ -83,8 +89,11 @@ def main():
     ms_prev = np.zeros(4)
     for count, cloud in enumerate(clouds):
         if a.vloam:
-            m = synth.synth_matches(seq, count) if count > 0 else (None, None)
-            hd.process_frame(cloud, m[0], m[1])
+            if a.images:
+                hd.process_frame_image(cloud, synth.render_image(seq, count))
+            else:
+                m = synth.synth_matches(seq, count) if count > 0 else (None, None)
+                hd.process_frame(cloud, m[0], m[1])
             row = hd.trajectory(count, 1)[0]
             q_lo, t_lo, q_mo, t_mo = row[0:4], row[4:7], row[7:11], row[11:14]
             v = hd.vo_trajectory(count, 1)[0]
@@ -113,6 +122,8 @@ def main():
                 rv = hd.vo_result()
                 rec["vo"] = {"counter32": rv["counter32"], "counter22": rv["counter22"], "angles_0to1": [float(x) for x in rv["angles"]],
                              "t_0to1": [float(x) for x in rv["t"]]}
+            if a.images:
+                rec["image"] = {"keypoints": int(hd.vo_keypoints().shape[0]), "tracked": int(hd.vo_flow_matches()[0].shape[0])}
             if not a.vloam:
                 ms, _ = hd.stage_ms()
                 rec["stage_ms"] = {"scanRegistration": float(ms[0] - ms_prev[0]), "laserOdometry": float(ms[1] - ms_prev[1]),

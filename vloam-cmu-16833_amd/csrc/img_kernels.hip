@@ -5,7 +5,7 @@
 //   k_img_sobel       1 thread / pixel     Sobel 3x3 (ints) of the 8-bit image + contiguous copy = pyramid level 0
 //   k_img_eig         32 x 8 tiles         5 x 5 box sums of the gradient products through LDS, min eigenvalue (f64 -> f32), global max
 //   k_img_localmax    1 thread / pixel     quality threshold + 3 x 3 non-maximum suppression -> candidate list + pixel -> candidate map
-//   k_img_neighbours  1 thread / candidate the stronger candidates closer than minDistance (what the greedy pass can be blocked by)
+//   k_img_neighbours  1 wavefront / cand.  the stronger candidates closer than minDistance (what the greedy pass can be blocked by)
 //   k_img_select      1 workgroup          the greedy minDistance pass as a fixed point over "blocked by an accepted stronger
 //                                          neighbour" (order-free: the result equals the sorted sequential pass), then the
 //                                          (strength, address)-sorted cut at maxCorners through an LDS bitonic network
@@ -113,34 +113,46 @@ __global__ __launch_bounds__(256) void k_img_localmax(const float* __restrict__ 
   cmap[idx] = c;
 }
 
+// one wavefront per candidate: the (2R + 1)^2 positions of its neighbourhood spread over the lanes (one round trip for the candidate
+// map, one for the strengths), the stronger candidates appended through a ballot prefix
 __global__ __launch_bounds__(256) void k_img_neighbours(const float* __restrict__ eig, int w, int h, const int* __restrict__ cmap,
                                                         const int* __restrict__ clist, const int* __restrict__ n_cand, float md2, int R,
                                                         int* __restrict__ nbr, unsigned char* __restrict__ nbr_cnt, int* err) {
   const int n = min(*n_cand, kImgCandCap);
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  const int side = 2 * R + 1, npos = side * side;
+  for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n; c += gridDim.x * 4) {
     const int p = clist[c];
     const int y = p / w, x = p - y * w;
     const float v = eig[p];
     int cnt = 0;
-    for (int dy = -R; dy <= R; dy++) {
-      const int yy = y + dy;
-      if (yy < 0 || yy >= h) continue;
-      for (int dx = -R; dx <= R; dx++) {
-        const int xx = x + dx;
-        if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
-        if (!((float)(dx * dx + dy * dy) < md2)) continue;        // featureselect.cpp: dx*dx + dy*dy < minDistance^2
-        const int q = yy * w + xx;
-        const int cq = cmap[q];
-        if (cq < 0) continue;
-        const float vq = eig[q];
-        if (vq > v || (vq == v && q > p)) {   // sorted ahead of this candidate (greaterThanPtr: value, then the larger address)
-          if (cnt < kImgNbrCap) nbr[(size_t)c * kImgNbrCap + cnt] = cq;
-          cnt++;
+    for (int base = 0; base < npos; base += 64) {
+      const int pos = base + lane;
+      int cq = -1, q = 0;
+      if (pos < npos) {
+        const int dy = pos / side - R, dx = pos - (pos / side) * side - R;
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w && (dx != 0 || dy != 0) && (float)(dx * dx + dy * dy) < md2) {   // featureselect.cpp: dx*dx + dy*dy < minDistance^2
+          q = yy * w + xx;
+          cq = cmap[q];
         }
       }
+      bool stronger = false;
+      if (cq >= 0) {
+        const float vq = eig[q];
+        stronger = vq > v || (vq == v && q > p);   // sorted ahead of this candidate (greaterThanPtr: value, then the larger address)
+      }
+      const unsigned long long m = __ballot(stronger);
+      if (stronger) {
+        const int k = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < kImgNbrCap) nbr[(size_t)c * kImgNbrCap + k] = cq;
+      }
+      cnt += __popcll(m);
     }
-    if (cnt > kImgNbrCap) { atomicOr(err, kErrImgNeighbours); cnt = kImgNbrCap; }
-    nbr_cnt[c] = (unsigned char)cnt;
+    if (lane == 0) {
+      if (cnt > kImgNbrCap) { atomicOr(err, kErrImgNeighbours); cnt = kImgNbrCap; }
+      nbr_cnt[c] = (unsigned char)cnt;
+    }
   }
 }
 
@@ -207,8 +219,13 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
           if (desc ? a < b : a > b) { keys[t] = b; keys[l] = a; }
         }
       }
-      __syncthreads();
+      // a stride below 64 pairs elements of one 64-element block, i.e. of one wavefront (element t belongs to lane t % 64 of wavefront
+      // (t / 64) % 16): only the wide strides, and the step into one, need the workgroup barrier
+      const int next_j = j > 1 ? j >> 1 : k;
+      if (j >= 64 || next_j >= 64) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
     }
+  __syncthreads();
   const int nout = max_corners > 0 ? min(nacc, max_corners) : nacc;
   for (int t = tid; t < nout && t < kImgMaxCorners; t += kSelThreads) {
     const int p = (int)(keys[t] & 0xffffffffu);
@@ -249,9 +266,25 @@ __global__ __launch_bounds__(256) void k_img_scharr(const unsigned char* __restr
   deriv[idx] = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {  // exact integers below 2^53: the order of the adds does not matter
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+// Wavefront-wide integer sum through DPP row operations (no LDS crossbar): quad swaps, row rotations, then the row_bcast15 /
+// row_bcast31 carries of gfx9; the total lands in lane 63 and is broadcast.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_step(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);  // lanes without a source add 0
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v = dpp_add_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add_step<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_add_step<0x128, 0xf>(v);  // row_ror:8   -> every lane holds the sum of its row of 16
+  v = dpp_add_step<0x142, 0xa>(v);  // row_bcast15 -> rows 1 and 3 take in the row below
+  v = dpp_add_step<0x143, 0xc>(v);  // row_bcast31 -> rows 2 and 3 take in lane 31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// exact wavefront sum of per-lane integers below 2^31 in magnitude: low 16 bits and the (signed) rest are summed separately
+__device__ __forceinline__ long long wave_sum_exact(long long v) {
+  const int lo = (int)(v & 0xffff), hi = (int)(v >> 16);
+  return ((long long)wave_sum_i32(hi) << 16) + (long long)wave_sum_i32(lo);
 }
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }   // CV_DESCALE
 
@@ -300,7 +333,7 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
     int iw10 = (int)rintf((1.f - a) * b * (1 << W_BITS));
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
     int Iw[kQ], Ix[kQ], Iy[kQ];
-    double sA11 = 0.0, sA12 = 0.0, sA22 = 0.0;
+    long long sA11 = 0, sA12 = 0, sA22 = 0;   // per lane: 4 products of two 13-bit values
 #pragma unroll
     for (int q = 0; q < kQ; q++) {
       const int wi = q * 64 + lane;
@@ -317,10 +350,10 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
         const short2 d10 = (bx0 && by1) ? dI[(size_t)(Y + 1) * cw + X] : z, d11 = (bx1 && by1) ? dI[(size_t)(Y + 1) * cw + X + 1] : z;
         Ix[q] = descale((int)d00.x * iw00 + (int)d01.x * iw01 + (int)d10.x * iw10 + (int)d11.x * iw11, W_BITS);
         Iy[q] = descale((int)d00.y * iw00 + (int)d01.y * iw01 + (int)d10.y * iw10 + (int)d11.y * iw11, W_BITS);
-        sA11 += (double)Ix[q] * (double)Ix[q]; sA12 += (double)Ix[q] * (double)Iy[q]; sA22 += (double)Iy[q] * (double)Iy[q];
+        sA11 += (long long)(Ix[q] * Ix[q]); sA12 += (long long)(Ix[q] * Iy[q]); sA22 += (long long)(Iy[q] * Iy[q]);
       }
     }
-    sA11 = wave_sum_f64(sA11); sA12 = wave_sum_f64(sA12); sA22 = wave_sum_f64(sA22);
+    sA11 = wave_sum_exact(sA11); sA12 = wave_sum_exact(sA12); sA22 = wave_sum_exact(sA22);
     const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
       iw01 = (int)rintf(a * (1.f - b) * (1 << W_BITS));
       iw10 = (int)rintf((1.f - a) * b * (1 << W_BITS));
       iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-      double sb1 = 0.0, sb2 = 0.0;
+      long long sb1 = 0, sb2 = 0;
 #pragma unroll
       for (int q = 0; q < kQ; q++) {
         const int wi = q * 64 + lane;
@@ -351,11 +384,11 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
           const int x0 = reflect101(inx + wx, cw), x1 = reflect101(inx + wx + 1, cw), y0 = reflect101(iny + wy, ch), y1 = reflect101(iny + wy + 1, ch);
           const int diff = descale((int)J[(size_t)y0 * cw + x0] * iw00 + (int)J[(size_t)y0 * cw + x1] * iw01 + (int)J[(size_t)y1 * cw + x0] * iw10 +
                                    (int)J[(size_t)y1 * cw + x1] * iw11, W_BITS - 5) - Iw[q];
-          sb1 += (double)diff * (double)Ix[q];
-          sb2 += (double)diff * (double)Iy[q];
+          sb1 += (long long)(diff * Ix[q]);
+          sb2 += (long long)(diff * Iy[q]);
         }
       }
-      sb1 = wave_sum_f64(sb1); sb2 = wave_sum_f64(sb2);
+      sb1 = wave_sum_exact(sb1); sb2 = wave_sum_exact(sb2);
       const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       const float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
       nx += ddx; ny += ddy;
@@ -444,7 +477,7 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
                height, hs2, c->eig, c->maxbits);
   VLOAM_LAUNCH(ph, kKImgLocalMax, st, k_img_localmax, dim3(gpx), dim3(256), 0, st, c->eig, width, height, c->maxbits, quality, c->cmap, c->clist, c->n_cand,
                c->error);
-  VLOAM_LAUNCH(ph, kKImgNeighbours, st, k_img_neighbours, dim3(kImgCandCap / 256 / 4), dim3(256), 0, st, c->eig, width, height, c->cmap, c->clist, c->n_cand,
+  VLOAM_LAUNCH(ph, kKImgNeighbours, st, k_img_neighbours, dim3(1024), dim3(256), 0, st, c->eig, width, height, c->cmap, c->clist, c->n_cand,
                (float)(min_distance * min_distance), (int)min_distance, c->nbr, c->nbr_cnt, c->error);
   VLOAM_LAUNCH(ph, kKImgSelect, st, k_img_select, dim3(1), dim3(kSelThreads), sizeof(u64) * kImgAccCap, st, c->eig, width, c->clist, c->n_cand, c->nbr,
                c->nbr_cnt, c->acc, kImgMaxCorners, c->corners[cur], c->n_corners[cur], c->error);
