@@ -92,7 +92,29 @@ def run_vloam_case(n_rings, n_az, n_frames):
     return out
 
 
+def run_image_case(w, h, n_images, seed):
+    """Image front-end (optical-flow configuration): n_images views of one texture, corners of every image and the flow of image k's
+    corners from image k - 1 into image k (visual_odometry.cpp:91-132)."""
+    synth = conftest.load_synth()
+    canvas = synth.synth_texture(w + 128, h + 128, seed)
+    out = {}
+    prev = None
+    for k in range(n_images):
+        c, s = np.cos(0.004 * k) * (1 + 0.002 * k), np.sin(0.004 * k) * (1 + 0.002 * k)
+        B = np.array([[c, -s], [s, c]])
+        img = synth.warp_image(canvas, w, h, B, np.array([64 - 3.1 * k, 64 + 1.2 * k]) - (B - np.eye(2)) @ np.array([w / 2, h / 2]))
+        out["img_%d" % k] = img
+        corners = orc.good_features(img)
+        out["corners_%d" % k] = corners
+        if prev is not None:
+            tracked, status = orc.pyr_lk(prev, img, corners)
+            out["tracked_%d" % k], out["status_%d" % k] = tracked, status
+        prev = img
+    return out
+
+
 if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "image_320x96_3frames.npz"), **run_image_case(320, 96, 3, seed=21))
     vl4 = run_vloam_case(64, 256, 5)
     np.savez_compressed(os.path.join(HERE, "vloam_64x256_5frames.npz"), **vl4)
     small = run_case(64, 256, 3, store_inputs=True)

@@ -95,3 +95,18 @@ def test_golden_coupled_vloam_frames(vl):
         assert qdist(tj[0:4], gq[0:4]) < tolp and np.linalg.norm(tj[4:7] - gq[4:7]) < tolp
         assert qdist(tj[7:11], gq[7:11]) < tolp and np.linalg.norm(tj[11:14] - gq[11:14]) < tolp
         assert qdist(vj[0:4], gq[14:18]) < tolp and np.linalg.norm(vj[4:7] - gq[18:21]) < tolp
+
+
+def test_golden_image_front_end(vl):
+    """The HIP image front-end reproduces the committed corners / flow of tests/golden/image_320x96_3frames.npz bit for bit."""
+    g = np.load(os.path.join(HERE, "golden", "image_320x96_3frames.npz"))
+    h = vl.Handle(0, with_mapping=0, image_width=320, image_height=96)
+    for k in range(3):
+        h.vo_process_image(g["img_%d" % k])
+        assert np.array_equal(h.vo_keypoints(), g["corners_%d" % k])
+        a, b, st = h.vo_flow()
+        if k == 0:
+            assert a.shape[0] == 0
+        else:
+            assert np.array_equal(a, g["corners_%d" % k]) and np.array_equal(b, g["tracked_%d" % k]) and np.array_equal(st, g["status_%d" % k])
+    h.close()

@@ -72,3 +72,171 @@ def test_pyr_lk_recovers_a_known_warp(orc, synth):
     pu, cu = orc.flow_matches(c, out, st)
     assert pu.dtype == np.int32 and pu.shape == cu.shape and pu.shape[0] == int(st.sum())
     assert np.array_equal(pu, c[st == 1].astype(np.int32)) and np.all(np.abs(cu - out[st == 1]) < 1.0)
+
+
+# ---- a second, independent transcription in numpy (array formulation, written from OpenCV's algorithm description, not from
+# oracle/orc_img.cpp) must reproduce the C++ restatement exactly
+def _np_good_features(img, max_corners=1024, quality=0.03, min_distance=7.5, block=5):
+    from scipy.ndimage import maximum_filter
+    a = np.pad(img.astype(np.int64), 1, mode="reflect")                      # BORDER_REFLECT_101
+    dx = (a[:-2, 2:] - a[:-2, :-2]) + 2 * (a[1:-1, 2:] - a[1:-1, :-2]) + (a[2:, 2:] - a[2:, :-2])
+    dy = (a[2:, :-2] - a[:-2, :-2]) + 2 * (a[2:, 1:-1] - a[:-2, 1:-1]) + (a[2:, 2:] - a[:-2, 2:])
+    r = block // 2
+
+    def box(p):
+        q = np.pad(p, r, mode="reflect")
+        c = np.cumsum(np.cumsum(np.pad(q, ((1, 0), (1, 0))), axis=0), axis=1)   # exact integers
+        return c[block:, block:] - c[:-block, block:] - c[block:, :-block] + c[:-block, :-block]
+    sxx, sxy, syy = box(dx * dx), box(dx * dy), box(dy * dy)
+    scale = 1.0 / (4.0 * block * 255.0)
+    d = sxx - syy
+    eig = (((sxx + syy).astype(np.float64) - np.sqrt((d * d + 4 * sxy * sxy).astype(np.float64))) * (0.5 * scale * scale)).astype(np.float32)
+    thr = np.float32(np.float64(max(eig.max(), np.float32(0))) * quality)
+    tz = np.where(eig > thr, eig, np.float32(0))
+    dil = maximum_filter(tz, size=3, mode="constant", cval=0.0)
+    ok = (tz != 0) & (tz == dil)
+    ok[0, :] = ok[-1, :] = False
+    ok[:, 0] = ok[:, -1] = False
+    ys, xs = np.nonzero(ok)
+    addr = ys * img.shape[1] + xs
+    order = np.lexsort((-addr, -eig[ys, xs].astype(np.float64)))            # value descending, then the larger address first
+    out = []
+    md2 = np.float32(min_distance * min_distance)
+    for j in order:
+        x, y = int(xs[j]), int(ys[j])
+        if all((np.float32(x - u) * np.float32(x - u) + np.float32(y - v) * np.float32(y - v)) >= md2 for u, v in out):
+            out.append((x, y))
+            if len(out) == max_corners:
+                break
+    return np.array(out, dtype=np.float32).reshape(-1, 2), eig
+
+
+def test_good_features_vs_numpy_transcription(orc, synth):
+    for (w, h, seed) in ((320, 96, 4), (401, 131, 9)):
+        img, _, _ = synth.synth_image_pair(w, h, seed=seed)
+        c, eig = orc.good_features(img, want_eig=True)
+        c_np, eig_np = _np_good_features(img)
+        assert np.array_equal(eig, eig_np)
+        assert np.array_equal(c, c_np)
+
+
+def _np_pyr_down(a):
+    k = np.array([1, 4, 6, 4, 1], dtype=np.int64)
+    h, w = a.shape
+    nh, nw = (h + 1) // 2, (w + 1) // 2
+    p = np.pad(a.astype(np.int64), 2, mode="reflect")
+    if p.shape[0] < 2 * nh + 3:
+        p = np.pad(p, ((0, 2 * nh + 3 - p.shape[0]), (0, 0)), mode="reflect")
+    if p.shape[1] < 2 * nw + 3:
+        p = np.pad(p, ((0, 0), (0, 2 * nw + 3 - p.shape[1])), mode="reflect")
+    rows = sum(k[i] * p[:, i:i + 2 * nw:2] for i in range(5))
+    full = sum(k[j] * rows[j:j + 2 * nh:2, :] for j in range(5))
+    return ((full + 128) >> 8).astype(np.uint8)
+
+
+def _np_scharr(a):
+    p = np.pad(a.astype(np.int64), 1, mode="reflect")
+    t0 = 3 * (p[:-2] + p[2:]) + 10 * p[1:-1]          # vertical smoothing, all columns incl. the padded ones
+    t1 = p[2:] - p[:-2]
+    ix = t0[:, 2:] - t0[:, :-2]
+    iy = 3 * (t1[:, 2:] + t1[:, :-2]) + 10 * t1[:, 1:-1]
+    return np.stack([ix, iy], -1).astype(np.int16)
+
+
+def _np_lk_point(I, J, dI, pt, guess, level, top, win=15):
+    """One point on one level (lkpyramid.cpp LKTrackerInvoker).  Returns (next point, lost_at_this_level)."""
+    h, w = I.shape
+    half = np.float32((win - 1) * 0.5)
+    f32 = np.float32
+    inv = f32(1.0 / (1 << level))
+    px, py = f32(pt[0]) * inv, f32(pt[1]) * inv
+    nx, ny = (px, py) if level == top else (f32(guess[0]) * f32(2), f32(guess[1]) * f32(2))
+    out = (nx, ny)
+    px, py = px - half, py - half
+    ipx, ipy = int(np.floor(px)), int(np.floor(py))
+    if ipx < -win or ipx >= w or ipy < -win or ipy >= h:
+        return out, True
+    R = win                                               # REFLECT_101 border of winSize pixels; zero border for the derivatives
+    Ip = np.pad(I.astype(np.int64), R + 1, mode="reflect")
+    Jp = np.pad(J.astype(np.int64), R + 1, mode="reflect")
+    Dp = np.pad(dI.astype(np.int64), ((R + 1, R + 1), (R + 1, R + 1), (0, 0)))
+
+    def weights(a, b):
+        one = f32(1)
+        w00 = int(np.rint((one - a) * (one - b) * f32(16384)))
+        w01 = int(np.rint(a * (one - b) * f32(16384)))
+        w10 = int(np.rint((one - a) * b * f32(16384)))
+        return w00, w01, w10, 16384 - w00 - w01 - w10
+
+    def interp(P, x0, y0, ws, n):
+        s = P[y0 + R + 1:y0 + R + 1 + win, x0 + R + 1:x0 + R + 1 + win] * ws[0] + P[y0 + R + 1:y0 + R + 1 + win, x0 + R + 2:x0 + R + 2 + win] * ws[1] + \
+            P[y0 + R + 2:y0 + R + 2 + win, x0 + R + 1:x0 + R + 1 + win] * ws[2] + P[y0 + R + 2:y0 + R + 2 + win, x0 + R + 2:x0 + R + 2 + win] * ws[3]
+        return (s + (1 << (n - 1))) >> n
+    ws = weights(px - f32(ipx), py - f32(ipy))
+    Iw = interp(Ip, ipx, ipy, ws, 9)
+    Ix = interp(Dp[:, :, 0], ipx, ipy, ws, 14)
+    Iy = interp(Dp[:, :, 1], ipx, ipy, ws, 14)
+    sc = f32(1.0 / (1 << 20))
+    A11, A12, A22 = f32(int((Ix * Ix).sum())) * sc, f32(int((Ix * Iy).sum())) * sc, f32(int((Iy * Iy).sum())) * sc
+    D = A11 * A22 - A12 * A12
+    min_eig = (A22 + A11 - np.sqrt((A11 - A22) * (A11 - A22) + f32(4) * A12 * A12)) / f32(2 * win * win)
+    if float(min_eig) < 1e-4 or D < np.finfo(np.float32).eps:
+        return out, True
+    D = f32(1) / D
+    nx, ny = nx - half, ny - half
+    pdx = pdy = f32(0)
+    lost = False
+    for j in range(10):
+        inx, iny = int(np.floor(nx)), int(np.floor(ny))
+        if inx < -win or inx >= w or iny < -win or iny >= h:
+            lost = True
+            break
+        ws = weights(nx - f32(inx), ny - f32(iny))
+        diff = interp(Jp, inx, iny, ws, 9) - Iw
+        b1, b2 = f32(int((diff * Ix).sum())) * sc, f32(int((diff * Iy).sum())) * sc
+        ddx, ddy = (A12 * b2 - A22 * b1) * D, (A12 * b1 - A11 * b2) * D
+        nx, ny = nx + ddx, ny + ddy
+        out = (nx + half, ny + half)
+        if float(ddx) * float(ddx) + float(ddy) * float(ddy) <= 0.03 * 0.03:
+            break
+        if j > 0 and abs(float(ddx + pdx)) < 0.01 and abs(float(ddy + pdy)) < 0.01:
+            out = (out[0] - ddx * f32(0.5), out[1] - ddy * f32(0.5))
+            break
+        pdx, pdy = ddx, ddy
+    if not lost and level == 0:
+        ix, iy = int(np.floor(out[0] - half)), int(np.floor(out[1] - half))
+        lost = ix < -win or ix >= w or iy < -win or iy >= h
+    return out, lost
+
+
+def test_pyramid_and_lk_vs_numpy_transcription(orc, synth):
+    prev, nxt, _ = synth.synth_image_pair(320, 96, seed=6, shift=(6.4, -2.8), rot=0.01, scale=1.006)
+    lv = orc.pyramid_levels(prev)
+    P, N = [prev], [nxt]
+    for _ in range(2):
+        P.append(_np_pyr_down(P[-1])); N.append(_np_pyr_down(N[-1]))
+    for l in range(3):
+        assert np.array_equal(lv[l][0], P[l]) and np.array_equal(lv[l][1], _np_scharr(P[l]))
+    c = orc.good_features(nxt)
+    extra = np.array([[1.5, 2.25], [318.0, 94.0], [160.3, 0.2], [0.0, 50.0]], dtype=np.float32)   # windows hanging over every border
+    pts = np.concatenate([c[:60], extra])
+    out, st = orc.pyr_lk(prev, nxt, pts)
+    for i, p in enumerate(pts):
+        g, lost0 = (0, 0), False
+        for level in (2, 1, 0):
+            g, lost = _np_lk_point(P[level], N[level], _np_scharr(P[level]), p, g, level, 2)
+            lost0 = lost if level == 0 else lost0
+        assert np.float32(g[0]) == out[i, 0] and np.float32(g[1]) == out[i, 1], (i, p, g, out[i])
+        assert int(not lost0) == int(st[i]), (i, p)
+
+
+def test_golden_image_fixture(orc):
+    """tests/golden/image_320x96_3frames.npz (tests/golden/make_golden.py): the oracle still reproduces its committed outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image_320x96_3frames.npz"))
+    for k in range(3):
+        c = orc.good_features(g["img_%d" % k])
+        assert np.array_equal(c, g["corners_%d" % k])
+        if k > 0:
+            t, s = orc.pyr_lk(g["img_%d" % (k - 1)], g["img_%d" % k], c)
+            assert np.array_equal(t, g["tracked_%d" % k]) and np.array_equal(s, g["status_%d" % k])
