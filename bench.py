@@ -489,6 +489,10 @@ def main():
                      "image_front_end_alone": {"value": reps / (a1 - a0), "unit": "images/s", "us_per_image": 1e6 * (a1 - a0) / reps,
                                                "kernels_us": {k: round(1e3 * ms / n, 2) for k, (ms, n) in sorted(itab.items(), key=lambda kv: -kv[1][0])},
                                                "algorithmic_bytes_per_image": int(IW * IH * (1 + 1.33 + 4 * 1.33) + 2 * 1024 * 8),
+                                               "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                            "achieved": IW * IH * (1 + 1.33 + 4 * 1.33) / ((a1 - a0) / reps) / 1e9,
+                                                            "frac": IW * IH * (1 + 1.33 + 4 * 1.33) / ((a1 - a0) / reps) / 1e9 / HBM_PEAK_GBS,
+                                                            "bytes": "the image once, its 8-bit pyramid (x1.33) and the int16 Scharr pairs of every level (4 B x 1.33) once"},
                                                "cpu_oracle_ms_per_image": 1e3 * (c1 - c0) / max(min(ni, 4) - 1, 1)},
                      "note": "images are synthetic renders of the LiDAR scene (synth.render_image); ORB + brute-force matching (optical_flow_match = false) is not provided"}
 
