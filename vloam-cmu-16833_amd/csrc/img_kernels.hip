@@ -12,7 +12,8 @@
 //   k_img_pyrdown     1 thread / pixel     cv::pyrDown
 //   k_img_scharr      1 thread / pixel     calcSharrDeriv
 //   k_img_lk          1 wavefront / corner pyramidal Lucas-Kanade, all levels in one launch; the 15 x 15 window lives in registers
-//                                          (4 pixels per lane), the 2 x 2 system in exact integer sums
+//                                          (4 pixels per lane), the search patch of the next image in LDS, the 2 x 2 system in exact
+//                                          integer sums (DPP row reductions)
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <float.h>
@@ -294,6 +295,12 @@ __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1)
 __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const float2* __restrict__ pts, const int* __restrict__ n_pts,
                                                 float2* __restrict__ out, unsigned char* __restrict__ status, int* __restrict__ prev_uv,
                                                 int* __restrict__ curr_uv, double eps2) {
+  // The search region of the NEXT image, staged once per level in LDS: the window moves by fractions of a pixel per iteration, so
+  // the ten iterations read the same 32 x 32 patch (window + 8 pixels of slack all round) instead of making ten dependent trips to
+  // L2; a window that walks out of the patch reloads it.  Border pixels are reflected when the patch is loaded.
+  constexpr int kPS = 32, kSlack = (kPS - (kImgWin + 1)) / 2;
+  __shared__ unsigned char s_patch[4][kPS][kPS + 4];
+  unsigned char (*patch)[kPS + 4] = s_patch[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= kImgMaxCorners) return;
   if (p >= *n_pts) {
@@ -364,11 +371,26 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
     D = 1.f / D;
     nx -= half; ny -= half;
     float pdx = 0.f, pdy = 0.f;
+    int pox = INT_MIN, poy = 0;   // top-left corner of the staged patch (this level's image)
     for (int j = 0; j < kImgLkIters; j++) {
       const int inx = (int)floorf(nx), iny = (int)floorf(ny);
       if (inx < -win || inx >= cw || iny < -win || iny >= ch) {
         if (level == 0) st = false;
         break;
+      }
+      if (pox == INT_MIN || inx < pox || inx > pox + kPS - (win + 1) || iny < poy || iny > poy + kPS - (win + 1)) {   // wavefront-uniform
+        pox = inx - kSlack; poy = iny - kSlack;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();          // earlier reads of the old patch are done
+        const int row = lane >> 1, c0 = (lane & 1) * (kPS / 2);
+        const unsigned char* src = J + (size_t)reflect101(poy + row, ch) * cw;
+        unsigned char v[kPS / 2];
+#pragma unroll
+        for (int i = 0; i < kPS / 2; i++) v[i] = src[reflect101(pox + c0 + i, cw)];
+#pragma unroll
+        for (int i = 0; i < kPS / 2; i++) patch[row][c0 + i] = v[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
       }
       a = nx - inx; b = ny - iny;
       iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << W_BITS));
@@ -381,9 +403,9 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
         const int wi = q * 64 + lane;
         if (wi < win * win) {
           const int wy = wi / win, wx = wi - wy * win;
-          const int x0 = reflect101(inx + wx, cw), x1 = reflect101(inx + wx + 1, cw), y0 = reflect101(iny + wy, ch), y1 = reflect101(iny + wy + 1, ch);
-          const int diff = descale((int)J[(size_t)y0 * cw + x0] * iw00 + (int)J[(size_t)y0 * cw + x1] * iw01 + (int)J[(size_t)y1 * cw + x0] * iw10 +
-                                   (int)J[(size_t)y1 * cw + x1] * iw11, W_BITS - 5) - Iw[q];
+          const int lx = inx - pox + wx, ly = iny - poy + wy;
+          const int diff = descale((int)patch[ly][lx] * iw00 + (int)patch[ly][lx + 1] * iw01 + (int)patch[ly + 1][lx] * iw10 +
+                                   (int)patch[ly + 1][lx + 1] * iw11, W_BITS - 5) - Iw[q];
           sb1 += (long long)(diff * Ix[q]);
           sb2 += (long long)(diff * Iy[q]);
         }
