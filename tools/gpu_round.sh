@@ -16,6 +16,11 @@ for W in map lo; do
   python tools/rocprof_summary.py $DB $OUT/kernel_stats_$W.txt "bench.py --workload $W ($TAG)" | head -34
   python tools/timeline.py $OUT/prof_$W > $OUT/timeline_$W.txt 2>&1; head -60 $OUT/timeline_$W.txt
 done
+# image front-end alone: per-kernel stats of tools/image_probe.py
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_image -- python $GRAFT_REPO_ROOT/tools/image_probe.py --no-table > $OUT/prof_image.log 2>&1)
+DB=$(find $OUT/prof_image -name '*.db' | head -1)
+python tools/rocprof_summary.py $DB $OUT/kernel_stats_image.txt "tools/image_probe.py --no-table ($TAG)" | head -16
+timeout 200 python tools/image_probe.py > $OUT/image_probe.txt 2>&1; grep -v amdgpu.ids $OUT/image_probe.txt | head -24
 if [ -n "$PMC" ] && [ "$PMC" != "-" ]; then
   for W in map; do
     for CTR in FETCH_SIZE WRITE_SIZE; do
