@@ -113,3 +113,22 @@ def test_coupled_frame_loop_from_raw_images(vl, synth):
     h2.sync()
     assert np.array_equal(h2.trajectory(), h.trajectory()) and np.array_equal(h2.vo_trajectory(), h.vo_trajectory())
     h.close(); h2.close()
+
+
+@pytest.mark.gpu
+def test_image_frontend_capacity_is_reported(vl, orc):
+    """More 3 x 3 local maxima above the quality threshold than the candidate list holds: VLOAM_ERR_CAPACITY, not a silent cut."""
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, size=(1024, 2048), dtype=np.uint8)
+    assert orc.good_features(noise, max_corners=0).shape[0] > 0          # the oracle itself has no such limit
+    h = vl.Handle(0, with_mapping=0, image_width=2048, image_height=1024)
+    h.vo_process_image(noise)
+    with pytest.raises(vl.VloamError) as e:
+        h.vo_keypoints()
+    assert e.value.status == vl.ERR_CAPACITY and "candidates" in str(e.value)
+    h.close()
+    # the same texture at a size whose candidates fit is processed normally (and equals the oracle)
+    h = vl.Handle(0, with_mapping=0, image_width=512, image_height=256)
+    h.vo_process_image(noise[:256, :512])
+    assert np.array_equal(h.vo_keypoints(), orc.good_features(noise[:256, :512]))
+    h.close()
