@@ -75,3 +75,43 @@ def test_tf_algebra_and_rows(vl, tmp_path):
     with open(gold) as f:
         for line, T in zip(f, ref):
             assert k.format_pose_row(T) == line
+
+
+def test_png_gray_reader_all_row_filters(tmp_path):
+    """load_png_gray against a PNG whose rows use all five filter types (None, Sub, Up, Average, Paeth), encoded here."""
+    import importlib
+    import struct
+    import zlib
+    import conftest
+    conftest.load_pkg()
+    kio = importlib.import_module("vloam_amd.kitti_io")
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(23, 41), dtype=np.uint8)
+    rows = []
+    prev = np.zeros(41, dtype=np.int64)
+    for y in range(23):
+        cur = img[y].astype(np.int64)
+        left = np.concatenate([[0], cur[:-1]])
+        ul = np.concatenate([[0], prev[:-1]])
+        f = y % 5
+        if f == 0:
+            enc = cur
+        elif f == 1:
+            enc = cur - left
+        elif f == 2:
+            enc = cur - prev
+        elif f == 3:
+            enc = cur - ((left + prev) >> 1)
+        else:
+            pa, pb, pc = np.abs(prev - ul), np.abs(left - ul), np.abs(left + prev - 2 * ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            enc = cur - pred
+        rows.append(bytes([f]) + (enc & 255).astype(np.uint8).tobytes())
+        prev = cur
+    ch = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)   # noqa: E731
+    raw = zlib.compress(b"".join(rows))
+    path = tmp_path / "f.png"
+    path.write_bytes(b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", 41, 23, 8, 0, 0, 0, 0)) + ch(b"IDAT", raw[:50]) + ch(b"IDAT", raw[50:]) + ch(b"IEND", b""))
+    assert np.array_equal(kio.load_png_gray(path), img)
+    kio.save_png_gray(tmp_path / "g.png", img)
+    assert np.array_equal(kio.load_png_gray(tmp_path / "g.png"), img)

@@ -10,7 +10,10 @@ LO0.txt / MO0.txt in the reference's results format — the part of vloam_main_n
                  on synthetic pixel matches, also writes VO0.txt
       --images:  with --vloam: the matches come from grey camera images instead (vloam_process_frame_image: Shi-Tomasi corners +
                  pyramidal Lucas-Kanade on the device, the reference's optical_flow_match = true); the synthetic sequence's images are
-                 rendered from the same scene (synth.render_image)
+                 rendered from the same scene (synth.render_image).  Real data: --velodyne DIR --image-dir .../image_00/data
+                 --calib-cam-to-cam calib_cam_to_cam.txt --calib-velo-to-cam calib_velo_to_cam.txt (KITTI raw layout, 8-bit grey PNGs)
+  python tools/run_sequence.py --vloam --images --velodyne DRIVE/velodyne_points/data --image-dir DRIVE/image_00/data \
+      --calib-cam-to-cam CALIB/calib_cam_to_cam.txt --calib-velo-to-cam CALIB/calib_velo_to_cam.txt --out results/
       --metrics: one JSON object per frame — the reference prints these through ROS_INFO / TicToc: feature counts
                  (scan_registration.cpp), correspondences and solver iterations (laser_odometry.cpp:453-465, laser_mapping.cpp:606-618),
                  per-stage milliseconds
@@ -46,6 +49,9 @@ def main():
     ap.add_argument("--mapping-skip-frame", type=int, default=2)
     ap.add_argument("--vloam", action="store_true", help="coupled VO + LiDAR frames (synthetic sequences only: synthetic pixel matches)")
     ap.add_argument("--images", action="store_true", help="with --vloam: take the pixel matches from grey images (device image front-end)")
+    ap.add_argument("--image-dir", help="directory of 8-bit grey PNGs, one per sweep (KITTI raw image_00/data)")
+    ap.add_argument("--calib-cam-to-cam", help="KITTI calib_cam_to_cam.txt (R_rect_00, P_rect_00)")
+    ap.add_argument("--calib-velo-to-cam", help="KITTI calib_velo_to_cam.txt (R, T)")
     ap.add_argument("--metrics", help="write per-frame metrics as JSON lines to this file")
     ap.add_argument("--imu-T-velo", help="16 numbers, row major (default: KITTI 2011_09_26 extrinsics, approx.)")
     ap.add_argument("--imu-T-cam0", help="16 numbers, row major")
@@ -73,15 +79,28 @@ def main():
     imu_T_cam0 = mat(a.imu_T_cam0, kio.make_T([0.5, -0.5, 0.5, -0.5], [1.08, -0.32, 0.72]))
     tf = kio.VloamTF(imu_T_velo, imu_T_cam0)
 
+    real_images = None
     if a.vloam and a.velodyne:
-        sys.exit("--vloam needs pixel matches: only available for --synthetic sequences (the image front-end is out of scope)")
+        if not (a.images and a.image_dir and a.calib_cam_to_cam and a.calib_velo_to_cam):
+            sys.exit("--vloam on recorded sweeps needs --images --image-dir DIR --calib-cam-to-cam FILE --calib-velo-to-cam FILE "
+                     "(the pixel matches come from the images; ORB matching is not provided)")
+        real_images = sorted(glob.glob(os.path.join(a.image_dir, "*.png")))
+        if len(real_images) < n:
+            sys.exit("%d sweeps but only %d images in %s" % (n, len(real_images), a.image_dir))
     if a.images and not a.vloam:
         sys.exit("--images belongs to the coupled loop: add --vloam")
+    img_cfg = {}
+    if a.images:
+        ih, iw = (kio.load_png_gray(real_images[0]).shape if real_images else (375, 1242))
+        img_cfg = dict(image_width=int(iw), image_height=int(ih))
     loam = vl.LidarOdometryMapping(device=a.device, mapping_skip_frame=a.mapping_skip_frame, detach_VO_LO=0 if a.vloam else 1,
-                                   timing=1 if (a.metrics and not a.vloam) else 0, **(dict(image_width=1242, image_height=375) if a.images else {}))
+                                   timing=1 if (a.metrics and not a.vloam) else 0, **img_cfg)
     hd = loam.hd
     if a.vloam:
-        hd.vo_set_calib(*synth.kitti_like_calib())
+        if real_images:   # PointCloudUtil::loadTransformations (point_cloud_util.cpp:5-116)
+            hd.vo_set_calib(*kio.load_transformations(a.calib_cam_to_cam, a.calib_velo_to_cam))
+        else:
+            hd.vo_set_calib(*synth.kitti_like_calib())
         hd.set_extrinsics(tf.base_T_cam0, tf.velo_T_cam0)
     os.makedirs(a.out, exist_ok=True)
     lo_rows, mo_rows, vo_rows = [], [], []
@@ -90,7 +109,7 @@ def main():
     for count, cloud in enumerate(clouds):
         if a.vloam:
             if a.images:
-                hd.process_frame_image(cloud, synth.render_image(seq, count))
+                hd.process_frame_image(cloud, kio.load_png_gray(real_images[count]) if real_images else synth.render_image(seq, count))
             else:
                 m = synth.synth_matches(seq, count) if count > 0 else (None, None)
                 hd.process_frame(cloud, m[0], m[1])

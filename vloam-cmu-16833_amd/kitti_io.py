@@ -29,6 +29,75 @@ def save_kitti_bin(path, cloud, reflectance=None):
     out.tofile(path)
 
 
+# ---------------------------------------------------------------------------------------------- images
+def load_png_gray(path):
+    """8-bit greyscale PNG (KITTI raw image_00 / image_01: colour type 0, bit depth 8, not interlaced) -> uint8 [h, w].
+    A dependency-free reader for exactly that format (zlib + the five PNG row filters); anything else raises."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("%s: not a PNG file" % path)
+    pos, idat, w = 8, [], None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            if depth != 8 or ctype != 0 or interlace != 0:
+                raise ValueError("%s: only 8-bit greyscale, non-interlaced PNGs are read here (got depth %d, colour type %d, interlace %d)" %
+                                 (path, depth, ctype, interlace))
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, w + 1)
+    out = np.zeros((h, w), dtype=np.uint8)
+    prev = np.zeros(w, dtype=np.int64)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int64)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        elif f in (1, 3, 4):   # Sub / Average / Paeth depend on the pixel to the left: sequential
+            cur = np.zeros(w, dtype=np.int64)
+            left = 0
+            up_left = 0
+            for x in range(w):
+                up = int(prev[x])
+                if f == 1:
+                    pred = left
+                elif f == 3:
+                    pred = (left + up) >> 1
+                else:
+                    pa, pb, pc = abs(up - up_left), abs(left - up_left), abs(left + up - 2 * up_left)
+                    pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else up_left)
+                left = (int(line[x]) + pred) & 255
+                cur[x] = left
+                up_left = up
+        else:
+            raise ValueError("%s: bad PNG filter type %d" % (path, f))
+        out[y] = cur
+        prev = cur
+    return out
+
+
+def save_png_gray(path, img):
+    """uint8 [h, w] -> 8-bit greyscale PNG (filter 0 on every row)."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
 # ---------------------------------------------------------------------------------------------- calibration
 def _numbers_after(line, key):
     return [np.float32(v) for v in line[len(key):].split()]
