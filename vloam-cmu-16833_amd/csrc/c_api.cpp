@@ -250,6 +250,7 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
     }
     if (cfg->image_width > 0 && hipStreamCreateWithFlags(&h->s_img, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
+    if (cfg->image_width > 0 && img_init() != hipSuccess) { set_err("img_init failed"); st = VLOAM_ERR_HIP; break; }
     auto body = [&]() -> vloam_status {
       // 1. measure one session, 2. one allocation for all sessions (zeroed), 3. lay session 0 out for real
       Arena dry;

@@ -55,6 +55,7 @@ struct ImgContext {
 
 constexpr int kErrImgCandidates = 1, kErrImgNeighbours = 2, kErrImgAccepted = 4;
 
+hipError_t img_init();   // once per device a handle with an image front-end is created on
 vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // session 0 only (the frame loop is single-session)
 // processImage for the image in d_gray (device, row stride in bytes): pyramid + derivatives, corners, and — from the second image
 // on — the flow of the new corners from the previous image into this one.  prev_uv / curr_uv (device, [kImgMaxCorners][2] ints, may be

@@ -453,6 +453,11 @@ static void pyr_dims(int w, int h, ImgPyrDev* P) {   // buildOpticalFlowPyramid'
   }
 }
 
+// per device (function attributes belong to the device's code object): k_img_select sorts up to kImgAccCap keys in 128 KB of dynamic LDS
+hipError_t img_init() {
+  return hipFuncSetAttribute((const void*)k_img_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(u64) * kImgAccCap));
+}
+
 vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
   c->max_w = cfg.image_width; c->max_h = cfg.image_height;
   if (c->max_w <= 0 || c->max_h <= 0) { c->max_w = c->max_h = 0; return VLOAM_OK; }
@@ -478,12 +483,6 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
   if (c->max_w == 0) return VLOAM_ERR_ORDER;
   if (width < 2 * kImgWin || height < 2 * kImgWin || (size_t)width * height > (size_t)c->max_w * c->max_h || stride < width) return VLOAM_ERR_INVALID;
   if (c->count >= 0 && (width != c->w || height != c->h)) return VLOAM_ERR_INVALID;   // one image size per sequence
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_img_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(u64) * kImgAccCap)) != hipSuccess)
-      return VLOAM_ERR_HIP;
-    attr_set = true;
-  }
   c->w = width; c->h = height;
   c->count++;
   const int cur = c->count % 2;

@@ -704,12 +704,17 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
   const bool lead = NB == 1 || blockIdx.x == 0;  // the workgroup that owns every global side effect other than its factors' residuals
-  if (enable_flag && *enable_flag == 0) {
+  constexpr int na = QUAT ? 7 : 6;
+  // the gate word, the parameters and this lane's first row counter are fetched in ONE round trip (a branch on the gate first would
+  // put a dependent ~1.5 us memory trip in front of everything else the solve reads)
+  const int enabled = enable_flag ? *enable_flag : 1;
+  const double x_first = tid < na ? x_io[tid] : 0.0;
+  const int row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
+  if (enabled == 0) {
     if (lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
     return;
   }
-  constexpr int na = QUAT ? 7 : 6;
-  if (tid < na) { sh.x[tid] = x_io[tid]; sh.x0[tid] = sh.x[tid]; }
+  if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
   if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; }
 
   // ---- prologue: the factors were compacted by k_lm_compact; count them and release the row counters
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   {
     const int nrows = F.cap >> 6;
     int c = 0, ce = 0;
-    for (int r = tid; r < nrows; r += kLmThreads) { const int q = F.rowcnt[r]; c += q; if (r < edge_rows) ce += q; }
+    for (int r = tid; r < nrows; r += kLmThreads) { const int q = r == tid ? row_first : F.rowcnt[r]; c += q; if (r < edge_rows) ce += q; }
     for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d); ce += __shfl_xor(ce, d); }
     if ((tid & 63) == 0) { sh.scan[tid >> 6] = c; sh.scan2[tid >> 6] = ce; }
     __syncthreads();
