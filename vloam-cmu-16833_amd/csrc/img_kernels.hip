@@ -91,10 +91,10 @@ __global__ __launch_bounds__(kTileW * kTileH) void k_img_eig(const short2* __res
 __global__ __launch_bounds__(256) void k_img_localmax(const float* __restrict__ eig, int w, int h, const unsigned* __restrict__ maxbits,
                                                       double quality, int* __restrict__ cmap, int* __restrict__ clist, int* n_cand, int* err) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= w * h) return;
-  const int y = idx / w, x = idx - y * w;
-  int c = -1;
-  if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+  const bool inside = idx < w * h;
+  const int y = inside ? idx / w : 0, x = inside ? idx - y * w : 0;
+  bool is_cand = false;
+  if (inside && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
     const float thr = (float)((double)__uint_as_float(*maxbits) * quality);   // threshold(eig, maxVal * qualityLevel, THRESH_TOZERO)
     const float v = eig[idx];
     if (v > thr) {
@@ -104,14 +104,24 @@ __global__ __launch_bounds__(256) void k_img_localmax(const float* __restrict__ 
       for (int j = -1; j <= 1; j++)
 #pragma unroll
         for (int i = -1; i <= 1; i++) is_max = is_max && !(eig[idx + j * w + i] > v);
-      if (is_max) {
-        c = atomicAdd(n_cand, 1);
-        if (c < kImgCandCap) clist[c] = idx;
-        else { c = -1; atomicOr(err, kErrImgCandidates); }
-      }
+      is_cand = is_max;
     }
   }
-  cmap[idx] = c;
+  // one counter update per wavefront (thousands of single atomics on one word serialise for tens of microseconds)
+  const unsigned long long m = __ballot(is_cand);
+  int c = -1;
+  if (m) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(n_cand, __popcll(m));
+    base = __shfl(base, leader);
+    if (is_cand) {
+      c = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (c < kImgCandCap) clist[c] = idx;
+      else { c = -1; atomicOr(err, kErrImgCandidates); }
+    }
+  }
+  if (inside) cmap[idx] = c;
 }
 
 // one wavefront per candidate: the (2R + 1)^2 positions of its neighbourhood spread over the lanes (one round trip for the candidate
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(256) void k_img_neighbours(const float* __restrict_
 }
 
 constexpr int kSelThreads = 1024;
+static_assert(kImgCandCap <= 65536, "candidate indices travel as 16-bit values in k_img_select");
 __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restrict__ eig, int w, const int* __restrict__ clist,
                                                             const int* __restrict__ n_cand, const int* __restrict__ nbr,
                                                             const unsigned char* __restrict__ nbr_cnt, u64* acc, int max_corners,
@@ -166,6 +177,8 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
   unsigned char* status = smem;          // [kImgCandCap]: 0 undecided, 1 accepted, 2 dropped;   later reused as u64 keys[kImgAccCap]
   __shared__ int s_changed, s_nacc;
   const int tid = threadIdx.x;
+  long long tst[8]; int nst = 0, nsweep = 0;
+  tst[nst++] = clock64();
   const int n = min(*n_cand, kImgCandCap);
   for (int c = tid; c < n; c += kSelThreads) status[c] = 0;
   if (tid == 0) s_nacc = 0;
@@ -173,12 +186,70 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
   // The sequential pass accepts a candidate iff no ACCEPTED candidate sorted ahead of it lies closer than minDistance.  A candidate is
   // therefore decided as soon as one such neighbour is accepted (dropped) or all of them are dropped (accepted): decisions never
   // change, every sweep decides at least the strongest undecided candidate, and any update order reaches the same fixed point.
+  // The lists of a lane's first kFast candidates (tid, tid + 1024, ...) are fetched ONCE, in one round trip, and kept in registers as
+  // 16-bit indices when they have at most kFastN entries: a sweep is then LDS reads between two barriers.  Longer lists and
+  // candidates beyond kFast x 1024 are read from memory in every sweep.
+  constexpr int kFast = 3, kFastN = 16;
+  int f_cnt[kFast];
+  unsigned f_pk[kFast][kFastN / 2];
+#pragma unroll
+  for (int m = 0; m < kFast; m++) {
+    const int c = tid + m * kSelThreads;
+    f_cnt[m] = -1;
+#pragma unroll
+    for (int k = 0; k < kFastN / 2; k++) f_pk[m][k] = 0u;
+    if (c < n) {
+      const int cnt = nbr_cnt[c];
+      const int4* row = reinterpret_cast<const int4*>(nbr + (size_t)c * kImgNbrCap);   // 256-byte rows
+      int4 v[kFastN / 4];
+#pragma unroll
+      for (int k = 0; k < kFastN / 4; k++) v[k] = row[k];   // entries past cnt are stale or zero candidate indices: never looked at
+      if (cnt <= kFastN) {
+        f_cnt[m] = cnt;
+#pragma unroll
+        for (int k = 0; k < kFastN / 4; k++) {
+          f_pk[m][2 * k] = ((unsigned)v[k].x & 0xffffu) | ((unsigned)v[k].y << 16);
+          f_pk[m][2 * k + 1] = ((unsigned)v[k].z & 0xffffu) | ((unsigned)v[k].w << 16);
+        }
+      }
+    }
+  }
+  tst[nst++] = clock64();
   for (int sweep = 0; sweep <= n; sweep++) {
+    nsweep++;
     if (tid == 0) s_changed = 0;
     __syncthreads();
     bool changed = false;
-    for (int c = tid; c < n; c += kSelThreads) {
+#pragma unroll
+    for (int m = 0; m < kFast; m++) {
+      const int c = tid + m * kSelThreads;
+      const bool open = c < n && f_cnt[m] >= 0 && status[c] == 0;
+      if (!__any(open)) continue;           // after the first sweeps most wavefronts have nothing left to decide
+      bool any_acc = false, all_drop = true;
+#pragma unroll
+      for (int k0 = 0; k0 < kFastN; k0 += 4) {
+        if (!__any(open && k0 < f_cnt[m])) break;
+#pragma unroll
+        for (int k = k0; k < k0 + 4; k++)
+          if (open && k < f_cnt[m]) {
+            const int s = status[(f_pk[m][k >> 1] >> ((k & 1) * 16)) & 0xffffu];
+            any_acc = any_acc || s == 1;
+            all_drop = all_drop && s == 2;
+          }
+      }
+      if (open && any_acc) { status[c] = 2; changed = true; }
+      else if (open && all_drop) { status[c] = 1; changed = true; }
+    }
+    bool any_long = false;
+#pragma unroll
+    for (int q = 0; q < kFast; q++) any_long = any_long || (tid + q * kSelThreads < n && f_cnt[q] < 0);
+    for (int c = tid; (any_long || n > kFast * kSelThreads) && c < n; c += kSelThreads) {
       if (status[c] != 0) continue;
+      const int m = c / kSelThreads;
+      bool fast = false;
+#pragma unroll
+      for (int q = 0; q < kFast; q++) fast = fast || (m == q && f_cnt[q] >= 0);   // handled above
+      if (fast) continue;
       const int cnt = nbr_cnt[c];
       bool any_acc = false, all_drop = true;
       for (int k = 0; k < cnt; k++) {
@@ -194,6 +265,7 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
     if (!s_changed) break;
     __syncthreads();
   }
+  tst[nst++] = clock64();
   for (int c = tid; c < n; c += kSelThreads)
     if (status[c] == 1) {
       const int k = atomicAdd(&s_nacc, 1);
@@ -210,30 +282,69 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
   __syncthreads();  // everyone is done with `status`
   for (int t = tid; t < P; t += kSelThreads) keys[t] = t < nacc ? acc[t] : 0ull;
   __syncthreads();
-  for (int k = 2; k <= P; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < P; t += kSelThreads) {
-        const int l = t ^ j;
-        if (l > t) {
+  tst[nst++] = clock64();
+  // Bitonic network, descending.  A wavefront owns 128-element blocks (lane l: elements l and l + 64 of the block) and runs every
+  // stage of stride <= 64 on them in REGISTERS (cross-lane exchange for strides < 64, the lane's own pair for stride 64); only the
+  // strides >= 128 go through LDS with a workgroup barrier — 10 of the 66 stages at 2 048 keys.
+  const int lane = tid & 63, wv = tid >> 6;
+  auto reg_stages = [&](int k_lo, int k_hi) {   // for k = k_lo .. k_hi (doubling): strides min(k / 2, 64) .. 1 of merge level k
+    for (int blk = wv; blk * 128 < P; blk += kSelThreads / 64) {
+      const int base = blk * 128;
+      u64 a0 = keys[base + lane], a1 = keys[base + 64 + lane];
+      for (int k = k_lo; k <= k_hi; k <<= 1) {
+        const bool desc0 = ((base + lane) & k) == 0, desc1 = ((base + 64 + lane) & k) == 0;
+        if (k > 64) {   // stride 64: the lane's own pair (same direction: bit k is above bit 6)
+          const u64 hi = a0 > a1 ? a0 : a1, lo = a0 > a1 ? a1 : a0;
+          a0 = desc0 ? hi : lo; a1 = desc0 ? lo : hi;
+        }
+        for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
+          const u64 b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
+          const bool lower = (lane & j) == 0;
+          const u64 mx0 = a0 > b0 ? a0 : b0, mn0 = a0 > b0 ? b0 : a0, mx1 = a1 > b1 ? a1 : b1, mn1 = a1 > b1 ? b1 : a1;
+          a0 = (desc0 == lower) ? mx0 : mn0;
+          a1 = (desc1 == lower) ? mx1 : mn1;
+        }
+      }
+      keys[base + lane] = a0; keys[base + 64 + lane] = a1;
+    }
+  };
+  if (P < 128) {   // tiny lists: the plain network
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < (P >> 1); i += kSelThreads) {
+          const int t = ((i & ~(j - 1)) << 1) | (i & (j - 1)), l = t | j;
+          const u64 a = keys[t], b = keys[l];
+          const bool desc = (t & k) == 0;
+          if (desc ? a < b : a > b) { keys[t] = b; keys[l] = a; }
+        }
+        __syncthreads();
+      }
+  } else {
+    reg_stages(2, 128);        // merge levels 2 .. 128 entirely in registers
+    __syncthreads();
+    for (int k = 256; k <= P; k <<= 1) {
+      for (int j = k >> 1; j >= 128; j >>= 1) {
+        for (int i = tid; i < (P >> 1); i += kSelThreads) {   // one compare-exchange per lane: pair i = (t, t | j)
+          const int t = ((i & ~(j - 1)) << 1) | (i & (j - 1)), l = t | j;
           const u64 a = keys[t], b = keys[l];
           const bool desc = (t & k) == 0;   // descending blocks first: the whole array ends up descending
           if (desc ? a < b : a > b) { keys[t] = b; keys[l] = a; }
         }
+        __syncthreads();
       }
-      // a stride below 64 pairs elements of one 64-element block, i.e. of one wavefront (element t belongs to lane t % 64 of wavefront
-      // (t / 64) % 16): only the wide strides, and the step into one, need the workgroup barrier
-      const int next_j = j > 1 ? j >> 1 : k;
-      if (j >= 64 || next_j >= 64) __syncthreads();
-      else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+      reg_stages(k, k);        // strides 64 .. 1 of this level
+      __syncthreads();
     }
+  }
   __syncthreads();
+  tst[nst++] = clock64();
   const int nout = max_corners > 0 ? min(nacc, max_corners) : nacc;
   for (int t = tid; t < nout && t < kImgMaxCorners; t += kSelThreads) {
     const int p = (int)(keys[t] & 0xffffffffu);
     const int y = p / w, x = p - y * w;
     corners[t] = make_float2((float)x, (float)y);
   }
-  if (tid == 0) *n_corners = min(nout, kImgMaxCorners);
+  if (tid == 0) { *n_corners = min(nout, kImgMaxCorners); tst[nst++] = clock64(); for (int q = 0; q + 1 < nst; q++) acc[kImgAccCap - 8 + q] = (u64)(tst[q + 1] - tst[q]); acc[kImgAccCap - 2] = (u64)nsweep; acc[kImgAccCap - 1] = (u64)nacc; }
 }
 
 __global__ __launch_bounds__(256) void k_img_pyrdown(const unsigned char* __restrict__ src, int sw, int sh, unsigned char* __restrict__ dst, int dw,
@@ -384,11 +495,11 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
         __builtin_amdgcn_wave_barrier();          // earlier reads of the old patch are done
         const int row = lane >> 1, c0 = (lane & 1) * (kPS / 2);
         const unsigned char* src = J + (size_t)reflect101(poy + row, ch) * cw;
-        unsigned char v[kPS / 2];
+        int v[kPS / 2];
 #pragma unroll
-        for (int i = 0; i < kPS / 2; i++) v[i] = src[reflect101(pox + c0 + i, cw)];
+        for (int i = 0; i < kPS / 2; i++) v[i] = src[reflect101(pox + c0 + i, cw)];   // all 16 loads in flight together
 #pragma unroll
-        for (int i = 0; i < kPS / 2; i++) patch[row][c0 + i] = v[i];
+        for (int i = 0; i < kPS / 2; i++) patch[row][c0 + i] = (unsigned char)v[i];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
@@ -524,7 +635,8 @@ static vloam_status img_copy_out(const void* d, size_t bytes, void* buf, long lo
   return hipMemcpy(buf, d, m, hipMemcpyDeviceToHost) == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
-// items: 0 eig map, 1 + l pyramid level l of the last image, 4 + l its derivative level l, 8 candidate count, 9 error bits
+// items: 0 eig map, 1 + l pyramid level l of the last image, 4 + l its derivative level l, 8 candidate count, 9 error bits,
+// 10 k_img_select's shader cycles per phase {init + list prefetch, decision sweeps, collect, sort, output, -, number of sweeps, accepted}
 vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n) {
   if (c->max_w == 0 || c->count < 0) return VLOAM_ERR_ORDER;
   const ImgPyrDev& P = c->pyr[c->count % 2];
@@ -533,6 +645,7 @@ vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, lo
   if (item >= 4 && item <= 6) { const int l = item - 4; if (l >= P.levels) return VLOAM_ERR_INVALID; return img_copy_out(P.deriv[l], sizeof(short2) * (size_t)P.w[l] * P.h[l], buf, cap, n); }
   if (item == 8) return img_copy_out(c->n_cand, sizeof(int), buf, cap, n);
   if (item == 9) return img_copy_out(c->error, sizeof(int), buf, cap, n);
+  if (item == 10) return img_copy_out(c->acc + kImgAccCap - 8, 8 * sizeof(u64), buf, cap, n);
   return VLOAM_ERR_INVALID;
 }
 
