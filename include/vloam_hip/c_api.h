@@ -177,13 +177,19 @@ vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t
  *   vloam_vo_solve / vloam_process_frame.
  * vloam_process_frame_image[_device]: vloam_process_frame with the matches taken from the image instead of from the caller — cloud and
  *   image of one frame in, nothing comes back to the host (the image work rides on a stream of its own next to scan registration).
- * The ORB + brute-force Hamming configuration (optical_flow_match = false) is not provided: OpenCV's learned ORB sampling table
- * cannot be restated without the library. */
+ * vloam_vo_match_descriptors: ImageUtil::matchDescriptors (image_util.cpp:221-296) for binary descriptors in host memory —
+ *   BFMatcher(NORM_HAMMING): knnMatch k = 2 + ratio test 0.8 (select_knn != 0, the reference's SelectType::KNN) or match with crossCheck
+ *   (select_knn == 0); ties resolve like cv::batchDistance (lower index).  Matches come back in query order.
+ * Of the ORB + brute-force configuration (optical_flow_match = false) only the descriptor EXTRACTION is not provided: OpenCV's learned
+ * ORB sampling table cannot be restated without the library — compute the descriptors with OpenCV at the corners of
+ * vloam_vo_get_keypoints and match them here. */
 vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride);
 vloam_status vloam_vo_process_image_device(vloam_handle* h, const void* d_gray, int width, int height, int stride);
 vloam_status vloam_vo_get_keypoints(vloam_handle* h, float* xy, int cap, int* n);
 vloam_status vloam_vo_get_flow(vloam_handle* h, float* prev_xy, float* curr_xy, unsigned char* status, int cap, int* n);
 vloam_status vloam_vo_get_flow_matches(vloam_handle* h, int* prev_uv, int* curr_uv, int cap, int* n);
+vloam_status vloam_vo_match_descriptors(vloam_handle* h, const unsigned char* desc_prev, int n_prev, const unsigned char* desc_curr, int n_curr, int bytes_per_desc,
+                                        int select_knn, int* query_idx, int* train_idx, int cap, int* n_matches);
 vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride);
 vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride);
 

@@ -275,6 +275,18 @@ def pyr_lk(prev, nxt, pts, win=15, max_level=2, max_count=10, epsilon=0.03):
     return out, st[:pts.shape[0]]
 
 
+def bf_match_hamming(desc0, desc1, knn=True):
+    """image_util.cpp:221-296 (BF, NORM_HAMMING): (queryIdx, trainIdx) int32 arrays; knn: 2-NN + ratio 0.8, else NN + cross check."""
+    L = lib()
+    a = np.ascontiguousarray(desc0, dtype=np.uint8)
+    b = np.ascontiguousarray(desc1, dtype=np.uint8)
+    assert a.ndim == 2 and b.ndim == 2 and a.shape[1] == b.shape[1]
+    q = np.zeros(max(a.shape[0], 1), dtype=np.int32)
+    t = np.zeros(max(a.shape[0], 1), dtype=np.int32)
+    n = L.orc_bf_match_hamming(_p(a, U8), a.shape[0], _p(b, U8), b.shape[0], a.shape[1], int(knn), _p(q, I), _p(t, I), q.shape[0])
+    return q[:n], t[:n]
+
+
 def flow_matches(corners, tracked, status):
     """visual_odometry.cpp:296-308 with optical_flow_match: (prev_uv, curr_uv) int32 [m, 2] of the tracked corners, float -> int
     truncation; prev = the corner (detected in the current image, used as a point of the previous one), curr = where it went."""

@@ -328,4 +328,11 @@ int orc_pyr_lk(const unsigned char* prev, const unsigned char* next, int w, int 
   return 0;
 }
 
+// (queryIdx, trainIdx) pairs of ImageUtil::matchDescriptors (BF, NORM_HAMMING); returns the number of matches
+int orc_bf_match_hamming(const unsigned char* d0, int n0, const unsigned char* d1, int n1, int bytes, int knn, int* q_out, int* t_out, int cap) {
+  std::vector<std::pair<int, int>> m = bf_match_hamming(d0, n0, d1, n1, bytes, knn != 0);
+  for (size_t i = 0; i < m.size() && (int)i < cap; i++) { q_out[i] = m[i].first; t_out[i] = m[i].second; }
+  return (int)m.size();
+}
+
 }  // extern "C"

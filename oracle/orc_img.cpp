@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <cstdint>
 
 namespace orc {
 
@@ -44,8 +45,7 @@ std::vector<ImgCorner> good_features_to_track(const uint8_t* img, int w, int h, 
   const double hs2 = 0.5 * scale * scale;
   const int r = block_size / 2;  // anchor at the centre (odd block sizes; the reference uses 5)
   std::vector<float> eig((size_t)w * h);
-  float max_val = 0.f;  // eig >= 0 up to rounding; an image without any positive response yields no corners either way
-  bool any = false;
+  float max_val = 0.f;  // eig >= 0 up to rounding; an image without any positive response yields no corners
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) {
       long long sxx = 0, sxy = 0, syy = 0;
@@ -61,7 +61,7 @@ std::vector<ImgCorner> good_features_to_track(const uint8_t* img, int w, int h, 
       const double root = std::sqrt((double)(d * d + 4 * sxy * sxy));
       const float e = (float)(((double)(sxx + syy) - root) * hs2);
       eig[(size_t)y * w + x] = e;
-      if (!any || e > max_val) { max_val = e; any = true; }
+      if (e > max_val) max_val = e;
     }
   if (eig_out) *eig_out = eig;
   const float thr = (float)((double)max_val * quality_level);
@@ -260,6 +260,41 @@ void calc_optical_flow_pyr_lk(const Pyramid& P, const Pyramid& N, const std::vec
       }
     }
   }
+}
+
+static inline int hamming(const uint8_t* a, const uint8_t* b, int bytes) {
+  int d = 0;
+  for (int k = 0; k < bytes; k++) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+  return d;
+}
+
+std::vector<std::pair<int, int>> bf_match_hamming(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, int bytes, bool knn) {
+  std::vector<std::pair<int, int>> out;
+  if (knn) {
+    for (int q = 0; q < n0; q++) {
+      int d0 = INT32_MAX, t0 = -1, d1 = INT32_MAX, t1 = -1;   // the two smallest, ties to the lower train index
+      for (int t = 0; t < n1; t++) {
+        const int d = hamming(desc0 + (size_t)q * bytes, desc1 + (size_t)t * bytes, bytes);
+        if (d < d1) {
+          if (d < d0) { d1 = d0; t1 = t0; d0 = d; t0 = t; }
+          else { d1 = d; t1 = t; }
+        }
+      }
+      if (t1 < 0) continue;   // fewer than two train descriptors: the reference would index knn_match[1] out of range
+      if ((double)(float)d0 < 0.8 * (double)(float)d1) out.emplace_back(q, t0);
+    }
+  } else {
+    std::vector<int> bq((size_t)n0, -1), bt((size_t)n1, -1), dq((size_t)n0, INT32_MAX), dt((size_t)n1, INT32_MAX);
+    for (int q = 0; q < n0; q++)
+      for (int t = 0; t < n1; t++) {
+        const int d = hamming(desc0 + (size_t)q * bytes, desc1 + (size_t)t * bytes, bytes);
+        if (d < dq[q]) { dq[q] = d; bq[q] = t; }
+        if (d < dt[t]) { dt[t] = d; bt[t] = q; }
+      }
+    for (int q = 0; q < n0; q++)
+      if (bq[q] >= 0 && bt[bq[q]] == q) out.emplace_back(q, bq[q]);
+  }
+  return out;
 }
 
 }  // namespace orc

@@ -21,10 +21,12 @@
 //     f32 running sums (boxFilter's RowSum / ColumnSum), identical on every machine;
 //   * Lucas-Kanade: the 2x2 gradient matrix and the mismatch vector are sums of integer products (OpenCV's fixed-point
 //     window, W_BITS = 14); they are summed exactly and rounded to f32 once (OpenCV: f32 accumulation, order build-dependent).
-// The ORB descriptor / brute-force Hamming configuration (optical_flow_match = false) needs OpenCV's learned 256-pair sampling
-// table (orb.cpp, bit_pattern_31_), which cannot be restated without the library: not covered.
+// Of the ORB descriptor / brute-force Hamming configuration (optical_flow_match = false) the MATCHER is restated (bf_match_hamming,
+// image_util.cpp:221-296); the ORB descriptor itself needs OpenCV's learned 256-pair sampling table (orb.cpp, bit_pattern_31_), which
+// cannot be restated without the library: descriptors are an input there.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace orc {
@@ -47,5 +49,14 @@ struct Pyramid {                      // cv::buildOpticalFlowPyramid without the
 // (COUNT + EPS, max_count, epsilon), flags = 0, minEigThreshold = 1e-4, err requested (its bounds check clears status too).
 void calc_optical_flow_pyr_lk(const Pyramid& prev, const Pyramid& next, const std::vector<ImgCorner>& prev_pts, std::vector<ImgCorner>* next_pts,
                               std::vector<uint8_t>* status, int win, int max_count, double epsilon);
+
+// ImageUtil::matchDescriptors with MatcherType::BF on binary descriptors (NORM_HAMMING), image_util.cpp:221-296:
+//   knn != 0 (SelectType::KNN, the reference's setting, visual_odometry.cpp:37): BFMatcher::knnMatch(desc0, desc1, 2) and the ratio
+//            test  d_best < 0.8 * d_second  (:262-271);
+//   knn == 0 (SelectType::NN): BFMatcher(NORM_HAMMING, crossCheck = true)::match (:225,:250).
+// cv::batchDistance keeps the K smallest distances per query, admitting a train descriptor only on a strictly smaller distance: equal
+// distances resolve to the lower train index (and, for the cross check, to the lower query index).  Returns (queryIdx, trainIdx) pairs
+// in query order.  desc: n x bytes, row major.
+std::vector<std::pair<int, int>> bf_match_hamming(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, int bytes, bool knn);
 
 }  // namespace orc

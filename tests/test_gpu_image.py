@@ -132,3 +132,24 @@ def test_image_frontend_capacity_is_reported(vl, orc):
     h.vo_process_image(noise[:256, :512])
     assert np.array_equal(h.vo_keypoints(), orc.good_features(noise[:256, :512]))
     h.close()
+
+
+@pytest.mark.gpu
+def test_bf_hamming_matcher_parity(vl, orc):
+    """vloam_vo_match_descriptors == the oracle's ImageUtil::matchDescriptors (BF, NORM_HAMMING), both selector types, ties included."""
+    from test_oracle_image import _rand_desc
+    rng = np.random.default_rng(1)
+    h = vl.Handle(0, with_mapping=0, image_width=64, image_height=64)
+    for (n0, n1, nbytes) in ((300, 250, 32), (1024, 1024, 32), (77, 500, 64), (5, 1, 32)):
+        a, b = _rand_desc(rng, max(n0, 12), max(n1, 8), nbytes)
+        a, b = a[:n0], b[:n1]
+        for knn in (True, False):
+            q, t = h.vo_match_descriptors(a, b, knn)
+            qo, to = orc.bf_match_hamming(a, b, knn)
+            assert np.array_equal(q, qo) and np.array_equal(t, to), (n0, n1, nbytes, knn)
+    q, t = h.vo_match_descriptors(np.zeros((0, 32), dtype=np.uint8), b, True)
+    assert q.size == 0
+    with pytest.raises(vl.VloamError) as e:
+        h.vo_match_descriptors(np.zeros((4, 30), dtype=np.uint8), np.zeros((4, 30), dtype=np.uint8))
+    assert e.value.status == vl.ERR_INVALID
+    h.close()

@@ -240,3 +240,31 @@ def test_golden_image_fixture(orc):
         if k > 0:
             t, s = orc.pyr_lk(g["img_%d" % (k - 1)], g["img_%d" % k], c)
             assert np.array_equal(t, g["tracked_%d" % k]) and np.array_equal(s, g["status_%d" % k])
+
+
+def _rand_desc(rng, n0, n1, nbytes):
+    a = rng.integers(0, 256, (n0, nbytes), dtype=np.uint8)
+    b = a[rng.permutation(n0)[:n1] % n0].copy() if n1 <= n0 else rng.integers(0, 256, (n1, nbytes), dtype=np.uint8)
+    flip = rng.integers(0, 256, b.shape, dtype=np.uint8) & rng.integers(0, 256, b.shape, dtype=np.uint8) & rng.integers(0, 256, b.shape, dtype=np.uint8)
+    b ^= flip
+    b[3] = b[7]                      # duplicates: ties must resolve to the lower index
+    a[5] = a[11]
+    return a, b
+
+
+def test_bf_hamming_matcher_vs_numpy(orc):
+    """image_util.cpp:221-296 (BF, NORM_HAMMING): 2-NN + ratio 0.8 and NN + cross check against a stable-argsort numpy formulation."""
+    rng = np.random.default_rng(0)
+    for nbytes in (32, 64):
+        a, b = _rand_desc(rng, 300, 250, nbytes)
+        D = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+        o = np.argsort(D, axis=1, kind="stable")[:, :2]
+        d0, d1 = D[np.arange(300), o[:, 0]].astype(np.float32), D[np.arange(300), o[:, 1]].astype(np.float32)
+        keep = d0.astype(np.float64) < 0.8 * d1.astype(np.float64)
+        q, t = orc.bf_match_hamming(a, b, True)
+        assert np.array_equal(q, np.nonzero(keep)[0]) and np.array_equal(t, o[keep, 0]) and 100 < q.size < 300
+        q2, t2 = orc.bf_match_hamming(a, b, False)
+        bq, bt = np.argmin(D, axis=1), np.argmin(D, axis=0)
+        k2 = bt[bq] == np.arange(300)
+        assert np.array_equal(q2, np.nonzero(k2)[0]) and np.array_equal(t2, bq[k2])
+    assert orc.bf_match_hamming(a, b[:1], True)[0].size == 0     # one train descriptor: no second neighbour, no match

@@ -314,6 +314,17 @@ class Handle:
         self._chk(self.L.vloam_vo_get_flow_matches(self.h, _fp(a), _fp(b), K_IMG_MAX_CORNERS, C.byref(n)))
         return a[:n.value], b[:n.value]
 
+    def vo_match_descriptors(self, desc_prev, desc_curr, knn=True):
+        """ImageUtil::matchDescriptors (BF, NORM_HAMMING): (queryIdx, trainIdx) int32 arrays in query order."""
+        a = np.ascontiguousarray(desc_prev, dtype=np.uint8)
+        b = np.ascontiguousarray(desc_curr, dtype=np.uint8)
+        q = np.zeros(max(a.shape[0], 1), dtype=np.int32)
+        t = np.zeros(max(a.shape[0], 1), dtype=np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.vloam_vo_match_descriptors(self.h, _fp(a), a.shape[0], _fp(b), b.shape[0], a.shape[1] if a.ndim == 2 else 0, int(knn), _fp(q), _fp(t),
+                                                    q.shape[0], C.byref(n)))
+        return q[:n.value], t[:n.value]
+
     def process_frame_image(self, cloud, gray):
         """One frame of the coupled loop from raw inputs: sweep + grey image (matches come from the image front-end)."""
         cloud = np.ascontiguousarray(cloud, dtype=np.float32)

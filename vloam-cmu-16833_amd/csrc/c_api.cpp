@@ -803,6 +803,20 @@ vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, 
   return vloam_vo_process_image_device(h, h->img.staging, width, height, width);
 }
 
+// ImageUtil::matchDescriptors (image_util.cpp:221-296) for binary descriptors: BFMatcher(NORM_HAMMING), knnMatch k = 2 + ratio 0.8 (select_knn != 0,
+// the reference's SelectType::KNN) or match with crossCheck (select_knn == 0, SelectType::NN).  Descriptors in host memory, n x bytes_per_desc.
+vloam_status vloam_vo_match_descriptors(vloam_handle* h, const unsigned char* desc_prev, int n_prev, const unsigned char* desc_curr, int n_curr, int bytes_per_desc,
+                                        int select_knn, int* query_idx, int* train_idx, int cap, int* n_matches) {
+  if (!h || !n_matches || cap < 0 || (n_prev > 0 && !desc_prev) || (n_curr > 0 && !desc_curr) || (cap > 0 && (!query_idx || !train_idx))) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  HIPCHK(hipSetDevice(h->device));
+  vloam_status s = img_match_descriptors(&h->img, h->s_img, desc_prev, n_prev, desc_curr, n_curr, bytes_per_desc, select_knn != 0, query_idx, train_idx, cap, n_matches);
+  if (s == VLOAM_ERR_CAPACITY) set_err("more than %d descriptors", kImgMaxDesc);
+  if (s == VLOAM_ERR_INVALID) set_err("bytes_per_desc must be a multiple of 4 up to %d", kImgMaxDescBytes);
+  return s;
+}
+
 static vloam_status img_results(vloam_handle* h, std::vector<float2>* corners, std::vector<float2>* tracked, std::vector<unsigned char>* status, int* n_corners,
                                 bool* have_flow) {
   if (h->img.max_w == 0 || h->img.count < 0) { set_err("no image processed yet"); return VLOAM_ERR_ORDER; }

@@ -23,6 +23,8 @@ constexpr int kImgCandCap = 65536;     // local maxima above the quality thresho
 constexpr int kImgNbrCap = 64;         // stronger candidates within minDistance of a candidate (3x3 local maxima are >= 2 px apart)
 constexpr int kImgAccCap = 16384;      // corners before the maxCorners cut (a 1242 x 375 image holds < 10 600 at minDistance 7.5)
 constexpr int kImgMaxRadius = 8;       // floor(minDistance) the neighbourhood scan supports
+constexpr int kImgMaxDesc = 8192;      // descriptors per image the brute-force matcher takes
+constexpr int kImgMaxDescBytes = 64;   // ORB / BRISK: 32 / 64 bytes
 
 struct ImgPyrDev {
   unsigned char* img[kImgLevels];
@@ -51,6 +53,8 @@ struct ImgContext {
   unsigned char* status = nullptr;
   int* error = nullptr;        // sticky capacity bits
   unsigned char* staging = nullptr;   // [max_w * max_h] upload buffer of the host-pointer entry
+  unsigned* desc[2] = {nullptr, nullptr};   // [kImgMaxDesc][kImgMaxDescBytes / 4] descriptors of the two images (brute-force matcher)
+  uint2* best2[2] = {nullptr, nullptr};     // [kImgMaxDesc] per descriptor: the two smallest (distance << 16 | index) keys against the other set
 };
 
 constexpr int kErrImgCandidates = 1, kErrImgNeighbours = 2, kErrImgAccepted = 4;
@@ -63,5 +67,9 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // 
 vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
                          ProfHook* ph);
 vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n);
+// ImageUtil::matchDescriptors, MatcherType::BF + NORM_HAMMING (image_util.cpp:221-296): descriptors in HOST memory (n x bytes), matches
+// (queryIdx into desc0, trainIdx into desc1) in query order; knn: 2-NN + ratio 0.8 (SelectType::KNN), else NN with cross check.
+vloam_status img_match_descriptors(ImgContext* c, hipStream_t st, const unsigned char* desc0, int n0, const unsigned char* desc1, int n1, int bytes, bool knn,
+                                   int* query_idx, int* train_idx, int cap, int* n_matches);
 
 }  // namespace vloam

@@ -11,6 +11,7 @@
 //                                          (strength, address)-sorted cut at maxCorners through an LDS bitonic network
 //   k_img_pyrdown     1 thread / pixel     cv::pyrDown
 //   k_img_scharr      1 thread / pixel     calcSharrDeriv
+//   k_img_bf_knn      1 wavefront / query  brute-force Hamming 2-NN over the other image's descriptors (image_util.cpp:221-296)
 //   k_img_lk          1 wavefront / corner pyramidal Lucas-Kanade, all levels in one launch; the 15 x 15 window lives in registers
 //                                          (4 pixels per lane), the search patch of the next image in LDS, the 2 x 2 system in exact
 //                                          integer sums (DPP row reductions)
@@ -18,6 +19,7 @@
 #include <limits.h>
 #include <float.h>
 #include <math.h>
+#include <vector>
 #include "img_kernels.h"
 
 namespace vloam {
@@ -549,6 +551,33 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
   }
 }
 
+
+// Brute-force Hamming matcher (cv::BFMatcher(NORM_HAMMING)::knnMatch with k = 2): one wavefront per query descriptor; every lane walks
+// the train descriptors with stride 64 and keeps its two smallest keys (distance << 16 | train index): unique, and ordered the way
+// cv::batchDistance resolves ties (strictly smaller distance wins, i.e. the lower index among equals).
+__global__ __launch_bounds__(256) void k_img_bf_knn(const unsigned* __restrict__ q_desc, int nq, const unsigned* __restrict__ t_desc, int nt, int words,
+                                                    uint2* __restrict__ best2) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  unsigned qw[kImgMaxDescBytes / 4];
+#pragma unroll
+  for (int w = 0; w < kImgMaxDescBytes / 4; w++) qw[w] = w < words ? q_desc[(size_t)q * words + w] : 0u;
+  unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
+  for (int t = lane; t < nt; t += 64) {
+    const unsigned* td = t_desc + (size_t)t * words;
+    int d = 0;
+#pragma unroll
+    for (int w = 0; w < kImgMaxDescBytes / 4; w++) if (w < words) d += __popc(qw[w] ^ td[w]);
+    const unsigned key = ((unsigned)d << 16) | (unsigned)t;
+    if (key < k1) { if (key < k0) { k1 = k0; k0 = key; } else k1 = key; }
+  }
+  unsigned g0 = k0;
+  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(g0, s); g0 = o < g0 ? o : g0; }
+  unsigned c1 = (k0 == g0 && g0 != 0xffffffffu) ? k1 : k0;   // the winner's lane offers its runner-up
+  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(c1, s); c1 = o < c1 ? o : c1; }
+  if (lane == 0) best2[q] = make_uint2(g0, c1);
+}
+
 __global__ void k_img_no_matches(int* prev_uv, int* curr_uv) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p < kImgMaxCorners) { prev_uv[2 * p] = INT_MIN; prev_uv[2 * p + 1] = 0; curr_uv[2 * p] = INT_MIN; curr_uv[2 * p + 1] = 0; }
@@ -586,6 +615,7 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
   ok = ok && A.take(&c->sobel, npx) && A.take(&c->eig, npx) && A.take(&c->maxbits, 1) && A.take(&c->cmap, npx) && A.take(&c->clist, kImgCandCap) &&
        A.take(&c->n_cand, 1) && A.take(&c->nbr, (size_t)kImgCandCap * kImgNbrCap) && A.take(&c->nbr_cnt, kImgCandCap) && A.take(&c->acc, kImgAccCap) &&
        A.take(&c->tracked, kImgMaxCorners) && A.take(&c->status, kImgMaxCorners) && A.take(&c->error, 1) && A.take(&c->staging, npx);
+  for (int k = 0; k < 2; k++) ok = ok && A.take(&c->desc[k], (size_t)kImgMaxDesc * (kImgMaxDescBytes / 4)) && A.take(&c->best2[k], kImgMaxDesc);
   return ok ? VLOAM_OK : VLOAM_ERR_CAPACITY;
 }
 
@@ -626,6 +656,42 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
     VL_RAW_LAUNCH(k_img_no_matches, dim3(kImgMaxCorners / 256), dim3(256), 0, st, prev_uv, curr_uv);
   }
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+
+vloam_status img_match_descriptors(ImgContext* c, hipStream_t st, const unsigned char* desc0, int n0, const unsigned char* desc1, int n1, int bytes, bool knn,
+                                   int* query_idx, int* train_idx, int cap, int* n_matches) {
+  if (c->max_w == 0) return VLOAM_ERR_ORDER;
+  if (n0 < 0 || n1 < 0 || n0 > kImgMaxDesc || n1 > kImgMaxDesc) return VLOAM_ERR_CAPACITY;
+  if (bytes <= 0 || bytes > kImgMaxDescBytes || (bytes & 3)) return VLOAM_ERR_INVALID;
+  *n_matches = 0;
+  if (n0 == 0 || n1 == 0) return VLOAM_OK;
+  const int words = bytes / 4;
+  // (hipMemcpyAsync from pageable memory has read its source when it returns)
+  if (hipMemcpyAsync(c->desc[0], desc0, (size_t)n0 * bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(c->desc[1], desc1, (size_t)n1 * bytes, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  VL_RAW_LAUNCH(k_img_bf_knn, dim3((n0 + 3) / 4), dim3(256), 0, st, c->desc[0], n0, c->desc[1], n1, words, c->best2[0]);
+  if (!knn) VL_RAW_LAUNCH(k_img_bf_knn, dim3((n1 + 3) / 4), dim3(256), 0, st, c->desc[1], n1, c->desc[0], n0, words, c->best2[1]);
+  std::vector<uint2> fwd((size_t)n0), bwd((size_t)(knn ? 0 : n1));
+  if (hipMemcpyAsync(fwd.data(), c->best2[0], sizeof(uint2) * (size_t)n0, hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (!knn && hipMemcpyAsync(bwd.data(), c->best2[1], sizeof(uint2) * (size_t)n1, hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  int m = 0;
+  for (int q = 0; q < n0; q++) {
+    const unsigned g0 = fwd[(size_t)q].x, g1 = fwd[(size_t)q].y;
+    bool keep;
+    if (knn) {   // image_util.cpp:262-271: knn_match[0].distance < 0.8 * knn_match[1].distance (float distance, double product)
+      if (g1 == 0xffffffffu) continue;   // a single train descriptor: the reference would read knn_match[1] out of range
+      keep = (double)(float)(g0 >> 16) < 0.8 * (double)(float)(g1 >> 16);
+    } else {     // crossCheck: q is also the best query of its best train descriptor
+      keep = (bwd[(size_t)(g0 & 0xffffu)].x & 0xffffu) == (unsigned)q;
+    }
+    if (!keep) continue;
+    if (m < cap) { query_idx[m] = q; train_idx[m] = (int)(g0 & 0xffffu); }
+    m++;
+  }
+  *n_matches = m;
+  return VLOAM_OK;
 }
 
 static vloam_status img_copy_out(const void* d, size_t bytes, void* buf, long long cap, long long* n) {
