@@ -317,6 +317,32 @@ __device__ __forceinline__ void bitonic_stage(u64* a, int P, int j, int k, int t
   }
 }
 
+// Merge levels k_lo .. k_hi (doubling) of an ASCENDING bitonic network, strides min(k / 2, 64) .. 1, on 128-element blocks held in
+// registers: wavefront w of the workgroup owns blocks w, w + nwaves, ...; lane l holds elements l and l + 64 of its block, so a stride
+// below 64 is a cross-lane exchange and stride 64 the lane's own pair — no LDS round trip, no barrier between these stages.
+__device__ __forceinline__ void bitonic_reg_stages(u64* a, int P, int k_lo, int k_hi, int tid, int nthreads) {
+  const int lane = tid & 63, wv = tid >> 6, nwaves = nthreads >> 6;
+  for (int blk = wv; blk * 128 < P; blk += nwaves) {
+    const int base = blk * 128;
+    u64 a0 = a[base + lane], a1 = a[base + 64 + lane];
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+      const bool up0 = ((base + lane) & k) == 0, up1 = ((base + 64 + lane) & k) == 0;
+      if (k > 64) {  // stride 64 (both elements see the same direction: bit k lies above bit 6)
+        const u64 hi = a0 > a1 ? a0 : a1, lo = a0 > a1 ? a1 : a0;
+        a0 = up0 ? lo : hi; a1 = up0 ? hi : lo;
+      }
+      for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
+        const u64 b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
+        const bool lower = (lane & j) == 0;
+        const u64 mx0 = a0 > b0 ? a0 : b0, mn0 = a0 > b0 ? b0 : a0, mx1 = a1 > b1 ? a1 : b1, mn1 = a1 > b1 ? b1 : a1;
+        a0 = (up0 == lower) ? mn0 : mx0;
+        a1 = (up1 == lower) ? mn1 : mx1;
+      }
+    }
+    a[base + lane] = a0; a[base + 64 + lane] = a1;
+  }
+}
+
 __device__ __forceinline__ void bitonic_step(u64* a, int t, int j, int k) {
   const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
   const int l = i | j;
@@ -695,12 +721,27 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   SR_STAMP();
   // a stage with stride j <= 64 only moves data inside 128-element blocks that belong to one wavefront (64 consecutive
   // compare-exchanges), so only the wide strides need a workgroup barrier
-  for (int k = 2; k <= P2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      bitonic_stage(K2, P2, j, k, tid, kRingThreads);
-      const int next_j = j > 1 ? j >> 1 : k;  // first stride of the next merge level
-      if (j > 64 || next_j > 64) __syncthreads(); else lds_fence_wave();
+  if (P2 < 128) {
+    for (int k = 2; k <= P2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        bitonic_stage(K2, P2, j, k, tid, kRingThreads);
+        const int next_j = j > 1 ? j >> 1 : k;  // first stride of the next merge level
+        if (j > 64 || next_j > 64) __syncthreads(); else lds_fence_wave();
+      }
+  } else {
+    // strides <= 64 run in registers (one 128-key block per wavefront and pass); only the strides >= 128 — 10 of the 66 stages at
+    // 2 048 run keys — go through LDS behind a workgroup barrier
+    bitonic_reg_stages(K2, P2, 2, 128, tid, kRingThreads);
+    __syncthreads();
+    for (int k = 256; k <= P2; k <<= 1) {
+      for (int j = k >> 1; j >= 128; j >>= 1) {
+        bitonic_stage(K2, P2, j, k, tid, kRingThreads);
+        __syncthreads();
+      }
+      bitonic_reg_stages(K2, P2, k, k, tid, kRingThreads);
+      __syncthreads();
     }
+  }
   __syncthreads();
   SR_STAMP();
   // voxel heads -> output rank
