@@ -103,6 +103,10 @@ def test_coupled_frame_loop_from_raw_images(vl, synth):
         assert qdist(vj[0:4], vq) < tol and np.linalg.norm(vj[4:7] - vt) < tol, "world_VOT_base_last, frame %d" % k
     # the VO chain built from tracked image corners follows the LiDAR chain (geometry-consistent images)
     assert np.linalg.norm(h.vo_trajectory()[nframes - 1][4:7] - h.trajectory()[nframes - 1][4:7]) < 0.6
+    # a frame with a wrong image size is refused before anything of it is enqueued: the handle carries on with the next good frame
+    with pytest.raises(vl.VloamError) as e:
+        h.process_frame_image(frames[0][0], frames[0][1][:200])
+    assert e.value.status == vl.ERR_INVALID and h.frame_count() == nframes
     # the same frames streamed without reading anything back in between give the same trajectory
     h2, _ = make(vl, synth, detach=False, with_mapping=1, image_width=W, image_height=H)
     for k in range(nframes):

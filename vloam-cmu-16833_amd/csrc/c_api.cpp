@@ -721,6 +721,10 @@ static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4
   if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
   if (n_match > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match, kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
   if (d_gray && h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  if (d_gray && img_check(&h->img, width, height, stride) != VLOAM_OK) {   // before anything of this frame is enqueued
+    set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h);
+    return VLOAM_ERR_INVALID;
+  }
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
   vloam_status s = enqueue_sr(h, one_sweep(d_xyz_pad4, n));

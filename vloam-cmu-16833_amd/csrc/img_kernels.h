@@ -64,6 +64,7 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // 
 // processImage for the image in d_gray (device, row stride in bytes): pyramid + derivatives, corners, and — from the second image
 // on — the flow of the new corners from the previous image into this one.  prev_uv / curr_uv (device, [kImgMaxCorners][2] ints, may be
 // null): the match loop's integer pixel pairs, x = INT_MIN in entries without a tracked corner.
+vloam_status img_check(const ImgContext* c, int width, int height, int stride);   // what img_process would refuse, without touching anything
 vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
                          ProfHook* ph);
 vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n);

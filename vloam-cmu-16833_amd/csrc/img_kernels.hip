@@ -619,11 +619,16 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
   return ok ? VLOAM_OK : VLOAM_ERR_CAPACITY;
 }
 
-vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
-                         ProfHook* ph) {
+vloam_status img_check(const ImgContext* c, int width, int height, int stride) {
   if (c->max_w == 0) return VLOAM_ERR_ORDER;
   if (width < 2 * kImgWin || height < 2 * kImgWin || (size_t)width * height > (size_t)c->max_w * c->max_h || stride < width) return VLOAM_ERR_INVALID;
   if (c->count >= 0 && (width != c->w || height != c->h)) return VLOAM_ERR_INVALID;   // one image size per sequence
+  return VLOAM_OK;
+}
+
+vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
+                         ProfHook* ph) {
+  { const vloam_status chk = img_check(c, width, height, stride); if (chk != VLOAM_OK) return chk; }
   c->w = width; c->h = height;
   c->count++;
   const int cur = c->count % 2;
