@@ -5,6 +5,8 @@
 //   vloam::LaserOdometry      laser_odometry.h:70-84      init / input / solveLO / output
 //   vloam::LaserMapping       laser_mapping.h:85-94       init / reset / input / solveMapping
 //   vloam::LidarOdometryMapping  lidar_odometry_mapping.cpp:65-154  reset / scanRegistrationIO / laserOdometryIO / laserMappingIO
+//   vloam::VisualOdometry     visual_odometry.h:36-58     init / reset / processImage / setUpPointCloud / processPointCloud / solveNlsAll
+//                             (optical_flow_match = true; shares a Session with the LiDAR stages or owns one)
 // Same method names, argument meaning and call order.  Clouds are a PCL-free POD vector by default; define
 // VLOAM_HIP_WITH_PCL (and have PCL on the include path) to get overloads taking pcl::PointCloud — that adapter is
 // compile-guarded and untested here because PCL / ROS are absent from this image.  Errors: the reference aborts
@@ -26,6 +28,9 @@
 
 #include "c_api.h"
 
+#ifdef VLOAM_HIP_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
 #ifdef VLOAM_HIP_WITH_PCL
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
@@ -179,6 +184,50 @@ class LidarOdometryMapping {
   ScanRegistration scan_registration;
   LaserOdometry laser_odometry;
   LaserMapping laser_mapping;
+};
+
+// visual_odometry.h:36-58 in its optical-flow configuration.  processImage takes the 8-bit grey image as a pointer (cv::Mat::data /
+// cols / rows / step); define VLOAM_HIP_WITH_OPENCV for the cv::Mat overload.  The session needs cfg.image_width / image_height.
+// The reference reads its initial guess from the vloam_tf blackboard (cam0_curr_LOT_cam0_prev, visual_odometry.cpp:258-281): here the
+// caller leaves it in angles_0to1 / t_0to1 before solveNlsAll (zeros = reset_VO_to_identity), which also returns the estimate there.
+class VisualOdometry {
+ public:
+  explicit VisualOdometry(std::shared_ptr<Session> s) : s_(std::move(s)) {}
+  void init() {}
+  template <class TF> void init(std::shared_ptr<TF>&) {}   // visual_odometry.h:40 takes the vloam_tf blackboard
+  void reset() { ++count; i = count % 2; }                    // visual_odometry.cpp:85-89
+  void processImage(const unsigned char* gray, int width, int height, int stride) {   // visual_odometry.cpp:91-132
+    check(vloam_vo_process_image(s_->get(), gray, width, height, stride));
+    int n = 0;
+    keypoints.assign(2 * 1024, 0.f);
+    check(vloam_vo_get_keypoints(s_->get(), keypoints.data(), 1024, &n));
+    keypoints.resize(2 * static_cast<size_t>(n));
+    prev_uv.assign(2 * 1024, 0); curr_uv.assign(2 * 1024, 0);
+    int m = 0;
+    check(vloam_vo_get_flow_matches(s_->get(), prev_uv.data(), curr_uv.data(), 1024, &m));   // the match loop's pairs (:296-308)
+    prev_uv.resize(2 * static_cast<size_t>(m)); curr_uv.resize(2 * static_cast<size_t>(m));
+  }
+#ifdef VLOAM_HIP_WITH_OPENCV
+  void processImage(const cv::Mat& img00) { processImage(img00.data, img00.cols, img00.rows, static_cast<int>(img00.step)); }
+#endif
+  void setUpPointCloud(const vloam_calib& calib) { check(vloam_vo_set_calib(s_->get(), &calib)); }   // visual_odometry.cpp:134-155
+  void processPointCloud(const Cloud& cloud) {                                                        // visual_odometry.cpp:157-186
+    check(vloam_vo_process_point_cloud(s_->get(), cloud.empty() ? nullptr : &cloud[0].x, static_cast<int>(cloud.size())));
+  }
+  void solveNlsAll() {                                                                                 // visual_odometry.cpp:254-450
+    int counters[2] = {0, 0};
+    check(vloam_vo_solve(s_->get(), prev_uv.data(), curr_uv.data(), static_cast<int>(prev_uv.size() / 2), angles_0to1, t_0to1, counters));
+    counter32 = counters[0]; counter22 = counters[1];
+  }
+  void publish() {}
+  int i = 0, count = -1;
+  std::vector<float> keypoints;        // (x, y) of keypoints[i], goodFeaturesToTrack order
+  std::vector<int> prev_uv, curr_uv;   // integer pixel pairs of the tracked corners (previous image -> this image)
+  double angles_0to1[3] = {0, 0, 0}, t_0to1[3] = {0, 0, 0};
+  int counter32 = 0, counter22 = 0;
+
+ private:
+  std::shared_ptr<Session> s_;
 };
 
 }  // namespace vloam

@@ -93,3 +93,83 @@ def test_cpp_facade_runs_on_the_gpu_and_matches_the_oracle(tmp_path, orc, sweeps
     last = out[n].split()
     info = o.map_info()
     assert int(last[1]) == info["total_corner"] + info["total_surf"] and int(last[3]) == o.cloud(0).shape[0]
+
+
+VO_PROBE = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+#include "vloam_hip/compat.hpp"
+int main(int argc, char** argv) {
+  const int n_frames = std::atoi(argv[3]), n_pts = std::atoi(argv[4]), W = std::atoi(argv[5]), H = std::atoi(argv[6]);
+  std::FILE* fc = std::fopen(argv[1], "rb");
+  std::FILE* fi = std::fopen(argv[2], "rb");
+  vloam_config cfg; vloam_default_config(&cfg); cfg.with_mapping = 0; cfg.image_width = W; cfg.image_height = H;
+  auto session = std::make_shared<vloam::Session>(0, &cfg);
+  vloam::VisualOdometry VO(session);
+  VO.init();
+  vloam_calib calib;
+  if (std::fread(&calib, sizeof(calib), 1, fc) != 1) return 2;
+  VO.setUpPointCloud(calib);
+  for (int k = 0; k < n_frames; k++) {
+    vloam::Cloud cloud((size_t)n_pts);
+    std::vector<unsigned char> img((size_t)W * H);
+    if (std::fread(cloud.data(), sizeof(vloam::PointXYZI), (size_t)n_pts, fc) != (size_t)n_pts) return 2;
+    if (std::fread(img.data(), 1, img.size(), fi) != img.size()) return 2;
+    VO.reset();                          // the callback's order: vloam_main_node.cpp:133-160
+    VO.processImage(img.data(), W, H, W);
+    VO.processPointCloud(cloud);
+    if (VO.count > 0) {
+      for (int a = 0; a < 3; a++) { VO.angles_0to1[a] = 0; VO.t_0to1[a] = 0; }   // reset_VO_to_identity
+      VO.solveNlsAll();
+    }
+    std::printf("%d %zu %zu %d %d", k, VO.keypoints.size() / 2, VO.prev_uv.size() / 2, VO.counter32, VO.counter22);
+    for (int a = 0; a < 3; a++) std::printf(" %.17g", VO.angles_0to1[a]);
+    for (int a = 0; a < 3; a++) std::printf(" %.17g", VO.t_0to1[a]);
+    std::printf("\n");
+  }
+  return 0;
+}
+'''
+
+
+def test_cpp_visual_odometry_class_from_images(tmp_path, orc, synth, vl):
+    """vloam::VisualOdometry (compat.hpp) driven like the reference's callback: reset -> processImage -> processPointCloud -> solveNlsAll,
+    image front-end + depth-enhanced VO on the device; keypoint / match counts, counters and the estimate against the oracle."""
+    n, W, H = 3, 1242, 375
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=n + 1)
+    clouds = [seq.sweep(k) for k in range(n)]
+    images = [synth.render_image(seq, k, W, H) for k in range(n)]
+    cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
+    with open(tmp_path / "clouds.bin", "wb") as f:
+        f.write(np.concatenate([cam_T_velo.reshape(-1), rect0_T_cam.reshape(-1), P.reshape(-1)]).astype(np.float32).tobytes())
+        for c in clouds:
+            f.write(np.ascontiguousarray(c, dtype=np.float32).tobytes())
+    np.stack(images).tofile(tmp_path / "images.bin")
+    src, exe = tmp_path / "vo_probe.cpp", tmp_path / "vo_probe"
+    src.write_text(VO_PROBE)
+    libdir = os.path.join(ROOT, "vloam-cmu-16833_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lvloam_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(tmp_path / "clouds.bin"), str(tmp_path / "images.bin"), str(n), str(clouds[0].shape[0]), str(W), str(H)])
+    rows = [l.split() for l in out.decode().strip().split("\n")]
+    assert len(rows) == n
+    vo = orc.VOOracle(cam_T_velo, rect0_T_cam, P)
+    prev = None
+    for k in range(n):
+        vo.reset()
+        corners = orc.good_features(images[k])
+        vo.process_point_cloud(clouds[k])
+        assert int(rows[k][1]) == corners.shape[0]
+        if k == 0:
+            assert int(rows[k][2]) == 0
+        else:
+            tracked, status = orc.pyr_lk(prev, images[k], corners)
+            pu, cu = orc.flow_matches(corners, tracked, status)
+            assert int(rows[k][2]) == pu.shape[0]
+            r = vo.solve(pu, cu, np.zeros(3), np.zeros(3))
+            assert (int(rows[k][3]), int(rows[k][4])) == (r["counter32"], r["counter22"])
+            v = np.array([float(x) for x in rows[k][5:11]])
+            assert np.linalg.norm(v[:3] - r["angles"]) < 1e-8 and np.linalg.norm(v[3:] - r["t"]) < 1e-8
+        prev = images[k]
