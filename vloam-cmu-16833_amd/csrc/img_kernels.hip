@@ -10,7 +10,7 @@
 //                                          neighbour" (order-free: the result equals the sorted sequential pass), then the
 //                                          (strength, address)-sorted cut at maxCorners through an LDS bitonic network
 //   k_img_pyrdown     1 thread / pixel     cv::pyrDown
-//   k_img_scharr      1 thread / pixel     calcSharrDeriv
+//   k_img_scharr      1 thread / pixel     calcSharrDeriv of all pyramid levels in one launch
 //   k_img_bf_knn      1 wavefront / query  brute-force Hamming 2-NN over the other image's descriptors (image_util.cpp:221-296)
 //   k_img_lk          1 wavefront / corner pyramidal Lucas-Kanade, all levels in one launch; the 15 x 15 window lives in registers
 //                                          (4 pixels per lane), the search patch of the next image in LDS, the 2 x 2 system in exact
@@ -367,8 +367,18 @@ __global__ __launch_bounds__(256) void k_img_pyrdown(const unsigned char* __rest
   dst[idx] = (unsigned char)((s + 128) >> 8);
 }
 
-__global__ __launch_bounds__(256) void k_img_scharr(const unsigned char* __restrict__ img, int w, int h, short2* __restrict__ deriv) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+// calcSharrDeriv of every pyramid level in one launch (workgroup -> level by the levels' block counts)
+__global__ __launch_bounds__(256) void k_img_scharr(ImgPyrDev P) {
+  int b = blockIdx.x, level = 0;
+  for (; level < P.levels - 1; level++) {
+    const int nb = (P.w[level] * P.h[level] + 255) / 256;
+    if (b < nb) break;
+    b -= nb;
+  }
+  const int w = P.w[level], h = P.h[level];
+  const unsigned char* __restrict__ img = P.img[level];
+  short2* __restrict__ deriv = P.deriv[level];
+  const int idx = b * 256 + threadIdx.x;
   if (idx >= w * h) return;
   const int y = idx / w, x = idx - y * w;
   const unsigned char* s0 = img + (size_t)reflect101(y - 1, h) * w;
@@ -651,8 +661,9 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
   for (int l = 1; l < P.levels; l++)
     VLOAM_LAUNCH(ph, kKImgPyrDown, st, k_img_pyrdown, dim3((P.w[l] * P.h[l] + 255) / 256), dim3(256), 0, st, P.img[l - 1], P.w[l - 1], P.h[l - 1], P.img[l],
                  P.w[l], P.h[l]);
-  for (int l = 0; l < P.levels; l++)
-    VLOAM_LAUNCH(ph, kKImgScharr, st, k_img_scharr, dim3((P.w[l] * P.h[l] + 255) / 256), dim3(256), 0, st, P.img[l], P.w[l], P.h[l], P.deriv[l]);
+  int scharr_blocks = 0;
+  for (int l = 0; l < P.levels; l++) scharr_blocks += (P.w[l] * P.h[l] + 255) / 256;
+  VLOAM_LAUNCH(ph, kKImgScharr, st, k_img_scharr, dim3(scharr_blocks), dim3(256), 0, st, P);
   if (c->count > 0) {
     const double eps = 0.03;   // image_util.cpp:362 TermCriteria(COUNT + EPS, 10, 0.03); calcOpticalFlowPyrLK squares epsilon
     VLOAM_LAUNCH(ph, kKImgLk, st, k_img_lk, dim3(kImgMaxCorners / 4), dim3(256), 0, st, c->pyr[1 - cur], P, c->corners[cur], c->n_corners[cur], c->tracked,
