@@ -441,7 +441,6 @@ def main():
     # (vloam_process_frame_image_device; the reference's optical_flow_match = true configuration, visual_odometry.cpp:91-132)
     img_stage = None
     if extras and images is not None:
-        import orc as _orc
         ni, IH, IW = images.shape
         d_img = torch.from_numpy(images).cuda()
         hi = vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8, detach_VO_LO=0,
@@ -476,12 +475,15 @@ def main():
             hf.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
         itab = hf.profile_table()
         hf.close()
-        # CPU restatement beside it (oracle: cv::goodFeaturesToTrack + cv::calcOpticalFlowPyrLK restated, single thread)
-        c0 = time.perf_counter()
-        for j in range(1, min(ni, 4)):
-            cc = _orc.good_features(images[j])
-            _orc.pyr_lk(images[j - 1], images[j], cc)
-        c1 = time.perf_counter()
+        # CPU restatement beside it (part of the cpu_baseline leg; oracle: cv::goodFeaturesToTrack + cv::calcOpticalFlowPyrLK restated, one thread)
+        cpu_img_ms = None
+        if not args.no_cpu_baseline:
+            import orc as _orc
+            c0 = time.perf_counter()
+            for j in range(1, min(ni, 4)):
+                cc = _orc.good_features(images[j])
+                _orc.pyr_lk(images[j - 1], images[j], cc)
+            cpu_img_ms = 1e3 * (time.perf_counter() - c0) / max(min(ni, 4) - 1, 1)
         img_stage = {"workload": "configs[3] analogue from raw inputs: vloam_process_frame_image_device (sweep + %d x %d grey image per frame; corners + pyramidal LK flow + "
                                  "depth-enhanced VO + LiDAR odometry + mapping, all on the device)" % (IW, IH),
                      "value": (ni - 1) / (i1 - i0), "unit": "frames/s", "ms_per_frame": 1e3 * (i1 - i0) / (ni - 1), "frames": ni - 1, "corners_last": ncorn,
@@ -493,7 +495,7 @@ def main():
                                                             "achieved": IW * IH * (1 + 1.33 + 4 * 1.33) / ((a1 - a0) / reps) / 1e9,
                                                             "frac": IW * IH * (1 + 1.33 + 4 * 1.33) / ((a1 - a0) / reps) / 1e9 / HBM_PEAK_GBS,
                                                             "bytes": "the image once, its 8-bit pyramid (x1.33) and the int16 Scharr pairs of every level (4 B x 1.33) once"},
-                                               "cpu_oracle_ms_per_image": 1e3 * (c1 - c0) / max(min(ni, 4) - 1, 1)},
+                                               "cpu_oracle_ms_per_image": cpu_img_ms},
                      "note": "images are synthetic renders of the LiDAR scene (synth.render_image); ORB + brute-force matching (optical_flow_match = false) is not provided"}
 
     if rank == 0:
