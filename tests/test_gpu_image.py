@@ -6,7 +6,7 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,seed", [(320, 96, 1), (641, 203, 2), (1242, 375, 3)])
+@pytest.mark.parametrize("w,h,seed", [(96, 40, 5), (320, 96, 1), (641, 203, 2), (1242, 375, 3)])   # 96 x 40: a 20-row top level, two levels only
 def test_image_frontend_parity(vl, orc, synth, w, h, seed):
     prev, nxt, _ = synth.synth_image_pair(w, h, seed=seed, shift=(4.3, -1.7), rot=0.005, scale=1.003)
     hd = vl.Handle(0, with_mapping=0, image_width=w, image_height=h)

@@ -32,6 +32,14 @@ __device__ __forceinline__ int reflect101(int i, int n) {  // cv::borderInterpol
   return i;
 }
 
+// the same for indices at most one image size outside (|overshoot| < n): two folds, no loop — the Lucas-Kanade window hangs over a
+// border by at most winSize + 1 pixels and every pyramid level is larger than the window
+__device__ __forceinline__ int reflect101_near(int i, int n) {
+  i = i < 0 ? -i : i;
+  i = i >= n ? 2 * n - 2 - i : i;
+  return i < 0 ? -i : i;
+}
+
 __global__ __launch_bounds__(256) void k_img_sobel(const unsigned char* __restrict__ img, int w, int h, int stride, short2* __restrict__ out,
                                                    unsigned char* __restrict__ level0, unsigned* maxbits, int* n_cand) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -438,6 +446,9 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
   const float FLT_SCALE = 1.f / (1 << 20);
   const float half = (win - 1) * 0.5f;
   const float2 pt = pts[p];
+  int wxq[kQ], wyq[kQ];      // this lane's window pixels (wi = q * 64 + lane < win * win)
+#pragma unroll
+  for (int q = 0; q < kQ; q++) { const int wi = q * 64 + lane; wyq[q] = wi / win; wxq[q] = wi - wyq[q] * win; }
   float ox = 0.f, oy = 0.f;  // nextPts[ptidx]
   bool st = true;
   const int top = min(P.levels, N.levels) - 1;
@@ -469,9 +480,8 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
       const int wi = q * 64 + lane;
       Iw[q] = 0; Ix[q] = 0; Iy[q] = 0;
       if (wi < win * win) {
-        const int wy = wi / win, wx = wi - wy * win;
-        const int X = ipx + wx, Y = ipy + wy;
-        const int x0 = reflect101(X, cw), x1 = reflect101(X + 1, cw), y0 = reflect101(Y, ch), y1 = reflect101(Y + 1, ch);
+        const int X = ipx + wxq[q], Y = ipy + wyq[q];
+        const int x0 = reflect101_near(X, cw), x1 = reflect101_near(X + 1, cw), y0 = reflect101_near(Y, ch), y1 = reflect101_near(Y + 1, ch);
         Iw[q] = descale((int)I[(size_t)y0 * cw + x0] * iw00 + (int)I[(size_t)y0 * cw + x1] * iw01 + (int)I[(size_t)y1 * cw + x0] * iw10 +
                         (int)I[(size_t)y1 * cw + x1] * iw11, W_BITS - 5);
         const bool bx0 = X >= 0 && X < cw, bx1 = X + 1 >= 0 && X + 1 < cw, by0 = Y >= 0 && Y < ch, by1 = Y + 1 >= 0 && Y + 1 < ch;
@@ -506,10 +516,10 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();          // earlier reads of the old patch are done
         const int row = lane >> 1, c0 = (lane & 1) * (kPS / 2);
-        const unsigned char* src = J + (size_t)reflect101(poy + row, ch) * cw;
+        const unsigned char* src = J + (size_t)reflect101_near(poy + row, ch) * cw;
         int v[kPS / 2];
 #pragma unroll
-        for (int i = 0; i < kPS / 2; i++) v[i] = src[reflect101(pox + c0 + i, cw)];   // all 16 loads in flight together
+        for (int i = 0; i < kPS / 2; i++) v[i] = src[reflect101_near(pox + c0 + i, cw)];   // all 16 loads in flight together
 #pragma unroll
         for (int i = 0; i < kPS / 2; i++) patch[row][c0 + i] = (unsigned char)v[i];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -525,8 +535,7 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
       for (int q = 0; q < kQ; q++) {
         const int wi = q * 64 + lane;
         if (wi < win * win) {
-          const int wy = wi / win, wx = wi - wy * win;
-          const int lx = inx - pox + wx, ly = iny - poy + wy;
+          const int lx = inx - pox + wxq[q], ly = iny - poy + wyq[q];
           const int diff = descale((int)patch[ly][lx] * iw00 + (int)patch[ly][lx + 1] * iw01 + (int)patch[ly + 1][lx] * iw10 +
                                    (int)patch[ly + 1][lx + 1] * iw11, W_BITS - 5) - Iw[q];
           sb1 += (long long)(diff * Ix[q]);
