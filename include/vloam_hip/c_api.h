@@ -56,6 +56,7 @@ typedef struct vloam_config {
   int timing;                      /* 1: HIP-event per-stage timing (synchronises every sweep)   */
   int image_width;                 /* capacity of the image front-end (KITTI: 1242 x 375); 0 = none (0) */
   int image_height;
+  int CLAHE;                       /* 1: cv::createCLAHE(2.0)->apply on every image first (vloam_main.launch:8)  (0) */
 } vloam_config;
 
 typedef struct vloam_calib {  /* row-major f32, as PointCloudUtil holds them (point_cloud_util.h:43-46) */
@@ -169,7 +170,8 @@ vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t
  *   ImageUtil::calculateOpticalFlow       src/visual_odometry/src/image_util.cpp:351-372  cv::calcOpticalFlowPyrLK(15 x 15, 2 levels, 10 / 0.03)
  *   VisualOdometry::processImage          src/visual_odometry/src/visual_odometry.cpp:91-132 (the NEW image's corners are tracked from the
  *                                         previous image into the new one, :121-122)
- * vloam_vo_process_image[_device]: one 8-bit grey image (row stride in bytes); every image of a sequence has the same size.
+ * vloam_vo_process_image[_device]: one 8-bit grey image (row stride in bytes); every image of a sequence has the same size.  With
+ *   cfg.CLAHE = 1 the image first goes through cv::createCLAHE(2.0)->apply (visual_odometry.cpp:31,97-100), on the device.
  * vloam_vo_get_keypoints: the corners of the last image, (x, y) pairs in goodFeaturesToTrack's order.
  * vloam_vo_get_flow: for the last image, per corner: where it sits in the previous image (= the corner itself), where it was tracked to
  *   in the new image, and calcOpticalFlowPyrLK's status byte (n = 0 after the first image).

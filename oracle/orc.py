@@ -275,6 +275,15 @@ def pyr_lk(prev, nxt, pts, win=15, max_level=2, max_count=10, epsilon=0.03):
     return out, st[:pts.shape[0]]
 
 
+def clahe(img, clip_limit=2.0, tiles=8):
+    """cv::createCLAHE(2.0)->apply (visual_odometry.cpp:31,97-100): uint8 [h, w] -> uint8 [h, w]."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    L.orc_clahe(_p(img, U8), img.shape[1], img.shape[0], D(clip_limit), int(tiles), _p(out, U8))
+    return out
+
+
 def bf_match_hamming(desc0, desc1, knn=True):
     """image_util.cpp:221-296 (BF, NORM_HAMMING): (queryIdx, trainIdx) int32 arrays; knn: 2-NN + ratio 0.8, else NN + cross check."""
     L = lib()

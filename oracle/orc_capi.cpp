@@ -335,4 +335,9 @@ int orc_bf_match_hamming(const unsigned char* d0, int n0, const unsigned char* d
   return (int)m.size();
 }
 
+int orc_clahe(const unsigned char* img, int w, int h, double clip_limit, int tiles, unsigned char* out) {
+  clahe_apply(img, w, h, clip_limit, tiles, out);
+  return 0;
+}
+
 }  // extern "C"

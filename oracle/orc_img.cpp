@@ -262,6 +262,63 @@ void calc_optical_flow_pyr_lk(const Pyramid& P, const Pyramid& N, const std::vec
   }
 }
 
+void clahe_apply(const uint8_t* img, int w, int h, double clip_limit, int tiles, uint8_t* out) {
+  const int hist_size = 256;
+  // the LUTs are computed on an image padded to a multiple of the tile grid (bottom / right, REFLECT_101): note OpenCV pads by
+  // tiles - (size % tiles), i.e. only when the size does not divide
+  const int ew = (w % tiles == 0 && h % tiles == 0) ? w : w + (tiles - w % tiles);
+  const int eh = (w % tiles == 0 && h % tiles == 0) ? h : h + (tiles - h % tiles);
+  const int tw = ew / tiles, th = eh / tiles;
+  const int tile_area = tw * th;
+  const float lut_scale = (float)(hist_size - 1) / (float)tile_area;
+  int clip = 0;
+  if (clip_limit > 0.0) { clip = (int)(clip_limit * tile_area / hist_size); clip = std::max(clip, 1); }
+  std::vector<uint8_t> lut((size_t)tiles * tiles * hist_size);
+  for (int ty = 0; ty < tiles; ty++)
+    for (int tx = 0; tx < tiles; tx++) {
+      int hist[256] = {0};
+      for (int y = ty * th; y < (ty + 1) * th; y++)
+        for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[img[(size_t)reflect101(y, h) * w + reflect101(x, w)]]++;
+      if (clip > 0) {
+        int clipped = 0;
+        for (int i = 0; i < hist_size; i++)
+          if (hist[i] > clip) { clipped += hist[i] - clip; hist[i] = clip; }
+        const int batch = clipped / hist_size;
+        int residual = clipped - batch * hist_size;
+        for (int i = 0; i < hist_size; i++) hist[i] += batch;
+        if (residual != 0) {
+          const int step = std::max(hist_size / residual, 1);
+          for (int i = 0; i < hist_size && residual > 0; i += step, residual--) hist[i]++;
+        }
+      }
+      int sum = 0;
+      uint8_t* L = lut.data() + (size_t)(ty * tiles + tx) * hist_size;
+      for (int i = 0; i < hist_size; i++) {
+        sum += hist[i];
+        const int v = cv_round((float)sum * lut_scale);   // saturate_cast<uchar>(float)
+        L[i] = (uint8_t)std::min(std::max(v, 0), 255);
+      }
+    }
+  const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+  for (int y = 0; y < h; y++) {
+    const float tyf = (float)y * inv_th - 0.5f;
+    int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+    ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tiles - 1);
+    for (int x = 0; x < w; x++) {
+      const float txf = (float)x * inv_tw - 0.5f;
+      int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+      const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+      tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tiles - 1);
+      const int v = img[(size_t)y * w + x];
+      const float l11 = lut[(size_t)(ty1 * tiles + tx1) * hist_size + v], l12 = lut[(size_t)(ty1 * tiles + tx2) * hist_size + v];
+      const float l21 = lut[(size_t)(ty2 * tiles + tx1) * hist_size + v], l22 = lut[(size_t)(ty2 * tiles + tx2) * hist_size + v];
+      const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+      out[(size_t)y * w + x] = (uint8_t)std::min(std::max(cv_round(res), 0), 255);
+    }
+  }
+}
+
 static inline int hamming(const uint8_t* a, const uint8_t* b, int bytes) {
   int d = 0;
   for (int k = 0; k < bytes; k++) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));

@@ -50,6 +50,13 @@ struct Pyramid {                      // cv::buildOpticalFlowPyramid without the
 void calc_optical_flow_pyr_lk(const Pyramid& prev, const Pyramid& next, const std::vector<ImgCorner>& prev_pts, std::vector<ImgCorner>* next_pts,
                               std::vector<uint8_t>* status, int win, int max_count, double epsilon);
 
+// cv::CLAHE::apply of cv::createCLAHE(clip_limit, Size(tiles, tiles)) on an 8-bit image (imgproc/src/clahe.cpp) — the optional first step of
+// VisualOdometry::processImage (visual_odometry.cpp:31,97-100; vloam_main.launch:8 CLAHE = false by default): per-tile histograms (the image
+// padded REFLECT_101 to a multiple of the tile grid when it does not divide), clipping with uniform redistribution of the excess and
+// the residual spread at a fixed stride, cumulative LUTs scaled by 255 / tile area, bilinear interpolation of the four surrounding
+// tiles' LUT values in f32.  out: w * h bytes.
+void clahe_apply(const uint8_t* img, int w, int h, double clip_limit, int tiles, uint8_t* out);
+
 // ImageUtil::matchDescriptors with MatcherType::BF on binary descriptors (NORM_HAMMING), image_util.cpp:221-296:
 //   knn != 0 (SelectType::KNN, the reference's setting, visual_odometry.cpp:37): BFMatcher::knnMatch(desc0, desc1, 2) and the ratio
 //            test  d_best < 0.8 * d_second  (:262-271);

@@ -161,6 +161,8 @@ class VloamOracle:
         """One callback() from raw inputs with optical_flow_match = true: VisualOdometry::processImage (visual_odometry.cpp:91-132) —
         corners of the new image, tracked from the previous image into the new one — then the match loop's integer pairs."""
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        if getattr(self, "CLAHE", False):                                  # visual_odometry.cpp:97-98
+            gray = orc.clahe(gray)
         corners = orc.good_features(gray)                                  # image_util.cpp:13-36
         prev_uv = curr_uv = None
         self.flow = None

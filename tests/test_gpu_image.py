@@ -157,3 +157,23 @@ def test_bf_hamming_matcher_parity(vl, orc):
         h.vo_match_descriptors(np.zeros((4, 30), dtype=np.uint8), np.zeros((4, 30), dtype=np.uint8))
     assert e.value.status == vl.ERR_INVALID
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,seed", [(320, 96, 1), (333, 101, 2), (1242, 375, 3)])
+def test_clahe_parity(vl, orc, synth, w, h, seed):
+    """cfg.CLAHE = 1: the equalised image is bit-identical to the oracle's cv::CLAHE restatement, and corners / flow are those of the
+    equalised images (visual_odometry.cpp:97-105)."""
+    prev, nxt, _ = synth.synth_image_pair(w, h, seed=seed, shift=(3.3, 1.4))
+    hd = vl.Handle(0, with_mapping=0, image_width=w, image_height=h, CLAHE=1)
+    hd.vo_process_image(prev)
+    e0 = orc.clahe(prev)
+    assert np.array_equal(hd.debug_raw(4, 11, np.uint8).reshape(h, w), e0)
+    assert np.array_equal(hd.vo_keypoints(), orc.good_features(e0))
+    hd.vo_process_image(nxt)
+    e1 = orc.clahe(nxt)
+    c1 = orc.good_features(e1)
+    out, st = orc.pyr_lk(e0, e1, c1)
+    a, b, s = hd.vo_flow()
+    assert np.array_equal(a, c1) and np.array_equal(b, out) and np.array_equal(s, st)
+    hd.close()

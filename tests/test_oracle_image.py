@@ -268,3 +268,50 @@ def test_bf_hamming_matcher_vs_numpy(orc):
         k2 = bt[bq] == np.arange(300)
         assert np.array_equal(q2, np.nonzero(k2)[0]) and np.array_equal(t2, bq[k2])
     assert orc.bf_match_hamming(a, b[:1], True)[0].size == 0     # one train descriptor: no second neighbour, no match
+
+
+def _np_clahe(img, clip_limit=2.0, tiles=8):
+    """cv::CLAHE::apply in array form (integral histogram per tile, fancy-indexed LUT interpolation), independent of orc_img.cpp."""
+    h, w = img.shape
+    ext = img if (w % tiles == 0 and h % tiles == 0) else np.pad(img, ((0, tiles - h % tiles), (0, tiles - w % tiles)), mode="reflect")
+    eh, ew = ext.shape
+    th, tw = eh // tiles, ew // tiles
+    area = tw * th
+    scale = np.float32(255) / np.float32(area)
+    clip = max(int(clip_limit * area / 256), 1) if clip_limit > 0 else 0
+    lut = np.zeros((tiles, tiles, 256), np.float32)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip > 0:
+                exc = int(np.maximum(hist - clip, 0).sum())
+                hist = np.minimum(hist, clip)
+                batch = exc // 256
+                res = exc - batch * 256
+                hist = hist + batch
+                if res:
+                    hist[np.arange(0, 256, max(256 // res, 1))[:res]] += 1
+            lut[ty, tx] = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * scale), 0, 255)
+    f32 = np.float32
+    ys = np.arange(h, dtype=f32) * f32(f32(1) / f32(th)) - f32(0.5)
+    xs = np.arange(w, dtype=f32) * f32(f32(1) / f32(tw)) - f32(0.5)
+    ty1, tx1 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    ya, xa = (ys - ty1.astype(f32))[:, None], (xs - tx1.astype(f32))[None, :]
+    ya1, xa1 = f32(1) - ya, f32(1) - xa
+    ty2, tx2 = np.minimum(ty1 + 1, tiles - 1), np.minimum(tx1 + 1, tiles - 1)
+    ty1, tx1 = np.maximum(ty1, 0), np.maximum(tx1, 0)
+    v = img.astype(int)
+    l11, l12 = lut[ty1[:, None], tx1[None, :], v], lut[ty1[:, None], tx2[None, :], v]
+    l21, l22 = lut[ty2[:, None], tx1[None, :], v], lut[ty2[:, None], tx2[None, :], v]
+    return np.clip(np.rint((l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya), 0, 255).astype(np.uint8)
+
+
+def test_clahe_vs_numpy_transcription(orc, synth):
+    """cv::createCLAHE(2.0)->apply (visual_odometry.cpp:31,97-100): sizes that divide the 8 x 8 tile grid and sizes that do not (padding)."""
+    for (w, h, seed) in ((320, 96, 1), (333, 101, 2), (1242, 375, 3)):
+        img, _, _ = synth.synth_image_pair(w, h, seed=seed)
+        out = orc.clahe(img)
+        assert np.array_equal(out, _np_clahe(img))
+        assert out.std() > img.std()                      # it does equalise
+    flat = np.full((64, 64), 100, dtype=np.uint8)
+    assert np.array_equal(orc.clahe(flat), _np_clahe(flat))

@@ -37,7 +37,7 @@ class Config(C.Structure):
                 ("mapping_line_resolution", C.c_float), ("mapping_plane_resolution", C.c_float), ("detach_VO_LO", C.c_int),
                 ("reset_VO_to_identity", C.c_int), ("remove_VO_outlier", C.c_int), ("with_mapping", C.c_int),
                 ("max_points", C.c_int), ("max_frames", C.c_int), ("map_capacity_log2", C.c_int), ("debug", C.c_int),
-                ("timing", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int)]
+                ("timing", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int), ("CLAHE", C.c_int)]
 
 
 class Calib(C.Structure):

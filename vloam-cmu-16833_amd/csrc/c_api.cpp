@@ -208,6 +208,7 @@ void vloam_default_config(vloam_config* c) {
   c->timing = 0;
   c->image_width = 0;
   c->image_height = 0;
+  c->CLAHE = 0;
 }
 
 const char* vloam_last_error(void) { return g_err.c_str(); }

@@ -23,6 +23,7 @@ constexpr int kImgCandCap = 65536;     // local maxima above the quality thresho
 constexpr int kImgNbrCap = 64;         // stronger candidates within minDistance of a candidate (3x3 local maxima are >= 2 px apart)
 constexpr int kImgAccCap = 16384;      // corners before the maxCorners cut (a 1242 x 375 image holds < 10 600 at minDistance 7.5)
 constexpr int kImgMaxRadius = 8;       // floor(minDistance) the neighbourhood scan supports
+constexpr int kImgClaheTiles = 8;       // cv::createCLAHE default tileGridSize (8, 8); clipLimit 2.0 (visual_odometry.cpp:31)
 constexpr int kImgMaxDesc = 8192;      // descriptors per image the brute-force matcher takes
 constexpr int kImgMaxDescBytes = 64;   // ORB / BRISK: 32 / 64 bytes
 
@@ -53,6 +54,9 @@ struct ImgContext {
   unsigned char* status = nullptr;
   int* error = nullptr;        // sticky capacity bits
   unsigned char* staging = nullptr;   // [max_w * max_h] upload buffer of the host-pointer entry
+  bool clahe = false;          // cfg.CLAHE
+  unsigned char* clahe_img = nullptr;   // [max_w * max_h] equalised image
+  unsigned char* clahe_lut = nullptr;   // [tiles^2][256]
   unsigned* desc[2] = {nullptr, nullptr};   // [kImgMaxDesc][kImgMaxDescBytes / 4] descriptors of the two images (brute-force matcher)
   uint2* best2[2] = {nullptr, nullptr};     // [kImgMaxDesc] per descriptor: the two smallest (distance << 16 | index) keys against the other set
 };

@@ -2,6 +2,7 @@
 // reference call sites; the arithmetic follows oracle/orc_img.h's statement of cv::goodFeaturesToTrack / cv::calcOpticalFlowPyrLK
 // (integer-exact structure tensor and Lucas-Kanade sums, everything else in OpenCV's own f32 / fixed-point order).
 //
+//   k_img_clahe_*     1 WG / tile, 1 thread / pixel   optional cv::CLAHE(2.0, 8 x 8) in front of everything (cfg.CLAHE)
 //   k_img_sobel       1 thread / pixel     Sobel 3x3 (ints) of the 8-bit image + contiguous copy = pyramid level 0
 //   k_img_eig         32 x 8 tiles         5 x 5 box sums of the gradient products through LDS, min eigenvalue (f64 -> f32), global max
 //   k_img_localmax    1 thread / pixel     quality threshold + 3 x 3 non-maximum suppression -> candidate list + pixel -> candidate map
@@ -54,6 +55,60 @@ __global__ __launch_bounds__(256) void k_img_sobel(const unsigned char* __restri
   const int dy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
   out[idx] = make_short2((short)dx, (short)dy);
   level0[idx] = r1[x];
+}
+
+// cv::CLAHE (imgproc/src/clahe.cpp), 8-bit: one workgroup per tile builds the tile's histogram in LDS (the image padded REFLECT_101 to a
+// multiple of the tile grid), clips it, spreads the excess (uniform batch + residual at a fixed stride) and writes the cumulative LUT.
+__global__ __launch_bounds__(256) void k_img_clahe_lut(const unsigned char* __restrict__ img, int w, int h, int stride, int tiles, int tw, int th, int clip,
+                                                       float lut_scale, unsigned char* __restrict__ lut) {
+  __shared__ int hist[256], scan[256], s_clipped;
+  const int tid = threadIdx.x, tx = blockIdx.x % tiles, ty = blockIdx.x / tiles;
+  hist[tid] = 0;
+  if (tid == 0) s_clipped = 0;
+  __syncthreads();
+  for (int e = tid; e < tw * th; e += 256) {
+    const int y = ty * th + e / tw, x = tx * tw + e % tw;
+    atomicAdd(&hist[img[(size_t)reflect101(y, h) * stride + reflect101(x, w)]], 1);   // integer counts: order-free
+  }
+  __syncthreads();
+  int v = hist[tid];
+  if (clip > 0) {
+    if (v > clip) { atomicAdd(&s_clipped, v - clip); v = clip; }
+    __syncthreads();
+    const int clipped = s_clipped, batch = clipped / 256, residual = clipped - batch * 256;
+    v += batch;
+    if (residual != 0) {
+      const int step = max(256 / residual, 1);
+      if (tid % step == 0 && tid / step < residual) v++;   // for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++
+    }
+  }
+  scan[tid] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {   // inclusive scan (exact integers)
+    const int o = tid >= d ? scan[tid - d] : 0;
+    __syncthreads();
+    scan[tid] += o;
+    __syncthreads();
+  }
+  const int r = (int)rintf((float)scan[tid] * lut_scale);   // saturate_cast<uchar>(float)
+  lut[(size_t)blockIdx.x * 256 + tid] = (unsigned char)min(max(r, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_img_clahe_apply(const unsigned char* __restrict__ img, int w, int h, int stride, int tiles, float inv_tw, float inv_th,
+                                                         const unsigned char* __restrict__ lut, unsigned char* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * h) return;
+  const int y = idx / w, x = idx - y * w;
+  const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
+  int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
+  const float ya = tyf - (float)ty1, ya1 = 1.0f - ya, xa = txf - (float)tx1, xa1 = 1.0f - xa;
+  const int ty2 = min(ty1 + 1, tiles - 1), tx2 = min(tx1 + 1, tiles - 1);
+  ty1 = max(ty1, 0); tx1 = max(tx1, 0);
+  const int v = img[(size_t)y * stride + x];
+  const float l11 = lut[(size_t)(ty1 * tiles + tx1) * 256 + v], l12 = lut[(size_t)(ty1 * tiles + tx2) * 256 + v];
+  const float l21 = lut[(size_t)(ty2 * tiles + tx1) * 256 + v], l22 = lut[(size_t)(ty2 * tiles + tx2) * 256 + v];
+  const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+  out[idx] = (unsigned char)min(max((int)rintf(res), 0), 255);
 }
 
 constexpr int kTileW = 32, kTileH = 8, kHalo = kImgBlock / 2;
@@ -634,6 +689,8 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
   ok = ok && A.take(&c->sobel, npx) && A.take(&c->eig, npx) && A.take(&c->maxbits, 1) && A.take(&c->cmap, npx) && A.take(&c->clist, kImgCandCap) &&
        A.take(&c->n_cand, 1) && A.take(&c->nbr, (size_t)kImgCandCap * kImgNbrCap) && A.take(&c->nbr_cnt, kImgCandCap) && A.take(&c->acc, kImgAccCap) &&
        A.take(&c->tracked, kImgMaxCorners) && A.take(&c->status, kImgMaxCorners) && A.take(&c->error, 1) && A.take(&c->staging, npx);
+  c->clahe = cfg.CLAHE != 0;
+  ok = ok && A.take(&c->clahe_img, npx) && A.take(&c->clahe_lut, (size_t)kImgClaheTiles * kImgClaheTiles * 256);
   for (int k = 0; k < 2; k++) ok = ok && A.take(&c->desc[k], (size_t)kImgMaxDesc * (kImgMaxDescBytes / 4)) && A.take(&c->best2[k], kImgMaxDesc);
   return ok ? VLOAM_OK : VLOAM_ERR_CAPACITY;
 }
@@ -654,6 +711,17 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
   ImgPyrDev& P = c->pyr[cur];
   pyr_dims(width, height, &P);
   const int npx = width * height, gpx = (npx + 255) / 256;
+  if (c->clahe) {   // visual_odometry.cpp:97-98: clahe->apply(img00, images[i]) — everything below then sees the equalised image
+    const int T = kImgClaheTiles;
+    const bool fits = width % T == 0 && height % T == 0;
+    const int ew = fits ? width : width + (T - width % T), eh = fits ? height : height + (T - height % T);
+    const int tw = ew / T, th = eh / T;
+    const int clip = max((int)(2.0 * (tw * th) / 256), 1);   // clipLimit 2.0 (visual_odometry.cpp:31)
+    VL_RAW_LAUNCH(k_img_clahe_lut, dim3(T * T), dim3(256), 0, st, d_gray, width, height, stride, T, tw, th, clip, 255.0f / (float)(tw * th), c->clahe_lut);
+    VL_RAW_LAUNCH(k_img_clahe_apply, dim3(gpx), dim3(256), 0, st, d_gray, width, height, stride, T, 1.0f / (float)tw, 1.0f / (float)th, c->clahe_lut, c->clahe_img);
+    d_gray = c->clahe_img;
+    stride = width;
+  }
   // image_util.cpp:17-31: block_size 5, min_distance 7.5, maxCorners 1024, quality_level 0.03
   const double quality = 0.03, min_distance = kImgBlock * 1.5;
   const double scale = 1.0 / (4.0 * (double)kImgBlock * 255.0);
@@ -737,6 +805,7 @@ vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, lo
   if (item == 8) return img_copy_out(c->n_cand, sizeof(int), buf, cap, n);
   if (item == 9) return img_copy_out(c->error, sizeof(int), buf, cap, n);
   if (item == 10) return img_copy_out(c->acc + kImgAccCap - 8, 8 * sizeof(u64), buf, cap, n);
+  if (item == 11) { if (!c->clahe) return VLOAM_ERR_ORDER; return img_copy_out(c->clahe_img, (size_t)c->w * c->h, buf, cap, n); }   // the equalised image
   return VLOAM_ERR_INVALID;
 }
 
