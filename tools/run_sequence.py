@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--mapping-skip-frame", type=int, default=2)
     ap.add_argument("--vloam", action="store_true", help="coupled VO + LiDAR frames (synthetic sequences only: synthetic pixel matches)")
     ap.add_argument("--images", action="store_true", help="with --vloam: take the pixel matches from grey images (device image front-end)")
+    ap.add_argument("--clahe", action="store_true", help="with --images: cv::createCLAHE(2.0) on every image first (the launch file's CLAHE parameter)")
     ap.add_argument("--image-dir", help="directory of 8-bit grey PNGs, one per sweep (KITTI raw image_00/data)")
     ap.add_argument("--calib-cam-to-cam", help="KITTI calib_cam_to_cam.txt (R_rect_00, P_rect_00)")
     ap.add_argument("--calib-velo-to-cam", help="KITTI calib_velo_to_cam.txt (R, T)")
@@ -92,7 +93,7 @@ def main():
     img_cfg = {}
     if a.images:
         ih, iw = (kio.load_png_gray(real_images[0]).shape if real_images else (375, 1242))
-        img_cfg = dict(image_width=int(iw), image_height=int(ih))
+        img_cfg = dict(image_width=int(iw), image_height=int(ih), CLAHE=int(a.clahe))
     loam = vl.LidarOdometryMapping(device=a.device, mapping_skip_frame=a.mapping_skip_frame, detach_VO_LO=0 if a.vloam else 1,
                                    timing=1 if (a.metrics and not a.vloam) else 0, **img_cfg)
     hd = loam.hd
