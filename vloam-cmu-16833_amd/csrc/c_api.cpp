@@ -123,7 +123,7 @@ static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
 }
 
 constexpr int kSyncCand = 48;          // candidate cache lines for the sync words of the cooperative solves
-constexpr size_t kSyncStride = 4352;   // 4 KB + 256 B: walks page and sub-page address bits; >= one slot
+constexpr size_t kSyncStride = 8448;   // 8 KB + 256 B: walks page and sub-page address bits; >= one slot
 static_assert(kSyncStride >= kLmSyncDoubles * sizeof(double), "slots must not overlap");
 
 // Carve one session's device state out of its arena.  Runs twice: dry (A.base == nullptr) to measure, then for real.

@@ -29,6 +29,7 @@ namespace vloam {
 constexpr int kLmThreads = 256;
 
 constexpr int kAcc = 28;  // cost, g[6], H upper triangle[21]
+typedef unsigned long long u64;
 
 struct D3 { double x, y, z; };
 __device__ __forceinline__ D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -317,8 +318,9 @@ constexpr int kRedStride = kLmThreads + 8;
 struct LmShared {
   double red[kAcc * kRedStride];  // [value][thread] transpose buffer of the block reduction (rows padded against bank conflicts)
   double part[8 * kAcc];          // [sub-sum][value]
-  double cur[kAcc];    // accumulators at x
-  double cand[kAcc];   // accumulators at the candidate
+  double acc2[2][kAcc];  // accumulators at x (acc2[curidx]) and at the candidate (acc2[curidx ^ 1]): accepting a step flips the index
+  double Hs[21], gs[6];  // Jacobi-scaled normal equations of the current point (packed lower triangle), refreshed when the point changes
+  int curidx;
   double x[8], xc[8];
   double mcc;          // model_cost_change of the pending candidate
   double gmax_c, xnorm_c;  // gradient max-norm / |x| at the point just evaluated (computed by helper lanes in parallel)
@@ -358,7 +360,7 @@ struct LmCache {
 // evaluations of this solve (barrier target and double-buffer parity of the partial sums).
 template <bool QUAT, bool DIRECT, int NB>
 __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
-                                            double* s_out, bool first, LmCache& C, long long* cyc_factors, int eval_idx) {
+                                            double* s_out, bool first, LmCache& C, long long* cyc_factors, int eval_idx, unsigned tag_base) {
   static_assert(NB == 1 || QUAT, "the cooperative form exists for the quaternion problems");
   const int tid = threadIdx.x;
   const int blk = NB > 1 ? (int)blockIdx.x : 0;
@@ -550,46 +552,57 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     sh.part[sub * kAcc + i] = s;
   }
   __syncthreads();
-  double* gpart = NB > 1 ? F.gsync + 8 + (size_t)(eval_idx & 1) * kLmMaxBlocks * 32 : nullptr;
   if (tid < kAcc) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; w++) s += sh.part[w * kAcc + tid];
-    if (NB == 1) s_out[tid] = s;
-    else __hip_atomic_store(&gpart[blk * 32 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if constexpr (NB > 1) {
-    // Ordering: the kAcc publishing lanes all sit in wavefront 0, the wavefront of thread 0, so the RELEASE of thread 0's
-    // fetch_add (which waits for that wavefront's outstanding stores) covers every partial sum before the counter moves.
-    static_assert(kAcc <= 64, "the publishers must share thread 0's wavefront");
-    if (tid == 0) {  // grid barrier number eval_idx + 1 of this solve (the counter starts every solve at zero)
-      unsigned* bar = reinterpret_cast<unsigned*>(F.gsync);
-      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (unsigned)(eval_idx + 1) * (unsigned)NB;
-      int spins = 0;
-      unsigned v;
-      // never hang the device: a workgroup that gives up sets the counter's top bit — every waiter (now or later) falls out of its
-      // loop on the value it polls anyway, the host is told through the sticky error word (vloam_sync), and the solve is abandoned
-      while ((v = __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) {
-          v = __hip_atomic_fetch_or(bar, 0x80000000u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) | 0x80000000u;
+    if constexpr (NB == 1) s_out[tid] = s;
+    else {
+      // Exchange of the partial sums between the NB workgroups WITHOUT a barrier: every f64 travels as two naturally aligned 8-byte
+      // granules {32 payload bits, 32-bit tag}, tag = (solve generation, evaluation) — an 8-byte store is single-copy atomic, so a
+      // reader that sees the tag it waits for holds the payload that was written with it, and there is nothing to order.  Each lane
+      // publishes its value and then polls the NB x 2 granules of its own column: one store trip + the slowest workgroup's arrival,
+      // instead of store -> release fetch-add -> poll -> load (two and a half trips).  Double-buffered by evaluation parity: nobody can
+      // publish evaluation e + 2 before everybody has READ evaluation e (it needs everybody's e + 1 for that).  Every workgroup adds
+      // the partials in workgroup order, so all of them hold bit-identical accumulators and run the (cheap) trust-region bookkeeping
+      // redundantly.  Never hangs: a lane that gives up poisons the solve (every poller reads the poison word each round), the host is
+      // told through the sticky error word (vloam_sync), and the solve is abandoned with x unchanged.
+      u64* gw = reinterpret_cast<u64*>(F.gsync);
+      u64* gran = gw + 8 + (size_t)(eval_idx & 1) * kLmMaxBlocks * 64;
+      const u64 tag = (u64)(tag_base + (unsigned)eval_idx + 1u) << 32;
+      const u64 poison = (u64)(tag_base >> 8) + 1ull;
+      const u64 bits = (u64)__double_as_longlong(s);
+      __hip_atomic_store(&gran[blk * 64 + tid], (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gran[blk * 64 + 32 + tid], (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 lo[NB], hi[NB];
+      bool bad = false;
+      for (int spins = 0;; spins++) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+          lo[q] = __hip_atomic_load(&gran[q * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[q] = __hip_atomic_load(&gran[q * 64 + 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < NB; q++) all = all && (lo[q] >> 32 << 32) == tag && (hi[q] >> 32 << 32) == tag;
+        if (all) break;
+        if (__hip_atomic_load(&gw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == poison) { bad = true; break; }
+        if (spins > (1 << 18)) {
+          __hip_atomic_store(&gw[1], poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (F.err) atomicOr(F.err, kErrSolverSync);
+          bad = true;
           break;
         }
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (v & 0x80000000u) sh.failed = 1;  // nobody continues with partial sums that may be incomplete
-    }
-    __syncthreads();
-    if (tid < kAcc) {
-      double s = 0.0;
+      if (bad) sh.failed = 1;  // nobody continues with partial sums that may be incomplete
+      double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < NB; q++) s += __hip_atomic_load(&gpart[q * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_out[tid] = s;
+      for (int q = 0; q < NB; q++) tot += __longlong_as_double((long long)((hi[q] << 32) | (lo[q] & 0xffffffffull)));
+      s_out[tid] = tot;
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 // packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
@@ -705,17 +718,22 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   const int tid = threadIdx.x;
   const bool lead = NB == 1 || blockIdx.x == 0;  // the workgroup that owns every global side effect other than its factors' residuals
   constexpr int na = QUAT ? 7 : 6;
-  // the gate word, the parameters and this lane's first row counter are fetched in ONE round trip (a branch on the gate first would
-  // put a dependent ~1.5 us memory trip in front of everything else the solve reads)
+  // the gate word, the parameters, this lane's first row counter and the solve generation are fetched in ONE round trip (a branch on
+  // the gate first would put a dependent ~1.5 us memory trip in front of everything else the solve reads)
   const int enabled = enable_flag ? *enable_flag : 1;
   const double x_first = tid < na ? x_io[tid] : 0.0;
   const int row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
+  // generation of this table's cooperative solves: tags the partial sums every workgroup publishes (lm_evaluate); bumped by the lead
+  // workgroup on its way out — every workgroup has read it by then, because the lead needed their first partial sums
+  u64 gen = 0;
+  if constexpr (NB > 1) gen = __hip_atomic_load(reinterpret_cast<u64*>(F.gsync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned tag_base = (unsigned)(gen & 0xffffffull) << 8;
   if (enabled == 0) {
     if (lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
     return;
   }
   if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
-  if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; }
+  if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
 
   // ---- prologue: the factors were compacted by k_lm_compact; count them and release the row counters
   const long long t_start = clock64();
@@ -741,13 +759,12 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   LmCache cache;
   t_mark = clock64();
   int eval_idx = 0;
-  lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.cur, true, cache, &cyc_fac, eval_idx++);
+  lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.acc2[0], true, cache, &cyc_fac, eval_idx++, tag_base);
   cyc_eval += clock64() - t_mark;
-  if (NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone is past the first barrier, i.e. past its prologue
+  if (NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone has published its first partial sums, i.e. is past its prologue
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
-  bool reuse_diagonal = false;
   int num_invalid = 0, iteration = 0, n_rec = 0, termination = 0, n_evals = 1;
   double it_cost = 0, it_cost_change = 0, it_step_norm = 0, it_rho = 0;
   bool it_valid = true, it_success = true;
@@ -770,13 +787,37 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int i = 0; i < na; i++) s += xx[i] * xx[i];
     return sqrt(s);
   };
-  if (tid >= 192 && tid < 198) sh.scale[tid - 192] = 1.0 / (1.0 + sqrt(Hget(sh.cur, tid - 192, tid - 192)));  // jacobi_scaling, fixed at iteration 0
-  if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.cur);
+  // What LevenbergMarquardtStrategy::ComputeStep needs of a point — the Jacobi-scaled normal equations Hs = S H S (packed lower
+  // triangle), gs = S g, and the clamped LM diagonal — by 27 lanes of wavefront 3 at once, whenever the point changes (the start and
+  // every accepted step; rejected steps keep all three, which is Ceres' reuse_diagonal).  The trust-region step of thread 0 then
+  // starts from 33 LDS reads instead of rebuilding ~150 products on one lane.  jacobi_scaling is fixed at iteration 0.
+  auto refresh_normal_equations = [&](const double* acc, bool first) {
+    const int j = tid - 192;
+    if (j < 0 || j >= 27) return;
+    if (j < 21) {
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= j) a++;
+      const int b = j - a * (a + 1) / 2;   // j == LIDX(a, b), a >= b
+      const double sa = first ? 1.0 / (1.0 + sqrt(acc[7 + a * 6 - (a * (a - 1)) / 2])) : sh.scale[a];
+      const double sb = first ? 1.0 / (1.0 + sqrt(acc[7 + b * 6 - (b * (b - 1)) / 2])) : sh.scale[b];
+      sh.Hs[j] = acc[7 + b * 6 - (b * (b - 1)) / 2 + (a - b)] * sa * sb;
+    } else {
+      const int a = j - 21;
+      const double haa = acc[7 + a * 6 - (a * (a - 1)) / 2];
+      const double sa = first ? 1.0 / (1.0 + sqrt(haa)) : sh.scale[a];
+      if (first) sh.scale[a] = sa;
+      sh.gs[a] = acc[1 + a] * sa;
+      sh.diagonal[a] = fmin(fmax(haa * sa * sa, 1e-6), 1e32);
+    }
+  };
+  refresh_normal_equations(sh.acc2[0], true);
+  if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.acc2[0]);
   if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
   __syncthreads();
   const bool failed_at_start = NB > 1 && sh.failed;  // (uniform: written before the barrier that ends lm_evaluate)
   if (tid == 0) {
-    x_cost = sh.cur[0];
+    const double* cur = sh.acc2[0];
+    x_cost = cur[0];
     gmax = sh.gmax_c;
     x_norm = sh.xnorm_c;
     current_cost = x_cost;
@@ -787,14 +828,15 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
       for (int i = 0; i < 7; i++) rec->x_in[i] = sh.best[i];
 #pragma unroll
-      for (int a = 0; a < 6; a++) { rec->g0[a] = sh.cur[1 + a];
+      for (int a = 0; a < 6; a++) { rec->g0[a] = cur[1 + a];
 #pragma unroll
-        for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(sh.cur, a, b); }
+        for (int b = 0; b < 6; b++) rec->H0[a * 6 + b] = Hget(cur, a, b); }
       rec->initial_cost = x_cost;
       rec->n_factors = n_valid;
     }
   }
 
+  int curidx = 0;  // uniform copy of sh.curidx
   for (; !failed_at_start;) {
     t_mark = clock64();
     if (tid == 0) {
@@ -814,39 +856,28 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         if (gmax <= 1e-10) { termination = 1; go = 0; break; }
         if (radius <= 1e-32) { termination = 1; go = 0; break; }
         iteration++;
-        // ---- LevenbergMarquardtStrategy::ComputeStep on the normal equations of the column-scaled Jacobian
-        double gs[6], L[21], y[6], step[6], cur[kAcc], sc6[6];
+        // ---- LevenbergMarquardtStrategy::ComputeStep on the normal equations of the column-scaled Jacobian:
+        // (Hs + D / radius) y = gs by Cholesky, step = -y
+        double gs[6], dg[6], L[21], y[6], sc6[6];
 #pragma unroll
-        for (int i = 0; i < kAcc; i++) cur[i] = sh.cur[i];  // one batch of independent LDS reads
+        for (int i = 0; i < 21; i++) L[i] = sh.Hs[i];  // one batch of independent LDS reads
 #pragma unroll
-        for (int a = 0; a < 6; a++) sc6[a] = sh.scale[a];
-#pragma unroll
-        for (int a = 0; a < 6; a++) gs[a] = cur[1 + a] * sc6[a];
-        if (!reuse_diagonal) {
-#pragma unroll
-          for (int a = 0; a < 6; a++) sh.diagonal[a] = fmin(fmax(Hget(cur, a, a) * sc6[a] * sc6[a], 1e-6), 1e32);
-        }
+        for (int a = 0; a < 6; a++) { gs[a] = sh.gs[a]; dg[a] = sh.diagonal[a]; sc6[a] = sh.scale[a]; }
         const double inv_radius = 1.0 / radius;
 #pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int b = 0; b <= a; b++) L[LIDX(a, b)] = Hget(cur, a, b) * sc6[a] * sc6[b] + (a == b ? sh.diagonal[a] * inv_radius : 0.0);
+        for (int a = 0; a < 6; a++) { dg[a] = dg[a] * inv_radius; L[LIDX(a, a)] += dg[a]; }
         bool ok = chol6_solve(L, gs, y);
 #pragma unroll
         for (int a = 0; a < 6; a++) ok = ok && isfinite(y[a]);
-        reuse_diagonal = true;
         double model_cost_change = 0;
         it_valid = false;
         if (ok) {
-          double sg = 0, sHs = 0;
+          // model_cost_change = -(Js s)^T (r + Js s / 2) = -s.gs - s^T Hs s / 2 with s = -y; Hs y = gs - (D / radius) y gives
+          // s^T Hs s = y.gs - sum (D_a / radius) y_a^2 — twelve products instead of the 6 x 6 quadratic form
+          double yg = 0, yDy = 0;
 #pragma unroll
-          for (int a = 0; a < 6; a++) step[a] = -y[a];
-#pragma unroll
-          for (int a = 0; a < 6; a++) { sg += step[a] * gs[a]; double t = 0;
-#pragma unroll
-            for (int b = 0; b < 6; b++) t += Hget(cur, a, b) * sc6[a] * sc6[b] * step[b];
-            sHs += step[a] * t; }
-          model_cost_change = -sg - 0.5 * sHs;  // == -(Js s)^T (r + Js s / 2)
+          for (int a = 0; a < 6; a++) { yg += y[a] * gs[a]; yDy += dg[a] * y[a] * y[a]; }
+          model_cost_change = 0.5 * (yg + yDy);
           it_valid = model_cost_change > 0.0;
         }
         if (!it_valid) {
@@ -859,7 +890,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         num_invalid = 0;
         double delta[6];
 #pragma unroll
-        for (int a = 0; a < 6; a++) delta[a] = step[a] * sc6[a];
+        for (int a = 0; a < 6; a++) delta[a] = -y[a] * sc6[a];
         lm_plus_t<QUAT>(sh.x, delta, sh.xc);
         sh.mcc = model_cost_change;
         go = 1;
@@ -870,18 +901,19 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
-    lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, sh.cand, false, cache, &cyc_fac, eval_idx++);
+    double* cand = sh.acc2[curidx ^ 1];
+    lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, cand, false, cache, &cyc_fac, eval_idx++, tag_base);
     cyc_eval += clock64() - t_mark;
-    if (NB > 1 && sh.failed) break;  // uniform across the workgroup; every workgroup sees the flag at this or its next barrier
+    if (NB > 1 && sh.failed) break;  // uniform across the workgroup; every workgroup that still waits sees the poison word
     t_mark = clock64();
     // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
-    if (tid == 64) sh.gmax_c = grad_max(sh.xc, sh.cand);
+    if (tid == 64) sh.gmax_c = grad_max(sh.xc, cand);
     if (tid == 128) sh.xnorm_c = x_norm_of(sh.xc);
     bool accepted = false;
     if (tid == 0) {
       n_evals++;
       const double model_cost_change = sh.mcc;
-      double candidate_cost = sh.cand[0];
+      double candidate_cost = cand[0];
       if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
       bool stop = false;
       { double s = 0;
@@ -899,20 +931,17 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
           accepted = true;
 #pragma unroll
           for (int i = 0; i < na; i++) sh.x[i] = sh.xc[i];
-#pragma unroll
-          for (int i = 0; i < kAcc; i++) sh.cur[i] = sh.cand[i];
+          sh.curidx = curidx ^ 1;  // the candidate's accumulators become the current point's
           x_cost = candidate_cost;
           it_cost = x_cost; it_success = true;
           { const double c = 2.0 * it_rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - c * c * c); }
           radius = fmin(1e16, radius);
           decrease_factor = 2.0;
-          reuse_diagonal = false;
           current_cost = candidate_cost;
         } else {              // HandleUnsuccessfulStep
           it_success = false;
           radius = radius * (1.0 / decrease_factor);  // decrease_factor is a power of two: exact, and folded to a multiply
           decrease_factor *= 2.0;
-          reuse_diagonal = true;
           it_cost = candidate_cost;
         }
       }
@@ -922,18 +951,13 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     if (accepted) { gmax = sh.gmax_c; x_norm = sh.xnorm_c; }
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
+    if (sh.curidx != curidx) {   // accepted (uniform): new point -> new scaled normal equations and LM diagonal
+      curidx ^= 1;
+      refresh_normal_equations(sh.acc2[curidx], false);
+    }
     __syncthreads();
   }
 
-  if constexpr (NB > 1) {  // re-arm the barrier for the next solve: the last workgroup out zeroes both counters (nobody waits any more)
-    if (tid == 0) {
-      unsigned* bar = reinterpret_cast<unsigned*>(F.gsync);
-      if (__hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)NB - 1u) {
-        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
   if (tid == 0 && lead) {
     if (NB > 1 && sh.failed) {  // abandoned: the solve degrades to "no update" (x unchanged) instead of corrupting the state
 #pragma unroll
@@ -952,6 +976,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
     (void)t_pro; rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
     rec->cyc[3] = (double)(clock64() - t_start);
+    if constexpr (NB > 1) __hip_atomic_store(reinterpret_cast<u64*>(F.gsync), gen + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next solve, next generation
   }
 }
 

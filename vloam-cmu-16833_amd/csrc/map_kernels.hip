@@ -26,8 +26,10 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include "lm_solve.h"
 #include "map_kernels.h"
+#include "subwave.h"
 
 namespace vloam {
 
@@ -462,7 +464,7 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
+__global__ __launch_bounds__(256) void k_map_assoc_wave(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
                                                    VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
                                                    float4* __restrict__ nbr, int outer, int4* __restrict__ cbox, float4* __restrict__ ccand, size_t ss) {
   VL_SESSION(ss); RB(stack0); RB(stack1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(nbr); RB(cbox); RB(ccand);
@@ -702,6 +704,305 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
     }
     if (lane == 0 && total > kCandChunk) atomicMax(&fr->max_candidates, total);
     if (__ballot(chain_too_long || overflow) && lane == 0) atomicOr(&fr->error, kErrMapFull);
+  }
+}
+
+// ---- k_map_assoc: the 5-NN search with G lanes per stack point (G = 16 / 32 / 64; 64 / G queries share a wavefront).
+// One query's work is ~27 block probes and ~30 candidate records along a chain of three dependent memory trips: a full wavefront per
+// query leaves most lanes idle most of the time and the chip runs out of wave slots, not of bandwidth (round 2: 38 % active, 5 120
+// resident waves per 14 us).  Here a group of G lanes walks the same chain for its own query — piece tables by three lanes, one block
+// per lane and trip, up to four candidate records per lane in flight — and the best five are taken by five group arg-min rounds over
+// the (d2, tie) keys through DPP row operations (keys are unique: distinct voxels), so no candidate list is ranked in LDS any more.
+// Results do not depend on G: the keys, not the visiting order, decide.
+template <int G, int KB>
+__global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
+                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
+                                                   float4* __restrict__ nbr, int outer, int4* __restrict__ cbox, float4* __restrict__ ccand,
+                                                   long long* __restrict__ dbg_cyc /* [16] phase cycle sums + wavefront count, or null */, size_t ss) {
+  VL_SESSION(ss); RB(stack0); RB(stack1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(nbr); RB(cbox); RB(ccand); RB(dbg_cyc);
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (dbg_cyc) tp[0] = clock64();
+  constexpr int Q = 64 / G, QW = 4 * Q;     // queries per wavefront / per workgroup
+  constexpr int U = 4, CH = U * G;          // candidates per lane and pass / per query and pass
+  // KB: blocks per lane and trip
+  static_assert(CH <= kCandChunk, "the second round's candidate cache holds kCandChunk entries per slot");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), qi = wave * Q + lane / G;
+  const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
+  // XCD-aware assignment as before, in units of QW queries: workgroup b runs on XCD b % 8 and every XCD takes a contiguous eighth of
+  // the corner points and a contiguous eighth of the surf points (VoxelGrid output is spatially sorted: neighbours share an L2)
+  const int wc = (nc + QW - 1) / QW, ws = (nsf + QW - 1) / QW, cpc = (wc + 7) >> 3, cps = (ws + 7) >> 3;
+  const int bq = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+  if (bq >= cpc + cps || !ms->do_optimize) return;
+  const int kind = bq < cpc ? 0 : 1;        // a workgroup serves one kind
+  const int i = (kind ? xcd * cps + (bq - cpc) : xcd * cpc + bq) * QW + qi;
+  const bool live = i < (kind ? nsf : nc);
+  if (__ballot(live) == 0ull) return;
+  const int slot = kind ? kStackCapCorner + i : i;
+  const VoxelTable T = kind ? T1 : T0;
+  const float inv = kind ? inv1 : inv0;
+  __shared__ u64 s_cand[QW][CH + 8];        // voxel keys of the pass, flattened per query
+  __shared__ u64 s_bestk[QW][8];            // the best five so far: key ...
+  __shared__ float4 s_bestp[QW][8];         // ... and centroid
+  __shared__ int s_piece[QW][3][8];         // per axis: (cube, 4-voxel block, 4-bit mask) pieces of the search range
+  __shared__ int s_np[QW][4];               // pieces per axis | overflow flag
+  float4 pointOri = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) pointOri = kind ? stack1[i] : stack0[i];
+  const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
+  const float q0 = sel.x, q1 = sel.y, q2 = sel.z;
+  const int cen0 = ms->cenW, cen1 = ms->cenH, cen2 = ms->cenD;
+  const int ctr0 = ms->centerCube[0] - cen0, ctr1 = ms->centerCube[1] - cen1, ctr2 = ms->centerCube[2] - cen2;  // absolute centre cube
+  // voxel-index box that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547)
+  const int blo0 = (int)floorf((q0 - 1.001f) * inv), bhi0 = (int)floorf((q0 + 1.001f) * inv);
+  const int blo1 = (int)floorf((q1 - 1.001f) * inv), bhi1 = (int)floorf((q1 + 1.001f) * inv);
+  const int blo2 = (int)floorf((q2 - 1.001f) * inv), bhi2 = (int)floorf((q2 + 1.001f) * inv);
+  // second outer round: same box as the first round => same candidates, re-ranked from the cache without a hash probe
+  bool from_cache = false;
+  int total = 0;
+  if (outer > 0 && live) {
+    const int4 b0 = cbox[2 * slot], b1 = cbox[2 * slot + 1];
+    from_cache = b1.z >= 0 && b1.z <= CH && b0.x == blo0 && b0.y == bhi0 && b0.z == blo1 && b0.w == bhi1 && b1.x == blo2 && b1.y == bhi2;
+    if (from_cache) total = b1.z;
+  }
+  const bool search = live && !from_cache;
+  bool chain_too_long = false;
+  if (dbg_cyc) tp[1] = clock64() + (__float_as_int(q0) & 0) + (total & 0);   // (the stamp waits for the loads above)
+  if (gl < 8) s_bestk[qi][gl] = ~0ull;
+  if (gl < 4) s_np[qi][gl] = 0;
+  sw_lds_sync();
+  if (__ballot(search) != 0ull) {
+    // per axis the index range [lo, hi] is cut into (cube, 4-voxel block) pieces — a voxel that straddles a 50 m cube face exists once
+    // per cube — each with the 4-bit mask of its voxels inside the range; lane a of the group lists axis a
+    if (search && gl < 3) {
+      const int lo = gl == 0 ? blo0 : (gl == 1 ? blo1 : blo2), hi = gl == 0 ? bhi0 : (gl == 1 ? bhi1 : bhi2);
+      const int ctr = gl == 0 ? ctr0 : (gl == 1 ? ctr1 : ctr2), cen = gl == 0 ? cen0 : (gl == 1 ? cen1 : cen2);
+      const int halfw = gl == 2 ? 1 : 2, wdim = gl == 0 ? kCubeW : (gl == 1 ? kCubeH : kCubeD);   // valid block: 5 x 5 x 3 cubes (LM:404-420)
+      const double leaf = 1.0 / (double)inv;
+      const int Amin = cube_lo((double)lo * leaf), Amax = cube_hi((double)(hi + 1) * leaf);
+      int n = 0;
+      bool ovf = false;
+      for (int A = Amin; A <= Amax; A++) {
+        if (abs(A - ctr) > halfw) continue;
+        const int wv = A + cen;
+        if (wv < 0 || wv >= wdim) continue;
+        // voxels that can hold points of cube A: from the voxel containing its lower face to the one containing its upper face
+        const int base = cube_voxel_base(A, inv);
+        const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
+        if (ia > ib) continue;
+        for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2); blk++) {
+          if ((unsigned)blk > 63u || n >= 8) { ovf = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
+          int m4 = 0;
+#pragma unroll
+          for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
+          s_piece[qi][gl][n] = ((A + 8192) << 10) | (blk << 4) | m4;
+          n++;
+        }
+      }
+      s_np[qi][gl] = n;
+      if (ovf) s_np[qi][3] = 1;
+    }
+    sw_lds_sync();
+  }
+  const int np0 = s_np[qi][0], np1 = s_np[qi][1], np2 = s_np[qi][2];
+  const bool overflow = s_np[qi][3] != 0;
+  if (dbg_cyc) tp[2] = clock64() + (np0 & 0);
+  const int nblocks = search ? np0 * np1 * np2 : 0;
+  // Candidate lists longer than CH (a dense map at a fine leaf: up to 9^3 voxels in the box) take several passes: every pass regenerates
+  // the work list, keeps ordinals [c0, c0 + CH), and the best five so far compete again.
+  for (int c0 = 0;; c0 += CH) {
+    const bool act = live && (c0 == 0 || c0 < total);
+    if (__ballot(act) == 0ull) break;
+    u64 key_u[U + 1];
+    float px[U + 1], py[U + 1], pz[U + 1];
+#pragma unroll
+    for (int u = 0; u <= U; u++) { key_u[u] = ~0ull; px[u] = 0.f; py[u] = 0.f; pz[u] = 0.f; }
+    const bool gen = act && search;
+    int ncand = 0;
+    if (__ballot(gen) != 0ull) {
+      // phase 1 + 2: one block per lane and trip fetches its occupancy mask; the existing voxels are flattened into the query's list
+      int produced = 0;
+      for (int bb0 = 0; __ballot(gen && bb0 < nblocks) != 0ull; bb0 += KB * G) {
+        u64 occ[KB], bkey[KB];
+        unsigned bs[KB];
+        ulonglong2 e[KB];
+        int pA[KB][3];   // cube of the block per axis
+        int pb[KB][3];   // block index per axis
+        int pm[KB][3];   // voxel mask per axis
+        bool has[KB];
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          const int bb = bb0 + k * G + gl;
+          has[k] = gen && bb < nblocks;
+          occ[k] = 0ull; bkey[k] = 0ull; bs[k] = 0u;
+#pragma unroll
+          for (int a = 0; a < 3; a++) { pA[k][a] = 0; pb[k][a] = 0; pm[k][a] = 0; }
+          if (has[k]) {
+            const int n01 = np0 * np1;
+            const int ez = bb / n01, rem = bb - ez * n01, ey = rem / np0, ex = rem - ey * np0;
+            const int w0 = s_piece[qi][0][ex], w1 = s_piece[qi][1][ey], w2 = s_piece[qi][2][ez];
+            pA[k][0] = (w0 >> 10) - 8192; pb[k][0] = (w0 >> 4) & 63; pm[k][0] = w0 & 15;
+            pA[k][1] = (w1 >> 10) - 8192; pb[k][1] = (w1 >> 4) & 63; pm[k][1] = w1 & 15;
+            pA[k][2] = (w2 >> 10) - 8192; pb[k][2] = (w2 >> 4) & 63; pm[k][2] = w2 & 15;
+            bkey[k] = pack_key(pA[k][0], pA[k][1], pA[k][2], pb[k][0], pb[k][1], pb[k][2]) | (1ull << 63);
+            bs[k] = (unsigned)mix64(bkey[k]) & T.bslots_mask;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; k++) if (has[k]) e[k] = T.blk[bs[k]];   // all first probes in flight together
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          if (has[k]) {
+            for (int probe = 0;;) {
+              if (e[k].x == 0ull) break;
+              if (e[k].x == bkey[k]) { occ[k] = e[k].y; break; }
+              if (++probe == kMaxProbe) { chain_too_long = true; break; }
+              bs[k] = (bs[k] + 1) & T.bslots_mask;
+              e[k] = T.blk[bs[k]];
+            }
+            // voxels of the block inside the search box: bit = z * 16 + y * 4 + x
+            const int mx = pm[k][0], my = pm[k][1], mz = pm[k][2];
+            const u64 ex4 = (u64)mx * 0x1111111111111111ull;
+            const u64 ey4 = ((u64)((my & 1) * 0xF) | ((u64)(((my >> 1) & 1) * 0xF) << 4) | ((u64)(((my >> 2) & 1) * 0xF) << 8) | ((u64)(((my >> 3) & 1) * 0xF) << 12)) * 0x0001000100010001ull;
+            const u64 ez4 = ((mz & 1) ? 0xFFFFull : 0ull) | ((mz & 2) ? 0xFFFFull << 16 : 0ull) | ((mz & 4) ? 0xFFFFull << 32 : 0ull) | ((mz & 8) ? 0xFFFFull << 48 : 0ull);
+            occ[k] &= ex4 & ey4 & ez4;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+          // flatten: exclusive prefix of the per-lane voxel counts inside the group, then every lane appends its voxel keys
+          const int mine = __popcll(occ[k]);
+          const int inc = grp_scan_incl<G>(mine);
+          const int tot = grp_sum<G>(mine);
+          int o = produced + inc - mine;
+          u64 oc = occ[k];
+          while (oc) {
+            const int bit = __ffsll((long long)oc) - 1;
+            oc &= oc - 1;
+            if (o >= c0 && o < c0 + CH)
+              s_cand[qi][o - c0] = pack_key(pA[k][0], pA[k][1], pA[k][2], (pb[k][0] << 2) | (bit & 3), (pb[k][1] << 2) | ((bit >> 2) & 3), (pb[k][2] << 2) | (bit >> 4));
+            o++;
+          }
+          produced += tot;
+        }
+      }
+      if (gen) total = produced;
+      sw_lds_sync();
+      ncand = gen ? min(total - c0, CH) : 0;
+      if (dbg_cyc && c0 == 0) tp[3] = clock64() + (ncand & 0);
+      // phase 3: up to U voxel records per lane, all first probes in flight together; centroid out of the record, squared distance,
+      // key = (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the valid
+      // cubes in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so equal
+      // distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
+      // (two candidates per lane and trip: the second pair is only touched when some query of the wavefront has more than 2 G candidates)
+      auto probe_pair = [&](auto UB) {
+        constexpr int u0 = decltype(UB)::value;
+        u64 ck[2];
+        unsigned sl[2];
+        RecVal rv[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int w = gl + (u0 + h) * G;
+          ck[h] = w < ncand ? s_cand[qi][w] : 0ull;
+          sl[h] = (unsigned)mix64(ck[h]) & T.mask;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          rv[h].key = 0ull; rv[h].sum = make_float4(0.f, 0.f, 0.f, 0.f); rv[h].count = 0; rv[h].pend_cnt = 0;
+          if (gl + (u0 + h) * G < ncand) rv[h] = rec_load(&T.rec[sl[h]]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int u = u0 + h;
+          if (gl + u * G < ncand) {
+            const u64 key = ck[h];
+            for (int probe = 0;;) {
+              if (rv[h].key == 0ull) break;
+              if (rv[h].key == key) {
+                const int n = rv[h].count;
+                float4 p = rv[h].sum;
+                if (n > 0) {
+                  if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+                  const float d0 = q0 - p.x, d1 = q1 - p.y, d2 = q2 - p.z;
+                  int Ai, Aj, Ak;
+                  unpack_cube(key, &Ai, &Aj, &Ak);
+                  const unsigned tie = ((unsigned)(Ai - ctr0 + 2) << 29) | ((unsigned)(Aj - ctr1 + 2) << 26) | ((unsigned)(Ak - ctr2 + 1) << 24) |
+                                       ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
+                  key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+                  px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+                }
+                break;
+              }
+              if (++probe == kMaxProbe) { chain_too_long = true; break; }
+              sl[h] = (sl[h] + 1) & T.mask;
+              rv[h] = rec_load(&T.rec[sl[h]]);
+            }
+            if (outer == 0 && c0 == 0 && total <= CH)   // leave the candidate for the second round
+              ccand[(size_t)slot * kCandChunk + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
+          }
+        }
+      };
+      probe_pair(std::integral_constant<int, 0>{});
+      if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{});
+    }
+    if (c0 == 0 && __ballot(from_cache) != 0ull) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int w = gl + u * G;
+        if (from_cache && w < total) {
+          const float4 c = ccand[(size_t)slot * kCandChunk + w];
+          const unsigned tie = __float_as_uint(c.w);
+          if (tie != 0xffffffffu) {
+            const float d0 = q0 - c.x, d1 = q1 - c.y, d2 = q2 - c.z;
+            key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+            px[u] = c.x; py[u] = c.y; pz[u] = c.z;
+          }
+        }
+      }
+    }
+    if (dbg_cyc && c0 == 0) tp[4] = clock64() + ((int)key_u[0] & 0);
+    // the best five of the earlier passes compete again
+    if (c0 > 0 && act && gl < 5) {
+      key_u[U] = s_bestk[qi][gl];
+      const float4 bp = s_bestp[qi][gl];
+      px[U] = bp.x; py[U] = bp.y; pz[U] = bp.z;
+    }
+    sw_lds_sync();
+    // phase 4: five group arg-min rounds; the winner's lane publishes its centroid and retires the candidate
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      u64 m = key_u[0];
+#pragma unroll
+      for (int u = 1; u <= U; u++) m = key_u[u] < m ? key_u[u] : m;
+      const u64 gm = grp_min_u64<G>(m);
+      if (gm != ~0ull) {
+#pragma unroll
+        for (int u = 0; u <= U; u++)
+          if (key_u[u] == gm) { s_bestk[qi][r] = gm; s_bestp[qi][r] = make_float4(px[u], py[u], pz[u], 0.f); key_u[u] = ~0ull; }
+      } else if (act && gl == 0) s_bestk[qi][r] = ~0ull;
+    }
+    sw_lds_sync();
+    if (dbg_cyc && c0 == 0) tp[5] = clock64();
+  }
+  if (outer == 0 && search && gl == 0) {
+    cbox[2 * slot] = make_int4(blo0, bhi0, blo1, bhi1);
+    cbox[2 * slot + 1] = make_int4(blo2, bhi2, (total <= CH && !overflow) ? total : -1, 0);
+  }
+  // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in registers
+  // and pure per-query math) — as points, so that the fit does not have to go back to the table
+  if (live && gl < 5) {
+    const u64 k4 = s_bestk[qi][4];
+    const bool ok = k4 != ~0ull && __uint_as_float((unsigned)(k4 >> 32)) < 1.0f;  // LM:479 / LM:547
+    float4 p = s_bestp[qi][gl];
+    p.w = ok ? 1.0f : 0.0f;
+    nbr[slot * 5 + gl] = p;
+  }
+  if (live && gl == 0 && total > kCandChunk) atomicMax(&fr->max_candidates, total);
+  if (__ballot(chain_too_long || (live && overflow)) && lane == 0) atomicOr(&fr->error, kErrMapFull);
+  if (dbg_cyc && lane == 0) {   // debug builds of the handle: where a wavefront's time goes (setup | pieces | blocks + flatten | records | arg-min rounds)
+    tp[6] = clock64();
+    if (tp[3] == 0) tp[3] = tp[2];
+    if (tp[4] == 0) tp[4] = tp[3];
+    for (int k = 0; k < 6; k++) atomicAdd((unsigned long long*)&dbg_cyc[outer * 8 + k], (unsigned long long)(tp[k + 1] - tp[k]));
+    atomicAdd((unsigned long long*)&dbg_cyc[outer * 8 + 7], 1ull);
   }
 }
 
@@ -1049,7 +1350,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
   ok = ok && A.take(&m->cbox, 2 * (size_t)kMapFactorCap) && A.take(&m->ccand, (size_t)kMapFactorCap * kCandChunk);
   m->rebuild_cap = (int)(slots / 2);
   ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 1);
-  ok = ok && A.take(&m->registered, (size_t)cfg.max_points);
+  ok = ok && A.take(&m->registered, (size_t)cfg.max_points) && A.take(&m->assoc_cyc, 16);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
   m->inv_leaf[0] = 1.0f / cfg.mapping_line_resolution;   // inverse_leaf_size_ of downSizeFilterCorner (LM:100)
@@ -1116,7 +1417,7 @@ vloam_status map_force_rebuild(MapContext* m, hipStream_t st) {
 
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
                          bool skip_frame, int set, ProfHook* ph, hipEvent_t done) {
-  (void)cfg; (void)cur;
+  (void)cur;
   MapState* ms = m->state;
   MapFrame* fr = m->frame;
   const unsigned Z = (unsigned)m->se.B;
@@ -1139,8 +1440,26 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
                   skip_frame ? 1 : 0, traj_row14, m->stack_info[set], ss);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
-    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc, dim3(kMapFactorCap / 4, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1],
-                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, outer, m->cbox, m->ccand, ss);
+    // lanes per query of the 5-NN search: a batch fills the chip with 16-lane groups (four queries per wavefront); a single sequence
+    // (9 000 queries on 5 120 wave slots) is quickest with two per wavefront.  VLOAM_MAP_ASSOC_LANES = 16 / 32 / 64 overrides,
+    // 0 selects the round-2 kernel (one wavefront per query, rank counting in LDS) for A/B runs.
+    static const int g_env = getenv("VLOAM_MAP_ASSOC_LANES") ? atoi(getenv("VLOAM_MAP_ASSOC_LANES")) : -1;
+    const int G = g_env >= 0 ? g_env : (m->se.B > 1 ? 16 : 32);
+    auto grid_for = [](int g) { const int qw = 256 / g; return dim3(8 * ((kStackCapCorner / qw + 7) / 8 + (kStackCapSurf / qw + 7) / 8), 1, 1); };
+#define VL_MAP_ASSOC_WAVE()                                                                                                            \
+    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc_wave, dim3(kMapFactorCap / 4, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], \
+                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, outer, m->cbox, m->ccand, ss)
+#define VL_MAP_ASSOC(KERN, GRID)                                                                                                      \
+    VLOAM_LAUNCH(ph, kKMapAssoc, st, KERN, dim3((GRID).x, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], \
+                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, outer, m->cbox, m->ccand, cfg.debug ? m->assoc_cyc : (long long*)nullptr, ss)
+    static const int kb_env = getenv("VLOAM_MAP_ASSOC_KB") ? atoi(getenv("VLOAM_MAP_ASSOC_KB")) : 2;   // blocks per lane and trip of the 16-lane groups
+    if (G == 0) VL_MAP_ASSOC_WAVE();
+    else if (G == 16 && kb_env == 1) VL_MAP_ASSOC((k_map_assoc<16, 1>), grid_for(16));
+    else if (G == 16) VL_MAP_ASSOC((k_map_assoc<16, 2>), grid_for(16));
+    else if (G == 64) VL_MAP_ASSOC((k_map_assoc<64, 1>), grid_for(64));
+    else VL_MAP_ASSOC((k_map_assoc<32, 1>), grid_for(32));
+#undef VL_MAP_ASSOC
+#undef VL_MAP_ASSOC_WAVE
     VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nbr,
                  m->F[outer], outer, ss);
     lm_launch(st, m->se, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
@@ -1281,6 +1600,7 @@ vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, l
     if (buf && c) memcpy(buf, rows.data(), c);
     return VLOAM_OK;
   }
+  if (item == 71) return copy_dev(m->assoc_cyc, sizeof(long long) * 16, buf, cap, n);   // k_map_assoc phase cycles (debug handles): [outer][6 phases, spare, wavefronts]
   if (item == 69) {  // table health: {keys, purged, block keys, spare} x {corner, surf}, rebuilds, largest candidate list
     int out[12] = {0};
     for (int k = 0; k < 2; k++) if (hipMemcpy(out + 4 * k, m->tab[k].stats, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;

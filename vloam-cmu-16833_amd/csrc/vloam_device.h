@@ -169,7 +169,7 @@ struct FactorTable {
   double* cpack;  // [11][cap] compacted factors: p, then (e1, e2, d1, d2) of an edge / (n, d) of a plane / A, B otherwise
   int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
   int cap;
-  double* gsync;  // optional [kLmSyncDoubles]: barrier counters + per-workgroup partial sums of the multi-workgroup solve (null: one workgroup)
+  double* gsync;  // optional [kLmSyncDoubles]: solve generation + the tagged partial sums the workgroups of a cooperative solve exchange (null: one workgroup)
   int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
   __host__ __device__ void rebase(size_t off) {
     rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off);
@@ -177,7 +177,7 @@ struct FactorTable {
   }
 };
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
-constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 32;  // 2 counters (+ flags) | [parity][workgroup][32] partial accumulators
+constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 64;  // generation, poison word (+ spare) | [parity][workgroup][2][32] tagged 8-byte granules of the partial accumulators
 
 // ---------------------------------------------------------------- vloam_tf blackboard (coupled VO <-> LiDAR odometry loop)
 // tf2::Transform restated: row-major 3x3 basis + origin, double precision, the same operation order as tf2/LinearMath
