@@ -523,6 +523,8 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "points_per_sweep": int(n_pts), "sequences": world,
                        "map_warmup_sweeps": M0, "map_points_at_last_sweep": counts["M"],
                        "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run",
+                       "gathered_trajectories": {"ranks": len(trajectories), "frames": [int(t.shape[0]) for t in trajectories],
+                                                 "last_map_position": [[float(v) for v in t[-1, 11:14]] for t in trajectories]},
                        "pipelining": "SR / LO / mapping of consecutive sweeps overlap on their own HIP streams (one sequence, one GPU)"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

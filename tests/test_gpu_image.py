@@ -50,6 +50,13 @@ def test_image_frontend_edge_cases(vl, orc):
         hd.vo_process_image(np.zeros((64, 256), dtype=np.uint8))   # one size per sequence
     assert e.value.status == vl.ERR_INVALID
     hd.close()
+    # same area, other aspect ratio: the pyramid levels of 128 x 256 do not fit the buffers laid out for 256 x 128 — refused, not overrun
+    hd = vl.Handle(0, with_mapping=0, image_width=256, image_height=128)
+    with pytest.raises(vl.VloamError) as e:
+        hd.vo_process_image(np.zeros((256, 128), dtype=np.uint8))
+    assert e.value.status == vl.ERR_INVALID
+    hd.vo_process_image(np.zeros((96, 160), dtype=np.uint8))   # smaller in both dimensions is fine
+    hd.close()
     # a corner tracked out of the image: a bright square near the right border that moves out
     a = np.full((96, 160), 40, dtype=np.uint8)
     b = a.copy()
@@ -130,6 +137,9 @@ def test_image_frontend_capacity_is_reported(vl, orc):
     with pytest.raises(vl.VloamError) as e:
         h.vo_keypoints()
     assert e.value.status == vl.ERR_CAPACITY and "candidates" in str(e.value)
+    with pytest.raises(vl.VloamError) as e:     # vloam_sync reports it as well (the coupled loop has no getter in its path)
+        h.sync()
+    assert e.value.status == vl.ERR_CAPACITY and "image front-end" in str(e.value)
     h.close()
     # the same texture at a size whose candidates fit is processed normally (and equals the oracle)
     h = vl.Handle(0, with_mapping=0, image_width=512, image_height=256)

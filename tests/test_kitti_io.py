@@ -4,6 +4,7 @@ import importlib
 import os
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -115,3 +116,9 @@ def test_png_gray_reader_all_row_filters(tmp_path):
     assert np.array_equal(kio.load_png_gray(path), img)
     kio.save_png_gray(tmp_path / "g.png", img)
     assert np.array_equal(kio.load_png_gray(tmp_path / "g.png"), img)
+    # a file without an IHDR chunk is refused with a ValueError (not a NameError further down)
+    good = open(tmp_path / "g.png", "rb").read()
+    n_ihdr = 12 + 13
+    (tmp_path / "bad.png").write_bytes(good[:8] + good[8 + n_ihdr:])
+    with pytest.raises(ValueError):
+        kio.load_png_gray(tmp_path / "bad.png")

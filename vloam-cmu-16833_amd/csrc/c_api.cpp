@@ -117,6 +117,7 @@ static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
   TAKE(F->cslot, cap);
   TAKE(F->cpack, 11 * (size_t)cap);
   TAKE(F->rowcnt, (size_t)cap / 64 + 1);
+  F->rowmask = nullptr;  // the odometry / VO tables use the per-row counters
   F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated
   F->err = nullptr;    // set once the mapping context (owner of the sticky error word) exists
   return VLOAM_OK;
@@ -781,7 +782,7 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
-  if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
+  if (width <= 0 || height <= 0 || stride < width || width > h->img.max_w || height > h->img.max_h) { set_err("bad image size (%d x %d; the handle was created for at most %d x %d)", width, height, h->img.max_w, h->img.max_h); return VLOAM_ERR_INVALID; }
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
@@ -794,7 +795,8 @@ vloam_status vloam_vo_process_image_device(vloam_handle* h, const void* d_gray, 
   SINGLE_SESSION_ONLY(h);
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   HIPCHK(hipSetDevice(h->device));
-  vloam_status s = img_process(&h->img, h->s_img, (const unsigned char*)d_gray, width, height, stride, h->vo.d_prev, h->vo.d_curr, &h->prof);
+  // (no match outputs here: vloam_vo_solve uploads host matches into d_prev / d_curr on another stream; nothing consumes device-side matches in standalone mode)
+  vloam_status s = img_process(&h->img, h->s_img, (const unsigned char*)d_gray, width, height, stride, nullptr, nullptr, &h->prof);
   if (s != VLOAM_OK) set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h);
   return s;
 }
@@ -802,7 +804,7 @@ vloam_status vloam_vo_process_image_device(vloam_handle* h, const void* d_gray, 
 vloam_status vloam_vo_process_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride) {
   if (!h || !gray) return VLOAM_ERR_INVALID;
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
-  if (width <= 0 || height <= 0 || stride < width || (long long)width * height > (long long)h->img.max_w * h->img.max_h) { set_err("bad image size"); return VLOAM_ERR_INVALID; }
+  if (width <= 0 || height <= 0 || stride < width || width > h->img.max_w || height > h->img.max_h) { set_err("bad image size (%d x %d; the handle was created for at most %d x %d)", width, height, h->img.max_w, h->img.max_h); return VLOAM_ERR_INVALID; }
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
   return vloam_vo_process_image_device(h, h->img.staging, width, height, width);
@@ -934,6 +936,13 @@ vloam_status vloam_sync(vloam_handle* h) {
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }
     if (merr & kErrVoDegenerate) { set_err("a VO solve returned a zero rotation angle: poses are NaN from that frame on, as in the reference (visual_odometry.cpp:427-430)"); return VLOAM_ERR_INVALID; }
+  }
+  if (h->img.max_w != 0 && h->img.count >= 0) {
+    // the image front-end's own sticky word: a corner / match set cut by one of its capacities differs from goodFeaturesToTrack's and was
+    // fed into the VO solve of the coupled loop — say so here too, not only in the vloam_vo_get_* getters
+    int ierr = 0;
+    HIPCHK(hipMemcpy(&ierr, h->img.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (ierr) { set_err("image front-end capacity exceeded (bits %d: 1 candidates > %d, 2 neighbours > %d, 4 corners > %d)", ierr, kImgCandCap, kImgNbrCap, kImgAccCap); return VLOAM_ERR_CAPACITY; }
   }
   return VLOAM_OK;
 }

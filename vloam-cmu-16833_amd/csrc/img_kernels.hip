@@ -697,7 +697,9 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
 
 vloam_status img_check(const ImgContext* c, int width, int height, int stride) {
   if (c->max_w == 0) return VLOAM_ERR_ORDER;
-  if (width < 2 * kImgWin || height < 2 * kImgWin || (size_t)width * height > (size_t)c->max_w * c->max_h || stride < width) return VLOAM_ERR_INVALID;
+  // per DIMENSION, not per area: the pyramid and derivative buffers are sized from the level dimensions of max_w x max_h, and an image of the
+  // same area but another aspect ratio has larger (and possibly more) levels than were allocated
+  if (width < 2 * kImgWin || height < 2 * kImgWin || width > c->max_w || height > c->max_h || stride < width) return VLOAM_ERR_INVALID;
   if (c->count >= 0 && (width != c->w || height != c->h)) return VLOAM_ERR_INVALID;   // one image size per sequence
   return VLOAM_OK;
 }

@@ -348,6 +348,60 @@ struct LmCache {
   unsigned live_e, live_p;  // direct mode: which of this lane's slots hold a factor
 };
 
+// ---- factor sources of a solve
+//   kLmPacked  the factors were compacted into cpack by k_lm_compact (the visual-odometry problem)
+//   kLmDirect  scan-to-scan odometry: lane t owns the table slots t + 256 m themselves (see lm_evaluate)
+//   kLmRowMask scan-to-map: the fit kernel left one 64-bit mask of accepted slots per 64-slot row; the solve compacts ON ITS OWN — a
+//              workgroup-wide scan of the row counts gives every row its offset, compact index k -> (row by binary search over the
+//              offsets, bit = k-th accepted slot of the row) -> slot, and every lane fetches ITS factors straight from the raw table
+//              and digests them (edge -> orthonormal pair, plane -> normal + offset) into its register cache.  Same lane ownership and
+//              the same summation order as the packed form, without the k_lm_compact launch in front of every solve
+//              (5.9 us + a launch boundary, twice per sweep on the stream that bounds the sweep period).
+constexpr int kLmPacked = 0, kLmDirect = 1, kLmRowMask = 2;
+
+__device__ __forceinline__ int nth_set_bit(u64 m, int j) {   // position of the j-th (0-based) set bit of m; j < popcount(m)
+  unsigned w = (unsigned)m;
+  int pos = 0;
+  int c = __popc(w);
+  if (j >= c) { j -= c; pos = 32; w = (unsigned)(m >> 32); }
+#pragma unroll
+  for (int width = 16; width > 0; width >>= 1) {
+    c = __popc(w & ((1u << width) - 1u));
+    if (j >= c) { j -= c; pos += width; w >>= width; }
+  }
+  return pos;
+}
+// compact index k (< total) -> table slot, from the row offsets / row masks staged in LDS
+__device__ __forceinline__ int lm_slot_of(const int* rowoff, const u64* rowmask, int nrows, int k) {
+  int r = 0;   // the largest row index with rowoff[r] <= k (empty rows share their successor's offset and are skipped by "largest")
+#pragma unroll
+  for (int step = 256; step > 0; step >>= 1) {
+    const int t = r + step;
+    if (t <= nrows && rowoff[t] <= k) r = t;
+  }
+  return (r << 6) + nth_set_bit(rowmask[r], k - rowoff[r]);
+}
+// raw table slot -> what the evaluation consumes (the digest k_lm_compact writes for the packed form)
+__device__ __forceinline__ void lm_digest_edge(const FactorTable& F, int slot, double (&p)[3], double (&fr)[8]) {
+  const int cap = F.cap;
+  double a[3], b[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) { p[q] = F.p[q * cap + slot]; a[q] = F.A[q * cap + slot]; b[q] = F.B[q * cap + slot]; }
+  edge_frame(a[0], a[1], a[2], b[0], b[1], b[2], fr);
+}
+__device__ __forceinline__ void lm_digest_plane(const FactorTable& F, int slot, double (&p)[3], double (&nd)[4]) {
+  const int cap = F.cap;
+  const int ty = F.type[slot];
+  double a[3], b[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) { p[q] = F.p[q * cap + slot]; a[q] = F.A[q * cap + slot]; b[q] = F.B[q * cap + slot]; }
+  if (ty == 2) {  // LidarPlaneFactor (lp - j) . n  ->  n . lp + d with d = -(n . j)
+    nd[0] = b[0]; nd[1] = b[1]; nd[2] = b[2]; nd[3] = -(b[0] * a[0] + b[1] * a[1] + b[2] * a[2]);
+  } else {        // LidarPlaneNormFactor: n . lp + negative_OA_dot_norm
+    nd[0] = a[0]; nd[1] = a[1]; nd[2] = a[2]; nd[3] = b[0];
+  }
+}
+
 // Evaluate the compacted factors at x: cost, g = J^T r, H = J^T J (upper triangle) -> s_out[kAcc] (LDS).
 // DIRECT (scan-to-scan odometry, table of exactly 256 x (kCacheE + kCacheP) slots): lane t owns the table slots t + 256 m
 // themselves — corner slots feed its edge cache, plane slots its plane cache — and builds the solver's form of each factor on
@@ -358,10 +412,11 @@ struct LmCache {
 // grid barrier and ALL add the partials in workgroup order, so every workgroup holds bit-identical accumulators and runs the
 // (cheap) trust-region bookkeeping redundantly: one barrier per evaluation, nothing to broadcast.  `eval_idx` counts the
 // evaluations of this solve (barrier target and double-buffer parity of the partial sums).
-template <bool QUAT, bool DIRECT, int NB>
+template <bool QUAT, int MODE, int NB>
 __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, int n_valid, const double* x, double huber_a, LmShared& sh,
                                             double* s_out, bool first, LmCache& C, long long* cyc_factors, int eval_idx, unsigned tag_base) {
   static_assert(NB == 1 || QUAT, "the cooperative form exists for the quaternion problems");
+  constexpr bool DIRECT = MODE == kLmDirect;
   const int tid = threadIdx.x;
   const int blk = NB > 1 ? (int)blockIdx.x : 0;
   const int vt = blk * kLmThreads + tid;     // lane of the virtual workgroup
@@ -421,7 +476,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         if (live) C.live_p |= 1u << m;
       }
     }
-    if (first && !DIRECT) {
+    if (first && MODE == kLmPacked) {
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
         const int k = vt + m * VT;
@@ -440,6 +495,58 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int a = 0; a < 4; a++) C.dp[m][a] = live ? cp[(3 + a) * cap + n_edge + q] : 0.0;
       }
+    }
+    if (first && MODE == kLmRowMask) {
+      // self-compaction (see kLmRowMask): row offsets / masks were staged by the solve's prologue in the reduction buffer, which is free
+      // until the first reduction.  Cached factors go to registers, factors beyond the cache are digested into cpack once (their later
+      // evaluations stream them like the packed form), every factor leaves its slot in cslot for the residual hook.
+      const int* rowoff = reinterpret_cast<const int*>(sh.red);
+      const u64* rowmask = reinterpret_cast<const u64*>(sh.red + 512);
+      const int nrows = cap >> 6;
+      double* cpw = F.cpack;
+#pragma unroll
+      for (int m = 0; m < kCacheE; m++) {
+        const int k = vt + m * VT;
+        const bool live = k < n_edge;
+        double p[3] = {0, 0, 0}, fr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) { const int slot = lm_slot_of(rowoff, rowmask, nrows, k); F.cslot[k] = slot; lm_digest_edge(F, slot, p, fr); }
+#pragma unroll
+        for (int a = 0; a < 3; a++) C.pe[m][a] = (float)p[a];
+#pragma unroll
+        for (int a = 0; a < 8; a++) C.de[m][a] = fr[a];
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheP; m++) {
+        const int q = vt + m * VT;
+        const bool live = q < n_plane;
+        double p[3] = {0, 0, 0}, nd[4] = {0, 0, 0, 0};
+        if (live) { const int slot = lm_slot_of(rowoff, rowmask, nrows, n_edge + q); F.cslot[n_edge + q] = slot; lm_digest_plane(F, slot, p, nd); }
+#pragma unroll
+        for (int a = 0; a < 3; a++) C.pp[m][a] = (float)p[a];
+#pragma unroll
+        for (int a = 0; a < 4; a++) C.dp[m][a] = nd[a];
+      }
+      for (int k = kCacheE * VT + vt; k < n_edge; k += VT) {
+        double p[3], fr[8];
+        const int slot = lm_slot_of(rowoff, rowmask, nrows, k);
+        F.cslot[k] = slot;
+        lm_digest_edge(F, slot, p, fr);
+#pragma unroll
+        for (int a = 0; a < 3; a++) cpw[a * cap + k] = p[a];
+#pragma unroll
+        for (int a = 0; a < 8; a++) cpw[(3 + a) * cap + k] = fr[a];
+      }
+      for (int q = kCacheP * VT + vt; q < n_plane; q += VT) {
+        double p[3], nd[4];
+        const int slot = lm_slot_of(rowoff, rowmask, nrows, n_edge + q);
+        F.cslot[n_edge + q] = slot;
+        lm_digest_plane(F, slot, p, nd);
+#pragma unroll
+        for (int a = 0; a < 3; a++) cpw[a * cap + n_edge + q] = p[a];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cpw[(3 + a) * cap + n_edge + q] = nd[a];
+      }
+      __syncthreads();   // the staged tables make way for the reduction; the cpack / cslot stores above have landed before anything reads them back
     }
     auto put_resid = [&](int k, const double* r3) {
       const int slot = DIRECT ? k : F.cslot[k];
@@ -710,7 +817,7 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
   }
 }
 
-template <bool QUAT, bool DIRECT, int NB>
+template <bool QUAT, int MODE, int NB>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
   VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
@@ -722,22 +829,45 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   // the gate first would put a dependent ~1.5 us memory trip in front of everything else the solve reads)
   const int enabled = enable_flag ? *enable_flag : 1;
   const double x_first = tid < na ? x_io[tid] : 0.0;
-  const int row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
+  int row_first = 0;
+  ulonglong2 mask_first = make_ulonglong2(0ull, 0ull);   // kLmRowMask: the accepted-slot masks of rows 2 tid, 2 tid + 1
+  if constexpr (MODE == kLmRowMask) { if (2 * tid < (F.cap >> 6)) mask_first = *reinterpret_cast<const ulonglong2*>(F.rowmask + 2 * tid); }
+  else row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
   // generation of this table's cooperative solves: tags the partial sums every workgroup publishes (lm_evaluate); bumped by the lead
   // workgroup on its way out — every workgroup has read it by then, because the lead needed their first partial sums
   u64 gen = 0;
   if constexpr (NB > 1) gen = __hip_atomic_load(reinterpret_cast<u64*>(F.gsync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned tag_base = (unsigned)(gen & 0xffffffull) << 8;
   if (enabled == 0) {
-    if (lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
+    if (MODE != kLmRowMask && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
     return;
   }
   if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
   if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
 
-  // ---- prologue: the factors were compacted by k_lm_compact; count them and release the row counters
+  // ---- prologue: count the factors.  Packed / direct: per-row counters (released for the next solve); row-mask form: scan the row
+  // masks into row offsets and stage both in LDS for the self-compaction of the first evaluation (lm_evaluate)
   const long long t_start = clock64();
-  {
+  if constexpr (MODE == kLmRowMask) {
+    static_assert(kLmThreads == 256, "two rows per lane cover tables of up to 512 rows");
+    int* rowoff = reinterpret_cast<int*>(sh.red);            // [513]
+    u64* rowmask_s = reinterpret_cast<u64*>(sh.red + 512);   // [512]
+    const int nrows = F.cap >> 6;
+    const int c0 = __popcll(mask_first.x), c = c0 + __popcll(mask_first.y);
+    int inc = c;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((tid & 63) >= d) inc += o; }
+    if ((tid & 63) == 63) sh.scan[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += sh.scan[w];
+    const int excl = base + inc - c;
+    rowoff[2 * tid] = excl; rowoff[2 * tid + 1] = excl + c0;
+    rowmask_s[2 * tid] = mask_first.x; rowmask_s[2 * tid + 1] = mask_first.y;
+    if (tid == kLmThreads - 1) rowoff[2 * kLmThreads] = excl + c;
+    __syncthreads();
+    if (tid == 0) { sh.n_valid = rowoff[nrows]; sh.n_edge = rowoff[edge_rows]; }
+    __syncthreads();
+  } else {
     const int nrows = F.cap >> 6;
     int c = 0, ce = 0;
     for (int r = tid; r < nrows; r += kLmThreads) { const int q = r == tid ? row_first : F.rowcnt[r]; c += q; if (r < edge_rows) ce += q; }
@@ -759,9 +889,9 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   LmCache cache;
   t_mark = clock64();
   int eval_idx = 0;
-  lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.acc2[0], true, cache, &cyc_fac, eval_idx++, tag_base);
+  lm_evaluate<QUAT, MODE, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.acc2[0], true, cache, &cyc_fac, eval_idx++, tag_base);
   cyc_eval += clock64() - t_mark;
-  if (NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone has published its first partial sums, i.e. is past its prologue
+  if (MODE != kLmRowMask && NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone has published its first partial sums, i.e. is past its prologue
 
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
@@ -902,7 +1032,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     if (sh.go == 0) break;
     t_mark = clock64();
     double* cand = sh.acc2[curidx ^ 1];
-    lm_evaluate<QUAT, DIRECT, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, cand, false, cache, &cyc_fac, eval_idx++, tag_base);
+    lm_evaluate<QUAT, MODE, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, cand, false, cache, &cyc_fac, eval_idx++, tag_base);
     cyc_eval += clock64() - t_mark;
     if (NB > 1 && sh.failed) break;  // uniform across the workgroup; every workgroup that still waits sees the poison word
     t_mark = clock64();
@@ -1089,27 +1219,24 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
   const int edge_rows = n_edge_slots >> 6;
   const unsigned Z = (unsigned)se.B;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
+  const bool rowmask = quat && !direct && F.rowmask != nullptr && (F.cap >> 6) <= 2 * kLmThreads;   // the fit kernel left row masks: the solve compacts on its own
   // Batches keep the cooperative form: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured only 3 % faster at
   // B = 8 (10 785 vs 10 435 scans/s) and gives up the bit-identity of a batched session with the same sequence run alone (the f64
   // sums of the normal equations would be added in a different order).
   static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
   const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1);
-  if (!direct) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
-  if (direct && coop)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, kCoop>), dim3(kCoop, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj, se.ss);
-  else if (direct)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, true, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a, d_enable,
-                 fin_lo, fin_traj, se.ss);
-  else if (quat && coop)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, kCoopMap>), dim3(kCoopMap, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters,
-                 huber_a, d_enable, fin_lo, fin_traj, se.ss);
-  else if (quat)
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<true, false, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj, se.ss);
-  else
-    VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<false, false, 1>), dim3(1, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, huber_a,
-                 d_enable, fin_lo, fin_traj, se.ss);
+  if (!direct && !rowmask) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
+#define VL_SOLVE(Q, M, N)                                                                                                                   \
+  VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<Q, M, N>), dim3(N, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, \
+                  huber_a, d_enable, fin_lo, fin_traj, se.ss)
+  if (direct && coop) VL_SOLVE(true, kLmDirect, kCoop);
+  else if (direct) VL_SOLVE(true, kLmDirect, 1);
+  else if (rowmask && coop) VL_SOLVE(true, kLmRowMask, kCoopMap);
+  else if (rowmask) VL_SOLVE(true, kLmRowMask, 1);
+  else if (quat && coop) VL_SOLVE(true, kLmPacked, kCoopMap);
+  else if (quat) VL_SOLVE(true, kLmPacked, 1);
+  else VL_SOLVE(false, kLmPacked, 1);
+#undef VL_SOLVE
 }
 
 }  // namespace vloam

@@ -836,8 +836,11 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
 #pragma unroll
           for (int a = 0; a < 3; a++) { pA[k][a] = 0; pb[k][a] = 0; pm[k][a] = 0; }
           if (has[k]) {
+            // bb -> (ex, ey, ez), bb < 512 and np <= 8: quotients through an f32 reciprocal ((bb + 0.5) / n is at least 0.5 / 64 away from
+            // an integer, the reciprocal is good to 1 ulp) instead of two ~35-instruction integer divisions
             const int n01 = np0 * np1;
-            const int ez = bb / n01, rem = bb - ez * n01, ey = rem / np0, ex = rem - ey * np0;
+            const int ez = (int)(((float)bb + 0.5f) * __builtin_amdgcn_rcpf((float)n01)), rem = bb - ez * n01;
+            const int ey = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)np0)), ex = rem - ey * np0;
             const int w0 = s_piece[qi][0][ex], w1 = s_piece[qi][1][ey], w2 = s_piece[qi][2][ez];
             pA[k][0] = (w0 >> 10) - 8192; pb[k][0] = (w0 >> 4) & 63; pm[k][0] = w0 & 15;
             pA[k][1] = (w1 >> 10) - 8192; pb[k][1] = (w1 >> 4) & 63; pm[k][1] = w1 & 15;
@@ -851,7 +854,8 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
 #pragma unroll
         for (int k = 0; k < KB; k++) {
           if (has[k]) {
-            for (int probe = 0;;) {
+#pragma nounroll
+            for (int probe = 0;;) {   // (collisions are rare: keep the chain walk a compact loop)
               if (e[k].x == 0ull) break;
               if (e[k].x == bkey[k]) { occ[k] = e[k].y; break; }
               if (++probe == kMaxProbe) { chain_too_long = true; break; }
@@ -914,6 +918,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
           const int u = u0 + h;
           if (gl + u * G < ncand) {
             const u64 key = ck[h];
+#pragma nounroll
             for (int probe = 0;;) {
               if (rv[h].key == 0ull) break;
               if (rv[h].key == key) {
@@ -944,18 +949,21 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{});
     }
     if (c0 == 0 && __ballot(from_cache) != 0ull) {
+      // all of a lane's cache entries in flight together, complete 16-byte entries (a load that is conditional on the entry's own tie
+      // field turns into two dependent trips per entry)
+      float4 cc[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int w = gl + u * G;
-        if (from_cache && w < total) {
-          const float4 c = ccand[(size_t)slot * kCandChunk + w];
-          const unsigned tie = __float_as_uint(c.w);
-          if (tie != 0xffffffffu) {
-            const float d0 = q0 - c.x, d1 = q1 - c.y, d2 = q2 - c.z;
-            key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
-            px[u] = c.x; py[u] = c.y; pz[u] = c.z;
-          }
-        }
+        cc[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+        if (from_cache && w < total) cc[u] = ccand[(size_t)slot * kCandChunk + w];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned tie = __float_as_uint(cc[u].w);
+        const float d0 = q0 - cc[u].x, d1 = q1 - cc[u].y, d2 = q2 - cc[u].z;
+        const u64 k = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+        if (from_cache && tie != 0xffffffffu) { key_u[u] = k; px[u] = cc[u].x; py[u] = cc[u].y; pz[u] = cc[u].z; }
       }
     }
     if (dbg_cyc && c0 == 0) tp[4] = clock64() + ((int)key_u[0] & 0);
@@ -1066,11 +1074,12 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
     }
   }
   F.type[slot] = type;
-  // one atomic per wavefront and counter
+  // a wavefront == one 64-slot row of the table: its accepted slots as one mask (every row, every launch: nothing to clear); the solve
+  // compacts from the masks on its own
   const unsigned long long m = __ballot(type != 0);
-  if (m && (threadIdx.x & 63) == 0) {
-    atomicAdd(&fr->n_factors[outer][kind], __popcll(m));
-    atomicAdd(&F.rowcnt[slot >> 6], __popcll(m));
+  if ((threadIdx.x & 63) == 0) {
+    F.rowmask[slot >> 6] = m;
+    if (m) atomicAdd(&fr->n_factors[outer][kind], __popcll(m));
   }
 }
 
@@ -1342,7 +1351,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
     F.cap = kMapFactorCap;
     ok = ok && A.take(&F.type, (size_t)F.cap) && A.take(&F.p, 3 * (size_t)F.cap) && A.take(&F.A, 3 * (size_t)F.cap) && A.take(&F.B, 3 * (size_t)F.cap) &&
          A.take(&F.resid, 3 * (size_t)F.cap) && A.take(&F.ctype, (size_t)F.cap) && A.take(&F.cslot, (size_t)F.cap) && A.take(&F.cpack, 11 * (size_t)F.cap) &&
-         A.take(&F.rowcnt, (size_t)F.cap / 64 + 1);
+         A.take(&F.rowcnt, (size_t)F.cap / 64 + 1) && A.take(&F.rowmask, (size_t)F.cap / 64 + 2);
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
   }

@@ -168,12 +168,14 @@ struct FactorTable {
   int* cslot;     // [cap]    original slot of every compacted factor
   double* cpack;  // [11][cap] compacted factors: p, then (e1, e2, d1, d2) of an edge / (n, d) of a plane / A, B otherwise
   int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
+  unsigned long long* rowmask;  // optional [cap / 64 (+ 2)]: accepted slots of every 64-slot row as a bit mask, rewritten in full by the producer
+                               // (k_map_fit) for every solve: the solve then compacts on its own and k_lm_compact is not launched (lm_solve.hip, kLmRowMask)
   int cap;
   double* gsync;  // optional [kLmSyncDoubles]: solve generation + the tagged partial sums the workgroups of a cooperative solve exchange (null: one workgroup)
   int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
   __host__ __device__ void rebase(size_t off) {
     rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off);
-    rbp(rowcnt, off); rbp(gsync, off); rbp(err, off);
+    rbp(rowcnt, off); rbp(rowmask, off); rbp(gsync, off); rbp(err, off);
   }
 };
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use

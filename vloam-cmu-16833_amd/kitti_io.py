@@ -38,7 +38,7 @@ def load_png_gray(path):
     data = open(path, "rb").read()
     if data[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("%s: not a PNG file" % path)
-    pos, idat, w = 8, [], None
+    pos, idat, w, h = 8, [], None, None
     while pos < len(data):
         n, typ = struct.unpack(">I4s", data[pos:pos + 8])
         body = data[pos + 8:pos + 8 + n]
@@ -49,38 +49,51 @@ def load_png_gray(path):
                 raise ValueError("%s: only 8-bit greyscale, non-interlaced PNGs are read here (got depth %d, colour type %d, interlace %d)" %
                                  (path, depth, ctype, interlace))
         elif typ == b"IDAT":
+            if w is None:
+                raise ValueError("%s: IDAT before IHDR" % path)
             idat.append(body)
         elif typ == b"IEND":
             break
+    if w is None or not idat:
+        raise ValueError("%s: no IHDR / IDAT chunk" % path)
+    try:   # a library decoder when one is around (neither is part of this image); the reader below is the dependency-free path
+        import io
+        from PIL import Image
+        return np.asarray(Image.open(io.BytesIO(data)).convert("L"), dtype=np.uint8).reshape(h, w)
+    except ImportError:
+        pass
     raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, w + 1)
     out = np.zeros((h, w), dtype=np.uint8)
-    prev = np.zeros(w, dtype=np.int64)
+    prev = np.zeros(w, dtype=np.uint8)
     for y in range(h):
-        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int64)
+        f, line = int(raw[y, 0]), raw[y, 1:]
         if f == 0:
             cur = line
-        elif f == 2:
-            cur = (line + prev) & 255
-        elif f in (1, 3, 4):   # Sub / Average / Paeth depend on the pixel to the left: sequential
-            cur = np.zeros(w, dtype=np.int64)
-            left = 0
-            up_left = 0
-            for x in range(w):
-                up = int(prev[x])
-                if f == 1:
-                    pred = left
-                elif f == 3:
-                    pred = (left + up) >> 1
-                else:
+        elif f == 1:     # Sub: a running sum modulo 256
+            cur = np.cumsum(line, dtype=np.uint8)
+        elif f == 2:     # Up
+            cur = line + prev            # uint8 arithmetic wraps modulo 256
+        elif f in (3, 4):   # Average / Paeth depend on the decoded pixel to the left: one pass over plain Python ints (no numpy scalars)
+            src, up_row = line.tolist(), prev.tolist()
+            dst = [0] * w
+            left = up_left = 0
+            if f == 3:
+                for x in range(w):
+                    left = (src[x] + ((left + up_row[x]) >> 1)) & 255
+                    dst[x] = left
+            else:
+                for x in range(w):
+                    up = up_row[x]
                     pa, pb, pc = abs(up - up_left), abs(left - up_left), abs(left + up - 2 * up_left)
                     pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else up_left)
-                left = (int(line[x]) + pred) & 255
-                cur[x] = left
-                up_left = up
+                    left = (src[x] + pred) & 255
+                    dst[x] = left
+                    up_left = up
+            cur = np.array(dst, dtype=np.uint8)
         else:
             raise ValueError("%s: bad PNG filter type %d" % (path, f))
         out[y] = cur
-        prev = cur
+        prev = out[y]
     return out
 
 
