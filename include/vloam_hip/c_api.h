@@ -79,7 +79,13 @@ vloam_status vloam_destroy(vloam_handle* h);
  * vloam_batch_process_scan[_device]: session b gets sweep xyz_pad4[b] with n[b] points (arrays of n_sessions entries).
  * vloam_select_session: which session the getters below (trajectory, features, counts, map, parity hooks) read; 0 after creation.
  * The single-sequence entry points (vloam_scan_registration*, vloam_laser_*, vloam_process_scan*, vloam_process_frame*) return
- * VLOAM_ERR_INVALID on a handle with more than one session. */
+ * VLOAM_ERR_INVALID on a handle with more than one session.
+ * Co-residency bound: the Levenberg-Marquardt solves of a sweep run as cooperating workgroups (4 for the odometry, 6 for the mapping,
+ * one compute unit's worth of registers each) that exchange partial sums INSIDE one launch, so all workgroups of a solve must be
+ * resident together; a session can have one odometry and one mapping solve in flight, i.e. 10 such workgroups.  vloam_create_batch
+ * refuses (VLOAM_ERR_CAPACITY) when 10 * n_sessions exceeds the device's compute-unit count (256 on MI355X, so n_sessions <= 16 is
+ * always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  A
+ * workgroup that still waits for its partners after ~0.5 s abandons the solve (pose unchanged) and vloam_sync reports VLOAM_ERR_HIP. */
 vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessions, vloam_handle** out);
 vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions);
 vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n);
@@ -167,7 +173,7 @@ vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t
 /* ---- Image front-end of the visual odometry, optical-flow configuration (vloam_main.launch: optical_flow_match = true); needs
  * cfg.image_width / image_height > 0.  Replaces, on the device:
  *   ImageUtil::detKeypoints (ShiTomasi)   src/visual_odometry/src/image_util.cpp:13-36    cv::goodFeaturesToTrack(img, 1024, 0.03, 7.5, 5)
- *   ImageUtil::calculateOpticalFlow       src/visual_odometry/src/image_util.cpp:351-372  cv::calcOpticalFlowPyrLK(15 x 15, 2 levels, 10 / 0.03)
+ *   ImageUtil::calculateOpticalFlow       src/visual_odometry/src/image_util.cpp:351-372  cv::calcOpticalFlowPyrLK(15 x 15, maxLevel = 2 i.e. three pyramid levels, 10 / 0.03)
  *   VisualOdometry::processImage          src/visual_odometry/src/visual_odometry.cpp:91-132 (the NEW image's corners are tracked from the
  *                                         previous image into the new one, :121-122)
  * vloam_vo_process_image[_device]: one 8-bit grey image (row stride in bytes); every image of a sequence has the same size.  With

@@ -78,3 +78,13 @@ for stage in ('sr', 'ds', 'lo', 'map'):
             if best:
                 line += '  | starts %6.1f us after %s(k%+d) ended' % (best[0], d, best[1])
     print(line)
+
+if len(sys.argv) > 2 and sys.argv[2] == '--dump':
+    # every kernel of three steady-state periods, in start order: t (us, from the first), duration, stream, name
+    sr = al['sr']
+    t_lo, t_hi = sr[lo_i + 4][0], sr[lo_i + 7][0]
+    sid = {st: i for i, st in enumerate(sorted(by_stream))}
+    print('--- kernels between the starts of scan registration of sweeps %d and %d' % (lo_i + 4, lo_i + 7))
+    for n_, s_, e_, st_ in rows:
+        if t_lo <= s_ < t_hi:
+            print('%9.1f %7.1f  s%d %s%s' % ((s_ - t_lo) / 1e3, (e_ - s_) / 1e3, sid[st_], '      ' * sid[st_], short(n_)))

@@ -8,6 +8,9 @@ import os
 import sys
 import time
 
+# the stage streams of a handle (+ torch's) must not share hardware queues (the runtime's default is 4); before the HIP runtime loads
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -8,6 +8,8 @@ reference: src/lidar_odometry_mapping/include/lidar_odometry_mapping/*.h) used b
 There is no CPU path in this package: importing it requires the built shared library and creating a
 handle requires a HIP device.  (The CPU oracle lives in ``oracle/`` and is test infrastructure only.)
 """
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the stage streams of a handle must not share hardware queues (before the HIP runtime loads)
 import ctypes as C
 import os
 import numpy as np

@@ -35,7 +35,8 @@ void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, con
 // Slot layout of the LO factor table: [0, kMaxSharp) corner features, [kMaxSharp, kMaxLoFactors) plane features.
 // corr: [kMaxLoFactors][4] ints (feature index or -1, closest, 2nd, 3rd).
 void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
-                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc, ProfHook* ph = nullptr);
+                     const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc,
+                     int* queue /* [kMaxLoFactors] left-over slots of the 16-lane form, or null */, int* queue_n /* [2] */, int launch_no, ProfHook* ph = nullptr);
 // copy_to_para: LO:223-236 (combined mode).  vo_row7 != nullptr: first publish this frame's visual odometry (see k_lo_set_prior).
 void lo_set_prior_launch(hipStream_t st, Sess se, LOState* lo, bool copy_to_para = true, const double* vo_x = nullptr, bool vo_solved = false,
                          double* vo_row7 = nullptr, int* err = nullptr);

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "lo_kernels.h"
+#include "subwave.h"
+#include <stdlib.h>
 
 namespace vloam {
 
@@ -398,8 +400,10 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
                                                   const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
                                                   const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
                                                   const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
-                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */, size_t ss) {
-  VL_SESSION(ss); RB(sharp); RB(flat); RB(Sc); RB(CL); RB(SL); RB(Sp); G.rebase(so_); RB(lo); F.rebase(so_); RB(corr); RB(dbg_cyc);
+                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */,
+                                                  const int* __restrict__ queue /* null: every slot; else the slots k_lo_assoc_fast left over */,
+                                                  int* __restrict__ queue_n /* [2]: [parity] entries of `queue`, [parity ^ 1] re-armed here */, int parity, size_t ss) {
+  VL_SESSION(ss); RB(sharp); RB(flat); RB(Sc); RB(CL); RB(SL); RB(Sp); G.rebase(so_); RB(lo); F.rebase(so_); RB(corr); RB(dbg_cyc); RB(queue); RB(queue_n);
   __shared__ int s_inc_all[4][512], s_rel_all[4][512];  // per-wavefront staging of cell prefix sums (for_each_candidate, KC > 2)
   const int lane = threadIdx.x & 63;
   int* s_inc = s_inc_all[threadIdx.x >> 6];
@@ -410,7 +414,14 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   constexpr int kWc = kMaxSharp / 4 / 8, kWp = kMaxFlat / 4 / 8;   // corner / plane workgroups per XCD
   static_assert(kMaxSharp % 32 == 0 && kMaxFlat % 32 == 0 && (kMaxLoFactors + 3) / 4 == 8 * (kWc + kWp), "bijective remap");
   const int bq_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);
-  const int slot = (bq_ < kWc ? (xcd_ * kWc + bq_) * 4 : kMaxSharp + (xcd_ * kWp + (bq_ - kWc)) * 4) + (int)(threadIdx.x >> 6);
+  int slot = (bq_ < kWc ? (xcd_ * kWc + bq_) * 4 : kMaxSharp + (xcd_ * kWp + (bq_ - kWc)) * 4) + (int)(threadIdx.x >> 6);
+  if (queue) {   // second pass behind k_lo_assoc_fast: one wavefront per left-over query, in queue order
+    const int qn = queue_n[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue_n[parity ^ 1] = 0;   // the next launch pair's counter (its last readers finished a launch ago)
+    const int qi_ = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (qi_ >= qn) return;
+    slot = queue[qi_];
+  }
   if (slot >= kMaxLoFactors) return;
   const bool is_corner = slot < kMaxSharp;
   const int i = is_corner ? slot : slot - kMaxSharp;
@@ -592,6 +603,177 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
   }
 }
 
+// ---- k_lo_assoc_fast: the common query with G = 16 lanes (four queries per wavefront, sixteen per workgroup).
+// ~85 % of the queries are answered by the radius-1 block of the 1 m level alone (closest point within 1 m, second / third point
+// within 1 m: stage 0 of both plans of k_lo_assoc).  A full wavefront per such query spends its time in cross-lane round trips
+// (prefix sums, item -> cell searches, three 64-bit reductions through ds_bpermute) around ~200 candidate points; here a 16-lane
+// group does the same work for its own query with DPP row operations, its 27 bucket ranges two per lane, its candidates
+// (<= 256) sixteen per lane in chunks of four loads, (d2, tag) of every candidate parked in LDS for the second / third point pass.
+// A query the block cannot answer conclusively is NOT continued here: its slot goes onto a queue and k_lo_assoc (one wavefront per
+// query, all stages) takes it from scratch in the launch right behind — the long tail runs with full wavefronts and balanced, the
+// short queries no longer wait in line behind it.  Same keys, same bounds, same emission as k_lo_assoc: results are identical.
+template <int G>
+__global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict__ sharp, const float4* __restrict__ flat,
+                                                       const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
+                                                       const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid Gd,
+                                                       const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
+                                                       long long* __restrict__ dbg_cyc, int* __restrict__ queue, int* __restrict__ queue_n,
+                                                       int parity, size_t ss) {
+  VL_SESSION(ss); RB(sharp); RB(flat); RB(Sc); RB(CL); RB(SL); RB(Sp); Gd.rebase(so_); RB(lo); F.rebase(so_); RB(corr); RB(dbg_cyc); RB(queue); RB(queue_n);
+  static_assert(G == 16, "27 bucket ranges two per lane, 256 candidates sixteen per lane");
+  constexpr int Q = 64 / G, QW = 4 * Q, CHK = 4;   // queries per wavefront / workgroup, candidate loads per lane and trip
+  constexpr int kWc = kMaxSharp / QW / 8, kWp = kMaxFlat / QW / 8;   // corner / plane workgroups per XCD (XCD-aware remap as in k_lo_assoc)
+  static_assert(kMaxSharp % (8 * QW) == 0 && kMaxFlat % (8 * QW) == 0, "bijective remap");
+  __shared__ int s_stops[2 * kStopLen];
+  __shared__ int s_inc[QW][32], s_rel[QW][32];
+  __shared__ u64 s_item[QW][256];
+  __shared__ int s_ring[QW];
+  const int tid = threadIdx.x, lane = tid & 63, gl = lane & (G - 1), qi = (tid >> 6) * Q + lane / G;
+  const int bq = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+  const bool is_corner = bq < kWc;                                    // a workgroup serves one kind
+  const int slot = (is_corner ? (xcd * kWc + bq) * QW : kMaxSharp + (xcd * kWp + (bq - kWc)) * QW) + qi;
+  {
+    const int* stops = is_corner ? Gd.stops : Gd.stops + 2 * kStopLen;  // where the reference's walks break (see k_lo_assoc)
+    if (tid < 2 * kStopLen) s_stops[tid] = stops[tid];
+  }
+  __syncthreads();
+  const int i = is_corner ? slot : slot - kMaxSharp;
+  const int nfeat = is_corner ? Sc->n_sharp : Sc->n_flat;
+  const int n = is_corner ? Sp->n_less_sharp : Sp->n_less_flat;
+  const bool live = i < nfeat;
+  const bool act = live && n > 0;
+  float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) pf = is_corner ? sharp[i] : flat[i];
+  const float3 sel = transform_to_start(pf, lo->para_q, lo->para_t);  // LO:268 / LO:355
+  const float4* cand = is_corner ? CL : SL;
+  const int* fstart = is_corner ? Gd.start[0] : Gd.start[1];
+  const float4* fpts = is_corner ? Gd.pts[0] : Gd.pts[1];
+  const unsigned fmask = (unsigned)(is_corner ? Gd.mask[0] : Gd.mask[1]);
+  const int fcx = (int)floorf(sel.x), fcy = (int)floorf(sel.y), fcz = (int)floorf(sel.z);
+  // the 27 bucket ranges of the radius-1 block: cells gl and gl + 16
+  int bs[2] = {0, 0}, cnt[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int c = gl + 16 * k;
+    if (act && c < 27) {
+      const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
+      const unsigned b = grid_hash(fcx + ox, fcy + oy, fcz + oz) & fmask;
+      bs[k] = fstart[b];
+      cnt[k] = fstart[b + 1] - bs[k];
+    }
+  }
+  const int inc0 = grp_scan_incl<G>(cnt[0]), tot0 = grp_sum<G>(cnt[0]);
+  const int inc1 = tot0 + grp_scan_incl<G>(cnt[1]);
+  const int total = tot0 + grp_sum<G>(cnt[1]);
+  s_inc[qi][gl] = inc0; s_inc[qi][16 + gl] = inc1;                      // inclusive sums in (k, lane) order
+  s_rel[qi][gl] = bs[0] - (inc0 - cnt[0]); s_rel[qi][16 + gl] = bs[1] - (inc1 - cnt[1]);   // item i of a cell lives at rel + i
+  sw_lds_sync();
+  const bool kept = act && total <= 256;   // (more: k_lo_assoc walks the block through for_each_candidate)
+  // ---- closest point (LO:269 / LO:356): every candidate once; (d2, tag) parked for the second / third point
+  u64 loc = ~0ull;
+  int ring = 0;
+  for (int u0 = 0; __ballot(kept && u0 * G < total) != 0ull; u0 += CHK) {
+    int addr[CHK];
+    float4 c4[CHK];
+#pragma unroll
+    for (int u = 0; u < CHK; u++) {
+      const int item = (u0 + u) * G + gl;
+      addr[u] = -1;
+      if (kept && item < total) {
+        int pos = 0;   // number of cells whose inclusive sum is <= item == the cell holding the item
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) if (s_inc[qi][pos + step - 1] <= item) pos += step;
+        addr[u] = s_rel[qi][pos & 31] + item;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CHK; u++) c4[u] = fpts[addr[u] >= 0 ? addr[u] : 0];   // unconditional: the loads go out back to back
+#pragma unroll
+    for (int u = 0; u < CHK; u++) {
+      if (addr[u] >= 0) {
+        const float d = sqdist(c4[u], sel);
+        const unsigned tag = __float_as_uint(c4[u].w);
+        s_item[qi][(u0 + u) * G + gl] = ((u64)__float_as_uint(d) << 32) | tag;
+        const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)tag_index(tag);
+        const bool better = key < loc;
+        loc = better ? key : loc;
+        ring = better ? tag_ring(tag) : ring;
+      }
+    }
+  }
+  const u64 best = grp_min_u64<G>(loc);
+  constexpr float kBound0 = 1.0f * 0.999999f;   // every point outside the radius-1 block is farther than 1 m
+  const bool fastq = kept && best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= kBound0;
+  if (fastq && loc == best) s_ring[qi] = ring;   // the index part makes the key unique: one owner
+  sw_lds_sync();
+  // ---- second / third point on the same candidates (stage 0 of the plan in k_lo_assoc; class filter of VisitAdjacent)
+  const int idx = (int)(best & 0xffffffffu);
+  const int ringA = fastq ? s_ring[qi] : 0;
+  const int stop_f = s_stops[ringA + 3], stop_b = s_stops[kStopLen + ringA];
+  u64 l2 = ~0ull, l3 = ~0ull;
+  for (int u = 0; __ballot(fastq && u * G < total) != 0ull; u++) {
+    const int item = u * G + gl;
+    if (fastq && item < total) {
+      const u64 v = s_item[qi][item];
+      const float d = __uint_as_float((unsigned)(v >> 32));
+      const unsigned tag = (unsigned)v;
+      const int j = tag_index(tag), rj = tag_ring(tag);
+      const bool fwd = j > idx;
+      const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
+      const bool ok = d < 25.0f && j != idx && j < stop_f && j > stop_b;
+      const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : (fwd ? rj <= ringA : rj >= ringA);
+      const bool to3 = !is_corner && !to2;
+      if (ok && to2) l2 = key < l2 ? key : l2;
+      if (ok && to3) l3 = key < l3 ? key : l3;
+    }
+  }
+  const u64 b2 = grp_min_u64<G>(l2);
+  const u64 b3 = grp_min_u64<G>(l3);
+  const bool done2 = b2 != ~0ull && __uint_as_float((unsigned)(b2 >> 32)) <= kBound0;
+  const bool done3 = is_corner || (b3 != ~0ull && __uint_as_float((unsigned)(b3 >> 32)) <= kBound0);
+  const bool resolved = !act || (fastq && done2 && done3);
+  if (gl == 0) {
+    if (!resolved) {
+      queue[atomicAdd(&queue_n[parity], 1)] = slot;   // k_lo_assoc takes it from scratch
+    } else {
+      int type = 0, ia = -1, ib = -1, ic = -1;
+      if (act) {
+        auto decode = [&](u64 k) {
+          const unsigned o = (unsigned)(k & 0xffffffffu);
+          return o >= kBack ? idx - (int)(o - kBack) : idx + (int)o;
+        };
+        const int cap = F.cap;
+        if (is_corner) {  // LO:326-349
+          ia = idx; ib = decode(b2);
+          type = 1;
+          const float4 a = cand[ia], b = cand[ib];
+          F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
+          F.A[slot] = a.x; F.A[cap + slot] = a.y; F.A[2 * cap + slot] = a.z;
+          F.B[slot] = b.x; F.B[cap + slot] = b.y; F.B[2 * cap + slot] = b.z;
+        } else {          // LO:419-442
+          ia = idx; ib = decode(b2); ic = decode(b3);
+          type = 2;
+          const float4 pj = cand[ia], pl = cand[ib], pm = cand[ic];
+          // LidarPlaneFactor ctor (lidarFactor.hpp:62-70): ljm_norm = normalize((j - l) x (j - m))
+          const double ax = (double)pj.x - (double)pl.x, ay = (double)pj.y - (double)pl.y, az = (double)pj.z - (double)pl.z;
+          const double bx = (double)pj.x - (double)pm.x, by = (double)pj.y - (double)pm.y, bz = (double)pj.z - (double)pm.z;
+          double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+          const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+          nx = nx / nn; ny = ny / nn; nz = nz / nn;
+          F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
+          F.A[slot] = pj.x; F.A[cap + slot] = pj.y; F.A[2 * cap + slot] = pj.z;
+          F.B[slot] = nx; F.B[cap + slot] = ny; F.B[2 * cap + slot] = nz;
+        }
+      }
+      F.type[slot] = type;
+      if (type) atomicAdd(&F.rowcnt[slot >> 6], 1);
+      if (dbg_cyc) { dbg_cyc[slot * 4] = 0; dbg_cyc[slot * 4 + 1] = 0; dbg_cyc[slot * 4 + 2] = 0; dbg_cyc[slot * 4 + 3] = act ? 0 : 0xffff; }
+      corr[slot * 4 + 0] = type ? i : -1;
+      corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
+    }
+  }
+}
+
 // LO:223-236 — combined mode overwrites the warm start with the VO prior at the top of each outer round.
 // With vo_row7 != nullptr this launch is also where the frame's visual odometry is PUBLISHED (MAIN/src/vloam_main_node.cpp:158-162):
 //   solveNlsAll's tail (VO:425-430): cam0_curr_T_cam0_last from (angle-axis, t) — only when a solve ran this frame (count > 0)
@@ -667,8 +849,21 @@ __global__ void k_lo_finish(LOState* lo, double* traj_row14, int integrate, size
 
 void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4* flat, const FrameScalars* Sc, const float4* CL, const float4* SL,
                      const FrameScalars* Sp, const LoGrid& G, const LOState* lo, const FactorTable& F, int* corr, long long* dbg_cyc,
-                     ProfHook* ph) {
-  VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc, se.ss);
+                     int* queue, int* queue_n, int launch_no, ProfHook* ph) {
+  // VLOAM_LO_ASSOC_LANES = 16: the common queries by 16-lane groups (k_lo_assoc_fast), the left-over ones by one wavefront each in a second
+  // launch; 0: every query by one wavefront (the round-2 form).  Default: 16 for batches (the chip is full of short queries), 0 for one sequence
+  static const int g_env = getenv("VLOAM_LO_ASSOC_LANES") ? atoi(getenv("VLOAM_LO_ASSOC_LANES")) : -1;
+  const int lanes = g_env >= 0 ? g_env : (se.B > 1 ? 16 : 0);
+  if (lanes == 16 && queue) {
+    const int parity = launch_no & 1;
+    VLOAM_LAUNCH(ph, kKLoAssocFast, st, k_lo_assoc_fast<16>, dim3(kMaxLoFactors / 16, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
+                 queue, queue_n, parity, se.ss);
+    VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
+                 (const int*)queue, queue_n, parity, se.ss);
+  } else {
+    VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
+                 (const int*)nullptr, (int*)nullptr, 0, se.ss);
+  }
 }
 void lo_grid_build_launch(hipStream_t st, Sess se, const float4* less_sharp, const float4* less_flat, const FrameScalars* S, const LoGrid& G, ProfHook* ph) {
   VLOAM_LAUNCH(ph, kKLoGridCount, st, k_lo_grid_count, dim3(64, 2, se.B), dim3(256), 0, st, less_sharp, less_flat, S, G, se.ss);

@@ -89,7 +89,7 @@ struct MapContext {
   VoxelTable tab[2];       // 0 corner, 1 surf
   int* cube_cnt = nullptr; // [2][kCubeNum] points per cube, window-relative index (== the reference's array index)
   DsScratch ds[2];
-  static constexpr int kSets = 4;             // == the SR buffer sets of the handle (same rotation)
+  static constexpr int kSets = kBufferSets;   // == the SR buffer sets of the handle (same rotation)
   float4* stack_sets[kSets][2] = {};          // laserCloudCornerStack / laserCloudSurfStack (sensor frame), one pair per set
   StackInfo* stack_info[kSets] = {};
   float4* stack[2] = {nullptr, nullptr};      // the pair of the sweep mapping is working on (host-side alias)

@@ -15,6 +15,12 @@ namespace vloam {
 // further on.  Hosts and kernels therefore hold session 0's pointers only and kernels rebase them by blockIdx.z * ss on entry —
 // one extra kernel argument instead of B copies of every argument.
 constexpr int kMaxBatch = 16;
+// Rotating buffer sets of everything one stage hands to a later stage (set = sweep mod kBufferSets): scan-registration output, NN grids,
+// mapping stack clouds, VO depth maps.  3 suffice for correctness; the host may enqueue scan registration kBufferSets - 1 sweeps ahead of
+// the odometry it waits for and kBufferSets ahead of the mapping.  With 4 sets the host blocked (hipEventSynchronize, ~50-100 us to wake up)
+// with only one mapping stage queued behind the running one, and every stream idled 60-75 us per 214 us period
+// (profiles/r03_critical_path_4_sets.txt); 8 sets keep several sweeps queued on every stream, so the period is the longest stage again.
+constexpr int kBufferSets = 8;
 struct Sess { int B = 1; size_t ss = 0; };
 struct BatchIn { const float4* in[kMaxBatch]; int n[kMaxBatch]; };   // the one thing that is not in the arenas: the callers' sweeps
 template <class T>
@@ -55,13 +61,13 @@ enum KernelId : int {
   kKNone = 0, kKSrFirstLast, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
   kKMapPrepare, kKMapStack, kKMapAssoc, kKMapInsert, kKMapFinalize, kKVoProject, kKVoMatch,
   kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsRank, kKMapDsScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig,
-  kKImgSobel, kKImgEig, kKImgLocalMax, kKImgNeighbours, kKImgSelect, kKImgPyrDown, kKImgScharr, kKImgLk, kKCount
+  kKImgSobel, kKImgEig, kKImgLocalMax, kKImgNeighbours, kKImgSelect, kKImgPyrDown, kKImgScharr, kKImgLk, kKLoAssocFast, kKCount
 };
 static const char* const kKernelNames[kKCount] = {"", "k_sr_first_last", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
   "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_ds_count", "k_map_assoc", "k_map_insert",
   "k_map_finalize", "k_vo_project", "k_vo_match", "k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter", "k_map_ds_rank",
   "k_map_ds_scatter", "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier",
-  "k_img_sobel", "k_img_eig", "k_img_localmax", "k_img_neighbours", "k_img_select", "k_img_pyrdown", "k_img_scharr", "k_img_lk"};
+  "k_img_sobel", "k_img_eig", "k_img_localmax", "k_img_neighbours", "k_img_select", "k_img_pyrdown", "k_img_scharr", "k_img_lk", "k_lo_assoc_fast"};
 constexpr int kKAll = -1;  // ProfHook::id: bracket every launch, whichever kernel
 
 // Records a HIP-event pair around every launch of one selected kernel (or of all kernels), on the stream it is launched on.
@@ -102,11 +108,13 @@ inline dim3 vl_hw_grid(dim3 g) { return dim3(g.z, g.x, g.y); }
 
 // Same, with the stage's "finished" event bound to the dispatch itself (its completion signal) instead of a marker packet
 // behind it: a separate hipEventRecord costs ~5 us of idle stream on MI355X, the bound event costs nothing.
+extern int g_vl_plain_events;   // VLOAM_PLAIN_EVENTS=1 (A/B switch): a marker packet behind the dispatch instead of the dispatch's own completion signal
 #define VLOAM_LAUNCH_EV(ph, kid, st, stop_ev, kern, grid, block, shmem, stream, ...)                        \
   do {                                                                                                      \
     bool prof_ = (ph) && (ph)->begin((kid), (st));                                                          \
-    if (stop_ev) hipExtLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), block, shmem, stream, nullptr, (stop_ev), 0, __VA_ARGS__); \
+    if ((stop_ev) && !::vloam::g_vl_plain_events) hipExtLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), block, shmem, stream, nullptr, (stop_ev), 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), block, shmem, stream, __VA_ARGS__);            \
+    if ((stop_ev) && ::vloam::g_vl_plain_events) (void)hipEventRecord((stop_ev), (stream));                 \
     if (prof_) (ph)->end((st));                                                                             \
   } while (0)
 

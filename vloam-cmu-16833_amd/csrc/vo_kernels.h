@@ -24,7 +24,7 @@ struct VOContext {
   // The reference ping-pongs two PointCloudUtil objects (i = count % 2).  Here the depth maps rotate with the handle's buffer sets:
   // the scan-registration stream (which builds them) runs up to kSets - 1 sweeps ahead of the odometry stream (which reads the
   // previous frame's map in k_vo_match).
-  static constexpr int kSets = 4;
+  static constexpr int kSets = kBufferSets;
   DepthMapDev maps[kSets];
   int count = -1, i = 0;     // VisualOdometry::reset(): ++count; i = count % kSets
   float4* uvd = nullptr;     // [max_points] (u, v, depth, bucket id as int bits; -1 = not in a bucket)
