@@ -348,34 +348,37 @@ def test_full_size_steady_state_run(vl, orc, synth):
 
 def test_returns_beyond_the_valid_block(vl, orc, synth, monkeypatch):
     """Ranges up to 140 m put scan points into cubes OUTSIDE the valid 5x5x3 block (+-125 m / +-75 m around the centre cube).  The
-    reference keeps such points raw in their cube until the cube becomes valid; the device keeps (sum, count) per voxel on a list of
-    raw voxels and turns them into centroids the first sweep their cube is valid (the association of that one sweep
-    sees the centroid instead of the raw points).  The regime must run clean (list bounded, no error), stay within the north_star pose
-    bar of the oracle, and leave no raw voxel behind once the cubes have become valid."""
+    reference appends such points to their cube un-merged (laser_mapping.cpp:654-659) and only re-filters a cube while it is valid
+    (:689-702), so the kd-tree of the first sweep a cube turns valid sees them one by one.  The device keeps every such point as a
+    record of its own next to the voxel's running sum (k_map_finalize) and k_map_assoc expands a raw voxel into its points: every pose
+    and the whole published map must equal the oracle's, raw points included and in the reference's order."""
     monkeypatch.setattr(synth, "MAX_RANGE", 140.0)
     n = 16
     seq = synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=n + 1, speed=25.0)
     h = vl.Handle(0, with_mapping=1)
     o = orc.Oracle(with_mapping=True)
     seen = 0
+    ref = []
     for k in range(n):
         c = seq.sweep(k)
         h.process_scan(c)
         o.process(c)
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        ref.append(np.concatenate([qw, tw, qm, tm]))
         if k % 3 == 2:
             h.sync()
             seen = max(seen, sum(h.map_health()["deferred"]))
+            assert same_cloud(h.get_map(), oracle_published_map(o)), "published map after sweep %d" % k
     h.sync()
     assert seen > 0, "the sequence must reach cubes outside the valid block"
-    assert sum(h.map_health()["deferred"]) <= seen + 4096
     tj = h.trajectory()
-    qw, tw, _, _ = o.lo_pose()
-    qm, tm = o.map_published_pose()
-    assert qdist(tj[n - 1, 0:4], qw) < 1e-8 and np.linalg.norm(tj[n - 1, 4:7] - tw) < 1e-8       # odometry does not read the map
-    assert qdist(tj[n - 1, 7:11], qm) < 1e-4 and np.linalg.norm(tj[n - 1, 11:14] - tm) < 1e-4
-    got, ref = h.get_map(), oracle_published_map(o)
-    # the oracle's map still holds the raw points of never-valid cubes one by one; the device holds one voxel each
-    assert got.shape[0] <= ref.shape[0] and got.shape[0] > 0.9 * ref.shape[0]
+    ref = np.array(ref)
+    for k in range(n):
+        assert qdist(tj[k, 0:4], ref[k, 0:4]) < 1e-8 and np.linalg.norm(tj[k, 4:7] - ref[k, 4:7]) < 1e-8, k
+        assert qdist(tj[k, 7:11], ref[k, 7:11]) < 1e-8 and np.linalg.norm(tj[k, 11:14] - ref[k, 11:14]) < 1e-8, k
+    got, want = h.get_map(), oracle_published_map(o)
+    assert got.shape == want.shape and same_cloud(got, want)
 
 
 def test_long_drive_purges_and_rebuilds_the_tables(vl, orc, synth):

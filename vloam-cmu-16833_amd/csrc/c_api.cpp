@@ -977,6 +977,7 @@ vloam_status vloam_sync(vloam_handle* h) {
     if (merr & kErrRingTooLong) { set_err("a ring held more than %d points (dropped) in at least one sweep since the last vloam_sync", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
+    if (merr & kErrMapDeferred) { set_err("raw-point capacity of the map exceeded (more than 255 un-merged points in a voxel of a cube outside the valid block, or more than 64 raw voxels around one query)"); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }
     if (merr & kErrVoDegenerate) { set_err("a VO solve returned a zero rotation angle: poses are NaN from that frame on, as in the reference (visual_odometry.cpp:427-430)"); return VLOAM_ERR_INVALID; }
   }

@@ -1231,7 +1231,12 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
                   huber_a, d_enable, fin_lo, fin_traj, se.ss)
   if (direct && coop) VL_SOLVE(true, kLmDirect, kCoop);
   else if (direct) VL_SOLVE(true, kLmDirect, 1);
-  else if (rowmask && coop) VL_SOLVE(true, kLmRowMask, kCoopMap);
+  else if (rowmask && coop) {
+    static const int wgs_env = getenv("VLOAM_LM_MAP_WGS") ? atoi(getenv("VLOAM_LM_MAP_WGS")) : kCoopMap;   // A/B: workgroups of a scan-to-map solve
+    if (wgs_env == 8) VL_SOLVE(true, kLmRowMask, 8);
+    else if (wgs_env == 4) VL_SOLVE(true, kLmRowMask, 4);
+    else VL_SOLVE(true, kLmRowMask, kCoopMap);
+  }
   else if (rowmask) VL_SOLVE(true, kLmRowMask, 1);
   else if (quat && coop) VL_SOLVE(true, kLmPacked, kCoopMap);
   else if (quat) VL_SOLVE(true, kLmPacked, 1);

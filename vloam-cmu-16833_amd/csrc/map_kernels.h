@@ -77,6 +77,7 @@ struct MapFrame {         // per-sweep device counters
   int n_stack[2];
   int n_touched[2];
   int n_deferred[2];
+  int n_newraw[2];        // voxels that turned raw this sweep (merged into the deferred list by the next k_map_prepare)
   int rolled;
   int error;
   int n_factors[2][2];    // [outer][corner, surf] accepted factors
@@ -95,7 +96,8 @@ struct MapContext {
   float4* stack[2] = {nullptr, nullptr};      // the pair of the sweep mapping is working on (host-side alias)
   float4* stack_map[2] = {nullptr, nullptr};  // the same points in the map frame (at insert time)
   int* touched[2] = {nullptr, nullptr};       // table slots that received points this sweep
-  int* deferred[2] = {nullptr, nullptr};      // slots holding raw points outside the valid block
+  int* deferred[2] = {nullptr, nullptr};      // slots of the raw voxels (points that arrived while their cube was outside the valid block)
+  int* newraw[2] = {nullptr, nullptr};        // ... the ones that turned raw in the sweep being finalized
   FactorTable F[2];        // one per outer round (kept for the parity hooks)
   LMRecord* rec = nullptr; // [2]
   float4* nbr = nullptr;   // [kMapFactorCap][5] the 5 nearest map points of every stack point (.w of the first: 1 = accepted, LM:479 / LM:547)
@@ -115,7 +117,7 @@ struct MapContext {
     const size_t off = (size_t)b * se.ss;
     rbp(m.state, off); rbp(m.frame, off); m.tab[0].rebase(off); m.tab[1].rebase(off); rbp(m.cube_cnt, off); m.ds[0].rebase(off); m.ds[1].rebase(off);
     for (int c = 0; c < kSets; c++) { rbp(m.stack_sets[c][0], off); rbp(m.stack_sets[c][1], off); rbp(m.stack_info[c], off); }
-    for (int k = 0; k < 2; k++) { rbp(m.stack[k], off); rbp(m.stack_map[k], off); rbp(m.touched[k], off); rbp(m.deferred[k], off); m.F[k].rebase(off); }
+    for (int k = 0; k < 2; k++) { rbp(m.stack[k], off); rbp(m.stack_map[k], off); rbp(m.touched[k], off); rbp(m.deferred[k], off); rbp(m.newraw[k], off); m.F[k].rebase(off); }
     rbp(m.rec, off); rbp(m.nbr, off); rbp(m.cbox, off); rbp(m.ccand, off); rbp(m.registered, off); rbp(m.assoc_cyc, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
     if (m.host_flags) m.host_flags += 2 * b;
     m.se.B = 1; m.sel = 0;

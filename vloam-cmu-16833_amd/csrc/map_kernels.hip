@@ -52,13 +52,29 @@ __device__ __forceinline__ int cube_hi(double v) { return (int)floor((v + 1e-3 +
 // first global voxel index that can belong to cube A (minus one cell of slack so the local index is never negative)
 __device__ __forceinline__ int cube_voxel_base(int A, float inv) { return (int)floor((50.0 * (double)A - 25.0) * (double)inv) - 1; }
 
+// Voxel key: | seq 8 | cube i + 2048 (12) | cube j + 2048 (12) | cube k + 128 (8) | voxel lx, ly, lz inside the cube (8 each) |.
+// seq = 0: the voxel's record (centroid, or the running sum of a raw voxel); seq = 1..255: one RAW point of a voxel whose cube lies outside
+// the valid 5 x 5 x 3 block (see k_map_finalize) — the reference keeps such points un-merged in their cube until the cube is next
+// re-filtered, and its kd-tree sees them one by one.  Cubes are absolute (no window offset): +-102 km horizontally, +-6.4 km vertically
+// around the start (k_map_insert reports anything beyond).
+constexpr int kCubeOffXY = 2048, kCubeOffZ = 128;
 __device__ __forceinline__ u64 pack_key(int Ai, int Aj, int Ak, int lx, int ly, int lz) {
-  return ((u64)(unsigned)(Ai + 8192) << 50) | ((u64)(unsigned)(Aj + 8192) << 36) | ((u64)(unsigned)(Ak + 2048) << 24) |
+  return ((u64)(unsigned)(Ai + kCubeOffXY) << 44) | ((u64)(unsigned)(Aj + kCubeOffXY) << 32) | ((u64)(unsigned)(Ak + kCubeOffZ) << 24) |
          ((u64)(unsigned)lx << 16) | ((u64)(unsigned)ly << 8) | (u64)(unsigned)lz;
 }
 __device__ __forceinline__ void unpack_cube(u64 k, int* Ai, int* Aj, int* Ak) {
-  *Ai = (int)((k >> 50) & 0x3fff) - 8192; *Aj = (int)((k >> 36) & 0x3fff) - 8192; *Ak = (int)((k >> 24) & 0xfff) - 2048;
+  *Ai = (int)((k >> 44) & 0xfff) - kCubeOffXY; *Aj = (int)((k >> 32) & 0xfff) - kCubeOffXY; *Ak = (int)((k >> 24) & 0xff) - kCubeOffZ;
 }
+__device__ __forceinline__ bool cube_in_key_range(int Ai, int Aj, int Ak) {
+  return Ai >= -kCubeOffXY && Ai < kCubeOffXY && Aj >= -kCubeOffXY && Aj < kCubeOffXY && Ak >= -kCubeOffZ && Ak < kCubeOffZ;
+}
+__device__ __forceinline__ int key_seq(u64 k) { return (int)(k >> 56); }
+__device__ __forceinline__ u64 key_with_seq(u64 k, int seq) { return (k & 0x00ffffffffffffffull) | ((u64)(unsigned)seq << 56); }
+// VoxelRec::count of a seq-0 record: points in the sum (low 16 bits) | kRecRaw when the voxel holds raw points (its cube was outside the
+// valid block when they arrived): then records seq = 1..n hold the points themselves
+constexpr int kRecRaw = 1 << 30;
+__device__ __forceinline__ int rec_n(int count) { return count & 0xffff; }
+__device__ __forceinline__ bool rec_raw(int count) { return (count & kRecRaw) != 0; }
 
 // A voxel record as two 16-byte loads of one 32-byte line
 struct RecVal { u64 key; float4 sum; int count, pend_cnt; };
@@ -107,10 +123,29 @@ __device__ __forceinline__ void dquat_rot(const double* q, const double* v, doub
 
 // ---------------------------------------------------------------------------------------------- prepare
 __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr, const LOState* lo, int* cube_cnt, int skip_frame,
-                                                     double* traj_row14, StackInfo* si, size_t ss) {
-  VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si);
+                                                     double* traj_row14, StackInfo* si, int* deferred0, int* deferred1, const int* newraw0,
+                                                     const int* newraw1, size_t ss) {
+  VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si); RB(deferred0); RB(deferred1); RB(newraw0); RB(newraw1);
   __shared__ int shift[3];
   const int tid = threadIdx.x;
+  // voxels that turned raw in the previous sweep join the list of raw voxels (k_map_finalize could not append to the list it compacts)
+  for (int kind = 0; kind < 2; kind++) {
+    const int cap = kind ? kStackCapSurf : kStackCapCorner;
+    const int nn = min(fr->n_newraw[kind], cap), nd = fr->n_deferred[kind];
+    if (nn > 0) {
+      int* deferred = kind ? deferred1 : deferred0;
+      const int* newraw = kind ? newraw1 : newraw0;
+      for (int e = tid; e < nn; e += 256) { if (nd + e < cap) deferred[nd + e] = newraw[e]; }
+      if (nd + nn > cap && tid == 0) atomicOr(&fr->error, kErrMapFull);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) for (int kind = 0; kind < 2; kind++) {
+    const int cap = kind ? kStackCapSurf : kStackCapCorner;
+    fr->n_deferred[kind] = min(fr->n_deferred[kind] + min(fr->n_newraw[kind], cap), cap);
+    fr->n_newraw[kind] = 0;
+  }
+  __syncthreads();
   if (tid == 0) {
     // LaserMapping::input LM:182-195: q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom
     // the odometry pose of THIS sweep as k_lo_finish logged it (the live LOState may already belong to the next sweep: the
@@ -149,6 +184,7 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
         ms->n_corner_stack = ms->n_surf_stack = 0;
       }
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
+      ms->sweep_no++;
     }
   }
   __syncthreads();
@@ -371,28 +407,6 @@ __device__ __forceinline__ void lds_sync_wave() {
   __builtin_amdgcn_wave_barrier();
 }
 
-struct Top5 {
-  float d[5];
-  unsigned id[5];
-  __device__ __forceinline__ void init() { for (int k = 0; k < 5; k++) { d[k] = 3.0e38f; id[k] = 0xffffffffu; } }
-  __device__ __forceinline__ void push(float dd, unsigned ii) {
-    if (!(dd < d[4] || (dd == d[4] && ii < id[4]))) return;
-    d[4] = dd; id[4] = ii;
-#pragma unroll
-    for (int k = 4; k > 0; k--) {
-      const bool sw = d[k] < d[k - 1] || (d[k] == d[k - 1] && id[k] < id[k - 1]);
-      const float td = sw ? d[k - 1] : d[k]; const unsigned ti = sw ? id[k - 1] : id[k];
-      d[k - 1] = sw ? d[k] : d[k - 1]; id[k - 1] = sw ? id[k] : id[k - 1];
-      d[k] = td; id[k] = ti;
-    }
-  }
-  __device__ __forceinline__ void pop() {
-#pragma unroll
-    for (int k = 0; k < 4; k++) { d[k] = d[k + 1]; id[k] = id[k + 1]; }
-    d[4] = 3.0e38f; id[4] = 0xffffffffu;
-  }
-};
-
 // Largest two eigenvalues + unit eigenvector of the largest, of a symmetric 3x3 (the only outputs LM:500-506 uses of
 // Eigen::SelfAdjointEigenSolver).  Closed form (trigonometric solution of the characteristic cubic; eigenvector from the
 // best-conditioned cross product of two rows of A - lambda I): ~2 us of dependent f64 latency instead of ~25 us for the
@@ -464,249 +478,6 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_map_assoc_wave(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
-                                                   VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
-                                                   float4* __restrict__ nbr, int outer, int4* __restrict__ cbox, float4* __restrict__ ccand, size_t ss) {
-  VL_SESSION(ss); RB(stack0); RB(stack1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(nbr); RB(cbox); RB(ccand);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
-  // Wave d takes the d-th stack point (corners, then surfs).  The stack clouds are VoxelGrid output, i.e. spatially sorted, so
-  // neighbouring d search overlapping boxes — and workgroup b is dispatched to XCD b % 8, each XCD with an L2 of its own: the
-  // workgroups of one XCD are given a CONTIGUOUS eighth of the corner points and a contiguous eighth of the surf points (XCD-aware
-  // remap over the workgroups that have work; both kinds on every XCD, because a corner query at leaf 0.4 costs more than a surf
-  // query at leaf 0.8), so that overlapping boxes meet in one L2 instead of being fetched from HBM by up to eight.
-  const int wc = (nc + 3) >> 2, ws = (nsf + 3) >> 2, cpc = (wc + 7) >> 3, cps = (ws + 7) >> 3;
-  const int bq = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
-  if (bq >= cpc + cps || !ms->do_optimize) return;
-  int d;
-  if (bq < cpc) { const int i0 = (xcd * cpc + bq) * 4 + wave; if (i0 >= nc) return; d = i0; }
-  else { const int i0 = (xcd * cps + (bq - cpc)) * 4 + wave; if (i0 >= nsf) return; d = nc + i0; }
-  const int kind = d < nc ? 0 : 1;
-  const int i = kind ? d - nc : d;
-  const int slot = kind ? kStackCapCorner + i : i;
-  {
-    const VoxelTable T = kind ? T1 : T0;
-    const float inv = kind ? inv1 : inv0;
-    const float4 pointOri = kind ? stack1[i] : stack0[i];
-    const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
-    const float q3[3] = {sel.x, sel.y, sel.z};
-    // Voxels of the global lattice that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547).
-    // Per axis the voxel index range [lo, hi] is cut into (cube, 4-voxel block) pieces — a voxel that straddles a 50 m cube face
-    // exists once per cube — each with the 4-bit mask of its voxels inside the range.  Phase 1: one lane per candidate block
-    // fetches its occupancy mask.  Phase 2: the existing voxels of all blocks are flattened into an LDS work list so that
-    // phase 3 fetches one voxel RECORD (32 bytes, one line) per lane, all probes in flight together.
-    const int cenv[3] = {ms->cenW, ms->cenH, ms->cenD};
-    const int ctr[3] = {ms->centerCube[0] - cenv[0], ms->centerCube[1] - cenv[1], ms->centerCube[2] - cenv[2]};  // absolute centre cube
-    __shared__ u64 s_cand[4][kCandChunk + 8];
-    __shared__ float4 s_pt[4][kCandChunk + 8];
-    __shared__ u64 s_best[4][2][8];
-    __shared__ float4 s_best_p[4][2][8];
-    u64* my_cand = s_cand[wave];
-    float4* my_pt = s_pt[wave];
-    int gen = 0, total = 0;
-    bool chain_too_long = false, overflow = false;
-    // The second outer round (LM:458) searches the SAME map from a pose that moved by millimetres: when the voxel-index box of the
-    // query is the one the first round searched, the candidate set is identical and only the distances change — the first round left
-    // its candidates (centroid + tie rank) in HBM, so this round needs no hash probe at all: one coalesced read, distances, top five.
-    int blo[3], bhi[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {  // (the query is the wavefront's: uniform values, kept in scalar registers)
-      blo[a] = __builtin_amdgcn_readfirstlane((int)floorf((q3[a] - 1.001f) * inv));
-      bhi[a] = __builtin_amdgcn_readfirstlane((int)floorf((q3[a] + 1.001f) * inv));
-    }
-    bool from_cache = false;
-    if (outer > 0) {
-      const int4 b0 = cbox[2 * slot], b1 = cbox[2 * slot + 1];
-      from_cache = b1.z >= 0 && b0.x == blo[0] && b0.y == bhi[0] && b0.z == blo[1] && b0.w == bhi[1] && b1.x == blo[2] && b1.y == bhi[2];
-      if (from_cache) {
-        total = b1.z;
-        for (int w = lane; w < total; w += 64) {
-          const float4 c = ccand[(size_t)slot * kCandChunk + w];
-          const unsigned tie = __float_as_uint(c.w);
-          u64 out = ~0ull;
-          if (tie != 0xffffffffu) {
-            const float d0 = q3[0] - c.x, d1 = q3[1] - c.y, d2 = q3[2] - c.z;
-            out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
-          }
-          my_cand[w] = out;
-          my_pt[w] = make_float4(c.x, c.y, c.z, 0.f);
-        }
-        u64* nb = s_best[wave][1];
-        float4* nbp = s_best_p[wave][1];
-        if (lane < 8) nb[lane] = ~0ull;
-        lds_sync_wave();
-        for (int w = lane; w < total; w += 64) {
-          const u64 mine = my_cand[w];
-          if (mine == ~0ull) continue;
-          int rank = 0;
-          for (int t = 0; t < total; t++) rank += my_cand[t] < mine;
-          if (rank < 5) { nb[rank] = mine; nbp[rank] = my_pt[w]; }
-        }
-        lds_sync_wave();
-        gen = 1;
-      }
-    }
-    if (!from_cache) {
-    const int halfw[3] = {2, 2, 1};   // valid block: 5 x 5 x 3 cubes (LM:404-420)
-    const int wdim[3] = {kCubeW, kCubeH, kCubeD};
-    const double leaf = 1.0 / (double)inv;
-    // Piece e of axis a — (cube, 4-voxel block, 4-bit mask of the block's voxels inside the range) — or, with e = -1, just the number
-    // of pieces.  A short wave-uniform loop that every lane walks with its OWN target index: no piece tables (tables written
-    // through a run-time counter cost ~70 VGPRs here and with them a wavefront of occupancy per SIMD).
-    auto axis_piece = [&](int a, int e, int& A_out, int& blk_out, int& m4_out) -> int {
-      const int lo = blo[a], hi = bhi[a];
-      const int Amin = cube_lo((double)lo * leaf), Amax = cube_hi((double)(hi + 1) * leaf);
-      int n = 0;
-      for (int A = Amin; A <= Amax; A++) {
-        if (abs(A - ctr[a]) > halfw[a]) continue;
-        const int wv = A + cenv[a];
-        if (wv < 0 || wv >= wdim[a]) continue;
-        // voxels that can hold points of cube A: from the voxel containing its lower face to the one containing its upper face
-        const int base = cube_voxel_base(A, inv);
-        const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
-        if (ia > ib) continue;
-        for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2); blk++) {
-          if ((unsigned)blk > 63u) { overflow = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
-          if (n == e) {
-            int m4 = 0;
-#pragma unroll
-            for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
-            A_out = A; blk_out = blk; m4_out = m4;
-          }
-          n++;
-        }
-      }
-      return n;
-    };
-    int np_[3];
-    { int d0, d1, d2;
-      np_[0] = __builtin_amdgcn_readfirstlane(axis_piece(0, -1, d0, d1, d2));
-      np_[1] = __builtin_amdgcn_readfirstlane(axis_piece(1, -1, d0, d1, d2));
-      np_[2] = __builtin_amdgcn_readfirstlane(axis_piece(2, -1, d0, d1, d2)); }
-    const int nblocks = np_[0] * np_[1] * np_[2];
-    if (lane < 8) s_best[wave][0][lane] = ~0ull;
-    // Candidate lists longer than kCandChunk (a dense map at a fine leaf: up to 9^3 voxels in the box) are handled in several
-    // passes: every pass regenerates the work list, keeps ordinals [c0, c0 + kCandChunk), and merges with the best five so far.
-    for (int c0 = 0;; c0 += kCandChunk) {
-      int produced = 0;   // wave-uniform running size of the work list
-      for (int bb0 = 0; bb0 < nblocks; bb0 += 64) {
-        const int bb = bb0 + lane;
-        u64 occ = 0ull;
-        int Ai = 0, bx = 0, Aj = 0, by = 0, Ak = 0, bz = 0;
-        if (bb < nblocks) {
-          const int ex = bb % np_[0], ey = (bb / np_[0]) % np_[1], ez = bb / (np_[0] * np_[1]);
-          int mx = 0, my = 0, mz = 0;
-          axis_piece(0, ex, Ai, bx, mx);
-          axis_piece(1, ey, Aj, by, my);
-          axis_piece(2, ez, Ak, bz, mz);
-          const u64 bkey = pack_key(Ai, Aj, Ak, bx, by, bz) | (1ull << 63);
-          unsigned bs = (unsigned)mix64(bkey) & T.bslots_mask;
-          int probe = 0;
-          for (; probe < kMaxProbe; probe++) {
-            const ulonglong2 e = T.blk[bs];
-            if (e.x == 0ull) break;
-            if (e.x == bkey) { occ = e.y; break; }
-            bs = (bs + 1) & T.bslots_mask;
-          }
-          if (probe == kMaxProbe) chain_too_long = true;
-          // voxels of the block inside the search box: bit = z * 16 + y * 4 + x
-          const u64 ex4 = (u64)mx * 0x1111111111111111ull;
-          const u64 ey4 = ((u64)((my & 1) * 0xF) | ((u64)(((my >> 1) & 1) * 0xF) << 4) | ((u64)(((my >> 2) & 1) * 0xF) << 8) | ((u64)(((my >> 3) & 1) * 0xF) << 12)) * 0x0001000100010001ull;
-          const u64 ez4 = ((mz & 1) ? 0xFFFFull : 0ull) | ((mz & 2) ? 0xFFFFull << 16 : 0ull) | ((mz & 4) ? 0xFFFFull << 32 : 0ull) | ((mz & 8) ? 0xFFFFull << 48 : 0ull);
-          occ &= ex4 & ey4 & ez4;
-        }
-        // flatten: exclusive prefix of the per-lane voxel counts, then every lane appends its voxel keys
-        const int mine = __popcll(occ);
-        int inc = mine;
-        for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
-        int o = produced + inc - mine;
-        while (occ) {
-          const int bit = __ffsll((long long)occ) - 1;
-          occ &= occ - 1;
-          if (o >= c0 && o < c0 + kCandChunk)
-            my_cand[o - c0] = pack_key(Ai, Aj, Ak, (bx << 2) | (bit & 3), (by << 2) | ((bit >> 2) & 3), (bz << 2) | (bit >> 4));
-          o++;
-        }
-        produced += __shfl(inc, 63);
-      }
-      total = produced;
-      lds_sync_wave();
-      const int ncand = min(total - c0, kCandChunk);
-      // phase 3: one voxel per lane and trip: probe, take the centroid out of the record, squared distance -> key back into the
-      // list.  Key = (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the
-      // valid cubes in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so
-      // equal distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
-      for (int w = lane; w < ncand; w += 64) {
-        const u64 key = my_cand[w];
-        unsigned s = (unsigned)mix64(key) & T.mask;
-        u64 out = ~0ull;
-        float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-        int probe = 0;
-        for (; probe < kMaxProbe; probe++) {
-          const RecVal r = rec_load(&T.rec[s]);
-          if (r.key == 0ull) break;
-          if (r.key == key) {
-            const int n = r.count;
-            float4 p = r.sum;
-            if (n > 0) {
-              if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
-              const float d0 = q3[0] - p.x, d1 = q3[1] - p.y, d2 = q3[2] - p.z;
-              int Ai, Aj, Ak;
-              unpack_cube(key, &Ai, &Aj, &Ak);
-              const unsigned tie = ((unsigned)(Ai - ctr[0] + 2) << 29) | ((unsigned)(Aj - ctr[1] + 2) << 26) | ((unsigned)(Ak - ctr[2] + 1) << 24) |
-                                   ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
-              out = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
-              pt = make_float4(p.x, p.y, p.z, 0.f);
-            }
-            break;
-          }
-          s = (s + 1) & T.mask;
-        }
-        if (probe == kMaxProbe) chain_too_long = true;
-        my_cand[w] = out;
-        my_pt[w] = pt;
-        if (outer == 0 && c0 == 0 && total <= kCandChunk)   // leave the candidate for the second round (see above)
-          ccand[(size_t)slot * kCandChunk + w] = make_float4(pt.x, pt.y, pt.z, __uint_as_float(out == ~0ull ? 0xffffffffu : (unsigned)out));
-      }
-      // the best five of the earlier passes compete again
-      const int nlist = ncand + (c0 > 0 ? 5 : 0);
-      if (c0 > 0 && lane < 5) { my_cand[ncand + lane] = s_best[wave][gen][lane]; my_pt[ncand + lane] = s_best_p[wave][gen][lane]; }
-      u64* nb = s_best[wave][gen ^ 1];
-      float4* nbp = s_best_p[wave][gen ^ 1];
-      if (lane < 8) nb[lane] = ~0ull;
-      lds_sync_wave();
-      // phase 4: the five smallest keys by rank counting (keys are unique: distinct voxels); ~30 candidates on average
-      for (int w = lane; w < nlist; w += 64) {
-        const u64 mine = my_cand[w];
-        if (mine == ~0ull) continue;
-        int rank = 0;
-        for (int t = 0; t < nlist; t++) rank += my_cand[t] < mine;
-        if (rank < 5) { nb[rank] = mine; nbp[rank] = my_pt[w]; }
-      }
-      lds_sync_wave();
-      gen ^= 1;
-      if (c0 + kCandChunk >= total) break;
-    }
-    if (outer == 0 && lane == 0) {
-      cbox[2 * slot] = make_int4(blo[0], bhi[0], blo[1], bhi[1]);
-      cbox[2 * slot + 1] = make_int4(blo[2], bhi[2], (total <= kCandChunk && !overflow) ? total : -1, 0);
-    }
-    }  // !from_cache
-    // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in
-    // registers and pure per-query math, so they should not hold 64 lanes and ~130 VGPRs hostage here) — as points, so that the
-    // fit does not have to go back to the table
-    if (lane < 5) {
-      const u64 k4 = s_best[wave][gen][4];
-      const bool ok = k4 != ~0ull && __uint_as_float((unsigned)(k4 >> 32)) < 1.0f;  // LM:479 / LM:547
-      float4 p = s_best_p[wave][gen][lane];
-      p.w = ok ? 1.0f : 0.0f;
-      nbr[slot * 5 + lane] = p;
-    }
-    if (lane == 0 && total > kCandChunk) atomicMax(&fr->max_candidates, total);
-    if (__ballot(chain_too_long || overflow) && lane == 0) atomicOr(&fr->error, kErrMapFull);
-  }
-}
-
 // ---- k_map_assoc: the 5-NN search with G lanes per stack point (G = 16 / 32 / 64; 64 / G queries share a wavefront).
 // One query's work is ~27 block probes and ~30 candidate records along a chain of three dependent memory trips: a full wavefront per
 // query leaves most lanes idle most of the time and the chip runs out of wave slots, not of bandwidth (round 2: 38 % active, 5 120
@@ -723,7 +494,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (dbg_cyc) tp[0] = clock64();
   constexpr int Q = 64 / G, QW = 4 * Q;     // queries per wavefront / per workgroup
-  constexpr int U = 4, CH = U * G;          // candidates per lane and pass / per query and pass
+  constexpr int U = G == 16 ? 4 : 2, CH = U * G;   // candidates per lane and pass / per query and pass (64 / 64 / 128: the typical query has ~30)
   // KB: blocks per lane and trip
   static_assert(CH <= kCandChunk, "the second round's candidate cache holds kCandChunk entries per slot");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), qi = wave * Q + lane / G;
@@ -745,6 +516,10 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   __shared__ float4 s_bestp[QW][8];         // ... and centroid
   __shared__ int s_piece[QW][3][8];         // per axis: (cube, 4-voxel block, 4-bit mask) pieces of the search range
   __shared__ int s_np[QW][4];               // pieces per axis | overflow flag
+  constexpr int kRawCap = 64;
+  __shared__ u64 s_rawk[QW][kRawCap];       // raw voxels among the candidates (key, point count): expanded in extra passes
+  __shared__ int s_rawn[QW][kRawCap];
+  __shared__ int s_nraw[QW];
   float4 pointOri = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) pointOri = kind ? stack1[i] : stack0[i];
   const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
@@ -768,6 +543,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   if (dbg_cyc) tp[1] = clock64() + (__float_as_int(q0) & 0) + (total & 0);   // (the stamp waits for the loads above)
   if (gl < 8) s_bestk[qi][gl] = ~0ull;
   if (gl < 4) s_np[qi][gl] = 0;
+  if (gl == 4) s_nraw[qi] = 0;
   sw_lds_sync();
   if (__ballot(search) != 0ull) {
     // per axis the index range [lo, hi] is cut into (cube, 4-voxel block) pieces — a voxel that straddles a 50 m cube face exists once
@@ -806,17 +582,106 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   const bool overflow = s_np[qi][3] != 0;
   if (dbg_cyc) tp[2] = clock64() + (np0 & 0);
   const int nblocks = search ? np0 * np1 * np2 : 0;
-  // Candidate lists longer than CH (a dense map at a fine leaf: up to 9^3 voxels in the box) take several passes: every pass regenerates
-  // the work list, keeps ordinals [c0, c0 + CH), and the best five so far compete again.
-  for (int c0 = 0;; c0 += CH) {
-    const bool act = live && (c0 == 0 || c0 < total);
-    if (__ballot(act) == 0ull) break;
-    u64 key_u[U + 1];
-    float px[U + 1], py[U + 1], pz[U + 1];
+  // ---- the pieces every pass shares
+  u64 key_u[U + 1];                       // (d2, tie) of this lane's candidates of the pass (+ one carried best)
+  float px[U + 1], py[U + 1], pz[U + 1];
+  int c0 = 0, ncand = 0;                  // pass window [c0, c0 + CH) of the query's candidate ordinals; candidates of this pass
+  bool cache_pass = false;                // first-round pass whose candidates are left for the second round
+  // phase 3: up to U voxel records per lane, two in flight per trip (the second pair is only touched when some query of the wavefront has
+  // more than 2 G candidates); centroid out of the record, squared distance, key = (f32 d2 bits, position of the voxel in the
+  // reference's gathered map cloud): laserCloud*FromMap concatenates the valid cubes in (i, j, k) loop order (LM:404-430) and every cube
+  // cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so equal distances resolve to the lowest index of that cloud, the oracle's
+  // canonical kNN tie rule.  A RAW voxel (points that arrived while its cube was outside the valid block, k_map_finalize) is no
+  // candidate itself: it goes onto the query's raw list and its points are looked at one by one in extra passes below.
+  auto probe_pair = [&](auto UB) {
+    constexpr int u0 = decltype(UB)::value;
+    u64 ck[2];
+    unsigned sl[2];
+    RecVal rv[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int w = gl + (u0 + h) * G;
+      ck[h] = w < ncand ? s_cand[qi][w] : 0ull;
+      sl[h] = (unsigned)mix64(ck[h]) & T.mask;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      rv[h].key = 0ull; rv[h].sum = make_float4(0.f, 0.f, 0.f, 0.f); rv[h].count = 0; rv[h].pend_cnt = 0;
+      if (gl + (u0 + h) * G < ncand) rv[h] = rec_load(&T.rec[sl[h]]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int u = u0 + h;
+      if (gl + u * G < ncand) {
+        const u64 key = ck[h];
+#pragma nounroll
+        for (int probe = 0;;) {
+          if (rv[h].key == 0ull) break;
+          if (rv[h].key == key) {
+            const int n = rec_n(rv[h].count);
+            const bool raw = rec_raw(rv[h].count);
+            float4 p = rv[h].sum;
+            if (raw && n >= 2) {   // (a raw voxel of one point IS that point)
+              const int pos = atomicAdd(&s_nraw[qi], 1);
+              if (pos < kRawCap) { s_rawk[qi][pos] = key; s_rawn[qi][pos] = min(n, 255); }
+            } else if (n > 0) {
+              if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
+              const float d0 = q0 - p.x, d1 = q1 - p.y, d2 = q2 - p.z;
+              int Ai, Aj, Ak;
+              unpack_cube(key, &Ai, &Aj, &Ak);
+              unsigned tie = ((unsigned)(Ai - ctr0 + 2) << 29) | ((unsigned)(Aj - ctr1 + 2) << 26) | ((unsigned)(Ak - ctr2 + 1) << 24) |
+                             ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
+              const int seq = key_seq(key);
+              if (seq) tie = (tie & 0xff000000u) | ((tie * 2654435761u + (unsigned)seq * 40503u) & 0x00ffffffu);   // raw points of one voxel: distinct ties inside the cube
+              key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
+              px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+            }
+            break;
+          }
+          if (++probe == kMaxProbe) { chain_too_long = true; break; }
+          sl[h] = (sl[h] + 1) & T.mask;
+          rv[h] = rec_load(&T.rec[sl[h]]);
+        }
+        if (cache_pass)   // leave the candidate for the second round
+          ccand[(size_t)slot * kCandChunk + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
+      }
+    }
+  };
+  // phase 4: five group arg-min rounds over this pass's candidates (and, with `carry`, the best five of the earlier passes); the
+  // winner's lane publishes its centroid and retires the candidate
+  auto select_rounds = [&](bool act, bool carry) {
+    if (carry && act && gl < 5) {
+      key_u[U] = s_bestk[qi][gl];
+      const float4 bp = s_bestp[qi][gl];
+      px[U] = bp.x; py[U] = bp.y; pz[U] = bp.z;
+    }
+    sw_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      u64 m = key_u[0];
+#pragma unroll
+      for (int u = 1; u <= U; u++) m = key_u[u] < m ? key_u[u] : m;
+      const u64 gm = grp_min_u64<G>(m);
+      if (gm != ~0ull) {
+#pragma unroll
+        for (int u = 0; u <= U; u++)
+          if (key_u[u] == gm) { s_bestk[qi][r] = gm; s_bestp[qi][r] = make_float4(px[u], py[u], pz[u], 0.f); key_u[u] = ~0ull; }
+      } else if (act && gl == 0) s_bestk[qi][r] = ~0ull;
+    }
+    sw_lds_sync();
+  };
+  auto reset_candidates = [&]() {
 #pragma unroll
     for (int u = 0; u <= U; u++) { key_u[u] = ~0ull; px[u] = 0.f; py[u] = 0.f; pz[u] = 0.f; }
+  };
+  // Candidate lists longer than CH (a dense map at a fine leaf: up to 9^3 voxels in the box) take several passes: every pass regenerates
+  // the work list, keeps ordinals [c0, c0 + CH), and the best five so far compete again.
+  for (c0 = 0;; c0 += CH) {
+    const bool act = live && (c0 == 0 || c0 < total);
+    if (__ballot(act) == 0ull) break;
+    reset_candidates();
     const bool gen = act && search;
-    int ncand = 0;
+    ncand = 0;
     if (__ballot(gen) != 0ull) {
       // phase 1 + 2: one block per lane and trip fetches its occupancy mask; the existing voxels are flattened into the query's list
       int produced = 0;
@@ -892,61 +757,10 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       sw_lds_sync();
       ncand = gen ? min(total - c0, CH) : 0;
       if (dbg_cyc && c0 == 0) tp[3] = clock64() + (ncand & 0);
-      // phase 3: up to U voxel records per lane, all first probes in flight together; centroid out of the record, squared distance,
-      // key = (f32 d2 bits, position of the voxel in the reference's gathered map cloud): laserCloud*FromMap concatenates the valid
-      // cubes in (i, j, k) loop order (LM:404-430) and every cube cloud is VoxelGrid output, i.e. sorted by (iz, iy, ix) — so equal
-      // distances resolve to the lowest index of that cloud, the oracle's canonical kNN tie rule.
-      // (two candidates per lane and trip: the second pair is only touched when some query of the wavefront has more than 2 G candidates)
-      auto probe_pair = [&](auto UB) {
-        constexpr int u0 = decltype(UB)::value;
-        u64 ck[2];
-        unsigned sl[2];
-        RecVal rv[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int w = gl + (u0 + h) * G;
-          ck[h] = w < ncand ? s_cand[qi][w] : 0ull;
-          sl[h] = (unsigned)mix64(ck[h]) & T.mask;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          rv[h].key = 0ull; rv[h].sum = make_float4(0.f, 0.f, 0.f, 0.f); rv[h].count = 0; rv[h].pend_cnt = 0;
-          if (gl + (u0 + h) * G < ncand) rv[h] = rec_load(&T.rec[sl[h]]);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int u = u0 + h;
-          if (gl + u * G < ncand) {
-            const u64 key = ck[h];
-#pragma nounroll
-            for (int probe = 0;;) {
-              if (rv[h].key == 0ull) break;
-              if (rv[h].key == key) {
-                const int n = rv[h].count;
-                float4 p = rv[h].sum;
-                if (n > 0) {
-                  if (n > 1) { const float nn = (float)n; p.x = p.x / nn; p.y = p.y / nn; p.z = p.z / nn; }
-                  const float d0 = q0 - p.x, d1 = q1 - p.y, d2 = q2 - p.z;
-                  int Ai, Aj, Ak;
-                  unpack_cube(key, &Ai, &Aj, &Ak);
-                  const unsigned tie = ((unsigned)(Ai - ctr0 + 2) << 29) | ((unsigned)(Aj - ctr1 + 2) << 26) | ((unsigned)(Ak - ctr2 + 1) << 24) |
-                                       ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
-                  key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
-                  px[u] = p.x; py[u] = p.y; pz[u] = p.z;
-                }
-                break;
-              }
-              if (++probe == kMaxProbe) { chain_too_long = true; break; }
-              sl[h] = (sl[h] + 1) & T.mask;
-              rv[h] = rec_load(&T.rec[sl[h]]);
-            }
-            if (outer == 0 && c0 == 0 && total <= CH)   // leave the candidate for the second round
-              ccand[(size_t)slot * kCandChunk + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
-          }
-        }
-      };
+      cache_pass = outer == 0 && c0 == 0 && total <= CH;
       probe_pair(std::integral_constant<int, 0>{});
-      if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{});
+      if constexpr (U > 2) { if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{}); }
+      cache_pass = false;
     }
     if (c0 == 0 && __ballot(from_cache) != 0ull) {
       // all of a lane's cache entries in flight together, complete 16-byte entries (a load that is conditional on the entry's own tie
@@ -967,32 +781,42 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       }
     }
     if (dbg_cyc && c0 == 0) tp[4] = clock64() + ((int)key_u[0] & 0);
-    // the best five of the earlier passes compete again
-    if (c0 > 0 && act && gl < 5) {
-      key_u[U] = s_bestk[qi][gl];
-      const float4 bp = s_bestp[qi][gl];
-      px[U] = bp.x; py[U] = bp.y; pz[U] = bp.z;
-    }
-    sw_lds_sync();
-    // phase 4: five group arg-min rounds; the winner's lane publishes its centroid and retires the candidate
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-      u64 m = key_u[0];
-#pragma unroll
-      for (int u = 1; u <= U; u++) m = key_u[u] < m ? key_u[u] : m;
-      const u64 gm = grp_min_u64<G>(m);
-      if (gm != ~0ull) {
-#pragma unroll
-        for (int u = 0; u <= U; u++)
-          if (key_u[u] == gm) { s_bestk[qi][r] = gm; s_bestp[qi][r] = make_float4(px[u], py[u], pz[u], 0.f); key_u[u] = ~0ull; }
-      } else if (act && gl == 0) s_bestk[qi][r] = ~0ull;
-    }
-    sw_lds_sync();
+    select_rounds(act, c0 > 0);
     if (dbg_cyc && c0 == 0) tp[5] = clock64();
+  }
+  // ---- raw voxels among the candidates (only with returns beyond the valid block, i.e. ranges over 100 m): their points, one record each
+  // (seq 1..n), go through the same probe + arg-min passes, the best five so far carried along
+  const int nraw = min(s_nraw[qi], kRawCap);
+  const bool raw_overflow = s_nraw[qi] > kRawCap;
+  if (__ballot(live && nraw > 0) != 0ull) {
+    int total_raw = 0;
+    for (c0 = 0;; c0 += CH) {
+      const bool act = live && nraw > 0 && (c0 == 0 || c0 < total_raw);
+      if (__ballot(act) == 0ull) break;
+      reset_candidates();
+      int produced = 0;
+      for (int r0 = 0; __ballot(act && r0 < nraw) != 0ull; r0 += G) {
+        const int r = r0 + gl;
+        const int nr = (act && r < nraw) ? s_rawn[qi][r] : 0;
+        const u64 vk = (act && r < nraw) ? s_rawk[qi][r] : 0ull;
+        const int inc = grp_scan_incl<G>(nr);
+        const int tot = grp_sum<G>(nr);
+        int o = produced + inc - nr;
+        for (int j = 1; j <= nr; j++, o++)
+          if (o >= c0 && o < c0 + CH) s_cand[qi][o - c0] = key_with_seq(vk, j);
+        produced += tot;
+      }
+      if (act) total_raw = produced;
+      sw_lds_sync();
+      ncand = act ? min(total_raw - c0, CH) : 0;
+      probe_pair(std::integral_constant<int, 0>{});
+      if constexpr (U > 2) { if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{}); }
+      select_rounds(act, true);
+    }
   }
   if (outer == 0 && search && gl == 0) {
     cbox[2 * slot] = make_int4(blo0, bhi0, blo1, bhi1);
-    cbox[2 * slot + 1] = make_int4(blo2, bhi2, (total <= CH && !overflow) ? total : -1, 0);
+    cbox[2 * slot + 1] = make_int4(blo2, bhi2, (total <= CH && !overflow && s_nraw[qi] == 0) ? total : -1, 0);
   }
   // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in registers
   // and pure per-query math) — as points, so that the fit does not have to go back to the table
@@ -1005,6 +829,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   }
   if (live && gl == 0 && total > kCandChunk) atomicMax(&fr->max_candidates, total);
   if (__ballot(chain_too_long || (live && overflow)) && lane == 0) atomicOr(&fr->error, kErrMapFull);
+  if (__ballot(live && raw_overflow) && lane == 0) atomicOr(&fr->error, kErrMapDeferred);
   if (dbg_cyc && lane == 0) {   // debug builds of the handle: where a wavefront's time goes (setup | pieces | blocks + flatten | records | arg-min rounds)
     tp[6] = clock64();
     if (tp[3] == 0) tp[3] = tp[2];
@@ -1115,6 +940,36 @@ __device__ bool map_publish_block(const VoxelTable& T, int Ai, int Aj, int Ak, i
   return false;
 }
 
+// One raw point of a voxel as a record of its own: key | seq, sum = the point, count = 1, pend_cnt = arrival stamp (sweep << 14 | stack
+// index; 0 for a centroid that became raw point number one).  find-or-insert: a purged record of the same key is reused.
+__device__ bool map_put_raw_point(const VoxelTable& T, u64 voxel_key, int seq, float4 p, int stamp) {
+  const u64 key = key_with_seq(voxel_key, seq);
+  unsigned s = (unsigned)mix64(key) & T.mask;
+  for (int probe = 0; probe < kMaxProbe; probe++, s = (s + 1) & T.mask) {
+    const u64 old = atomicCAS(&T.rec[s].key, 0ull, key);
+    if (old == 0ull || old == key) {
+      if (old == 0ull) atomicAdd(&T.stats[0], 1);
+      rec_store_value(&T.rec[s], p, 1, stamp);
+      return true;
+    }
+  }
+  return false;
+}
+// the cube is valid again: the raw points of the voxel are merged into its centroid and their records retire (key kept, count 0: purged)
+__device__ void map_drop_raw_points(const VoxelTable& T, u64 voxel_key, int n) {
+  int dead = 0;
+  for (int seq = 1; seq <= min(n, 255); seq++) {
+    const u64 key = key_with_seq(voxel_key, seq);
+    unsigned s = (unsigned)mix64(key) & T.mask;
+    for (int probe = 0; probe < kMaxProbe; probe++, s = (s + 1) & T.mask) {
+      const u64 k = T.rec[s].key;
+      if (k == 0ull) break;
+      if (k == key) { rec_store_value(&T.rec[s], make_float4(0.f, 0.f, 0.f, 0.f), 0, 0); dead++; break; }
+    }
+  }
+  if (dead) atomicAdd(&T.stats[1], dead);
+}
+
 __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ stack0, const float4* __restrict__ stack1,
                                                     float4* __restrict__ smap0, float4* __restrict__ smap1, VoxelTable T0, VoxelTable T1,
                                                     float inv0, float inv1, MapState* ms, MapFrame* fr, int* __restrict__ touched0,
@@ -1129,10 +984,9 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
   const float4* stack = kind ? stack1 : stack0;
   float4* smap = kind ? smap1 : smap0;
   int* touched = kind ? touched1 : touched0;
-  int* deferred = kind ? deferred1 : deferred0;
+  (void)deferred0; (void)deferred1;
   const int n = kind ? ms->n_surf_stack : ms->n_corner_stack;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
-  const int cI = ms->centerCube[0], cJ = ms->centerCube[1], cK = ms->centerCube[2];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 p = associate_to_map(stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
     smap[i] = p;
@@ -1141,7 +995,7 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
     if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) continue;  // LM:654-655: outside the grid -> dropped
     const int lx = (int)floorf(p.x * inv) - cube_voxel_base(Ai, inv), ly = (int)floorf(p.y * inv) - cube_voxel_base(Aj, inv),
               lz = (int)floorf(p.z * inv) - cube_voxel_base(Ak, inv);
-    if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u) { atomicOr(&fr->error, kErrMapFull); continue; }
+    if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u || !cube_in_key_range(Ai, Aj, Ak)) { atomicOr(&fr->error, kErrMapFull); continue; }
     const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
     unsigned s = (unsigned)mix64(key) & T.mask;
     bool done = false;
@@ -1158,14 +1012,7 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
           const int tpos = atomicAdd(&fr->n_touched[kind], 1);
           if (tpos < cap) touched[tpos] = (int)s; else atomicOr(&fr->error, kErrMapFull);
         }
-        const bool valid = abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1;
-        if (!valid && pos == 0) {  // raw accumulation until the cube next enters the valid block (LM:689 runs over valid cubes only)
-          atomicOr(&fr->error, kErrMapDeferred);
-          atomicAdd(&ms->deferred, 1);
-          const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
-          if (dpos < cap) deferred[dpos] = (int)s; else atomicOr(&fr->error, kErrMapFull);   // the list of raw voxels is full: say so
-        }
-        done = true;
+        done = true;   // (whether the cube is inside the valid block is k_map_finalize's business: raw points, see there)
       }
     }
     if (!done) atomicOr(&fr->error, kErrMapFull);
@@ -1173,12 +1020,12 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
 }
 
 __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__ smap0, const float4* __restrict__ smap1, VoxelTable T0,
-                                                      VoxelTable T1, const MapState* __restrict__ ms, MapFrame* fr,
+                                                      VoxelTable T1, MapState* ms, MapFrame* fr,
                                                       const int* __restrict__ touched0, const int* __restrict__ touched1,
-                                                      int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ cube_cnt,
-                                                      int* host_flags, size_t ss) {
+                                                      int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ newraw0,
+                                                      int* __restrict__ newraw1, int* __restrict__ cube_cnt, int* host_flags, size_t ss) {
   VL_SESSION(ss); RB(smap0); RB(smap1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(touched0); RB(touched1); RB(deferred0); RB(deferred1);
-  RB(cube_cnt);
+  RB(newraw0); RB(newraw1); RB(cube_cnt);
   if (host_flags) host_flags += 2 * blockIdx.z;   // host-mapped, one pair per session (not part of the arenas)
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
@@ -1188,6 +1035,8 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
   const int nt = min(fr->n_touched[kind], cap);
   const int cI = ms->centerCube[0], cJ = ms->centerCube[1], cK = ms->centerCube[2];
   const int t = blockIdx.x * 256 + threadIdx.x;
+  int* deferred = kind ? deferred1 : deferred0;
+  int* newraw = kind ? newraw1 : newraw0;
   if (t < nt) {
     const int s = touched[t];
     int idx[kPendCap];
@@ -1200,30 +1049,56 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
       while (c >= 0 && idx[c] > v) { idx[c + 1] = idx[c]; c--; }
       idx[c + 1] = v;
     }
-    int n = rv.count;
-    float4 acc = n > 0 ? rv.sum : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n_old = rec_n(rv.count);
+    const bool was_raw = rec_raw(rv.count);
+    float4 acc = n_old > 0 ? rv.sum : make_float4(0.f, 0.f, 0.f, 0.f);
     int Ai, Aj, Ak;
     unpack_cube(rv.key, &Ai, &Aj, &Ak);
     const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
-    if (n == 0) atomicAdd(&cube_cnt[kind * kCubeNum + wi + kCubeW * wj + kCubeW * kCubeH * wk], 1);
-    for (int a = 0; a < np; a++) { const float4 p = smap[idx[a]]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
-    n += np;
+    int* cube_n = &cube_cnt[kind * kCubeNum + wi + kCubeW * wj + kCubeW * kCubeH * wk];   // points of the cube's cloud (the LM:448 gate counts them)
     const bool valid = abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1;
-    if (valid) {  // VoxelGrid re-filter of a valid cube: centroid of (old centroid, new points...), LM:689-702
-      const float nn = (float)n;
+    if (valid) {
+      // VoxelGrid re-filter of a valid cube (LM:689-702): centroid of (what the cube held of this voxel — its centroid, or raw points in
+      // arrival order —, new points...): the running f32 sum already is that sum in that order
+      if (was_raw) map_drop_raw_points(T, rv.key, n_old);
+      for (int a = 0; a < np; a++) { const float4 p = smap[idx[a]]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+      const float nn = (float)(n_old + np);
       acc.x = acc.x / nn; acc.y = acc.y / nn; acc.z = acc.z / nn; acc.w = acc.w / nn;
-      n = 1;
+      const int held = was_raw ? n_old : (n_old > 0 ? 1 : 0);
+      if (held != 1) atomicAdd(cube_n, 1 - held);
+      rec_store_value(&T.rec[s], acc, 1, 0);
+    } else {
+      // The cube is outside the valid block: the reference appends the points to the cube's cloud and leaves them there un-merged until
+      // the cube is next valid (LM:654-659 push_back, LM:689 only filters valid cubes) — its kd-tree then sees them one by one.  The
+      // seq-0 record keeps the running sum (the eventual centroid), every point also gets a record of its own (seq 1..n: k_map_assoc
+      // expands a raw voxel into them, vloam_get_map emits them); an existing centroid becomes raw point number one.
+      int seq = n_old;
+      bool overflow = false;
+      if (!was_raw) {
+        if (n_old == 1 && !map_put_raw_point(T, rv.key, 1, rv.sum, 0)) overflow = true;   // stamp 0: belongs to the filtered (voxel-ordered) part
+        // (onto a list of its own: workgroup 0 compacts the raw-voxel list in this very launch; k_map_prepare of the next sweep merges)
+        const int dpos = atomicAdd(&fr->n_newraw[kind], 1);
+        if (dpos < cap) newraw[dpos] = s; else atomicOr(&fr->error, kErrMapFull);   // the list of raw voxels is full: say so
+        atomicAdd(&ms->deferred, 1);
+      }
+      for (int a = 0; a < np; a++) {
+        const float4 p = smap[idx[a]];
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        seq++;
+        if (seq > 255 || !map_put_raw_point(T, rv.key, seq, p, ((ms->sweep_no & 0x3ffff) << 14) | idx[a])) overflow = true;
+      }
+      if (overflow) atomicOr(&fr->error, kErrMapDeferred);   // more than 255 raw points in one voxel, or no slot for one
+      atomicAdd(cube_n, np);
+      rec_store_value(&T.rec[s], acc, min(seq, 0xffff) | kRecRaw, 0);
     }
-    rec_store_value(&T.rec[s], acc, n, 0);
   }
   // Raw voxels of earlier sweeps whose cube is valid now (only with ranges beyond the 5x5x3 block): the reference's re-filter of the
   // valid cubes (LM:689-702) merges them in the first sweep their cube is valid, touched or not.  One workgroup walks the list,
   // resolves what became valid and COMPACTS the rest in place (chunks of 256, left to right: an entry only ever moves left), so the
-  // list holds the currently-raw voxels only.  A slot that also received points this sweep (pend_cnt > 0, or already count == 1)
-  // is finalised by its own thread above — with the validity rule applied to the whole sum — and only leaves the list here.
+  // list holds the currently-raw voxels only.  A slot that also received points this sweep (pend_cnt > 0, or no longer raw) is
+  // finalised by its own thread above — with the validity rule applied to the whole sum — and only leaves the list here.
   if (blockIdx.x == 0) {
     __shared__ int s_wcnt[4], s_out;
-    int* deferred = kind ? deferred1 : deferred0;
     const int nd = min(fr->n_deferred[kind], cap);
     if (threadIdx.x == 0) s_out = 0;
     __syncthreads();
@@ -1236,12 +1111,15 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
         unpack_cube(dv.key, &Ai, &Aj, &Ak);
         const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;
         const bool in_window = wi >= 0 && wi < kCubeW && wj >= 0 && wj < kCubeH && wk >= 0 && wk < kCubeD;
-        if (!in_window || dv.count <= 0) s = -1;   // purged with its cube
+        if (!in_window || dv.count == 0) s = -1;   // purged with its cube
         else if (abs(wi - cI) <= 2 && abs(wj - cJ) <= 2 && abs(wk - cK) <= 1) {
-          if (dv.pend_cnt == 0 && dv.count > 1) {
-            float4 a = dv.sum; const float nn = (float)dv.count;
+          if (dv.pend_cnt == 0 && rec_raw(dv.count)) {
+            const int n = rec_n(dv.count);
+            map_drop_raw_points(T, dv.key, n);
+            float4 a = dv.sum; const float nn = (float)n;
             a.x /= nn; a.y /= nn; a.z /= nn; a.w /= nn;
             rec_store_value(&T.rec[s], a, 1, 0);
+            if (n != 1) atomicAdd(&cube_cnt[kind * kCubeNum + wi + kCubeW * wj + kCubeW * kCubeH * wk], 1 - n);
           }
           s = -1;
         }
@@ -1278,12 +1156,12 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
 // memsets, reinsert.  Voxel contents are untouched: only slot positions change (nothing keeps slot ids across sweeps except the
 // deferred list, which is rebuilt here).
 __global__ __launch_bounds__(256) void k_map_rebuild_gather(VoxelTable T, VoxelRec* __restrict__ tmp, int cap, int* n_tmp, MapFrame* fr, int kind) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_deferred[kind] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { fr->n_deferred[kind] = 0; fr->n_newraw[kind] = 0; }   // slot ids change: both lists are rebuilt from the raw flags
   for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
     const RecVal v = rec_load(&T.rec[s]);
-    if (v.key == 0ull || v.count <= 0) continue;
+    if (v.key == 0ull || v.count == 0) continue;
     const int o = atomicAdd(n_tmp, 1);
-    if (o < cap) { VoxelRec r; r.key = v.key; r.sx = v.sum.x; r.sy = v.sum.y; r.sz = v.sum.z; r.si = v.sum.w; r.count = v.count; r.pend_cnt = 0; tmp[o] = r; }
+    if (o < cap) { VoxelRec r; r.key = v.key; r.sx = v.sum.x; r.sy = v.sum.y; r.sz = v.sum.z; r.si = v.sum.w; r.count = v.count; r.pend_cnt = key_seq(v.key) ? v.pend_cnt : 0; tmp[o] = r; }   // (a raw point's pend_cnt is its arrival stamp)
     else atomicOr(&fr->error, kErrMapFull);
   }
 }
@@ -1296,11 +1174,11 @@ __global__ __launch_bounds__(256) void k_map_rebuild_insert(VoxelTable T, const 
     bool done = false;
     for (int probe = 0; probe < kMaxProbe && !done; probe++, s = (s + 1) & T.mask) {
       if (atomicCAS(&T.rec[s].key, 0ull, r.key) != 0ull) continue;   // keys are unique in the list
-      rec_store_value(&T.rec[s], make_float4(r.sx, r.sy, r.sz, r.si), r.count, 0);
+      rec_store_value(&T.rec[s], make_float4(r.sx, r.sy, r.sz, r.si), r.count, r.pend_cnt);
       int Ai, Aj, Ak;
       unpack_cube(r.key, &Ai, &Aj, &Ak);
-      if (!map_publish_block(T, Ai, Aj, Ak, (int)((r.key >> 16) & 0xff), (int)((r.key >> 8) & 0xff), (int)(r.key & 0xff))) atomicOr(&fr->error, kErrMapFull);
-      if (r.count > 1) {  // raw points of a cube outside the valid block: still owed a centroid (see k_map_finalize)
+      if (key_seq(r.key) == 0 && !map_publish_block(T, Ai, Aj, Ak, (int)((r.key >> 16) & 0xff), (int)((r.key >> 8) & 0xff), (int)(r.key & 0xff))) atomicOr(&fr->error, kErrMapFull);
+      if (key_seq(r.key) == 0 && rec_raw(r.count)) {  // raw voxel of a cube outside the valid block: still owed a centroid (see k_map_finalize)
         const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
         if (dpos < deferred_cap) deferred[dpos] = (int)s;
       }
@@ -1346,7 +1224,8 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
          A.take(&D.seg, (size_t)cfg.max_points) && A.take(&D.rank_slot, (size_t)D.stack_cap) && A.take(&D.rank_off, (size_t)D.stack_cap + 1);
     for (int c = 0; c < MapContext::kSets; c++) ok = ok && A.take(&m->stack_sets[c][k], (size_t)D.stack_cap);
     m->stack[k] = m->stack_sets[0][k];
-    ok = ok && A.take(&m->stack_map[k], (size_t)D.stack_cap) && A.take(&m->touched[k], (size_t)D.stack_cap) && A.take(&m->deferred[k], (size_t)D.stack_cap);
+    ok = ok && A.take(&m->stack_map[k], (size_t)D.stack_cap) && A.take(&m->touched[k], (size_t)D.stack_cap) && A.take(&m->deferred[k], (size_t)D.stack_cap) &&
+         A.take(&m->newraw[k], (size_t)D.stack_cap);
     FactorTable& F = m->F[k];
     F.cap = kMapFactorCap;
     ok = ok && A.take(&F.type, (size_t)F.cap) && A.take(&F.p, 3 * (size_t)F.cap) && A.take(&F.A, 3 * (size_t)F.cap) && A.take(&F.B, 3 * (size_t)F.cap) &&
@@ -1446,29 +1325,24 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   }
   // `done` (mapping of this sweep finished) rides on the sweep's last dispatch: a marker packet behind it costs ~5 us of idle stream
   VLOAM_LAUNCH_EV(ph, kKMapPrepare, st, skip_frame ? done : nullptr, k_map_prepare, dim3(1, 1, Z), dim3(256), 0, st, ms, fr, lo, m->cube_cnt,
-                  skip_frame ? 1 : 0, traj_row14, m->stack_info[set], ss);
+                  skip_frame ? 1 : 0, traj_row14, m->stack_info[set], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], ss);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     // lanes per query of the 5-NN search: a batch fills the chip with 16-lane groups (four queries per wavefront); a single sequence
-    // (9 000 queries on 5 120 wave slots) is quickest with two per wavefront.  VLOAM_MAP_ASSOC_LANES = 16 / 32 / 64 overrides,
-    // 0 selects the round-2 kernel (one wavefront per query, rank counting in LDS) for A/B runs.
+    // (9 000 queries on 5 120 wave slots) is quickest with two per wavefront.  VLOAM_MAP_ASSOC_LANES = 16 / 32 / 64 overrides (A/B runs;
+    // the round-2 form — one wavefront per query, rank counting in LDS — measured 27.8 / 184 us at B = 1 / 8 against 16 / 105 here).
     static const int g_env = getenv("VLOAM_MAP_ASSOC_LANES") ? atoi(getenv("VLOAM_MAP_ASSOC_LANES")) : -1;
     const int G = g_env >= 0 ? g_env : (m->se.B > 1 ? 16 : 32);
     auto grid_for = [](int g) { const int qw = 256 / g; return dim3(8 * ((kStackCapCorner / qw + 7) / 8 + (kStackCapSurf / qw + 7) / 8), 1, 1); };
-#define VL_MAP_ASSOC_WAVE()                                                                                                            \
-    VLOAM_LAUNCH(ph, kKMapAssoc, st, k_map_assoc_wave, dim3(kMapFactorCap / 4, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], \
-                 m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, outer, m->cbox, m->ccand, ss)
 #define VL_MAP_ASSOC(KERN, GRID)                                                                                                      \
     VLOAM_LAUNCH(ph, kKMapAssoc, st, KERN, dim3((GRID).x, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], \
                  m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->nbr, outer, m->cbox, m->ccand, cfg.debug ? m->assoc_cyc : (long long*)nullptr, ss)
     static const int kb_env = getenv("VLOAM_MAP_ASSOC_KB") ? atoi(getenv("VLOAM_MAP_ASSOC_KB")) : 2;   // blocks per lane and trip of the 16-lane groups
-    if (G == 0) VL_MAP_ASSOC_WAVE();
-    else if (G == 16 && kb_env == 1) VL_MAP_ASSOC((k_map_assoc<16, 1>), grid_for(16));
+    if (G == 16 && kb_env == 1) VL_MAP_ASSOC((k_map_assoc<16, 1>), grid_for(16));
     else if (G == 16) VL_MAP_ASSOC((k_map_assoc<16, 2>), grid_for(16));
     else if (G == 64) VL_MAP_ASSOC((k_map_assoc<64, 1>), grid_for(64));
     else VL_MAP_ASSOC((k_map_assoc<32, 1>), grid_for(32));
 #undef VL_MAP_ASSOC
-#undef VL_MAP_ASSOC_WAVE
     VLOAM_LAUNCH(ph, kKMapFit, st, k_map_fit, dim3(kMapFactorCap / 256, 1, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->tab[0], m->tab[1], ms, fr, m->nbr,
                  m->F[outer], outer, ss);
     lm_launch(st, m->se, m->F[outer], kStackCapCorner, ms->parameters, m->rec + outer, 4, 0.1, true, &ms->do_optimize, ph);
@@ -1476,34 +1350,38 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
                m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14, ss);
   VLOAM_LAUNCH_EV(ph, kKMapFinalize, st, done, k_map_finalize, dim3(kStackCapSurf / 256, 2, Z), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
-                  m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->cube_cnt, m->host_flags, ss);
+                  m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], m->cube_cnt, m->host_flags, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
 // ---------------------------------------------------------------------------------------------- map export
 // /laser_cloud_map (LM:778-793): for cube index 0..4850 the corner cloud then the surf cloud of the cube.  A cube cloud that has been
-// through its VoxelGrid re-filter (every cube that was ever valid) is ordered by voxel (iz, iy, ix); cubes that only ever received points
-// while outside the valid block hold raw points in the reference and (sum, count) accumulations here — emitted as their centroid
-// (see DESIGN.md "deferred"; unreachable for ranges <= 100 m).  The device compacts the live records with their order key; the
-// final ordering of this OUTPUT path is a host sort of the compacted list.
+// through its VoxelGrid re-filter (every cube that was ever valid) is ordered by voxel (iz, iy, ix); points that arrived while the cube
+// was outside the valid block follow un-merged, in arrival order (sweep, then stack order) — the raw point records of k_map_finalize; a
+// centroid that became raw point number one (stamp 0) keeps its place in the voxel-ordered part.  The device compacts the live records
+// with their order key; the final ordering of this OUTPUT path is a host sort of the compacted list.
 struct ExportRow { u64 okey; float x, y, z, w; };
 __global__ __launch_bounds__(256) void k_map_export(VoxelTable T, const MapState* __restrict__ ms, int kind, ExportRow* __restrict__ out, long long cap,
                                                     unsigned long long* n_out) {
   const int cW = ms->cenW, cH = ms->cenH, cD = ms->cenD;
   for (unsigned s = blockIdx.x * 256 + threadIdx.x; s <= T.mask; s += gridDim.x * 256) {
     const RecVal v = rec_load(&T.rec[s]);
-    if (v.key == 0ull || v.count <= 0) continue;
+    if (v.key == 0ull || v.count == 0) continue;
+    const int seq = key_seq(v.key);
+    if (seq == 0 && rec_raw(v.count)) continue;   // a raw voxel is published through its point records
     int Ai, Aj, Ak;
     unpack_cube(v.key, &Ai, &Aj, &Ak);
     const int i = Ai + cW, j = Aj + cH, k = Ak + cD;
     if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || k < 0 || k >= kCubeD) continue;
     const u64 cube = (u64)(i + kCubeW * j + kCubeW * kCubeH * k);
     const u64 lx = (v.key >> 16) & 0xff, ly = (v.key >> 8) & 0xff, lz = v.key & 0xff;
+    const bool tail = seq != 0 && v.pend_cnt != 0;   // an un-merged arrival: behind the voxel-ordered part, by arrival stamp
     ExportRow r;
-    r.okey = (cube << 32) | ((u64)kind << 24) | (lz << 16) | (ly << 8) | lx;
-    const float nn = (float)v.count;
-    r.x = v.count > 1 ? v.sum.x / nn : v.sum.x; r.y = v.count > 1 ? v.sum.y / nn : v.sum.y; r.z = v.count > 1 ? v.sum.z / nn : v.sum.z;
-    r.w = v.count > 1 ? v.sum.w / nn : v.sum.w;
+    r.okey = (cube << 50) | ((u64)kind << 49) | ((u64)(tail ? 1 : 0) << 48) | (tail ? (u64)(unsigned)v.pend_cnt : ((lz << 16) | (ly << 8) | lx));
+    const int n = seq ? 1 : rec_n(v.count);
+    const float nn = (float)n;
+    r.x = n > 1 ? v.sum.x / nn : v.sum.x; r.y = n > 1 ? v.sum.y / nn : v.sum.y; r.z = n > 1 ? v.sum.z / nn : v.sum.z;
+    r.w = n > 1 ? v.sum.w / nn : v.sum.w;
     const unsigned long long o = atomicAdd(n_out, 1ull);
     if ((long long)o < cap) out[o] = r;
   }
@@ -1599,6 +1477,7 @@ vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, l
     std::vector<unsigned> rows;
     for (size_t s = 0; s < slots; s++) {
       if (recs[s].key == 0 || recs[s].count == 0) continue;
+      if ((recs[s].key >> 56) == 0 && (recs[s].count & (1 << 30))) continue;   // a raw voxel shows up as its point records (seq != 0)
       unsigned r[7];
       r[0] = (unsigned)(recs[s].key & 0xffffffffu); r[1] = (unsigned)(recs[s].key >> 32); r[2] = (unsigned)recs[s].count;
       memcpy(r + 3, &recs[s].sx, 16);
@@ -1615,7 +1494,7 @@ vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, l
     for (int k = 0; k < 2; k++) if (hipMemcpy(out + 4 * k, m->tab[k].stats, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
     MapFrame fr;
     if (hipMemcpy(&fr, m->frame, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    out[8] = (int)m0->rebuilds; out[9] = fr.max_candidates; out[10] = fr.n_deferred[0]; out[11] = fr.n_deferred[1];
+    out[8] = (int)m0->rebuilds; out[9] = fr.max_candidates; out[10] = fr.n_deferred[0] + fr.n_newraw[0]; out[11] = fr.n_deferred[1] + fr.n_newraw[1];
     if (n) *n = sizeof(out);
     if (buf) memcpy(buf, out, (size_t)cap < sizeof(out) ? (size_t)cap : sizeof(out));
     return VLOAM_OK;

@@ -122,7 +122,7 @@ enum ErrorBits : int {
   kErrEmpty = 1,       // no point survived S1
   kErrRingTooLong = 2, // a ring exceeded kMaxRingLen
   kErrMapFull = 4,     // voxel hash out of slots
-  kErrMapDeferred = 8, // a scan point landed in a cube outside the valid 5x5x3 block
+  kErrMapDeferred = 8, // raw-point capacity: more than 255 un-merged points in one voxel of a cube outside the valid block, or more than 64 raw voxels around one query
   kErrStackFull = 16,
   kErrVoDegenerate = 64, // the VO solve returned a zero rotation angle: the reference divides by it (visual_odometry.cpp:427-430) -> NaN poses
   kErrSolverSync = 32,  // a workgroup of a cooperative LM solve gave up waiting at the grid barrier (result of that solve is invalid)
@@ -277,7 +277,8 @@ struct MapState {          // laser mapping state (laser_mapping.h:141-155)
   int n_corner_stack, n_surf_stack;
   int do_optimize;         // laserCloudCornerFromMapNum > 10 && laserCloudSurfFromMapNum > 50
   int n_map_corner, n_map_surf;  // points in the valid 5x5x3 block at gather time
-  int deferred;            // inserts outside the valid block
+  int deferred;            // voxels that turned raw (points arriving in a cube outside the valid block) since the start
+  int sweep_no;            // mapped sweeps so far (arrival stamps of raw points)
 };
 
 }  // namespace vloam
