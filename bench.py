@@ -434,6 +434,24 @@ def main():
                     "counter32_last": r["counter32"], "counter22_last": r["counter22"],
                     "note": "the VO solve of frame k needs the LiDAR odometry of frame k-1 and feeds the one of frame k: VO and LO are one serial chain per frame (mapping still overlaps)"}
         hv.close()
+        if args.sessions > 1:   # the same coupled loop for B sessions per launch chain (vloam_batch_process_frame_device)
+            Bv = args.sessions
+            hvb = vl.Handle(local_rank, n_sessions=Bv, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8, detach_VO_LO=0)
+            hvb.vo_set_calib(*synth.kitti_like_calib())
+            hvb.set_extrinsics(*synth.kitti_like_extrinsics())
+            for kk in range(0, f0 - 1):
+                hvb.batch_process_scan_device([base_ptr + kk * stride] * Bv, [n_pts] * Bv)
+            hvb.batch_process_frame_device([base_ptr + (f0 - 1) * stride] * Bv, [n_pts] * Bv, [(None, None)] * Bv)
+            hvb.sync()
+            w0 = time.perf_counter()
+            for k in range(f0, T):
+                hvb.batch_process_frame_device([base_ptr + k * stride] * Bv, [n_pts] * Bv, [ms_[k]] * Bv)
+            hvb.sync()
+            w1 = time.perf_counter()
+            vo_same = bool(np.array_equal(hvb.select(Bv - 1).trajectory(), hvb.select(0).trajectory()))
+            hvb.close()
+            vo_stage["batched"] = {"sessions": Bv, "value": Bv * nf / (w1 - w0), "unit": "frames/s", "ms_per_batch_frame": 1e3 * (w1 - w0) / nf,
+                                   "sessions_identical_to_each_other": vo_same}
 
 
     # ---- extra: the same coupled loop from RAW inputs — every frame hands over the sweep and a grey camera image; corners

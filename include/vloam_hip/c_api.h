@@ -91,6 +91,10 @@ vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions);
 vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n);
 vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_pad4, const int* n);
 vloam_status vloam_select_session(vloam_handle* h, int session);
+/* one coupled VLOAM frame (vloam_process_frame_device, below) for every session: prev_uv[b] / curr_uv[b] = session b's n_match[b] pixel
+ * matches in host memory; vloam_vo_set_calib / vloam_set_extrinsics apply to all sessions (one sensor rig) */
+vloam_status vloam_batch_process_frame_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n, const int* const* prev_uv,
+                                              const int* const* curr_uv, const int* n_match);
 
 /* == LidarOdometryMapping::reset (lidar_odometry_mapping.cpp:65-71) */
 vloam_status vloam_reset_frame(vloam_handle* h);

@@ -273,6 +273,19 @@ class Handle:
         pu, cu, pp, cp, n = self._matches(prev_uv, curr_uv)
         self._chk(self.L.vloam_process_frame_device(self.h, C.c_void_p(dptr), int(n_pts), pp, cp, n))
 
+    def batch_process_frame_device(self, dptrs, ns, matches):
+        """One coupled VLOAM frame for every session: matches[b] = (prev_uv, curr_uv) int32 [m, 2] (or (None, None))."""
+        B = self.n_sessions
+        assert len(dptrs) == B and len(ns) == B and len(matches) == B
+        keep = [self._matches(m[0], m[1]) for m in matches]
+        ptrs = (C.c_void_p * B)(*[int(p) for p in dptrs])
+        nn = (C.c_int * B)(*[int(n) for n in ns])
+        IP = C.POINTER(C.c_int)
+        pp = (IP * B)(*[C.cast(k[2], IP) for k in keep])
+        cp = (IP * B)(*[C.cast(k[3], IP) for k in keep])
+        nm = (C.c_int * B)(*[int(k[4]) for k in keep])
+        self._chk(self.L.vloam_batch_process_frame_device(self.h, ptrs, nn, pp, cp, nm))
+
     def vo_trajectory(self, first=0, count=None):
         if count is None:
             count = self.frame_count() - first

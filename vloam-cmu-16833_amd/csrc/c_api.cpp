@@ -299,6 +299,7 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       s = handle_layout(h, A);
       if (s != VLOAM_OK) return s;
       h->map.se = h->se;
+      h->vo.se = h->se;
       // ---- initial state of session 0
       for (int k = 0; k < vloam_handle::kSets; k++) {
         int arm[4 * kMaxRings];
@@ -726,17 +727,19 @@ vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
 // == vloam_tf->processStaticTransform()'s products base_T_cam0 / velo_T_cam0 (vloam_tf.cpp:55-56), row-major 4x4
 vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16], const double velo_T_cam0[16]) {
   if (!h || !base_T_cam0 || !velo_T_cam0) return VLOAM_ERR_INVALID;
-  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
-  VloamTfState tf;
-  HIPCHK(hipMemcpy(&tf, &h->lo->tf, sizeof(tf), hipMemcpyDeviceToHost));
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) { tf.base_T_cam0.m[r * 3 + c] = base_T_cam0[r * 4 + c]; tf.velo_T_cam0.m[r * 3 + c] = velo_T_cam0[r * 4 + c]; }
-    tf.base_T_cam0.o[r] = base_T_cam0[r * 4 + 3]; tf.velo_T_cam0.o[r] = velo_T_cam0[r * 4 + 3];
+  for (int b = 0; b < h->se.B; b++) {   // one sensor rig for all sessions of a batched handle
+    LOState* lo = (LOState*)((char*)h->lo + (size_t)b * h->se.ss);
+    VloamTfState tf;
+    HIPCHK(hipMemcpy(&tf, &lo->tf, sizeof(tf), hipMemcpyDeviceToHost));
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) { tf.base_T_cam0.m[r * 3 + c] = base_T_cam0[r * 4 + c]; tf.velo_T_cam0.m[r * 3 + c] = velo_T_cam0[r * 4 + c]; }
+      tf.base_T_cam0.o[r] = base_T_cam0[r * 4 + 3]; tf.velo_T_cam0.o[r] = velo_T_cam0[r * 4 + 3];
+    }
+    tf.coupled = 1;
+    HIPCHK(hipMemcpy(&lo->tf, &tf, sizeof(tf), hipMemcpyHostToDevice));
   }
-  tf.coupled = 1;
-  HIPCHK(hipMemcpy(&h->lo->tf, &tf, sizeof(tf), hipMemcpyHostToDevice));
   h->have_extrinsics = true;
   return VLOAM_OK;
 }
@@ -760,11 +763,14 @@ static vloam_status upload_image(vloam_handle* h, const unsigned char* gray, int
   return VLOAM_OK;
 }
 
-static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match,
+static vloam_status process_frame_common(vloam_handle* h, const BatchIn& bi, const int* const* prev_uv, const int* const* curr_uv, const int* n_match,
                                          const unsigned char* d_gray, int width, int height, int stride) {
-  SINGLE_SESSION_ONLY(h);
   if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
-  if (n_match > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match, kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
+  for (int b = 0; b < h->se.B; b++) {
+    if (n_match[b] < 0 || (n_match[b] > 0 && (!prev_uv[b] || !curr_uv[b]))) { set_err("bad match arrays for session %d", b); return VLOAM_ERR_INVALID; }
+    if (n_match[b] > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match[b], kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
+  }
+  if (d_gray && h->se.B != 1) { set_err("the image front-end drives one sequence per handle"); return VLOAM_ERR_INVALID; }
   if (d_gray && h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   if (d_gray && img_check(&h->img, width, height, stride) != VLOAM_OK) {   // before anything of this frame is enqueued
     set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h);
@@ -772,11 +778,12 @@ static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4
   }
   HIPCHK(hipSetDevice(h->device));
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
-  vloam_status s = enqueue_sr(h, one_sweep(d_xyz_pad4, n));
+  vloam_status s = enqueue_sr(h, bi);
   if (s != VLOAM_OK) return s;
   const int k = h->frame, cur = set_of(k);
   // depth map + matches ride on the scan-registration stream (they only need the sweep); the solve itself belongs to the odometry stream
-  s = vo_depth_enqueue(&h->vo, h->stream, (const float4*)d_xyz_pad4, n, k, prev_uv, curr_uv, d_gray ? 0 : n_match, &h->prof);
+  int no_match[kMaxBatch] = {0};
+  s = vo_depth_enqueue(&h->vo, h->stream, bi, k, prev_uv, curr_uv, d_gray ? no_match : n_match, &h->prof);
   if (s != VLOAM_OK) { set_err("vo_depth_enqueue failed"); return s; }
   HIPCHK(hipEventRecord(h->ev_vo[cur], h->stream));
   h->vo_frame[cur] = true;
@@ -786,7 +793,7 @@ static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4
     const int vset = k % VOContext::kSets;
     s = img_process(&h->img, h->s_img, d_gray, width, height, stride, h->vo.d_prev_set[vset], h->vo.d_curr_set[vset], &h->prof);
     if (s != VLOAM_OK) { set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h); return s; }
-    h->vo.n_match_set[vset] = k > 0 ? kImgMaxCorners : 0;
+    h->vo.n_match_set[vset].n[0] = k > 0 ? kImgMaxCorners : 0;
     HIPCHK(hipEventRecord(h->ev_img[cur], h->s_img));
     h->img_frame[cur] = true;
   }
@@ -803,7 +810,20 @@ static vloam_status process_frame_common(vloam_handle* h, const void* d_xyz_pad4
 
 vloam_status vloam_process_frame_device(vloam_handle* h, const void* d_xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
   if (!h || !d_xyz_pad4 || n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
-  return process_frame_common(h, d_xyz_pad4, n, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
+  SINGLE_SESSION_ONLY(h);
+  return process_frame_common(h, one_sweep(d_xyz_pad4, n), &prev_uv, &curr_uv, &n_match, nullptr, 0, 0, 0);
+}
+
+// Batched coupled frames: one call advances ALL sessions of the handle by one VLOAM frame (session b: sweep d_xyz_pad4[b] with n[b] points,
+// n_match[b] pixel matches prev_uv[b] -> curr_uv[b] in HOST memory); every kernel of the frame chain — depth map, match + VO solve,
+// VO2VeloAndBase, scan registration, odometry in combined mode, mapping — is launched once with the session index in blockIdx.z.
+vloam_status vloam_batch_process_frame_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n, const int* const* prev_uv,
+                                              const int* const* curr_uv, const int* n_match) {
+  if (!h || !d_xyz_pad4 || !n || !prev_uv || !curr_uv || !n_match) return VLOAM_ERR_INVALID;
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  for (int b = 0; b < h->se.B; b++) { bi.in[b] = (const float4*)d_xyz_pad4[b]; bi.n[b] = n[b]; }
+  return process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
 }
 
 vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
@@ -817,7 +837,9 @@ vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, 
 
 vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride) {
   if (!h || !d_xyz_pad4 || !d_gray) return VLOAM_ERR_INVALID;
-  return process_frame_common(h, d_xyz_pad4, n, nullptr, nullptr, 0, (const unsigned char*)d_gray, width, height, stride);
+  SINGLE_SESSION_ONLY(h);
+  { const int* none = nullptr; const int zero = 0;
+    return process_frame_common(h, one_sweep(d_xyz_pad4, n), &none, &none, &zero, (const unsigned char*)d_gray, width, height, stride); }
 }
 
 vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride) {
@@ -829,7 +851,9 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
-  return process_frame_common(h, h->d_in, n, nullptr, nullptr, 0, h->img.staging, width, height, width);
+  SINGLE_SESSION_ONLY(h);
+  { const int* none = nullptr; const int zero = 0;
+    return process_frame_common(h, one_sweep(h->d_in, n), &none, &none, &zero, h->img.staging, width, height, width); }
 }
 
 // ---- the image front-end on its own (VisualOdometry::processImage, optical_flow_match = true)
@@ -954,8 +978,8 @@ vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t
   double x[6];
   int cnt[2];
   LOState lo;
-  HIPCHK(hipMemcpy(x, h->vo.x, sizeof(x), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(cnt, h->vo.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(x, SEL(h, h->vo.x), sizeof(x), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cnt, SEL(h, h->vo.counters), sizeof(cnt), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&lo, SEL(h, h->lo), sizeof(lo), hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; k++) { if (angle_axis) angle_axis[k] = x[k]; if (t) t[k] = x[3 + k]; if (prior_t) prior_t[k] = lo.prior_t[k]; }
   if (counters32_22) { counters32_22[0] = cnt[0]; counters32_22[1] = cnt[1]; }
@@ -1013,7 +1037,6 @@ vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long lon
 // ------------------------------------------------------------------ VO
 vloam_status vloam_vo_set_calib(vloam_handle* h, const vloam_calib* c) {
   if (!h || !c) return VLOAM_ERR_INVALID;
-  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
   return vo_set_calib(&h->vo, h->stream, c) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP;
 }

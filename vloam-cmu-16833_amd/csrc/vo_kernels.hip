@@ -16,8 +16,13 @@
 
 namespace vloam {
 
-__global__ __launch_bounds__(256) void k_vo_project(const float4* __restrict__ in, int n, const vloam_calib* __restrict__ c,
-                                                    float4* __restrict__ uvd, int* __restrict__ bcount) {
+// (every kernel carries the session index of a batched handle in blockIdx.z and rebases its arena pointers by blockIdx.z * ss; the
+// sweeps themselves are the callers' buffers: BatchIn)
+__global__ __launch_bounds__(256) void k_vo_project(BatchIn bi, const vloam_calib* __restrict__ c,
+                                                    float4* __restrict__ uvd, int* __restrict__ bcount, size_t ss) {
+  VL_SESSION(ss); RB(c); RB(uvd); RB(bcount);
+  const float4* __restrict__ in = bi.in[blockIdx.z];
+  const int n = bi.n[blockIdx.z];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 q = in[i];
     const float t[4] = {q.x, q.y, q.z, 1.0f};
@@ -38,7 +43,8 @@ __global__ __launch_bounds__(256) void k_vo_project(const float4* __restrict__ i
   }
 }
 
-__global__ __launch_bounds__(1024) void k_vo_scan(int* bcount, int* bfill) {
+__global__ __launch_bounds__(1024) void k_vo_scan(int* bcount, int* bfill, size_t ss) {
+  VL_SESSION(ss); RB(bcount); RB(bfill);
   constexpr int kPer = (kBuckets + 1023) / 1024;  // 19: odd, so a lane stride of kPer words is LDS-bank-conflict free
   __shared__ int buf[1024 * kPer];                 // the counters pass through LDS: coalesced in, coalesced out
   __shared__ int wsum[16];
@@ -61,8 +67,10 @@ __global__ __launch_bounds__(1024) void k_vo_scan(int* bcount, int* bfill) {
   for (int k = tid; k <= kBuckets; k += 1024) { bcount[k] = buf[k]; if (k < kBuckets) bfill[k] = 0; }  // buf[kBuckets] == total (the tail counters are 0)
 }
 
-__global__ __launch_bounds__(256) void k_vo_scatter(const float4* __restrict__ uvd, int n, const int* __restrict__ boff, int* bfill,
-                                                    int* __restrict__ seg) {
+__global__ __launch_bounds__(256) void k_vo_scatter(const float4* __restrict__ uvd, BatchIn bi, const int* __restrict__ boff, int* bfill,
+                                                    int* __restrict__ seg, size_t ss) {
+  VL_SESSION(ss); RB(uvd); RB(boff); RB(bfill); RB(seg);
+  const int n = bi.n[blockIdx.z];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int b = __float_as_int(uvd[i].w);
     if (b < 0) continue;
@@ -70,7 +78,8 @@ __global__ __launch_bounds__(256) void k_vo_scatter(const float4* __restrict__ u
   }
 }
 
-__global__ __launch_bounds__(256) void k_vo_fold(const float4* __restrict__ uvd, int* __restrict__ boff, int* __restrict__ seg, DepthMapDev M) {
+__global__ __launch_bounds__(256) void k_vo_fold(const float4* __restrict__ uvd, int* __restrict__ boff, int* __restrict__ seg, DepthMapDev M, size_t ss) {
+  VL_SESSION(ss); RB(uvd); RB(boff); RB(seg); M.rebase(so_);
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= kBuckets) return;
   const int b0 = boff[b], cnt = boff[b + 1] - b0;
@@ -184,10 +193,12 @@ __device__ void solve3x3_colpiv_qr_f32(const float* A_, const float* b_, float* 
   for (int k = 0; k < 3; k++) x[perm[k]] = y[k];
 }
 
-__global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_uv, const int* __restrict__ curr_uv, int n_match,
+__global__ __launch_bounds__(256) void k_vo_match(const int* __restrict__ prev_uv, const int* __restrict__ curr_uv, VoMatchCounts nm,
                                                   const vloam_calib* __restrict__ c, DepthMapDev Mprev, int remove_outlier, FactorTable F,
                                                   double* __restrict__ dbg, int* counters, const LOState* __restrict__ lo, double* x_init,
-                                                  int reset_to_identity) {
+                                                  int reset_to_identity, size_t ss) {
+  VL_SESSION(ss); RB(prev_uv); RB(curr_uv); RB(c); Mprev.rebase(so_); F.rebase(so_); RB(dbg); RB(counters); RB(lo); RB(x_init);
+  const int n_match = nm.n[blockIdx.z];
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j == 0 && x_init) {  // solveNlsAll's initial guess (VO:258-281); the solve behind this launch reads it
     double a[3] = {0, 0, 0}, t[3] = {0, 0, 0};
@@ -285,53 +296,74 @@ vloam_status vo_layout(VOContext* v, const vloam_config& cfg, Arena& A) {
 }
 
 vloam_status vo_set_calib(VOContext* v, hipStream_t st, const vloam_calib* c) {
-  if (hipMemcpyAsync(v->d_calib, c, sizeof(*c), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  for (int b = 0; b < v->se.B; b++)   // one camera for all sessions of a batched handle
+    if (hipMemcpyAsync((char*)v->d_calib + (size_t)b * v->se.ss, c, sizeof(*c), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
   v->have_calib = true;
   return VLOAM_OK;
 }
 
-static vloam_status vo_depth_launch(VOContext* v, hipStream_t st, const float4* d_in, int n, int set, ProfHook* ph) {
-  if (hipMemsetAsync(v->bcount, 0, sizeof(int) * (kBuckets + 1), st) != hipSuccess) return VLOAM_ERR_HIP;
-  VLOAM_LAUNCH(ph, kKVoProject, st, k_vo_project, dim3(256), dim3(256), 0, st, d_in, n, v->d_calib, v->uvd, v->bcount);
-  VL_RAW_LAUNCH(k_vo_scan, dim3(1), dim3(1024), 0, st, v->bcount, v->bfill);
-  VL_RAW_LAUNCH(k_vo_scatter, dim3(256), dim3(256), 0, st, v->uvd, n, v->bcount, v->bfill, v->seg);
-  VLOAM_LAUNCH(ph, kKVoFold, st, k_vo_fold, dim3((kBuckets + 255) / 256), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[set]);
+// zero `bytes` at the same offset of every session's arena (one strided fill instead of B small ones)
+static hipError_t memset_sessions(void* p, size_t bytes, Sess se, hipStream_t st) {
+  return se.B > 1 ? hipMemset2DAsync(p, se.ss, 0, bytes, (size_t)se.B, st) : hipMemsetAsync(p, 0, bytes, st);
+}
+
+static vloam_status vo_depth_launch(VOContext* v, hipStream_t st, const BatchIn& bi, int set, ProfHook* ph) {
+  const Sess se = v->se;
+  const unsigned Z = (unsigned)se.B;
+  if (memset_sessions(v->bcount, sizeof(int) * (kBuckets + 1), se, st) != hipSuccess) return VLOAM_ERR_HIP;
+  VLOAM_LAUNCH(ph, kKVoProject, st, k_vo_project, dim3(256, 1, Z), dim3(256), 0, st, bi, v->d_calib, v->uvd, v->bcount, se.ss);
+  VL_RAW_LAUNCH(k_vo_scan, dim3(1, 1, Z), dim3(1024), 0, st, v->bcount, v->bfill, se.ss);
+  VL_RAW_LAUNCH(k_vo_scatter, dim3(256, 1, Z), dim3(256), 0, st, v->uvd, bi, v->bcount, v->bfill, v->seg, se.ss);
+  VLOAM_LAUNCH(ph, kKVoFold, st, k_vo_fold, dim3((kBuckets + 255) / 256, 1, Z), dim3(256), 0, st, v->uvd, v->bcount, v->seg, v->maps[set], se.ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+}
+
+static BatchIn vo_one(const float4* d_in, int n) {
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  bi.in[0] = d_in; bi.n[0] = n;
+  return bi;
 }
 
 vloam_status vo_process_point_cloud(VOContext* v, hipStream_t st, const float4* d_in, int n) {
   if (!v->have_calib) return VLOAM_ERR_ORDER;
   ++v->count;                // VisualOdometry::reset(), VO:86-90
   v->i = v->count % VOContext::kSets;
-  return vo_depth_launch(v, st, d_in, n, v->i, nullptr);
+  return vo_depth_launch(v, st, vo_one(d_in, n), v->i, nullptr);
 }
 
-// coupled frame loop: the depth map of frame `frame` goes to maps[frame % kSets]; the frame's pixel matches are staged into the same set
-vloam_status vo_depth_enqueue(VOContext* v, hipStream_t st, const float4* d_in, int n, int frame, const int* prev_uv, const int* curr_uv, int n_match,
-                              ProfHook* ph) {
+// coupled frame loop: the depth map of frame `frame` goes to maps[frame % kSets]; the frame's pixel matches (per session: host arrays
+// prev_uv[b] / curr_uv[b] of n_match[b] pairs) are staged into the same set
+vloam_status vo_depth_enqueue(VOContext* v, hipStream_t st, const BatchIn& bi, int frame, const int* const* prev_uv, const int* const* curr_uv,
+                              const int* n_match, ProfHook* ph) {
   if (!v->have_calib) return VLOAM_ERR_ORDER;
-  if (n_match > kVoMaxMatches || n_match < 0) return VLOAM_ERR_CAPACITY;
   const int set = frame % VOContext::kSets;
+  for (int b = 0; b < v->se.B; b++) if (n_match[b] > kVoMaxMatches || n_match[b] < 0) return VLOAM_ERR_CAPACITY;
   v->count = frame;
   v->i = set;
-  v->n_match_set[set] = n_match;
-  if (n_match > 0 && frame > 0) {
-    if (hipMemcpyAsync(v->d_prev_set[set], prev_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
-    if (hipMemcpyAsync(v->d_curr_set[set], curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  for (int b = 0; b < v->se.B; b++) {
+    v->n_match_set[set].n[b] = n_match[b];
+    if (n_match[b] > 0 && frame > 0) {
+      const size_t off = (size_t)b * v->se.ss;
+      if (hipMemcpyAsync((char*)v->d_prev_set[set] + off, prev_uv[b], sizeof(int) * 2 * n_match[b], hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+      if (hipMemcpyAsync((char*)v->d_curr_set[set] + off, curr_uv[b], sizeof(int) * 2 * n_match[b], hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+    }
   }
-  return vo_depth_launch(v, st, d_in, n, set, ph);
+  return vo_depth_launch(v, st, bi, set, ph);
 }
 
 vloam_status vo_solve_enqueue(VOContext* v, const vloam_config& cfg, hipStream_t st, int frame, LOState* lo, ProfHook* ph) {
   const int set = frame % VOContext::kSets, prev = (frame + VOContext::kSets - 1) % VOContext::kSets;
-  if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
-  VLOAM_LAUNCH(ph, kKVoMatch, st, k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev_set[set], v->d_curr_set[set], v->n_match_set[set],
-               v->d_calib, v->maps[prev], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters, lo, v->x, cfg.reset_VO_to_identity);
-  lm_launch(st, Sess(), v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr, ph);
+  const Sess se = v->se;
+  if (memset_sessions(v->counters, sizeof(int) * 2, se, st) != hipSuccess) return VLOAM_ERR_HIP;
+  VLOAM_LAUNCH(ph, kKVoMatch, st, k_vo_match, dim3(kVoMaxMatches / 256, 1, (unsigned)se.B), dim3(256), 0, st, v->d_prev_set[set], v->d_curr_set[set], v->n_match_set[set],
+               v->d_calib, v->maps[prev], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters, lo, v->x, cfg.reset_VO_to_identity, se.ss);
+  lm_launch(st, se, v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr, ph);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
+// the stage-wise VO entry points drive one sequence (session 0 of the handle)
 vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, const int* prev_uv, const int* curr_uv, int n_match,
                       double aa[3], double t[3], int counters[2]) {
   if (!v->have_calib || v->count < 1) return VLOAM_ERR_ORDER;  // needs the previous frame's depth map
@@ -342,9 +374,12 @@ vloam_status vo_solve(VOContext* v, const vloam_config& cfg, hipStream_t st, con
   if (hipMemcpyAsync(v->d_curr, curr_uv, sizeof(int) * 2 * n_match, hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemcpyAsync(v->x, x, sizeof(x), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
   if (hipMemsetAsync(v->counters, 0, sizeof(int) * 2, st) != hipSuccess) return VLOAM_ERR_HIP;
-  VL_RAW_LAUNCH(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, n_match, v->d_calib,
+  VoMatchCounts nm;
+  memset(&nm, 0, sizeof(nm));
+  nm.n[0] = n_match;
+  VL_RAW_LAUNCH(k_vo_match, dim3(kVoMaxMatches / 256), dim3(256), 0, st, v->d_prev, v->d_curr, nm, v->d_calib,
                      v->maps[(v->i + VOContext::kSets - 1) % VOContext::kSets], cfg.remove_VO_outlier, v->F, v->match_dbg, v->counters,
-                     (const LOState*)nullptr, (double*)nullptr, 0);
+                     (const LOState*)nullptr, (double*)nullptr, 0, (size_t)0);
   lm_launch(st, Sess(), v->F, 0, v->x, v->rec, 100, 0.1, false, nullptr);
   if (hipMemcpyAsync(x, v->x, sizeof(x), hipMemcpyDeviceToHost, st) != hipSuccess) return VLOAM_ERR_HIP;
   int cnt[2];
