@@ -62,7 +62,7 @@ def algorithmic_bytes(kernel, c):
     F = c["F_corner"] + c["F_plane"]
     nn = c["n_c"] + c["n_s"]
     n_less = c["n_lessSharp"] + c["n_lessFlat"]
-    if kernel == "k_lo_assoc":  # features + both candidate clouds read once, one 76-byte factor record written per factor
+    if kernel in ("k_lo_assoc", "k_lo_assoc_fast"):  # features + both candidate clouds read once, one 76-byte factor record written per factor
         return 16 * n_feat + 16 * (c["C"] + c["S"]) + 76 * F
     if kernel == "k_lm_solve":  # every evaluation consumes the factor records (76 B each); average over the solves of a sweep
         if c["K_m"] > 0:  # 2 odometry + 2 mapping solves per sweep
