@@ -24,6 +24,7 @@ ap.add_argument("--steps", type=int, default=120)
 ap.add_argument("--sweeps", type=int, default=48)
 ap.add_argument("--table", action="store_true", help="per-kernel HIP-event table of the batched run")
 ap.add_argument("--no-single", action="store_true")
+ap.add_argument("--map-log2", type=int, default=22, help="map_capacity_log2 of the handles (voxel table slots)")
 ap.add_argument("--procs", type=int, default=32, help="worker processes for the synthesis (1 under rocprofv3: it follows forked children)")
 a = ap.parse_args()
 synth = conftest.load_synth()
@@ -48,7 +49,7 @@ ptr = lambda k: d.data_ptr() + (k % a.sweeps) * npts * 16   # noqa: E731  (the s
 
 
 def run(B):
-    h = vl.Handle(0, n_sessions=B, with_mapping=1, max_frames=a.warm + a.steps + 8)
+    h = vl.Handle(0, n_sessions=B, with_mapping=1, max_frames=a.warm + a.steps + 8, map_capacity_log2=a.map_log2)
     step = (lambda k: h.process_scan_device(ptr(k), npts)) if B == 1 else (lambda k: h.batch_process_scan_device([ptr(k)] * B, [npts] * B))
     for k in range(a.warm):
         step(k)
