@@ -95,6 +95,8 @@ vloam_status vloam_select_session(vloam_handle* h, int session);
  * matches in host memory; vloam_vo_set_calib / vloam_set_extrinsics apply to all sessions (one sensor rig) */
 vloam_status vloam_batch_process_frame_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n, const int* const* prev_uv,
                                               const int* const* curr_uv, const int* n_match);
+vloam_status vloam_batch_process_frame(vloam_handle* h, const float* const* xyz_pad4, const int* n, const int* const* prev_uv,
+                                       const int* const* curr_uv, const int* n_match);   /* sweeps in host memory */
 
 /* == LidarOdometryMapping::reset (lidar_odometry_mapping.cpp:65-71) */
 vloam_status vloam_reset_frame(vloam_handle* h);

@@ -78,16 +78,15 @@ def test_single_sequence_entry_points_refuse_a_batched_handle(vl, sweeps):
 
 
 def test_batched_coupled_frames_equal_single_session_runs(vl, synth):
-    """vloam_batch_process_frame_device: B coupled VLOAM sessions (depth-enhanced VO + VO2VeloAndBase + scan registration + odometry in
+    """vloam_batch_process_frame[_device]: B coupled VLOAM sessions (depth-enhanced VO + VO2VeloAndBase + scan registration + odometry in
     combined mode + mapping, MAIN/src/vloam_main_node.cpp:125-180) advanced by one launch chain per frame — every session bit-identical to
-    the same sequence through vloam_process_frame_device on a handle of its own (trajectory, VO trajectory, VO estimate)."""
-    import torch
+    the same sequence through vloam_process_frame on a handle of its own (trajectory, VO trajectory, VO estimate)."""
     B, n = 4, 8
     cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
     base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
     seqs = [synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=n + 1, seed_scene=1234 + 17 * b, seed_traj=42 + b, seed_noise=5678 + 1000 * b)
             for b in range(B)]
-    clouds = [[torch.from_numpy(np.ascontiguousarray(s.sweep(k), dtype=np.float32)).cuda() for k in range(n)] for s in seqs]
+    clouds = [[np.ascontiguousarray(s.sweep(k), dtype=np.float32) for k in range(n)] for s in seqs]
     matches = [[synth.synth_matches(s, k) if k > 0 else (None, None) for k in range(n)] for s in seqs]
 
     def setup(h):
@@ -97,12 +96,12 @@ def test_batched_coupled_frames_equal_single_session_runs(vl, synth):
 
     hb = setup(vl.Handle(0, n_sessions=B, with_mapping=1, detach_VO_LO=0))
     for k in range(n):
-        hb.batch_process_frame_device([clouds[b][k].data_ptr() for b in range(B)], [clouds[b][k].shape[0] for b in range(B)], [matches[b][k] for b in range(B)])
+        hb.batch_process_frame([clouds[b][k] for b in range(B)], [matches[b][k] for b in range(B)])
     hb.sync()
     for b in range(B):
         hs = setup(vl.Handle(0, with_mapping=1, detach_VO_LO=0))
         for k in range(n):
-            hs.process_frame_device(clouds[b][k].data_ptr(), clouds[b][k].shape[0], matches[b][k][0], matches[b][k][1])
+            hs.process_frame(clouds[b][k], matches[b][k][0], matches[b][k][1])
         hs.sync()
         hb.select(b)
         assert np.array_equal(hb.trajectory(), hs.trajectory()), "session %d trajectory" % b

@@ -286,6 +286,20 @@ class Handle:
         nm = (C.c_int * B)(*[int(k[4]) for k in keep])
         self._chk(self.L.vloam_batch_process_frame_device(self.h, ptrs, nn, pp, cp, nm))
 
+    def batch_process_frame(self, clouds, matches):
+        """Host-memory variant of batch_process_frame_device: clouds[b] float32 [n, 4]."""
+        B = self.n_sessions
+        assert len(clouds) == B and len(matches) == B
+        cl = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        keep = [self._matches(m[0], m[1]) for m in matches]
+        FP, IP = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        ptrs = (FP * B)(*[C.cast(_fp(c), FP) for c in cl])
+        nn = (C.c_int * B)(*[int(c.shape[0]) for c in cl])
+        pp = (IP * B)(*[C.cast(k[2], IP) for k in keep])
+        cp = (IP * B)(*[C.cast(k[3], IP) for k in keep])
+        nm = (C.c_int * B)(*[int(k[4]) for k in keep])
+        self._chk(self.L.vloam_batch_process_frame(self.h, ptrs, nn, pp, cp, nm))
+
     def vo_trajectory(self, first=0, count=None):
         if count is None:
             count = self.frame_count() - first

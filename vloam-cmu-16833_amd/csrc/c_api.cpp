@@ -826,6 +826,23 @@ vloam_status vloam_batch_process_frame_device(vloam_handle* h, const void* const
   return process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
 }
 
+vloam_status vloam_batch_process_frame(vloam_handle* h, const float* const* xyz_pad4, const int* n, const int* const* prev_uv,
+                                       const int* const* curr_uv, const int* n_match) {
+  if (!h || !xyz_pad4 || !n || !prev_uv || !curr_uv || !n_match) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  for (int b = 0; b < h->se.B; b++) {
+    if (!xyz_pad4[b]) return VLOAM_ERR_INVALID;
+    if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+    if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
+    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    bi.in[b] = dst; bi.n[b] = n[b];
+  }
+  return process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
+}
+
 vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
   if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }

@@ -44,7 +44,8 @@ struct VoxelTable {       // open addressing, linear probing, probe chains bound
   __host__ __device__ void rebase(size_t off) { rbp(rec, off); rbp(pend, off); rbp(blk, off); rbp(stats, off); }
 };
 constexpr int kMaxProbe = 128;  // a longer chain means the table is overloaded: the lookup reports kErrMapFull instead of spinning
-constexpr int kCandChunk = 256; // candidates of the 5-NN search handled per pass (more are handled in further passes, exactly)
+constexpr int kCandChunk = 256; // candidate lists longer than this are reported in MapFrame::max_candidates (the 5-NN search takes them in several passes, exactly)
+constexpr int kCandCache = 128; // entries per stack point in the second outer round's candidate cache (>= the pass size of every lane count of k_map_assoc)
 
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
   unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
@@ -102,7 +103,7 @@ struct MapContext {
   LMRecord* rec = nullptr; // [2]
   float4* nbr = nullptr;   // [kMapFactorCap][5] the 5 nearest map points of every stack point (.w of the first: 1 = accepted, LM:479 / LM:547)
   int4* cbox = nullptr;    // [kMapFactorCap][2] voxel-index search box + candidate count of the first outer round's 5-NN search
-  float4* ccand = nullptr; // [kMapFactorCap][kCandChunk] its candidates (centroid, tie rank): the second round re-ranks them without a hash probe
+  float4* ccand = nullptr; // [kMapFactorCap][pass size <= kCandCache] its candidates (centroid, tie rank): the second round re-ranks them without a hash probe
   VoxelRec* rebuild_tmp = nullptr;  // live records while a table is being rebuilt (tombstone reclamation after grid rolls)
   int rebuild_cap = 0;
   int* rebuild_n = nullptr;

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
   constexpr int Q = 64 / G, QW = 4 * Q;     // queries per wavefront / per workgroup
   constexpr int U = G == 16 ? 4 : 2, CH = U * G;   // candidates per lane and pass / per query and pass (64 / 64 / 128: the typical query has ~30)
   // KB: blocks per lane and trip
-  static_assert(CH <= kCandChunk, "the second round's candidate cache holds kCandChunk entries per slot");
+  static_assert(CH <= kCandCache, "the second round's candidate cache holds kCandCache entries per slot");   // (rows of CH entries: a query's candidates sit in 1 - 2 KB, not in a 4 KB page of their own)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), qi = wave * Q + lane / G;
   const int nc = ms->n_corner_stack, nsf = ms->n_surf_stack;
   // XCD-aware assignment as before, in units of QW queries: workgroup b runs on XCD b % 8 and every XCD takes a contiguous eighth of
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
           rv[h] = rec_load(&T.rec[sl[h]]);
         }
         if (cache_pass)   // leave the candidate for the second round
-          ccand[(size_t)slot * kCandChunk + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
+          ccand[(size_t)slot * CH + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
       }
     }
   };
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ st
       for (int u = 0; u < U; u++) {
         const int w = gl + u * G;
         cc[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-        if (from_cache && w < total) cc[u] = ccand[(size_t)slot * kCandChunk + w];
+        if (from_cache && w < total) cc[u] = ccand[(size_t)slot * CH + w];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -1235,7 +1235,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
     F.err = ok ? &m->frame->error : nullptr;
   }
   ok = ok && A.take(&m->rec, 2) && A.take(&m->nbr, 5 * (size_t)kMapFactorCap);
-  ok = ok && A.take(&m->cbox, 2 * (size_t)kMapFactorCap) && A.take(&m->ccand, (size_t)kMapFactorCap * kCandChunk);
+  ok = ok && A.take(&m->cbox, 2 * (size_t)kMapFactorCap) && A.take(&m->ccand, (size_t)kMapFactorCap * kCandCache);
   m->rebuild_cap = (int)(slots / 2);
   ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 1);
   ok = ok && A.take(&m->registered, (size_t)cfg.max_points) && A.take(&m->assoc_cyc, 16);
