@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--image-frames", type=int, default=24, help="extra leg: frames of the coupled loop driven from raw images (rendered on the host before the GPU work starts; 0 = skip)")
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
                     help="extra leg: batched execution, this many independent sequences per launch chain on ONE GPU (vloam_create_batch); 0 = skip")
+    ap.add_argument("--sustain-seconds", type=float, default=float(os.environ.get("VLOAM_BENCH_SUSTAIN_S", "6")),
+                    help="extra leg: stream the headline workload for about this long (sweeps replayed back and forth; 0 = skip)")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
     args = ap.parse_args()
 
@@ -409,6 +411,36 @@ def main():
                    "note": "one sweep at a time (vloam_sync after each): no overlap between consecutive sweeps"}
         hl.close()
 
+    # ---- extra: SUSTAINED streaming of the headline workload for several seconds (a long drive).  The resident sweeps are replayed
+    # back and forth (0 .. T-1, T-2 .. 0, 1 .. ): driving the same road in reverse is a continuous trajectory (DISTORTION = 0: a sweep has
+    # no direction of travel baked in), the local map stays at its steady-state size, and the GPU stays busy for whole seconds, which a
+    # 5-second rocm-smi sample can see.  Also the long-run check of the voxel map's bookkeeping (stamps, deferred list, recentring).
+    sustained = None
+    if extras and args.sustain_seconds > 0:
+        n_s = int(min(max(K / (t1 - t0) * args.sustain_seconds, K), 80000))
+        hs = new_handle(frames=M0 + W + n_s + 8)
+        stream(hs, 0, M0 + W)
+        hs.sync()
+        order, pos, step = [], M0 + W - 1, 1
+        for _ in range(n_s):
+            if pos + step < 0 or pos + step > T - 1:
+                step = -step
+            pos += step
+            order.append(pos)
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for kk in order:
+            hs.process_scan_device(base_ptr + kk * stride, n_pts)
+        hs.sync()
+        torch.cuda.synchronize()
+        s1 = time.perf_counter()
+        cs = hs.counts()
+        tj = hs.trajectory()
+        hs.close()
+        sustained = {"value": n_s / (s1 - s0), "unit": "scans/s", "sweeps": n_s, "seconds": s1 - s0,
+                     "finite_poses": bool(np.isfinite(tj).all()), "map_points_at_end": cs["M"],
+                     "replay": "the %d resident sweeps back and forth, one session, mapping on" % T}
+
     # ---- extra: configs[3] (synthetic analogue) — the coupled per-frame VLOAM loop, one vloam_process_frame_device per frame:
     # depth-enhanced VO solve -> VO2VeloAndBase -> SR -> LO in combined mode (detach_VO_LO = 0) -> LO -> VO prior -> mapping, no host
     # round trip; pixel matches are synthetic (the image front-end is out of scope) and come from host memory like OpenCV's would
@@ -558,6 +590,8 @@ def main():
         }
         if latency:
             out["latency"] = latency
+        if sustained:
+            out["sustained"] = sustained
         if configs1:
             out["configs1"] = configs1
         if vo_stage:

@@ -39,6 +39,33 @@ def load_pkg():
     return mod
 
 
+def unwrap_boundary_points(cloud, band=4e-6):
+    """Points whose azimuth lies within `band` rad (about 2 float ulp at pi) of one of scanRegistration's unwrap thresholds
+    (scan_registration.cpp:236-262).  The azimuth is an f32 atan2 whose last bit differs between math libraries (the device's, glibc's),
+    so these are the points whose relTime could land one revolution apart between this library and a CPU run of the reference: the count
+    bounds the per-frame 'threshold flips'.  Computed from the input cloud with numpy; no device state involved."""
+    xyz = np.asarray(cloud, np.float32)[:, :3]
+    ok = np.isfinite(xyz).all(axis=1) & ((xyz.astype(np.float64) ** 2).sum(axis=1) >= 0.1 ** 2)
+    if not ok.any():
+        return 0
+    x, y = xyz[ok, 0], xyz[ok, 1]
+    ori = -np.arctan2(y, x).astype(np.float64)
+    start = float(ori[0])
+    end = float(ori[-1]) + 2 * np.pi
+    if end - start > 3 * np.pi:
+        end -= 2 * np.pi
+    elif end - start < np.pi:
+        end += 2 * np.pi
+    two_pi = 2 * np.pi
+    thresholds = (start - np.pi / 2, start + 1.5 * np.pi, start + np.pi, start - np.pi, end - 1.5 * np.pi - two_pi, end + np.pi / 2 - two_pi,
+                  end - 1.5 * np.pi, end + np.pi / 2)
+    near = np.zeros(ori.shape, bool)
+    for t in thresholds:
+        d = np.abs(((ori - t) + np.pi) % two_pi - np.pi)
+        near |= d < band
+    return int(near.sum())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--velodyne", help="directory of KITTI raw velodyne .bin sweeps")
@@ -131,7 +158,8 @@ def main():
         mo_rows.append(tf.MO2Cam0StartFrame(q_mo, t_mo, count))
         if mf:
             c = hd.counts()
-            rec = {"frame": count, "points_in": int(cloud.shape[0]), "counts": c, "lo_pose": [float(x) for x in list(q_lo) + list(t_lo)],
+            rec = {"frame": count, "points_in": int(cloud.shape[0]), "counts": c, "unwrap_boundary_points": unwrap_boundary_points(cloud),
+                   "lo_pose": [float(x) for x in list(q_lo) + list(t_lo)],
                    "map_pose": [float(x) for x in list(q_mo) + list(t_mo)]}
             if count > 0:
                 for name, st, item in (("lo_round0", 1, 2), ("lo_round1", 1, 18), ("map_round0", 2, 3), ("map_round1", 2, 19)):
