@@ -119,6 +119,33 @@ def test_scan_registration_edge_cases(vl, orc, sweeps):
     assert ei.value.status == vl.ERR_INVALID
 
 
+def test_rings_with_a_voxel_for_almost_every_point(vl, orc, synth):
+    """The per-ring VoxelGrid sorts RUNS of points sharing a 0.2 m voxel.  Returns from 120 m lie 0.3 m apart: a 2 100-point ring has
+    more than 2 048 runs, i.e. more than the small ring tier's power-of-two sort network holds (rank-by-counting path), and every run
+    is a single point (run keys with first == last)."""
+    n_az = 2100
+    el = np.deg2rad(synth.beam_elevations_deg(64))[:, None]
+    az = (-2 * np.pi * np.arange(n_az) / n_az)[None, :]
+    rng = np.random.default_rng(3)
+    rad = 120.0 + 0.01 * rng.standard_normal((64, n_az))
+    cloud = np.zeros((64, n_az, 4), dtype=np.float32)
+    cloud[..., 0] = rad * np.cos(el) * np.cos(az)
+    cloud[..., 1] = rad * np.cos(el) * np.sin(az)
+    cloud[..., 2] = rad * np.sin(el)
+    cloud = cloud.transpose(1, 0, 2).reshape(-1, 4).copy()   # firing order: all lasers of a column, then the next column
+    h = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+    h.scan_registration(cloud)
+    o = orc.Oracle(with_mapping=False)
+    assert o.scan_registration(cloud) == 0
+    sc = o.sr_scalars()
+    flips = check_cloud(h.features(0), o.cloud(0), "laserCloud", unwrap_bounds(sc["startOri"], sc["endOri"]))
+    less_flat = o.cloud(4)
+    per_ring = np.bincount(less_flat[:, 3].astype(np.int64))
+    assert per_ring.max() > 2048, "the case must exceed 2 048 voxels in a ring (largest: %d)" % per_ring.max()
+    for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+        check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
+
+
 def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
     """vloam_process_scan bursts rotate four buffer sets and rewrite each set's error word every sweep: an empty sweep (all NaN) or a
     dropped over-long ring in the MIDDLE of a burst must still be reported by the vloam_sync that ends it — once."""

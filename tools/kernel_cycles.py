@@ -16,14 +16,22 @@ import conftest  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweeps", type=int, default=8)
 ap.add_argument("--azimuth", type=int, default=2048)
+ap.add_argument("--sequence-sweeps", type=int, default=0, help="length of the synthetic drive the sweeps are taken from (0: sweeps + 1); bench.py's is 408")
+ap.add_argument("--first", type=int, default=0, help="first sweep of the drive to process")
+ap.add_argument("--no-mapping", action="store_true")
+ap.add_argument("--debug-level", type=int, default=2, help="2: phase stamps only (the production kernel's timing); 1: full debug build")
 a = ap.parse_args()
 vl = conftest.load_pkg()
 synth = conftest.load_synth()
-seq = synth.SynthSequence(n_rings=64, n_azimuth=a.azimuth, n_sweeps=a.sweeps + 1)
-h = vl.Handle(0, debug=1, with_mapping=1, max_frames=a.sweeps + 8)
-for k in range(a.sweeps):
-    h.process_scan(seq.sweep(k))
-h.sync()
+seq = synth.SynthSequence(n_rings=64, n_azimuth=a.azimuth, n_sweeps=a.sequence_sweeps or a.sweeps + 1)
+h = vl.Handle(0, debug=a.debug_level, with_mapping=0 if a.no_mapping else 1, max_frames=a.sweeps + 8)
+clouds = [seq.sweep(a.first + k) for k in range(a.sweeps)]
+h.profile_kernel("k_sr_ring", 4096)
+for c in clouds:
+    h.process_scan(c)
+    h.sync()
+ms, n = h.profile_read()
+print("k_sr_ring by HIP events: %.1f us per launch over %d launches (one sweep at a time)" % (1e3 * ms / max(n, 1), n))
 
 
 def pct(x, name, unit="cycles"):
@@ -38,7 +46,12 @@ def pct(x, name, unit="cycles"):
 cyc = h.debug_raw(0, 11, np.int64).reshape(-1, 8)[:64]
 names = ["load ring -> LDS", "gaps / reach (+ debug sort)", "greedy picks (6 wavefronts)", "bbox, voxel ids, run keys", "bitonic sort of runs",
          "voxel heads + centroids"]
-print("k_sr_ring: cycles per phase over the %d scan lines of the last sweep (debug build: includes the reference-order debug sort)" % cyc.shape[0])
+print("k_sr_ring: cycles per phase over the %d scan lines of the last sweep (debug level %d)" % (cyc.shape[0], a.debug_level))
+tot = cyc[:, :6].sum(axis=1)
+for r in np.argsort(-tot)[:6]:
+    m = int(cyc[r, 7])
+    print("  slowest: ring %2d  total %7d  phases %s   len %4d  lessFlat candidates %4d  runs %4d  voxels %4d" %
+          (r, tot[r], " ".join("%6d" % v for v in cyc[r, :6]), (m >> 32) & 0xffff, (m >> 48) & 0xffff, m & 0xffff, (m >> 16) & 0xffff))
 for q, n in enumerate(names):
     pct(cyc[:, q], n)
 pct(cyc[:, :6].sum(axis=1), "whole workgroup")

@@ -26,6 +26,8 @@ ap.add_argument("--table", action="store_true", help="per-kernel HIP-event table
 ap.add_argument("--no-single", action="store_true")
 ap.add_argument("--map-log2", type=int, default=22, help="map_capacity_log2 of the handles (voxel table slots)")
 ap.add_argument("--procs", type=int, default=32, help="worker processes for the synthesis (1 under rocprofv3: it follows forked children)")
+ap.add_argument("--from-idle", default="", help="comma-separated sweep counts: time that many sweeps of ONE sequence from a drained pipeline (5 repeats each) "
+                "and fit time = fill + period x sweeps; replaces the normal run")
 a = ap.parse_args()
 synth = conftest.load_synth()
 _SEQ = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=a.sweeps + 1)
@@ -72,6 +74,34 @@ def run(B):
     return tr
 
 
+def from_idle(counts):
+    h = vl.Handle(0, with_mapping=1, max_frames=a.warm + 6 * sum(counts) + 64)
+    k = 0
+    for _ in range(a.warm):
+        h.process_scan_device(ptr(k), npts); k += 1
+    h.sync()
+    xs, ys = [], []
+    for n in counts:
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                h.process_scan_device(ptr(k), npts); k += 1
+            h.sync()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print("%4d sweeps from idle: median %.3f ms (min %.3f)  -> %6.0f scans/s" % (n, 1e3 * ts[2], 1e3 * ts[0], n / ts[2]), flush=True)
+        xs.append(n); ys.append(ts[2])
+    if len(xs) >= 2:
+        b, c = np.polyfit(xs, ys, 1)
+        print("fit: fill %.3f ms + %.1f us per sweep" % (1e3 * c, 1e6 * b))
+    h.close()
+
+
+if a.from_idle:
+    from_idle([int(v) for v in a.from_idle.split(",")])
+    sys.exit(0)
 t1 = None if a.no_single else run(1)
 tb = run(a.sessions)
 if t1 is not None:

@@ -273,10 +273,19 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   *out = nullptr;
   vloam_status st = VLOAM_OK;
   do {
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s_lo, hipStreamNonBlocking) != hipSuccess ||
-        (cfg->with_mapping && (hipStreamCreateWithFlags(&h->s_map, hipStreamNonBlocking) != hipSuccess ||
-                               hipStreamCreateWithFlags(&h->s_ds, hipStreamNonBlocking) != hipSuccess))) {  // no mapping: no further hardware queues
-      set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
+    {
+      // VLOAM_STREAM_PRIO = "sr,lo,map,ds" (0 = default priority, 1 = the device's highest, -1 = its lowest): which stage's workgroups the
+      // dispatcher places first when several stages have work pending (batched handles fill the chip; a single sequence does not)
+      int lo_p = 0, hi_p = 0, pr[4] = {0, 0, 0, 0};
+      if (const char* e = getenv("VLOAM_STREAM_PRIO")) sscanf(e, "%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3]);
+      if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }   // lo_p = numerically greatest = lowest priority
+      auto mk = [&](hipStream_t* s, int which) {
+        const int p = pr[which] > 0 ? hi_p : (pr[which] < 0 ? lo_p : 0);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess;
+      };
+      if (!mk(&h->stream, 0) || !mk(&h->s_lo, 1) || (cfg->with_mapping && (!mk(&h->s_map, 2) || !mk(&h->s_ds, 3)))) {  // no mapping: no further hardware queues
+        set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
+      }
     }
     if (cfg->image_width > 0 && hipStreamCreateWithFlags(&h->s_img, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
@@ -433,7 +442,7 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   bool big_tier = k < 8;   // nothing is known about the ring lengths yet
   for (int b = 0; b < h->se.B; b++) big_tier = big_tier || __atomic_load_n(&h->ring_watch[b], __ATOMIC_RELAXED) != 0;
-  HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug != 0, &h->prof,
+  HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug, &h->prof,
                    h->ev_sr[cur], h->ring_watch, big_tier));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)

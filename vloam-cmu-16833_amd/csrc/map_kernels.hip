@@ -126,66 +126,69 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
                                                      double* traj_row14, StackInfo* si, int* deferred0, int* deferred1, const int* newraw0,
                                                      const int* newraw1, size_t ss) {
   VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si); RB(deferred0); RB(deferred1); RB(newraw0); RB(newraw1);
-  __shared__ int shift[3];
+  __shared__ int shift[3], s_cen[3];
   const int tid = threadIdx.x;
-  // voxels that turned raw in the previous sweep join the list of raw voxels (k_map_finalize could not append to the list it compacts)
-  for (int kind = 0; kind < 2; kind++) {
-    const int cap = kind ? kStackCapSurf : kStackCapCorner;
-    const int nn = min(fr->n_newraw[kind], cap), nd = fr->n_deferred[kind];
-    if (nn > 0) {
-      int* deferred = kind ? deferred1 : deferred0;
-      const int* newraw = kind ? newraw1 : newraw0;
-      for (int e = tid; e < nn; e += 256) { if (nd + e < cap) deferred[nd + e] = newraw[e]; }
-      if (nd + nn > cap && tid == 0) atomicOr(&fr->error, kErrMapFull);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) for (int kind = 0; kind < 2; kind++) {
-    const int cap = kind ? kStackCapSurf : kStackCapCorner;
-    fr->n_deferred[kind] = min(fr->n_deferred[kind] + min(fr->n_newraw[kind], cap), cap);
-    fr->n_newraw[kind] = 0;
-  }
-  __syncthreads();
+  // Every load that does not depend on another one is issued up front (one memory round trip for the lot): this launch is a single
+  // workgroup at the head of the stream that bounds the throughput, and each dependent trip costs ~1 us there.
+  const int nn0 = min(fr->n_newraw[0], kStackCapCorner), nn1 = min(fr->n_newraw[1], kStackCapSurf);
+  const int nd0 = fr->n_deferred[0], nd1 = fr->n_deferred[1];
+  double row[7], qmw[4], tmw[3];
+  int cen[3] = {0, 0, 0}, nst[2] = {0, 0}, si_err = 0, fr_err = 0, sweep_no = 0;
   if (tid == 0) {
-    // LaserMapping::input LM:182-195: q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom
     // the odometry pose of THIS sweep as k_lo_finish logged it (the live LOState may already belong to the next sweep: the
     // odometry stream runs ahead of the mapping stream)
     (void)lo;
-    for (int k = 0; k < 4; k++) ms->q_wodom_curr[k] = traj_row14[k];
-    for (int k = 0; k < 3; k++) ms->t_wodom_curr[k] = traj_row14[4 + k];
+    for (int k = 0; k < 7; k++) row[k] = traj_row14[k];
+    for (int k = 0; k < 4; k++) qmw[k] = ms->q_wmap_wodom[k];
+    for (int k = 0; k < 3; k++) tmw[k] = ms->t_wmap_wodom[k];
+    cen[0] = ms->cenW; cen[1] = ms->cenH; cen[2] = ms->cenD;
+    nst[0] = si->n_stack[0]; nst[1] = si->n_stack[1];
+    si_err = si->error; fr_err = fr->error; sweep_no = ms->sweep_no;
+  }
+  // voxels that turned raw in the previous sweep join the list of raw voxels (k_map_finalize could not append to the list it compacts)
+  if (nn0 > 0) for (int e = tid; e < nn0; e += 256) { if (nd0 + e < kStackCapCorner) deferred0[nd0 + e] = newraw0[e]; }
+  if (nn1 > 0) for (int e = tid; e < nn1; e += 256) { if (nd1 + e < kStackCapSurf) deferred1[nd1 + e] = newraw1[e]; }
+  if (tid == 0) {
+    if (nd0 + nn0 > kStackCapCorner || nd1 + nn1 > kStackCapSurf) { atomicOr(&fr->error, kErrMapFull); fr_err |= kErrMapFull; }
+    if (nn0 | nn1) {
+      fr->n_deferred[0] = min(nd0 + nn0, kStackCapCorner); fr->n_deferred[1] = min(nd1 + nn1, kStackCapSurf);
+      fr->n_newraw[0] = 0; fr->n_newraw[1] = 0;
+    }
+    // LaserMapping::input LM:182-195: q_w_curr = q_wmap_wodom * q_wodom_curr, t_w_curr = q_wmap_wodom * t_wodom_curr + t_wmap_wodom
+    for (int k = 0; k < 4; k++) ms->q_wodom_curr[k] = row[k];
+    for (int k = 0; k < 3; k++) ms->t_wodom_curr[k] = row[4 + k];
     double q[4], t[3];
-    dquat_mul(ms->q_wmap_wodom, ms->q_wodom_curr, q);
-    dquat_rot(ms->q_wmap_wodom, ms->t_wodom_curr, t);
-    for (int k = 0; k < 3; k++) t[k] = t[k] + ms->t_wmap_wodom[k];
+    dquat_mul(qmw, row, q);
+    dquat_rot(qmw, row + 4, t);
+    for (int k = 0; k < 3; k++) t[k] = t[k] + tmw[k];
     shift[0] = shift[1] = shift[2] = 0;
-    fr->rolled = 0;
+    int rolled = 0;
     if (skip_frame) {  // only the high-frequency pose is produced (LM:186-190)
       if (traj_row14) { for (int k = 0; k < 4; k++) traj_row14[7 + k] = q[k]; for (int k = 0; k < 3; k++) traj_row14[11 + k] = t[k]; }
     } else {
       for (int k = 0; k < 4; k++) ms->parameters[k] = q[k];
       for (int k = 0; k < 3; k++) ms->parameters[4 + k] = t[k];
       // LM:207-216
-      int cI = cube_abs(t[0]) + ms->cenW, cJ = cube_abs(t[1]) + ms->cenH, cK = cube_abs(t[2]) + ms->cenD;
+      int cI = cube_abs(t[0]) + cen[0], cJ = cube_abs(t[1]) + cen[1], cK = cube_abs(t[2]) + cen[2];
       // LM:218-402: the six while loops only move cube pointers and the centre offsets
-      while (cI < 3) { cI++; ms->cenW++; shift[0]++; }
-      while (cI >= kCubeW - 3) { cI--; ms->cenW--; shift[0]--; }
-      while (cJ < 3) { cJ++; ms->cenH++; shift[1]++; }
-      while (cJ >= kCubeH - 3) { cJ--; ms->cenH--; shift[1]--; }
-      while (cK < 3) { cK++; ms->cenD++; shift[2]++; }
-      while (cK >= kCubeD - 3) { cK--; ms->cenD--; shift[2]--; }
+      while (cI < 3) { cI++; cen[0]++; shift[0]++; }
+      while (cI >= kCubeW - 3) { cI--; cen[0]--; shift[0]--; }
+      while (cJ < 3) { cJ++; cen[1]++; shift[1]++; }
+      while (cJ >= kCubeH - 3) { cJ--; cen[1]--; shift[1]--; }
+      while (cK < 3) { cK++; cen[2]++; shift[2]++; }
+      while (cK >= kCubeD - 3) { cK--; cen[2]--; shift[2]--; }
       ms->centerCube[0] = cI; ms->centerCube[1] = cJ; ms->centerCube[2] = cK;
-      if (shift[0] | shift[1] | shift[2]) fr->rolled = 1;
+      s_cen[0] = cI; s_cen[1] = cJ; s_cen[2] = cK;
+      if (shift[0] | shift[1] | shift[2]) { rolled = 1; ms->cenW = cen[0]; ms->cenH = cen[1]; ms->cenD = cen[2]; }
       // the scan features were voxelised on the scan-registration stream (k_map_ds_*): adopt this sweep's stack
-      for (int k = 0; k < 2; k++) { fr->n_stack[k] = si->n_stack[k]; fr->n_touched[k] = 0; }
-      ms->n_corner_stack = si->n_stack[0]; ms->n_surf_stack = si->n_stack[1];
-      if (si->error) { atomicOr(&fr->error, si->error); si->error = 0; }
-      if (fr->error & kErrMapFull) {  // the map cannot take this sweep: no association, no insert; the pose stays the odometry guess (vloam_sync reports it)
-        fr->n_stack[0] = fr->n_stack[1] = 0;
-        ms->n_corner_stack = ms->n_surf_stack = 0;
-      }
+      if (si_err) { atomicOr(&fr->error, si_err); fr_err |= si_err; si->error = 0; }
+      if (fr_err & kErrMapFull) nst[0] = nst[1] = 0;  // the map cannot take this sweep: no association, no insert; the pose stays the odometry guess (vloam_sync reports it)
+      for (int k = 0; k < 2; k++) { fr->n_stack[k] = nst[k]; fr->n_touched[k] = 0; }
+      ms->n_corner_stack = nst[0]; ms->n_surf_stack = nst[1];
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
-      ms->sweep_no++;
+      ms->sweep_no = sweep_no + 1;
     }
+    fr->rolled = rolled;
   }
   __syncthreads();
   if (skip_frame) return;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
   if (tid < 64) {
     int s0 = 0, s1 = 0;
     for (int c = tid; c < 75; c += 64) {
-      const int i = ms->centerCube[0] - 2 + c / 15, j = ms->centerCube[1] - 2 + (c / 3) % 5, k = ms->centerCube[2] - 1 + c % 3;
+      const int i = s_cen[0] - 2 + c / 15, j = s_cen[1] - 2 + (c / 3) % 5, k = s_cen[2] - 1 + c % 3;
       if (i >= 0 && i < kCubeW && j >= 0 && j < kCubeH && k >= 0 && k < kCubeD) {
         const int ci = i + kCubeW * j + kCubeW * kCubeH * k;
         s0 += cube_cnt[ci]; s1 += cube_cnt[kCubeNum + ci];

@@ -46,6 +46,11 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+// LDS hand-over between lanes of one wavefront without waiting for the wavefront's global stores (a workgroup-scope fence does)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // SR:157 removeNaNFromPointCloud + SR:100-129 removeClosedPointCloud
 __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float thres) {
@@ -714,14 +719,42 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   const int nrun = block_exclusive_scan(iscratch, len, scan_tmp);
   int P2 = 2;
   while (P2 < nrun) P2 <<= 1;
-  for (int l = tid; l < len; l += kRingThreads)
-    if (vox[l] >= 0 && (l == 0 || vox[l - 1] != vox[l])) K2[iscratch[l]] = ((u64)(unsigned)vox[l] << 12) | (unsigned)l;
-  for (int t = nrun + tid; t < P2; t += kRingThreads) K2[t] = ~0ull;
+  // run key = voxel index : first point : last point (32 : 20 : 12 bits; a run is known by its first point, so the order is (voxel,
+  // first point)).  The run's head writes the voxel and its own position, its last point ORs in where the run ends: the centroid
+  // pass below then walks [first, last] without testing every point's voxel (a dependent LDS trip per point otherwise).
+  unsigned* K2w = (unsigned*)K2;   // [2 t] low word, [2 t + 1] high word
+  for (int t = tid; t < P2 && t < CAP; t += kRingThreads) K2[t] = t < nrun ? 0ull : ~0ull;
+  __syncthreads();
+  for (int l = tid; l < len; l += kRingThreads) {
+    const int v = vox[l];
+    if (v < 0) continue;
+    const bool head = l == 0 || vox[l - 1] != v, tail = l + 1 == len || vox[l + 1] != v;
+    const int run = iscratch[l] - (head ? 0 : 1);   // iscratch[l] = heads before l: a later point of a run counts its own head
+    if (head) { K2w[2 * run + 1] = (unsigned)v; atomicOr(&K2w[2 * run], (unsigned)l << 12); }
+    if (tail) atomicOr(&K2w[2 * run], (unsigned)l);
+  }
   __syncthreads();
   SR_STAMP();
   // a stage with stride j <= 64 only moves data inside 128-element blocks that belong to one wavefront (64 consecutive
   // compare-exchanges), so only the wide strides need a workgroup barrier
-  if (P2 < 128) {
+  if (P2 > CAP) {
+    // More runs than the largest power of two the key array holds (only the small tier's 2 176-point rings can get here, with a
+    // voxel of its own for almost every point): rank by counting instead of padding the network to 4 096 keys.  Keys are unique.
+    constexpr int NQ = (CAP + kRingThreads - 1) / kRingThreads;
+    u64 mine[NQ];
+    int rk[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int t = tid + q * kRingThreads;
+      mine[q] = t < nrun ? K2[t] : ~0ull;
+      int below = 0;
+      if (t < nrun) for (int e = 0; e < nrun; e++) below += K2[e] < mine[q];
+      rk[q] = below;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) if (tid + q * kRingThreads < nrun) K2[rk[q]] = mine[q];
+  } else if (P2 < 128) {
     for (int k = 2; k <= P2; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
         bitonic_stage(K2, P2, j, k, tid, kRingThreads);
@@ -745,26 +778,35 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   __syncthreads();
   SR_STAMP();
   // voxel heads -> output rank
-  for (int t = tid; t < nrun; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 12) != (K2[t - 1] >> 12)) ? 1 : 0;
+  for (int t = tid; t < nrun; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 32) != (K2[t - 1] >> 32)) ? 1 : 0;
   __syncthreads();
   const int nvox = block_exclusive_scan(iscratch, nrun, scan_tmp);
   for (int t = tid; t < nrun; t += kRingThreads) {
-    const u64 vid = K2[t] >> 12;
-    if (t == 0 || vid != (K2[t - 1] >> 12)) {
+    const u64 k0 = K2[t];
+    const unsigned vid = (unsigned)(k0 >> 32);
+    if (t == 0 || vid != (unsigned)(K2[t - 1] >> 32)) {
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in input order
       int npt = 0;
-      for (int u = t; u < nrun && (K2[u] >> 12) == vid; u++)
-        for (int l = (int)(K2[u] & 0xfffu); l < len && vox[l] == (int)vid; l++) {
-          sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l];
-          npt++;
-        }
+      u64 k = k0;
+      for (int u = t;;) {
+        const int l0 = (int)((k >> 12) & 0xfffu), l1 = (int)(k & 0xfffu);
+        for (int l = l0; l <= l1; l++) { sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l]; }
+        npt += l1 - l0 + 1;
+        if (++u >= nrun) break;
+        k = K2[u];
+        if ((unsigned)(k >> 32) != vid) break;
+      }
       const float cnt = (float)npt;
       out[iscratch[t]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     }
   }
   if (tid == 0) S->ring_ds_cnt[r] = nvox;
   SR_STAMP();
-  if (dbg_cyc && tid == 0) for (int q = 0; q < 7; q++) dbg_cyc[r * 8 + q] = q + 1 < nstamp ? tstamp[q + 1] - tstamp[q] : 0;
+  if (dbg_cyc && tid == 0) {
+    for (int q = 0; q < 6; q++) dbg_cyc[r * 8 + q] = q + 1 < nstamp ? tstamp[q + 1] - tstamp[q] : 0;
+    dbg_cyc[r * 8 + 6] = 0;
+    dbg_cyc[r * 8 + 7] = (long long)nrun | ((long long)nvox << 16) | ((long long)len << 32) | ((long long)ncand << 48);
+  }
 #undef SR_STAMP
 }
 
@@ -849,8 +891,9 @@ hipError_t sr_init() {
                              (int)sr_ring_smem_bytes<kMaxRingLen, kSectCap>());
 }
 
-hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, bool debug, ProfHook* ph, hipEvent_t done,
+hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, int debug_level, ProfHook* ph, hipEvent_t done,
                      int* ring_watch, bool big_tier) {
+  const bool debug = debug_level == 1, stamps = debug_level != 0;   // debug = 2: only the ring kernel's phase stamps (no reference-order debug sort)
   int n = 0;
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
@@ -865,12 +908,12 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-               debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, ring_watch, big_tier ? 1 : 0, se.ss);
+               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, big_tier ? 1 : 0, se.ss);
   if (big_tier)
     VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                  (sr_ring_smem_bytes<kMaxRingLen, kSectCap>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                  b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-                 debug ? b.dbg_label : nullptr, debug ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
+                 debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
   VLOAM_LAUNCH_EV(ph, kKSrCompact, st, done, k_sr_compact, dim3(kMaxRings, 1, Z), dim3(256), 0, st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx, b.flat_idx, b.ring_ds,
                      b.sharp, b.less_sharp, b.flat, b.less_flat, debug ? b.dbg_feat_idx : nullptr, b.sticky_err, se.ss);
   return hipGetLastError();
