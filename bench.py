@@ -506,7 +506,28 @@ def main():
         i1 = time.perf_counter()
         r = hi.vo_result()
         ncorn = int(hi.vo_keypoints().shape[0])
+        traj_i = hi.trajectory()
         hi.close()
+        img_batched = None
+        if args.sessions > 1:   # the same loop for B sessions per launch chain: each session's image runs through the front-end on the image stream
+            Bi = min(args.sessions, 4)
+            hib = vl.Handle(local_rank, n_sessions=Bi, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8,
+                            detach_VO_LO=0, image_width=IW, image_height=IH)
+            hib.vo_set_calib(*synth.kitti_like_calib())
+            hib.set_extrinsics(*synth.kitti_like_extrinsics())
+            for kk in range(0, f0):
+                hib.batch_process_scan_device([base_ptr + kk * stride] * Bi, [n_pts] * Bi)
+            hib.batch_process_frame_image_device([base_ptr + f0 * stride] * Bi, [n_pts] * Bi, [d_img.data_ptr()] * Bi, IW, IH)
+            hib.sync()
+            b0 = time.perf_counter()
+            for j in range(1, ni):
+                hib.batch_process_frame_image_device([base_ptr + (f0 + j) * stride] * Bi, [n_pts] * Bi, [d_img.data_ptr() + j * IW * IH] * Bi, IW, IH)
+            hib.sync()
+            b1 = time.perf_counter()
+            same_i = all(bool(np.array_equal(hib.select(b).trajectory(), traj_i)) for b in range(Bi))
+            hib.close()
+            img_batched = {"sessions": Bi, "value": Bi * (ni - 1) / (b1 - b0), "unit": "frames/s", "ms_per_batch_frame": 1e3 * (b1 - b0) / (ni - 1),
+                           "trajectories_identical_to_single_session": same_i}
         # the image front-end alone, images resident in HBM, and its per-kernel table
         hf = vl.Handle(local_rank, with_mapping=0, image_width=IW, image_height=IH)
         for j in range(2 * ni):
@@ -545,6 +566,8 @@ def main():
                                                             "bytes": "the image once, its 8-bit pyramid (x1.33) and the int16 Scharr pairs of every level (4 B x 1.33) once"},
                                                "cpu_oracle_ms_per_image": cpu_img_ms},
                      "note": "images are synthetic renders of the LiDAR scene (synth.render_image); ORB + brute-force matching (optical_flow_match = false) is not provided"}
+        if img_batched:
+            img_stage["batched"] = img_batched
 
     if rank == 0:
         value = multi.aggregate_throughput(K, world, elapsed)

@@ -206,6 +206,14 @@ vloam_status vloam_vo_match_descriptors(vloam_handle* h, const unsigned char* de
                                         int select_knn, int* query_idx, int* train_idx, int cap, int* n_matches);
 vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride);
 vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride);
+/* Batched coupled frames from raw inputs (handles of vloam_create_batch with an image front-end): session b gets sweep xyz_pad4[b] and the
+ * grey image gray[b]; all images of a call share width / height / stride.  The sessions' images run one after the other on the image
+ * stream (each session has the image buffers of its own arena); everything behind them is the batched frame chain.  The getters
+ * vloam_vo_get_keypoints / _flow / _flow_matches read the session chosen with vloam_select_session. */
+vloam_status vloam_batch_process_frame_image_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n, const void* const* d_gray, int width, int height,
+                                                    int stride);
+vloam_status vloam_batch_process_frame_image(vloam_handle* h, const float* const* xyz_pad4, const int* n, const unsigned char* const* gray, int width, int height,
+                                             int stride);
 
 /* Parity hooks (tests only; need cfg.debug = 1 for the per-point arrays).  Copies up to cap elements of
  * the named array into buf (element type given per item) and returns the element count in *n.

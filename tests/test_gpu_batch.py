@@ -111,3 +111,43 @@ def test_batched_coupled_frames_equal_single_session_runs(vl, synth):
         assert np.array_equal(hb.get_map().view(np.uint32), hs.get_map().view(np.uint32)), "session %d map" % b
         hs.close()
     hb.close()
+
+
+def test_batched_frames_from_raw_images_equal_single_session_runs(vl, synth):
+    """vloam_batch_process_frame_image: every session gets its own sweep AND its own grey image (corners + pyramidal LK on the device feed
+    the session's VO solve).  Each session must equal the same inputs through vloam_process_frame_image on a handle of its own:
+    trajectory, VO trajectory, key points, tracked matches."""
+    B, n, W, H = 3, 4, 1242, 375
+    cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
+    base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
+    seqs = [synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=n + 1, seed_scene=1234 + 17 * b, seed_traj=42 + b, seed_noise=5678 + 1000 * b)
+            for b in range(B)]
+    clouds = [[np.ascontiguousarray(s.sweep(k), dtype=np.float32) for k in range(n)] for s in seqs]
+    images = [[synth.render_image(s, k, width=W, height=H) for k in range(n)] for s in seqs]
+
+    def setup(h):
+        h.vo_set_calib(cam_T_velo, rect0_T_cam, P)
+        h.set_extrinsics(base_T_cam0, velo_T_cam0)
+        return h
+
+    hb = setup(vl.Handle(0, n_sessions=B, with_mapping=1, detach_VO_LO=0, image_width=W, image_height=H))
+    for k in range(n):
+        hb.batch_process_frame_image([clouds[b][k] for b in range(B)], [images[b][k] for b in range(B)])
+    hb.sync()
+    for b in range(B):
+        hs = setup(vl.Handle(0, with_mapping=1, detach_VO_LO=0, image_width=W, image_height=H))
+        for k in range(n):
+            hs.process_frame_image(clouds[b][k], images[b][k])
+        hs.sync()
+        hb.select(b)
+        assert np.array_equal(hb.trajectory(), hs.trajectory()), "session %d trajectory" % b
+        assert np.array_equal(hb.vo_trajectory(), hs.vo_trajectory()), "session %d VO trajectory" % b
+        assert np.array_equal(hb.vo_keypoints(), hs.vo_keypoints()) and hs.vo_keypoints().shape[0] > 50, "session %d key points" % b
+        mb, ms = hb.vo_flow_matches(), hs.vo_flow_matches()
+        assert np.array_equal(mb[0], ms[0]) and np.array_equal(mb[1], ms[1]) and ms[0].shape[0] > 20, "session %d tracked matches" % b
+        hs.close()
+    # distinct sessions really had distinct images
+    hb.select(0); k0 = hb.vo_keypoints()
+    hb.select(1); k1 = hb.vo_keypoints()
+    assert k0.shape != k1.shape or not np.array_equal(k0, k1)
+    hb.close()

@@ -360,6 +360,27 @@ class Handle:
         g = np.ascontiguousarray(gray, dtype=np.uint8)
         self._chk(self.L.vloam_process_frame_image(self.h, _fp(cloud), cloud.shape[0], _fp(g), g.shape[1], g.shape[0], g.shape[1]))
 
+    def batch_process_frame_image(self, clouds, grays):
+        """One coupled frame of every session of a batched handle from raw inputs: clouds[b] float32 [n, 4], grays[b] uint8 [h, w] (one size)."""
+        B = self.n_sessions
+        assert len(clouds) == B and len(grays) == B
+        cl = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        gs = [np.ascontiguousarray(g, dtype=np.uint8) for g in grays]
+        assert all(g.shape == gs[0].shape for g in gs), "the images of one call share their size"
+        FP, BP = C.POINTER(C.c_float), C.POINTER(C.c_ubyte)
+        ptrs = (FP * B)(*[C.cast(_fp(c), FP) for c in cl])
+        nn = (C.c_int * B)(*[int(c.shape[0]) for c in cl])
+        gp = (BP * B)(*[C.cast(_fp(g), BP) for g in gs])
+        self._chk(self.L.vloam_batch_process_frame_image(self.h, ptrs, nn, gp, gs[0].shape[1], gs[0].shape[0], gs[0].shape[1]))
+
+    def batch_process_frame_image_device(self, dptrs, n_pts, gptrs, width, height, stride=None):
+        B = self.n_sessions
+        assert len(dptrs) == B and len(n_pts) == B and len(gptrs) == B
+        ptrs = (C.c_void_p * B)(*[C.c_void_p(int(p)) for p in dptrs])
+        nn = (C.c_int * B)(*[int(v) for v in n_pts])
+        gp = (C.c_void_p * B)(*[C.c_void_p(int(p)) for p in gptrs])
+        self._chk(self.L.vloam_batch_process_frame_image_device(self.h, ptrs, nn, gp, int(width), int(height), int(stride or width)))
+
     def process_frame_image_device(self, dptr, n_pts, gptr, width, height, stride=None):
         self._chk(self.L.vloam_process_frame_image_device(self.h, C.c_void_p(dptr), int(n_pts), C.c_void_p(gptr), int(width), int(height),
                                                           int(stride or width)))

@@ -761,25 +761,25 @@ vloam_status vloam_set_extrinsics(vloam_handle* h, const double base_T_cam0[16],
 // Host image -> the device staging buffer, on the image stream.  hipMemcpyAsync from pageable memory has taken its copy of the source when
 // it returns; hipMemcpy2DAsync has NOT (measured: tools/microbench/pageable_async_copy.py) — so a padded image is packed on the host
 // first, and the caller may reuse its buffer as soon as the call is back either way.
-static vloam_status upload_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride) {
+static vloam_status upload_image(vloam_handle* h, const unsigned char* gray, int width, int height, int stride, int session = 0) {
   const unsigned char* src = gray;
   if (stride != width) {
     h->img_pack.resize((size_t)width * height);
     for (int y = 0; y < height; y++) memcpy(h->img_pack.data() + (size_t)y * width, gray + (size_t)y * stride, (size_t)width);
     src = h->img_pack.data();
   }
-  HIPCHK(hipMemcpyAsync(h->img.staging, src, (size_t)width * height, hipMemcpyHostToDevice, h->s_img));
+  HIPCHK(hipMemcpyAsync(h->img.staging + (size_t)session * h->se.ss, src, (size_t)width * height, hipMemcpyHostToDevice, h->s_img));
   return VLOAM_OK;
 }
 
 static vloam_status process_frame_common(vloam_handle* h, const BatchIn& bi, const int* const* prev_uv, const int* const* curr_uv, const int* n_match,
-                                         const unsigned char* d_gray, int width, int height, int stride) {
+                                         const unsigned char* const* d_gray /* one image per session, or null */, int width, int height, int stride) {
   if (!h->vo.have_calib || !h->have_extrinsics) { set_err("vloam_process_frame needs vloam_vo_set_calib and vloam_set_extrinsics first"); return VLOAM_ERR_ORDER; }
   for (int b = 0; b < h->se.B; b++) {
     if (n_match[b] < 0 || (n_match[b] > 0 && (!prev_uv[b] || !curr_uv[b]))) { set_err("bad match arrays for session %d", b); return VLOAM_ERR_INVALID; }
     if (n_match[b] > kVoMaxMatches) { set_err("%d matches exceed the capacity of %d", n_match[b], kVoMaxMatches); return VLOAM_ERR_CAPACITY; }
   }
-  if (d_gray && h->se.B != 1) { set_err("the image front-end drives one sequence per handle"); return VLOAM_ERR_INVALID; }
+  if (d_gray) for (int b = 0; b < h->se.B; b++) if (!d_gray[b]) { set_err("null image pointer for session %d", b); return VLOAM_ERR_INVALID; }
   if (d_gray && h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   if (d_gray && img_check(&h->img, width, height, stride) != VLOAM_OK) {   // before anything of this frame is enqueued
     set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h);
@@ -799,10 +799,18 @@ static vloam_status process_frame_common(vloam_handle* h, const BatchIn& bi, con
   if (d_gray) {
     // processImage on its own stream: corners + flow straight into this frame's match arrays (one entry per corner slot, untracked
     // slots marked), consumed by the VO solve in front of this frame's laser odometry
+    // (a batched handle runs its sessions' images one after the other on that stream: each session has the image buffers of its own arena)
     const int vset = k % VOContext::kSets;
-    s = img_process(&h->img, h->s_img, d_gray, width, height, stride, h->vo.d_prev_set[vset], h->vo.d_curr_set[vset], &h->prof);
-    if (s != VLOAM_OK) { set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h); return s; }
-    h->vo.n_match_set[vset].n[0] = k > 0 ? kImgMaxCorners : 0;
+    ImgContext after = h->img;
+    for (int b = 0; b < h->se.B; b++) {
+      const size_t so = (size_t)b * h->se.ss;
+      ImgContext cb = h->img.rebased(so);
+      s = img_process(&cb, h->s_img, d_gray[b], width, height, stride, (int*)((char*)h->vo.d_prev_set[vset] + so), (int*)((char*)h->vo.d_curr_set[vset] + so), &h->prof);
+      if (s != VLOAM_OK) { set_err("image front-end: bad image size (%d x %d, stride %d; capacity %d x %d, one size per sequence)", width, height, stride, h->img.max_w, h->img.max_h); return s; }
+      h->vo.n_match_set[vset].n[b] = k > 0 ? kImgMaxCorners : 0;
+      after = cb;
+    }
+    h->img.adopt_host_state(after);
     HIPCHK(hipEventRecord(h->ev_img[cur], h->s_img));
     h->img_frame[cur] = true;
   }
@@ -865,7 +873,8 @@ vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz
   if (!h || !d_xyz_pad4 || !d_gray) return VLOAM_ERR_INVALID;
   SINGLE_SESSION_ONLY(h);
   { const int* none = nullptr; const int zero = 0;
-    return process_frame_common(h, one_sweep(d_xyz_pad4, n), &none, &none, &zero, (const unsigned char*)d_gray, width, height, stride); }
+    const unsigned char* g = (const unsigned char*)d_gray;
+    return process_frame_common(h, one_sweep(d_xyz_pad4, n), &none, &none, &zero, &g, width, height, stride); }
 }
 
 vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride) {
@@ -879,7 +888,41 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
   SINGLE_SESSION_ONLY(h);
   { const int* none = nullptr; const int zero = 0;
-    return process_frame_common(h, one_sweep(h->d_in, n), &none, &none, &zero, h->img.staging, width, height, width); }
+    const unsigned char* g = h->img.staging;
+    return process_frame_common(h, one_sweep(h->d_in, n), &none, &none, &zero, &g, width, height, width); }
+}
+
+// Batched coupled frames from raw inputs: session b gets sweep d_xyz_pad4[b] and the 8-bit grey image d_gray[b] (all images of one size).
+vloam_status vloam_batch_process_frame_image_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n, const void* const* d_gray, int width, int height,
+                                                    int stride) {
+  if (!h || !d_xyz_pad4 || !n || !d_gray) return VLOAM_ERR_INVALID;
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  const int* none[kMaxBatch];
+  int zero[kMaxBatch];
+  const unsigned char* g[kMaxBatch];
+  for (int b = 0; b < h->se.B; b++) { bi.in[b] = (const float4*)d_xyz_pad4[b]; bi.n[b] = n[b]; none[b] = nullptr; zero[b] = 0; g[b] = (const unsigned char*)d_gray[b]; }
+  return process_frame_common(h, bi, none, none, zero, g, width, height, stride);
+}
+
+vloam_status vloam_batch_process_frame_image(vloam_handle* h, const float* const* xyz_pad4, const int* n, const unsigned char* const* gray, int width, int height,
+                                             int stride) {
+  if (!h || !xyz_pad4 || !n || !gray) return VLOAM_ERR_INVALID;
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  if (width <= 0 || height <= 0 || stride < width || width > h->img.max_w || height > h->img.max_h) { set_err("bad image size (%d x %d; the handle was created for at most %d x %d)", width, height, h->img.max_w, h->img.max_h); return VLOAM_ERR_INVALID; }
+  HIPCHK(hipSetDevice(h->device));
+  const void* d_in[kMaxBatch];
+  const void* d_img[kMaxBatch];
+  for (int b = 0; b < h->se.B; b++) {
+    if (!xyz_pad4[b] || !gray[b]) return VLOAM_ERR_INVALID;
+    if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
+    if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
+    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    { vloam_status s_ = upload_image(h, gray[b], width, height, stride, b); if (s_ != VLOAM_OK) return s_; }
+    d_in[b] = dst; d_img[b] = h->img.staging + (size_t)b * h->se.ss;
+  }
+  return vloam_batch_process_frame_image_device(h, d_in, n, d_img, width, height, width);
 }
 
 // ---- the image front-end on its own (VisualOdometry::processImage, optical_flow_match = true)
@@ -922,18 +965,19 @@ static vloam_status img_results(vloam_handle* h, std::vector<float2>* corners, s
   if (h->img.max_w == 0 || h->img.count < 0) { set_err("no image processed yet"); return VLOAM_ERR_ORDER; }
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  const ImgContext img = h->img.rebased((size_t)h->sel * h->se.ss);   // the session vloam_select_session chose
   int ierr = 0;
-  HIPCHK(hipMemcpy(&ierr, h->img.error, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&ierr, img.error, sizeof(int), hipMemcpyDeviceToHost));
   if (ierr) { set_err("image front-end capacity exceeded (bits %d: 1 candidates > %d, 2 neighbours > %d, 4 corners > %d)", ierr, kImgCandCap, kImgNbrCap, kImgAccCap); return VLOAM_ERR_CAPACITY; }
   const int cur = h->img.count % 2;
-  HIPCHK(hipMemcpy(n_corners, h->img.n_corners[cur], sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_corners, img.n_corners[cur], sizeof(int), hipMemcpyDeviceToHost));
   corners->resize((size_t)*n_corners + 1);
-  if (*n_corners) HIPCHK(hipMemcpy(corners->data(), h->img.corners[cur], sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
+  if (*n_corners) HIPCHK(hipMemcpy(corners->data(), img.corners[cur], sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
   *have_flow = h->img.count > 0;
   if (tracked && *have_flow && *n_corners) {
     tracked->resize((size_t)*n_corners); status->resize((size_t)*n_corners);
-    HIPCHK(hipMemcpy(tracked->data(), h->img.tracked, sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(status->data(), h->img.status, (size_t)*n_corners, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tracked->data(), img.tracked, sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status->data(), img.status, (size_t)*n_corners, hipMemcpyDeviceToHost));
   }
   return VLOAM_OK;
 }
@@ -1034,9 +1078,11 @@ vloam_status vloam_sync(vloam_handle* h) {
   if (h->img.max_w != 0 && h->img.count >= 0) {
     // the image front-end's own sticky word: a corner / match set cut by one of its capacities differs from goodFeaturesToTrack's and was
     // fed into the VO solve of the coupled loop — say so here too, not only in the vloam_vo_get_* getters
-    int ierr = 0;
-    HIPCHK(hipMemcpy(&ierr, h->img.error, sizeof(int), hipMemcpyDeviceToHost));
-    if (ierr) { set_err("image front-end capacity exceeded (bits %d: 1 candidates > %d, 2 neighbours > %d, 4 corners > %d)", ierr, kImgCandCap, kImgNbrCap, kImgAccCap); return VLOAM_ERR_CAPACITY; }
+    for (int b = 0; b < h->se.B; b++) {
+      int ierr = 0;
+      HIPCHK(hipMemcpy(&ierr, (const char*)h->img.error + (size_t)b * h->se.ss, sizeof(int), hipMemcpyDeviceToHost));
+      if (ierr) { set_err("image front-end capacity exceeded in session %d (bits %d: 1 candidates > %d, 2 neighbours > %d, 4 corners > %d)", b, ierr, kImgCandCap, kImgNbrCap, kImgAccCap); return VLOAM_ERR_CAPACITY; }
+    }
   }
   return VLOAM_OK;
 }

@@ -8,6 +8,7 @@
 // lkpyramid.cpp, pyramids.cpp) with the order-independent sums stated in oracle/orc_img.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/vloam_hip/c_api.h"
 #include "vloam_device.h"
 
@@ -59,12 +60,35 @@ struct ImgContext {
   unsigned char* clahe_lut = nullptr;   // [tiles^2][256]
   unsigned* desc[2] = {nullptr, nullptr};   // [kImgMaxDesc][kImgMaxDescBytes / 4] descriptors of the two images (brute-force matcher)
   uint2* best2[2] = {nullptr, nullptr};     // [kImgMaxDesc] per descriptor: the two smallest (distance << 16 | index) keys against the other set
+
+  // The same buffers of another session of a batched handle: every session's arena has the layout of session 0, `off` bytes further on.
+  // The host-side fields (image size, image count) are common to all sessions of a handle: they advance together.
+  ImgContext rebased(size_t off) const {
+    ImgContext c = *this;
+    if (off == 0) return c;
+    auto mv = [off](auto*& p) { if (p) p = (typename std::remove_reference<decltype(p)>::type)((char*)p + off); };
+    for (int k = 0; k < 2; k++) {
+      for (int l = 0; l < kImgLevels; l++) { mv(c.pyr[k].img[l]); mv(c.pyr[k].deriv[l]); }
+      mv(c.corners[k]); mv(c.n_corners[k]); mv(c.desc[k]); mv(c.best2[k]);
+    }
+    mv(c.sobel); mv(c.eig); mv(c.maxbits); mv(c.cmap); mv(c.clist); mv(c.n_cand); mv(c.nbr); mv(c.nbr_cnt); mv(c.acc); mv(c.tracked); mv(c.status);
+    mv(c.error); mv(c.staging); mv(c.clahe_img); mv(c.clahe_lut);
+    return c;
+  }
+  // img_process advanced a rebased copy: take over its host-side state (image size / count, pyramid level dimensions), not its pointers
+  void adopt_host_state(const ImgContext& o) {
+    w = o.w; h = o.h; count = o.count;
+    for (int k = 0; k < 2; k++) {
+      pyr[k].levels = o.pyr[k].levels;
+      for (int l = 0; l < kImgLevels; l++) { pyr[k].w[l] = o.pyr[k].w[l]; pyr[k].h[l] = o.pyr[k].h[l]; }
+    }
+  }
 };
 
 constexpr int kErrImgCandidates = 1, kErrImgNeighbours = 2, kErrImgAccepted = 4;
 
 hipError_t img_init();   // once per device a handle with an image front-end is created on
-vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // session 0 only (the frame loop is single-session)
+vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A);   // session 0's pointers; ImgContext::rebased() gives the other sessions'
 // processImage for the image in d_gray (device, row stride in bytes): pyramid + derivatives, corners, and — from the second image
 // on — the flow of the new corners from the previous image into this one.  prev_uv / curr_uv (device, [kImgMaxCorners][2] ints, may be
 // null): the match loop's integer pixel pairs, x = INT_MIN in entries without a tracked corner.
