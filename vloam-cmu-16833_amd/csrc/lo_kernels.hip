@@ -396,15 +396,13 @@ struct VisitAdjacent {  // LO:279-324 / LO:368-417 as a class filter (see k_lo_a
 };
 
 
-__global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sharp, const float4* __restrict__ flat,
-                                                  const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
-                                                  const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G,
-                                                  const LOState* __restrict__ lo, FactorTable F, int* __restrict__ corr,
-                                                  long long* __restrict__ dbg_cyc /* [slots][4] or null */,
-                                                  const int* __restrict__ queue /* null: every slot; else the slots k_lo_assoc_fast left over */,
-                                                  int* __restrict__ queue_n /* [2]: [parity] entries of `queue`, [parity ^ 1] re-armed here */, int parity, size_t ss) {
+#define LO_ASSOC_ARGS const float4* __restrict__ sharp, const float4* __restrict__ flat, const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL, \
+                      const float4* __restrict__ SL, const FrameScalars* __restrict__ Sp, LoGrid G, const LOState* __restrict__ lo, FactorTable F,              \
+                      int* __restrict__ corr, long long* __restrict__ dbg_cyc /* [slots][4] or null */,                                                         \
+                      const int* __restrict__ queue /* null: every slot; else the slots k_lo_assoc_fast left over */,                                          \
+                      int* __restrict__ queue_n /* [2]: [parity] entries of `queue`, [parity ^ 1] re-armed here */, int parity, size_t ss
+__device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[512], int (*s_rel_all)[512]) {
   VL_SESSION(ss); RB(sharp); RB(flat); RB(Sc); RB(CL); RB(SL); RB(Sp); G.rebase(so_); RB(lo); F.rebase(so_); RB(corr); RB(dbg_cyc); RB(queue); RB(queue_n);
-  __shared__ int s_inc_all[4][512], s_rel_all[4][512];  // per-wavefront staging of cell prefix sums (for_each_candidate, KC > 2)
   const int lane = threadIdx.x & 63;
   int* s_inc = s_inc_all[threadIdx.x >> 6];
   int* s_rel = s_rel_all[threadIdx.x >> 6];
@@ -601,6 +599,20 @@ __global__ __launch_bounds__(256) void k_lo_assoc(const float4* __restrict__ sha
     corr[slot * 4 + 0] = type ? i : -1;
     corr[slot * 4 + 1] = ia; corr[slot * 4 + 2] = ib; corr[slot * 4 + 3] = ic;
   }
+}
+
+// The wave-per-query kernel in two register budgets.  One sequence: 158 VGPRs, three wavefronts per SIMD — every query of the launch is resident at
+// once and none of its state spills.  Behind k_lo_assoc_fast in a batch (thousands of left-over queries from B sessions, on a chip the other
+// stages keep full): four wavefronts per SIMD at 128 VGPRs and a few spilled values finish the pass sooner (B = 8: 123 -> 102 us; the same
+// budget costs one sequence 36 -> 40 us).
+#define LO_ASSOC_PASS sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc, queue, queue_n, parity, ss
+__global__ __launch_bounds__(256) void k_lo_assoc(LO_ASSOC_ARGS) {
+  __shared__ int s_inc_all[4][512], s_rel_all[4][512];  // per-wavefront staging of cell prefix sums (for_each_candidate, KC > 2)
+  lo_assoc_body(LO_ASSOC_PASS, s_inc_all, s_rel_all);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_lo_assoc_dense(LO_ASSOC_ARGS) {
+  __shared__ int s_inc_all[4][512], s_rel_all[4][512];
+  lo_assoc_body(LO_ASSOC_PASS, s_inc_all, s_rel_all);
 }
 
 // ---- k_lo_assoc_fast: the common query with G = 16 lanes (four queries per wavefront, sixteen per workgroup).
@@ -858,7 +870,7 @@ void lo_assoc_launch(hipStream_t st, Sess se, const float4* sharp, const float4*
     const int parity = launch_no & 1;
     VLOAM_LAUNCH(ph, kKLoAssocFast, st, k_lo_assoc_fast<16>, dim3(kMaxLoFactors / 16, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
                  queue, queue_n, parity, se.ss);
-    VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
+    VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc_dense, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,
                  (const int*)queue, queue_n, parity, se.ss);
   } else {
     VLOAM_LAUNCH(ph, kKLoAssoc, st, k_lo_assoc, dim3((kMaxLoFactors + 3) / 4, 1, se.B), dim3(256), 0, st, sharp, flat, Sc, CL, SL, Sp, G, lo, F, corr, dbg_cyc,

@@ -488,8 +488,10 @@ __device__ bool householder_ls_5x3(double* A, double* b, double* x) {
 // per lane and trip, up to four candidate records per lane in flight — and the best five are taken by five group arg-min rounds over
 // the (d2, tie) keys through DPP row operations (keys are unique: distinct voxels), so no candidate list is ranked in LDS any more.
 // Results do not depend on G: the keys, not the visiting order, decide.
+// amdgpu_waves_per_eu(5): the 16-lane form would take 108 VGPRs (4 wavefronts per SIMD); held to 96 it spills nothing and runs 5
+// (B = 8: 101 -> 85 us per launch; 6 wavefronts / 80 VGPRs spills 16 values and loses again: 106 us).  The 32 / 64-lane forms use 80 anyway.
 template <int G, int KB>
-__global__ __launch_bounds__(256) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_map_assoc(const float4* __restrict__ stack0, const float4* __restrict__ stack1, VoxelTable T0,
                                                    VoxelTable T1, float inv0, float inv1, const MapState* __restrict__ ms, MapFrame* fr,
                                                    float4* __restrict__ nbr, int outer, int4* __restrict__ cbox, float4* __restrict__ ccand,
                                                    long long* __restrict__ dbg_cyc /* [16] phase cycle sums + wavefront count, or null */, size_t ss) {
