@@ -624,6 +624,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 // A query the block cannot answer conclusively is NOT continued here: its slot goes onto a queue and k_lo_assoc (one wavefront per
 // query, all stages) takes it from scratch in the launch right behind — the long tail runs with full wavefronts and balanced, the
 // short queries no longer wait in line behind it.  Same keys, same bounds, same emission as k_lo_assoc: results are identical.
+#ifndef VLOAM_LO_FAST_CAP
+#define VLOAM_LO_FAST_CAP 256
+#endif
+constexpr int kFastCap = VLOAM_LO_FAST_CAP;   // candidates of the radius-1 block a 16-lane group parks in LDS (8 B each)
 template <int G>
 __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict__ sharp, const float4* __restrict__ flat,
                                                        const FrameScalars* __restrict__ Sc, const float4* __restrict__ CL,
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
   static_assert(kMaxSharp % (8 * QW) == 0 && kMaxFlat % (8 * QW) == 0, "bijective remap");
   __shared__ int s_stops[2 * kStopLen];
   __shared__ int s_inc[QW][32], s_rel[QW][32];
-  __shared__ u64 s_item[QW][256];
+  __shared__ u64 s_item[QW][kFastCap];
   __shared__ int s_ring[QW];
   const int tid = threadIdx.x, lane = tid & 63, gl = lane & (G - 1), qi = (tid >> 6) * Q + lane / G;
   const int bq = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
   s_inc[qi][gl] = inc0; s_inc[qi][16 + gl] = inc1;                      // inclusive sums in (k, lane) order
   s_rel[qi][gl] = bs[0] - (inc0 - cnt[0]); s_rel[qi][16 + gl] = bs[1] - (inc1 - cnt[1]);   // item i of a cell lives at rel + i
   sw_lds_sync();
-  const bool kept = act && total <= 256;   // (more: k_lo_assoc walks the block through for_each_candidate)
+  const bool kept = act && total <= kFastCap;   // (more: k_lo_assoc walks the block through for_each_candidate)
   // ---- closest point (LO:269 / LO:356): every candidate once; (d2, tag) parked for the second / third point
   u64 loc = ~0ull;
   int ring = 0;
