@@ -45,7 +45,7 @@ WORKLOADS = {
 # the reference's per-substage timers -> the kernels that do that work here
 REFERENCE_TIMERS = {
     "scan registration: prepare + sort q time + seperate points (scan_registration.cpp:285,430-432)":
-        ["k_sr_label", "k_sr_scatter", "k_sr_ring", "k_sr_compact"],
+        ["k_sr_first_last", "k_sr_label", "k_sr_scatter", "k_sr_ring", "k_sr_compact"],
     "laser odometry: data association (laser_odometry.cpp:453)": ["k_lo_assoc"],
     "laser odometry / mapping: solver time (laser_odometry.cpp:465, laser_mapping.cpp:618)": ["k_lm_compact", "k_lm_solve"],
     "laser odometry: build tree -> NN grids (laser_odometry.cpp:525-526)": ["k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter"],
@@ -72,6 +72,8 @@ def algorithmic_bytes(kernel, c):
         return 2 * 76 * c["K_m"]
     if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
         return 16 * c["N2"] + 16 * c["n_lessFlat"] + 4 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"])
+    if kernel == "k_sr_first_last":
+        return 16 * c["N_in"]
     if kernel == "k_sr_label":
         return 16 * c["N_in"] + 5 * c["N_in"]
     if kernel == "k_sr_scatter":

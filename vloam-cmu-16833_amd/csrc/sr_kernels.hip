@@ -4,7 +4,8 @@
 // (cited per step as "SR:<line>").  Integer / index results are bit-identical to the CPU oracle; f32
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
 //
-// Kernels (one sweep = 4 launches, no host synchronisation):
+// Kernels (one sweep = 5 launches, no host synchronisation):
+//   k_sr_first_last  n/256 WGs   first / last surviving point per slice (folded by every k_sr_label workgroup)  SR:157-176
 //   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
 //   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, sort-free picks (wavefront arg-max rounds, six sectors
@@ -91,65 +92,64 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// First / last surviving point (SR:157-176) in two steps without a single-workgroup stage on the critical path: every 256-lane
+// workgroup of k_sr_first_last reports the first / last surviving point of its slice (one pass over the input at full width);
+// every workgroup of k_sr_label folds the ~512 slice records itself (4 KB from L2) and derives startOri / endOri locally.
+// 256-lane workgroups: small enough to slip onto CUs whose register file is mostly taken by the previous sweep's odometry
+// kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
+constexpr int kFLThreads = 256;
+__global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float thres, int2* __restrict__ slice, size_t ss) {
+  VL_SESSION(ss); RB(slice);
+  const float4* __restrict__ in = bi.in[blockIdx.z];
+  const int n = bi.n[blockIdx.z];
+  __shared__ int s_first, s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) { s_first = INT_MAX; s_last = -1; }
+  __syncthreads();
+  const int i = blockIdx.x * kFLThreads + tid;
+  bool v = false;
+  if (i < n) { const float4 p = in[i]; v = sr_survives_s1(p.x, p.y, p.z, thres); }
+  const unsigned long long m = __ballot(v);
+  if (m != 0ull) {
+    if (lane == __ffsll((long long)m) - 1) atomicMin(&s_first, i);
+    if (lane == 63 - __clzll((long long)m)) atomicMax(&s_last, i);
+  }
+  __syncthreads();
+  if (tid == 0) slice[blockIdx.x] = make_int2(s_first, s_last);
+}
+
+// ------------------------------------------------------------------------------------------------
 // blk: per-workgroup results for k_sr_scatter — [0, nblk): candidate pivot (SR:246-249) or INT_MAX, [nblk, 2 nblk): points
 // surviving S1.  Plain stores, no counters to re-arm between sweeps.
 __global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thres, int N_SCANS,
                                                           FrameScalars* S, signed char* __restrict__ sid,
                                                           float* __restrict__ ori_raw, int* __restrict__ blockhist,
-                                                          int* __restrict__ blk, size_t ss) {
-  VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(blk);
+                                                          const int2* __restrict__ slice, int nslice, int* __restrict__ blk, size_t ss) {
+  VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(slice); RB(blk);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
   __shared__ int hist[kMaxRings];
   __shared__ int s_istar, s_cnt, s_first, s_last;
-  __shared__ float s_start, s_fx, s_fy, s_lx, s_ly;
+  __shared__ float s_start;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < kMaxRings) hist[tid] = 0;
   if (tid == 0) { s_istar = INT_MAX; s_cnt = 0; s_first = INT_MAX; s_last = -1; }
   __syncthreads();
-  // First surviving point of the sweep (SR:157-166: startOri comes from it): every workgroup scans the cloud from its head, 1 024
-  // points a step — the first step almost always answers (one trip to L2, the same chunk for every workgroup), so no separate pass
-  // over the input and no kernel boundary in front of this one.  Workgroup 0 also scans from the tail for the last one (endOri).
-  for (int c0 = 0;;) {
-    const int j = c0 + tid;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < n) q = in[j];
-    const bool v = j < n && sr_survives_s1(q.x, q.y, q.z, thres);
-    const unsigned long long m = __ballot(v);
-    if (m != 0ull && lane == __ffsll((long long)m) - 1) atomicMin(&s_first, j);
-    __syncthreads();
-    const int f = s_first;
-    if (f != INT_MAX) { if (j == f) { s_fx = q.x; s_fy = q.y; } break; }
-    c0 += kLabelBlock;
-    if (c0 >= n) break;
-    __syncthreads();  // everybody has read s_first before the next step's atomics
-  }
-  if (blockIdx.x == 0) {
-    for (int c0 = 0;;) {
-      const int j = n - 1 - c0 - tid;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j >= 0) q = in[j];
-      const bool v = j >= 0 && sr_survives_s1(q.x, q.y, q.z, thres);
-      const unsigned long long m = __ballot(v);
-      if (m != 0ull && lane == __ffsll((long long)m) - 1) atomicMax(&s_last, j);   // lanes run backwards: the lowest lane holds the highest index
-      __syncthreads();
-      const int l = s_last;
-      if (l >= 0) { if (j == l) { s_lx = q.x; s_ly = q.y; } break; }
-      c0 += kLabelBlock;
-      if (c0 >= n) break;
-      __syncthreads();
-    }
+  {
+    int f = INT_MAX, l = -1;
+    for (int b = tid; b < nslice; b += kLabelBlock) { const int2 fl = slice[b]; f = min(f, fl.x); l = max(l, fl.y); }
+    for (int d = 32; d > 0; d >>= 1) { f = min(f, __shfl_xor(f, d)); l = max(l, __shfl_xor(l, d)); }
+    if (lane == 0) { atomicMin(&s_first, f); atomicMax(&s_last, l); }
   }
   __syncthreads();
   if (tid == 0) {
     float startOri = 0.f, endOri = 0.f;
-    if (s_first != INT_MAX) {
-      startOri = -atan2f(s_fy, s_fx);                                                  // SR:166
-      if (blockIdx.x == 0) {
-        endOri = (float)((double)(-atan2f(s_ly, s_lx)) + 2 * M_PI);                    // SR:167
-        if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
-        else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
-      }
+    if (s_last >= 0) {
+      const float4 pf = in[s_first], pl = in[s_last];
+      startOri = -atan2f(pf.y, pf.x);                                                // SR:166
+      endOri = (float)((double)(-atan2f(pl.y, pl.x)) + 2 * M_PI);                    // SR:167
+      if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
+      else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
     }
     s_start = startOri;
     if (blockIdx.x == 0) {  // the sweep's first writer of the scalars: also clears the error word
@@ -898,9 +898,12 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  int* blk = b.blockoff;                   // [2][nblk] (blockoff holds 64 ints per label workgroup)
+  const int nslice = (n + kFLThreads - 1) / kFLThreads;
+  int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
+  int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
+  VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice, 1, Z), dim3(kFLThreads), 0, st, bi, min_range, slice, se.ss);
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
-               blk, se.ss);
+               slice, nslice, blk, se.ss);
   VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
   VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,

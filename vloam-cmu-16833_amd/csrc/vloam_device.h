@@ -58,12 +58,12 @@ constexpr int kMaxLoFactors = kMaxSharp + kMaxFlat;                         // 2
 
 // Kernel ids for the per-kernel HIP-event timer (vloam_profile_kernel); names = the __global__ symbols.
 enum KernelId : int {
-  kKNone = 0, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
+  kKNone = 0, kKSrFirstLast, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
   kKMapPrepare, kKMapStack, kKMapAssoc, kKMapInsert, kKMapFinalize, kKVoProject, kKVoMatch,
   kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsRank, kKMapDsScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig,
   kKImgSobel, kKImgEig, kKImgLocalMax, kKImgNeighbours, kKImgSelect, kKImgPyrDown, kKImgScharr, kKImgLk, kKLoAssocFast, kKCount
 };
-static const char* const kKernelNames[kKCount] = {"", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
+static const char* const kKernelNames[kKCount] = {"", "k_sr_first_last", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
   "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_ds_count", "k_map_assoc", "k_map_insert",
   "k_map_finalize", "k_vo_project", "k_vo_match", "k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter", "k_map_ds_rank",
   "k_map_ds_scatter", "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier",
