@@ -278,24 +278,22 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(BatchIn bi, FrameSca
 // Block-wide helpers for k_sr_ring (512 threads = 8 wavefronts).
 constexpr int kRingThreads = 512;
 
-// In-place exclusive scan of an LDS int array (n <= 16 * kRingThreads); returns the total.
+// In-place exclusive scan of an LDS int array (n <= 16 * kRingThreads); returns the total.  Per-thread chunk sums, a shuffle scan inside
+// every wavefront, the eight wavefront totals through LDS: three workgroup barriers (a Hillis-Steele scan over 512 partial sums took 18).
 __device__ int block_exclusive_scan(int* a, int n, int* scratch /* kRingThreads ints */) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int per = (n + kRingThreads - 1) / kRingThreads;
   const int lo = tid * per, hi = min(lo + per, n);
   int s = 0;
   for (int k = lo; k < hi; k++) s += a[k];
-  scratch[tid] = s;
+  int inc = s;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  __syncthreads();   // (scratch may still be read by the caller's previous use)
+  if (lane == 63) scratch[wv] = inc;
   __syncthreads();
-  for (int d = 1; d < kRingThreads; d <<= 1) {  // Hillis–Steele inclusive scan of the per-thread sums
-    int v = tid >= d ? scratch[tid - d] : 0;
-    __syncthreads();
-    scratch[tid] += v;
-    __syncthreads();
-  }
-  const int total = scratch[kRingThreads - 1];
-  int run = tid ? scratch[tid - 1] : 0;
-  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < kRingThreads / 64; w++) { const int t = scratch[w]; base += w < wv ? t : 0; total += t; }
+  int run = base + inc - s;
   for (int k = lo; k < hi; k++) { int v = a[k]; a[k] = run; run += v; }
   __syncthreads();
   return total;
@@ -345,6 +343,51 @@ __device__ __forceinline__ void bitonic_reg_stages(u64* a, int P, int k_lo, int 
       }
     }
     a[base + lane] = a0; a[base + 64 + lane] = a1;
+  }
+}
+
+// The same with 256-element blocks, four keys per lane (elements l, l + 64, l + 128, l + 192): strides 128 and 64 are the lane's own pairs,
+// anything below a cross-lane exchange.  2 048 run keys are then eight blocks — one per wavefront — and only the strides >= 256 (6 of
+// the 66 stages) go through LDS behind a workgroup barrier.
+__device__ __forceinline__ void bitonic_reg_stages4(u64* a, int P, int k_lo, int k_hi, int tid, int nthreads) {
+  const int lane = tid & 63, wv = tid >> 6, nwaves = nthreads >> 6;
+  for (int blk = wv; blk * 256 < P; blk += nwaves) {
+    const int base = blk * 256;
+    u64 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = a[base + e * 64 + lane];
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+      bool up[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) up[e] = ((base + e * 64 + lane) & k) == 0;
+      if (k > 128) {  // stride 128: (0, 2) and (1, 3); both ends of a pair see the same direction (bit k lies above bit 7)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const u64 x = v[e], y = v[e + 2];
+          const u64 hi = x > y ? x : y, lo = x > y ? y : x;
+          v[e] = up[e] ? lo : hi; v[e + 2] = up[e] ? hi : lo;
+        }
+      }
+      if (k > 64) {   // stride 64: (0, 1) and (2, 3)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const u64 x = v[e], y = v[e + 1];
+          const u64 hi = x > y ? x : y, lo = x > y ? y : x;
+          v[e] = up[e] ? lo : hi; v[e + 1] = up[e] ? hi : lo;
+        }
+      }
+      for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
+        const bool lower = (lane & j) == 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const u64 b = __shfl_xor(v[e], j);
+          const u64 mx = v[e] > b ? v[e] : b, mn = v[e] > b ? b : v[e];
+          v[e] = (up[e] == lower) ? mn : mx;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) a[base + e * 64 + lane] = v[e];
   }
 }
 
@@ -507,16 +550,24 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   // first — only when a spilled-on point had been selected.  Marks are clipped to the own sector while picking (a later
   // sector must not disturb an earlier one); the full extents are applied at the end so that `picked` ends up exactly like
   // cloudNeighborPicked.
-  auto run_sector_q = [&](auto kq_tag, int s, int in_hi, bool redo) {
+  // A redone sector does not start over: its picks are taken in priority order, so every pick made BEFORE the first one the new spill
+  // invalidates stands — the picks of both walks are kept in LDS, the kept ones are replayed (marks only, all at once, one lane each)
+  // and the walk resumes behind them.  On average half of the second pass; a spill that hits a flat pick keeps the whole sharp walk.
+  unsigned* cbits = (unsigned*)keys;      // [CAP] curvature bits of the sector points (a redo reads them back instead of 33 LDS reads per point)
+  constexpr int kPickSlots = kMaxLessSharpPerSect + kMaxFlatPerSect;
+  int* s_plist = iscratch + 64;                         // [kSectors][kPickSlots] local index of the walks' picks, in pick order
+  int* s_pcnt = s_plist + kSectors * kPickSlots;        // [kSectors][2] picks of the sharp / flat walk
+  auto run_sector_q = [&](auto kq_tag, int s, int in_hi, bool redo, int keep_sharp, bool sharp_final, int keep_flat) {
     constexpr int kQ = decltype(kq_tag)::value;   // register slots per lane: sector length <= 64 kQ
     const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
     const int seclen = ep_l - sp_l + 1;
+    int* plist = s_plist + s * kPickSlots;
     if (redo) {  // forget the previous result, then apply the predecessor's spill
       for (int l = sp_l + lane; l <= ep_l; l += 64) { picked[l] = (l <= in_hi) ? 1 : 0; label[l] = 0; }
       lds_fence_wave();
     }
     unsigned cb[kQ];                      // curvature bits of point sp_l + q * 64 + lane
-    unsigned sharp_bits = 0, flat_bits = 0, elig = 0;
+    unsigned sharp_bits = 0, flat_bits = 0, elig = 0, inside = 0;
 #pragma unroll
     for (int q = 0; q < kQ; q++) {
       cb[q] = 0;
@@ -524,9 +575,16 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         const int t = q * 64 + lane;
         if (t < seclen) {
           const int i = sp_l + t;
-          const float c = curvature(i);
-          if (dbg_curv) dbg_curv[off + i] = c;
-          cb[q] = __float_as_uint(c);   // c >= 0: the bit pattern orders like the value
+          inside |= 1u << q;
+          if (redo) {
+            cb[q] = cbits[i];
+          } else {
+            const float c0 = curvature(i);
+            if (dbg_curv) dbg_curv[off + i] = c0;
+            cb[q] = __float_as_uint(c0);   // c >= 0: the bit pattern orders like the value
+            cbits[i] = cb[q];
+          }
+          const float c = __uint_as_float(cb[q]);
           if ((double)c > 0.1) sharp_bits |= 1u << q;
           if ((double)c < 0.1) flat_bits |= 1u << q;
           if (i > in_hi) elig |= 1u << q;
@@ -550,8 +608,33 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         if (t >= tlo && t <= thi) elig &= ~(1u << q);
       }
     };
+    // kept picks [first, first + n) of the pick list: lane k marks around pick k (labels, marks, extents), then every lane re-reads
+    // which of its points are still eligible
+    auto replay = [&](int first, int n, int n_marking, int sharp_walk) {
+      int lo_m = INT_MAX, hi_m = -1;
+      if (lane < n) {
+        const int lf = plist[first + lane];
+        label[lf] = sharp_walk ? (lane < kMaxSharpPerSect ? 2 : 1) : -1;
+        if (lane < n_marking) {
+          const int rb = reachb[lf];
+          lo_m = lf - (rb & 15); hi_m = lf + (rb >> 4);
+          for (int l = max(lo_m, sp_l); l <= min(hi_m, ep_l); l++) picked[l] = 1;
+        }
+      }
+      leak_lo = min(leak_lo, (int)wave_min_u32((unsigned)lo_m));
+      leak_hi = max(leak_hi, (int)wave_max_u32((unsigned)(hi_m + 1)) - 1);
+      lds_fence_wave();
+#pragma unroll
+      for (int q = 0; q < kQ; q++)
+        if (((inside >> q) & 1u) && picked[sp_l + q * 64 + lane]) elig &= ~(1u << q);
+    };
     // SR:327-378, descending curvature
-    for (int picks = 1;; picks++) {
+    if (keep_sharp > 0) {
+      replay(0, keep_sharp, keep_sharp, 1);
+      n_sharp = min(keep_sharp, kMaxSharpPerSect); n_less = keep_sharp;
+    }
+    if (!sharp_final)
+    for (int picks = keep_sharp + 1;; picks++) {
       const unsigned m = elig & sharp_bits;
       unsigned bh = 0, bl = 0;
 #pragma unroll
@@ -561,10 +644,10 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       if (mh == 0) break;
       const int lf = (int)wave_max_u32(bh == mh ? bl : 0u);
       if (picks <= 2) {
-        if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; }
+        if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; plist[n_less] = lf; }
         n_sharp++; n_less++;
       } else if (picks <= 20) {
-        if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; }
+        if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; plist[n_less] = lf; }
         n_less++;
       } else {
         break;
@@ -572,7 +655,11 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       suppress(lf);
     }
     // SR:380-422, ascending curvature
-    for (int picks = 1;; picks++) {
+    if (keep_flat > 0) {
+      replay(kMaxLessSharpPerSect, keep_flat, min(keep_flat, kMaxFlatPerSect - 1), 0);
+      n_flat = keep_flat;
+    }
+    for (int picks = keep_flat + 1;; picks++) {
       const unsigned m = elig & flat_bits;
       unsigned bh = 0xffffffffu, bl = 0xffffffffu;
 #pragma unroll
@@ -581,7 +668,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       if (__ballot(bl != 0xffffffffu) == 0ull) break;
       const unsigned mh = wave_min_u32(bl != 0xffffffffu ? bh : 0xffffffffu);
       const int lf = (int)wave_min_u32((bl != 0xffffffffu && bh == mh) ? bl : 0xffffffffu);
-      if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; }
+      if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; plist[kMaxLessSharpPerSect + n_flat] = lf; }
       n_flat++;
       if (picks >= 4) break;  // the 4th flat point is emitted but not suppressed (SR:390-394)
       suppress(lf);
@@ -591,21 +678,22 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
       s_leak_lo[s] = leak_lo; s_leak_hi[s] = leak_hi;
       s_zone[s] = in_hi;
+      s_pcnt[2 * s] = n_less; s_pcnt[2 * s + 1] = n_flat;
     }
   };
-  auto run_sector = [&](int s, int in_hi, bool redo) {
-    if (s_ep[s] - s_sp[s] + 1 <= 6 * 64) run_sector_q(std::integral_constant<int, 6>{}, s, in_hi, redo);   // HDL-64E: ~330 points per sector
-    else run_sector_q(std::integral_constant<int, SECT / 64>{}, s, in_hi, redo);
+  auto run_sector = [&](int s, int in_hi, bool redo, int keep_sharp, bool sharp_final, int keep_flat) {
+    if (s_ep[s] - s_sp[s] + 1 <= 6 * 64) run_sector_q(std::integral_constant<int, 6>{}, s, in_hi, redo, keep_sharp, sharp_final, keep_flat);   // HDL-64E: ~330 points per sector
+    else run_sector_q(std::integral_constant<int, SECT / 64>{}, s, in_hi, redo, keep_sharp, sharp_final, keep_flat);
   };
-  if (wave < kSectors) run_sector(wave, -1, false);
+  if (wave < kSectors) run_sector(wave, -1, false, 0, false, 0);
   __syncthreads();
   // fixed point over the boundaries: a sector is redone when the spill it was computed with differs from its predecessors'
   // current spill in a way that can matter.  Sector 0 never changes, so after round k sectors 0..k are final.
   for (int round = 0; round < kSectors - 1; round++) {
     if (tid == 0) *s_any = 0;
     __syncthreads();
-    bool redo = false;
-    int in_hi = -1;
+    bool redo = false, sharp_final = false;
+    int in_hi = -1, keep_sharp = 0, keep_flat = 0;
     if (wave >= 1 && wave < kSectors) {
       const int sp_l = s_sp[wave] - off, ep_l = s_ep[wave] - off;
       for (int q = 0; q < wave; q++) in_hi = max(in_hi, s_leak_hi[q]);  // a spill reaches 5 points: several sectors when they are tiny
@@ -613,17 +701,26 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       if (in_hi < sp_l) in_hi = -1;
       const int used = s_zone[wave];
       if (in_hi > used) {        // the spill grew: matters only if a newly covered point (at most 5) had been selected
-        const int l = max(used + 1, sp_l) + lane;
-        redo = __ballot(l <= in_hi && label[l] != 0) != 0ull;
+        const int nl = s_pcnt[2 * wave], nf = s_pcnt[2 * wave + 1];
+        int lf = -1;
+        if (lane < kMaxLessSharpPerSect) { if (lane < nl) lf = s_plist[wave * kPickSlots + lane]; }
+        else if (lane < kPickSlots) { if (lane - kMaxLessSharpPerSect < nf) lf = s_plist[wave * kPickSlots + lane]; }
+        const unsigned long long hit = __ballot(lf > used && lf <= in_hi);   // (picks lie inside the sector, i.e. at or above sp_l)
+        redo = hit != 0ull;
+        if (redo) {   // everything picked before the first invalidated pick stands
+          const int k = __ffsll((long long)hit) - 1;
+          if (k < kMaxLessSharpPerSect) { keep_sharp = k; }
+          else { keep_sharp = nl; sharp_final = true; keep_flat = k - kMaxLessSharpPerSect; }
+        }
         if (!redo && lane == 0) s_zone[wave] = in_hi;
-      } else if (in_hi < used) {  // the spill shrank: points that were blocked are free again
+      } else if (in_hi < used) {  // the spill shrank: points that were blocked are free again — from the start
         redo = true;
       }
       if (redo && lane == 0) *s_any = 1;
     }
     __syncthreads();  // every wavefront has read its predecessor's spill before anything is redone
     if (*s_any == 0) break;
-    if (redo) run_sector(wave, in_hi, true);
+    if (redo) run_sector(wave, in_hi, true, keep_sharp, sharp_final, keep_flat);
     __syncthreads();
   }
   if (wave == 0) {
@@ -761,9 +858,9 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         const int next_j = j > 1 ? j >> 1 : k;  // first stride of the next merge level
         if (j > 64 || next_j > 64) __syncthreads(); else lds_fence_wave();
       }
-  } else {
-    // strides <= 64 run in registers (one 128-key block per wavefront and pass); only the strides >= 128 — 10 of the 66 stages at
-    // 2 048 run keys — go through LDS behind a workgroup barrier
+  } else if (P2 < 256 * (kRingThreads / 64)) {
+    // up to 1 024 keys: 128-key blocks (two keys per lane) keep all eight wavefronts busy; strides <= 64 run in registers, the strides >= 128
+    // go through LDS behind a workgroup barrier
     bitonic_reg_stages(K2, P2, 2, 128, tid, kRingThreads);
     __syncthreads();
     for (int k = 256; k <= P2; k <<= 1) {
@@ -772,6 +869,20 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         __syncthreads();
       }
       bitonic_reg_stages(K2, P2, k, k, tid, kRingThreads);
+      __syncthreads();
+    }
+  } else {
+    // 2 048 keys and more: 256-key blocks (four keys per lane, one block per wavefront at 2 048); strides <= 128 run in registers, only the
+    // strides >= 256 — 6 of the 66 stages at 2 048 run keys — go through LDS (41.5 k -> 37 k cycles; at 1 024 keys the wider blocks would
+    // leave four wavefronts idle: 19 k -> 26 k)
+    bitonic_reg_stages4(K2, P2, 2, 256, tid, kRingThreads);
+    __syncthreads();
+    for (int k = 512; k <= P2; k <<= 1) {
+      for (int j = k >> 1; j >= 256; j >>= 1) {
+        bitonic_stage(K2, P2, j, k, tid, kRingThreads);
+        __syncthreads();
+      }
+      bitonic_reg_stages4(K2, P2, k, k, tid, kRingThreads);
       __syncthreads();
     }
   }
