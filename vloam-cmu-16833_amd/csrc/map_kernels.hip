@@ -278,17 +278,26 @@ __global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__
     const u64 rest = hl == 63 ? 0ull : (H >> (hl + 1));
     const int len = (rest ? hl + __ffsll((long long)rest) : 64) - hl;
     int found = -1;
+    bool fresh = false;   // this lane's run opened a new voxel
     if (act && lane == hl) {
       unsigned s = (unsigned)mix64(key) & D.hash_mask;
       for (int probe = 0; probe <= D.hash_mask; probe++, s = (s + 1) & D.hash_mask) {
         const u64 old = atomicCAS(&D.keys[s], 0ull, key);
-        if (old == 0ull) {  // new voxel
-          const int u = atomicAdd(&fr->n_uniq[kind], 1);
-          if (u < D.stack_cap) { D.uniq[u] = key; D.uslot[u] = (int)s; D.suidx[s] = u; } else atomicOr(&fr->error, kErrStackFull);
-        }
-        if (old == 0ull || old == key) { atomicAdd(&D.cnt[s], len); found = (int)s; break; }
+        if (old == 0ull || old == key) { atomicAdd(&D.cnt[s], len); found = (int)s; fresh = old == 0ull; break; }
       }
       if (found < 0) atomicOr(&fr->error, kErrStackFull);
+    }
+    // arrival numbers of the new voxels: one counter update per wavefront, not one per voxel on the same word
+    const u64 fm = __ballot(fresh);
+    if (fm != 0ull) {
+      const int leader = __ffsll((long long)fm) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&fr->n_uniq[kind], __popcll(fm));
+      base = __shfl(base, leader);
+      if (fresh) {
+        const int u = base + __popcll(fm & ((1ull << lane) - 1ull));
+        if (u < D.stack_cap) { D.uniq[u] = key; D.uslot[u] = found; D.suidx[found] = u; } else atomicOr(&fr->error, kErrStackFull);
+      }
     }
     found = __shfl(found, hl);
     if (act) D.point_slot[i] = found;
@@ -1014,35 +1023,50 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
   (void)deferred0; (void)deferred1;
   const int n = kind ? ms->n_surf_stack : ms->n_corner_stack;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const float4 p = associate_to_map(stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
-    smap[i] = p;
-    const int Ai = cube_abs((double)p.x), Aj = cube_abs((double)p.y), Ak = cube_abs((double)p.z);
-    const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;  // == cubeI, cubeJ, cubeK of LM:643-652
-    if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) continue;  // LM:654-655: outside the grid -> dropped
-    const int lx = (int)floorf(p.x * inv) - cube_voxel_base(Ai, inv), ly = (int)floorf(p.y * inv) - cube_voxel_base(Aj, inv),
-              lz = (int)floorf(p.z * inv) - cube_voxel_base(Ak, inv);
-    if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u || !cube_in_key_range(Ai, Aj, Ak)) { atomicOr(&fr->error, kErrMapFull); continue; }
-    const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
-    unsigned s = (unsigned)mix64(key) & T.mask;
-    bool done = false;
-    for (int probe = 0; probe < kMaxProbe && !done; probe++, s = (s + 1) & T.mask) {
-      const u64 old = atomicCAS(&T.rec[s].key, 0ull, key);
-      if (old == 0ull || old == key) {
-        if (old == 0ull) {  // new voxel: publish it in its block's occupancy mask
-          atomicAdd(&T.stats[0], 1);
-          if (!map_publish_block(T, Ai, Aj, Ak, lx, ly, lz)) atomicOr(&fr->error, kErrMapFull);
+  const int lane = threadIdx.x & 63;
+  for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += gridDim.x * 256) {   // wavefront-uniform
+    const int i = i0 + lane;
+    // returns the slot if this point is the first of the sweep in its voxel (the voxel joins the touched list), else -1
+    auto insert_point = [&]() -> int {
+      if (i >= n) return -1;
+      const float4 p = associate_to_map(stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
+      smap[i] = p;
+      const int Ai = cube_abs((double)p.x), Aj = cube_abs((double)p.y), Ak = cube_abs((double)p.z);
+      const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;  // == cubeI, cubeJ, cubeK of LM:643-652
+      if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) return -1;  // LM:654-655: outside the grid -> dropped
+      const int lx = (int)floorf(p.x * inv) - cube_voxel_base(Ai, inv), ly = (int)floorf(p.y * inv) - cube_voxel_base(Aj, inv),
+                lz = (int)floorf(p.z * inv) - cube_voxel_base(Ak, inv);
+      if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u || !cube_in_key_range(Ai, Aj, Ak)) { atomicOr(&fr->error, kErrMapFull); return -1; }
+      const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
+      unsigned s = (unsigned)mix64(key) & T.mask;
+      for (int probe = 0; probe < kMaxProbe; probe++, s = (s + 1) & T.mask) {
+        const u64 old = atomicCAS(&T.rec[s].key, 0ull, key);
+        if (old == 0ull || old == key) {
+          if (old == 0ull) {  // new voxel: publish it in its block's occupancy mask
+            atomicAdd(&T.stats[0], 1);
+            if (!map_publish_block(T, Ai, Aj, Ak, lx, ly, lz)) atomicOr(&fr->error, kErrMapFull);
+          }
+          const int pos = atomicAdd(&T.rec[s].pend_cnt, 1);
+          if (pos < kPendCap) T.pend[(size_t)s * kPendCap + pos] = i; else atomicOr(&fr->error, kErrMapFull);
+          return pos == 0 ? (int)s : -1;   // (whether the cube is inside the valid block is k_map_finalize's business: raw points, see there)
         }
-        const int pos = atomicAdd(&T.rec[s].pend_cnt, 1);
-        if (pos < kPendCap) T.pend[(size_t)s * kPendCap + pos] = i; else atomicOr(&fr->error, kErrMapFull);
-        if (pos == 0) {
-          const int tpos = atomicAdd(&fr->n_touched[kind], 1);
-          if (tpos < cap) touched[tpos] = (int)s; else atomicOr(&fr->error, kErrMapFull);
-        }
-        done = true;   // (whether the cube is inside the valid block is k_map_finalize's business: raw points, see there)
+      }
+      atomicOr(&fr->error, kErrMapFull);
+      return -1;
+    };
+    const int first = insert_point();
+    // touched list: one counter update per wavefront instead of one per voxel on the same word
+    const u64 tm = __ballot(first >= 0);
+    if (tm != 0ull) {
+      const int leader = __ffsll((long long)tm) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&fr->n_touched[kind], __popcll(tm));
+      base = __shfl(base, leader);
+      if (first >= 0) {
+        const int tpos = base + __popcll(tm & ((1ull << lane) - 1ull));
+        if (tpos < cap) touched[tpos] = first; else atomicOr(&fr->error, kErrMapFull);
       }
     }
-    if (!done) atomicOr(&fr->error, kErrMapFull);
   }
 }
 
