@@ -24,4 +24,12 @@ for name, st, item in (("LO round 0", 1, 2), ("LO round 1", 1, 18), ("map round 
     c = r["cyc"]
     print("%-12s factors %5d  iterations %d  evaluations %d  | cycles: factor loops %7.0f  evaluations %7.0f  serial %7.0f  whole solve %7.0f  (other %7.0f)" %
           (name, r["n_factors"], int(r["trace"].shape[0]), r["n_evals"], c[0], c[1], c[2], c[3], c[3] - c[1] - c[2]))
+if os.environ.get("VLOAM_LM_STAMPS_BUILD"):   # library built with -DVLOAM_LM_STAMPS: thread 0's serial sections, summed over the iterations
+    from vloam_amd import LMRecord, K_LM_MAX_TRACE
+    for name, st, item in (("LO round 0", 1, 2), ("map round 0", 2, 3)):
+        raw = h.debug_raw(st, item, np.uint8)
+        rec = LMRecord.from_buffer_copy(raw.tobytes())
+        row = np.ctypeslib.as_array(rec.trace).reshape(K_LM_MAX_TRACE, 8)[100]
+        print("%-12s serial sections (cycles, all iterations): bookkeeping+LDS reads %6.0f  1/radius+diagonal %6.0f  Cholesky %6.0f  model cost+step %6.0f  plus %6.0f | acceptance %6.0f" %
+              (name, row[1], row[2], row[3], row[4], row[5], row[7]))
 h.close()

@@ -319,15 +319,15 @@ struct LmShared {
   double red[kAcc * kRedStride];  // [value][thread] transpose buffer of the block reduction (rows padded against bank conflicts)
   double part[8 * kAcc];          // [sub-sum][value]
   double acc2[2][kAcc];  // accumulators at x (acc2[curidx]) and at the candidate (acc2[curidx ^ 1]): accepting a step flips the index
-  double Hs[21], gs[6];  // Jacobi-scaled normal equations of the current point (packed lower triangle), refreshed when the point changes
+  double Hs[2][21], gs[2][6], diag[2][6];  // Jacobi-scaled normal equations + clamped LM diagonal, one set per accumulator buffer (acc2): the candidate's set is prepared while thread 0 decides whether to accept it
   int curidx;
   double x[8], xc[8];
   double mcc;          // model_cost_change of the pending candidate
   double gmax_c, xnorm_c;  // gradient max-norm / |x| at the point just evaluated (computed by helper lanes in parallel)
-  double scale[6], diagonal[6], best[8];  // trust-region state that must survive the evaluations (kept out of registers)
+  double scale[6], best[8];  // trust-region state that must survive the evaluations (kept out of registers)
   int scan[kLmThreads], scan2[kLmThreads];
   int n_edge;
-  int go;              // 1: evaluate candidate next, 0: finished
+  int go, go2;         // 1: evaluate candidate next / go on to the next step, 0: finished (one word per hand-over: the loop has no barrier between the acceptance and the next step)
   int n_valid;
   int failed;          // cooperative solve: a workgroup gave up waiting at the grid barrier -> every workgroup abandons the solve
   double x0[8];        // the parameters the solve started from (what an abandoned solve hands back)
@@ -893,6 +893,12 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   cyc_eval += clock64() - t_mark;
   if (MODE != kLmRowMask && NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone has published its first partial sums, i.e. is past its prologue
 
+#ifdef VLOAM_LM_STAMPS   // debug build only: where thread 0's serial sections spend their cycles (sums over the iterations -> trace rows 100, 101)
+  long long lm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lm_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LM_STAMP(k) do { lm_t[k] = clock64(); if ((k) > 0 && (k) != 6) lm_sum[k] += lm_t[k] - lm_t[(k) - 1]; } while (0)
+#else
+#define LM_STAMP(k) do { } while (0)
+#endif
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
   int num_invalid = 0, iteration = 0, n_rec = 0, termination = 0, n_evals = 1;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   // triangle), gs = S g, and the clamped LM diagonal — by 27 lanes of wavefront 3 at once, whenever the point changes (the start and
   // every accepted step; rejected steps keep all three, which is Ceres' reuse_diagonal).  The trust-region step of thread 0 then
   // starts from 33 LDS reads instead of rebuilding ~150 products on one lane.  jacobi_scaling is fixed at iteration 0.
-  auto refresh_normal_equations = [&](const double* acc, bool first) {
+  auto refresh_normal_equations = [&](const double* acc, bool first, int buf) {
     const int j = tid - 192;
     if (j < 0 || j >= 27) return;
     if (j < 21) {
@@ -930,17 +936,17 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       const int b = j - a * (a + 1) / 2;   // j == LIDX(a, b), a >= b
       const double sa = first ? 1.0 / (1.0 + sqrt(acc[7 + a * 6 - (a * (a - 1)) / 2])) : sh.scale[a];
       const double sb = first ? 1.0 / (1.0 + sqrt(acc[7 + b * 6 - (b * (b - 1)) / 2])) : sh.scale[b];
-      sh.Hs[j] = acc[7 + b * 6 - (b * (b - 1)) / 2 + (a - b)] * sa * sb;
+      sh.Hs[buf][j] = acc[7 + b * 6 - (b * (b - 1)) / 2 + (a - b)] * sa * sb;
     } else {
       const int a = j - 21;
       const double haa = acc[7 + a * 6 - (a * (a - 1)) / 2];
       const double sa = first ? 1.0 / (1.0 + sqrt(haa)) : sh.scale[a];
       if (first) sh.scale[a] = sa;
-      sh.gs[a] = acc[1 + a] * sa;
-      sh.diagonal[a] = fmin(fmax(haa * sa * sa, 1e-6), 1e32);
+      sh.gs[buf][a] = acc[1 + a] * sa;
+      sh.diag[buf][a] = fmin(fmax(haa * sa * sa, 1e-6), 1e32);
     }
   };
-  refresh_normal_equations(sh.acc2[0], true);
+  refresh_normal_equations(sh.acc2[0], true, 0);
   if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.acc2[0]);
   if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
   __syncthreads();
@@ -970,6 +976,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   for (; !failed_at_start;) {
     t_mark = clock64();
     if (tid == 0) {
+      LM_STAMP(0);
       int go = -1;  // -1: invalid step, loop again inside thread 0; 0: stop; 1: evaluate the candidate
       while (go < 0) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -990,13 +997,16 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         // (Hs + D / radius) y = gs by Cholesky, step = -y
         double gs[6], dg[6], L[21], y[6], sc6[6];
 #pragma unroll
-        for (int i = 0; i < 21; i++) L[i] = sh.Hs[i];  // one batch of independent LDS reads
+        for (int i = 0; i < 21; i++) L[i] = sh.Hs[curidx][i];  // one batch of independent LDS reads
 #pragma unroll
-        for (int a = 0; a < 6; a++) { gs[a] = sh.gs[a]; dg[a] = sh.diagonal[a]; sc6[a] = sh.scale[a]; }
+        for (int a = 0; a < 6; a++) { gs[a] = sh.gs[curidx][a]; dg[a] = sh.diag[curidx][a]; sc6[a] = sh.scale[a]; }
+        LM_STAMP(1);   // bookkeeping + trace row + LDS reads issued
         const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int a = 0; a < 6; a++) { dg[a] = dg[a] * inv_radius; L[LIDX(a, a)] += dg[a]; }
+        LM_STAMP(2);   // reciprocal radius, damped diagonal
         bool ok = chol6_solve(L, gs, y);
+        LM_STAMP(3);   // Cholesky solve
 #pragma unroll
         for (int a = 0; a < 6; a++) ok = ok && isfinite(y[a]);
         double model_cost_change = 0;
@@ -1021,9 +1031,11 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         double delta[6];
 #pragma unroll
         for (int a = 0; a < 6; a++) delta[a] = -y[a] * sc6[a];
+        LM_STAMP(4);   // model cost change, step
         lm_plus_t<QUAT>(sh.x, delta, sh.xc);
         sh.mcc = model_cost_change;
         go = 1;
+        LM_STAMP(5);   // plus
       }
       sh.go = go;
     }
@@ -1036,11 +1048,14 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     cyc_eval += clock64() - t_mark;
     if (NB > 1 && sh.failed) break;  // uniform across the workgroup; every workgroup that still waits sees the poison word
     t_mark = clock64();
-    // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test
+    // speculative (used only if the step is accepted), concurrent with thread 0's acceptance test: gradient norm, |x|, and — on
+    // wavefront 3 — the candidate's scaled normal equations into the set that goes with its accumulators
     if (tid == 64) sh.gmax_c = grad_max(sh.xc, cand);
     if (tid == 128) sh.xnorm_c = x_norm_of(sh.xc);
+    refresh_normal_equations(cand, false, curidx ^ 1);
     bool accepted = false;
     if (tid == 0) {
+      LM_STAMP(6);
       n_evals++;
       const double model_cost_change = sh.mcc;
       double candidate_cost = cand[0];
@@ -1075,17 +1090,14 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
           it_cost = candidate_cost;
         }
       }
-      sh.go = stop ? 0 : 1;
+      sh.go2 = stop ? 0 : 1;
+      LM_STAMP(7);   // acceptance test
     }
     __syncthreads();
     if (accepted) { gmax = sh.gmax_c; x_norm = sh.xnorm_c; }
     cyc_serial += clock64() - t_mark;
-    if (sh.go == 0) break;
-    if (sh.curidx != curidx) {   // accepted (uniform): new point -> new scaled normal equations and LM diagonal
-      curidx ^= 1;
-      refresh_normal_equations(sh.acc2[curidx], false);
-    }
-    __syncthreads();
+    if (sh.go2 == 0) break;
+    curidx = sh.curidx;   // accepted (uniform): the candidate's accumulators and its prepared normal equations become the current point's
   }
 
   if (tid == 0 && lead) {
@@ -1106,6 +1118,9 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
     (void)t_pro; rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
     rec->cyc[3] = (double)(clock64() - t_start);
+#ifdef VLOAM_LM_STAMPS
+    for (int k = 0; k < 8; k++) rec->trace[100][k] = (double)lm_sum[k];
+#endif
     if constexpr (NB > 1) __hip_atomic_store(reinterpret_cast<u64*>(F.gsync), gen + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next solve, next generation
   }
 }

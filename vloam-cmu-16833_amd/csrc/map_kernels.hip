@@ -883,15 +883,20 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
   if (slot >= kMapFactorCap) return;
   const int kind = slot < kStackCapCorner ? 0 : 1;
   const int i = kind ? slot - kStackCapCorner : slot;
+  // the slot's inputs are requested together with the sweep's scalars, not behind them (every slot of the arrays is valid memory):
+  // one memory round trip in front of the arithmetic instead of three
+  float4 nb[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) nb[j] = nbr[slot * 5 + j];
+  const float4 pointOri = kind ? stack1[i] : stack0[i];
   const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
   int type = 0;
   (void)T0; (void)T1;
-  if (ms->do_optimize && i < nst && nbr[slot * 5].w != 0.0f) {
-    const float4 pointOri = kind ? stack1[i] : stack0[i];
+  if (ms->do_optimize && i < nst && nb[0].w != 0.0f) {
     double P[5][3];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      const float4 p = nbr[slot * 5 + j];
+      const float4 p = nb[j];
       P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
     }
     double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
@@ -1024,12 +1029,15 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
   const int n = kind ? ms->n_surf_stack : ms->n_corner_stack;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
   const int lane = threadIdx.x & 63;
+  // the thread's first stack point is requested together with the stack size, not behind it (the stale tail of the array is valid memory)
+  const int i_first = blockIdx.x * 256 + threadIdx.x;
+  const float4 p_first = stack[i_first < cap ? i_first : 0];
   for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += gridDim.x * 256) {   // wavefront-uniform
     const int i = i0 + lane;
     // returns the slot if this point is the first of the sweep in its voxel (the voxel joins the touched list), else -1
     auto insert_point = [&]() -> int {
       if (i >= n) return -1;
-      const float4 p = associate_to_map(stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
+      const float4 p = associate_to_map(i == i_first ? p_first : stack[i], ms->parameters, ms->parameters + 4);  // LM:641 / LM:664
       smap[i] = p;
       const int Ai = cube_abs((double)p.x), Aj = cube_abs((double)p.y), Ak = cube_abs((double)p.z);
       const int wi = Ai + ms->cenW, wj = Aj + ms->cenH, wk = Ak + ms->cenD;  // == cubeI, cubeJ, cubeK of LM:643-652
@@ -1083,13 +1091,14 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
   const float4* smap = kind ? smap1 : smap0;
   const int* touched = kind ? touched1 : touched0;
   const int cap = kind ? kStackCapSurf : kStackCapCorner;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int s_spec = touched[t < cap ? t : 0];   // requested together with the list's length, not behind it (stale entries are valid slots)
   const int nt = min(fr->n_touched[kind], cap);
   const int cI = ms->centerCube[0], cJ = ms->centerCube[1], cK = ms->centerCube[2];
-  const int t = blockIdx.x * 256 + threadIdx.x;
   int* deferred = kind ? deferred1 : deferred0;
   int* newraw = kind ? newraw1 : newraw0;
   if (t < nt) {
-    const int s = touched[t];
+    const int s = s_spec;
     int idx[kPendCap];
     const RecVal rv = rec_load(&T.rec[s]);
     const int np = min(rv.pend_cnt, kPendCap);
