@@ -883,20 +883,15 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
   if (slot >= kMapFactorCap) return;
   const int kind = slot < kStackCapCorner ? 0 : 1;
   const int i = kind ? slot - kStackCapCorner : slot;
-  // the slot's inputs are requested together with the sweep's scalars, not behind them (every slot of the arrays is valid memory):
-  // one memory round trip in front of the arithmetic instead of three
-  float4 nb[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) nb[j] = nbr[slot * 5 + j];
-  const float4 pointOri = kind ? stack1[i] : stack0[i];
   const int nst = kind ? ms->n_surf_stack : ms->n_corner_stack;
   int type = 0;
   (void)T0; (void)T1;
-  if (ms->do_optimize && i < nst && nb[0].w != 0.0f) {
+  if (ms->do_optimize && i < nst && nbr[slot * 5].w != 0.0f) {
+    const float4 pointOri = kind ? stack1[i] : stack0[i];
     double P[5][3];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      const float4 p = nb[j];
+      const float4 p = nbr[slot * 5 + j];
       P[j][0] = p.x; P[j][1] = p.y; P[j][2] = p.z;
     }
     double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
