@@ -379,8 +379,9 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
                                                        DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
                                                        StackInfo* __restrict__ fr, size_t ss) {
   VL_SESSION(ss); RB(corner_last); RB(surf_last); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
-  __shared__ int s_idx[4][1024];
-  __shared__ int s_sorted[4][1024];
+  constexpr int kBigVoxel = 256;   // sweep points of one voxel sorted in LDS (above: the serial fallback); 8 KB per workgroup, so that LDS does not cap the occupancy of the common (<= 64 points, registers only) case
+  __shared__ int s_idx[4][kBigVoxel];
+  __shared__ int s_sorted[4][kBigVoxel];
   const int kind = blockIdx.y;
   const DsScratch D = kind ? D1 : D0;
   const float4* pts = kind ? surf_last : corner_last;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
         const int src = __ffsll((long long)__ballot(rank == r && lane < cnt)) - 1;
         sx += rl(p.x, src); sy += rl(p.y, src); sz += rl(p.z, src); si += rl(p.w, src);
       }
-    } else if (cnt <= 1024) {
+    } else if (cnt <= kBigVoxel) {
       for (int j = lane; j < cnt; j += 64) s_idx[wave][j] = D.seg[b0 + j];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
         const float4 p = lane < m ? pts[s_sorted[wave][c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
       }
-    } else {  // > 1024 sweep points in one voxel: serial fallback in global memory
+    } else {  // more sweep points than that in one voxel: serial fallback in global memory
       int* b = D.seg + b0;
       if (lane == 0) {
         for (int a = 1; a < cnt; a++) { const int v = b[a]; int c = a - 1; while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; } b[c + 1] = v; }
