@@ -279,7 +279,20 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       int lo_p = 0, hi_p = 0, pr[4] = {0, 0, 0, 0};
       if (const char* e = getenv("VLOAM_STREAM_PRIO")) sscanf(e, "%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3]);
       if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }   // lo_p = numerically greatest = lowest priority
+      // VLOAM_RESERVE_CUS = "n[,stride]" (experiment): the scan-registration, odometry and VoxelGrid streams are created with a CU mask that
+      // leaves n compute units (every stride-th bit from 0) to the mapping stream alone
+      int rsv = 0, rstride = 1;
+      if (const char* e = getenv("VLOAM_RESERVE_CUS")) sscanf(e, "%d,%d", &rsv, &rstride);
+      hipDeviceProp_t prop;
+      const int ncu = (rsv > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
       auto mk = [&](hipStream_t* s, int which) {
+        if (ncu > 0 && which != 2) {
+          uint32_t mask[16];
+          for (int w = 0; w < 16; w++) mask[w] = 0;
+          for (int c = 0; c < ncu && c < 512; c++) mask[c >> 5] |= 1u << (c & 31);
+          for (int k = 0, c = 0; k < rsv && c < ncu; k++, c += rstride) mask[c >> 5] &= ~(1u << (c & 31));
+          return hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess;
+        }
         const int p = pr[which] > 0 ? hi_p : (pr[which] < 0 ? lo_p : 0);
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess;
       };

@@ -119,13 +119,14 @@ struct MapContext {
     rbp(m.state, off); rbp(m.frame, off); m.tab[0].rebase(off); m.tab[1].rebase(off); rbp(m.cube_cnt, off); m.ds[0].rebase(off); m.ds[1].rebase(off);
     for (int c = 0; c < kSets; c++) { rbp(m.stack_sets[c][0], off); rbp(m.stack_sets[c][1], off); rbp(m.stack_info[c], off); }
     for (int k = 0; k < 2; k++) { rbp(m.stack[k], off); rbp(m.stack_map[k], off); rbp(m.touched[k], off); rbp(m.deferred[k], off); rbp(m.newraw[k], off); m.F[k].rebase(off); }
-    rbp(m.rec, off); rbp(m.nbr, off); rbp(m.cbox, off); rbp(m.ccand, off); rbp(m.registered, off); rbp(m.assoc_cyc, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
+    rbp(m.rec, off); rbp(m.nbr, off); rbp(m.cbox, off); rbp(m.ccand, off); rbp(m.registered, off); rbp(m.assoc_cyc, off); rbp(m.ts_log, off); rbp(m.rebuild_tmp, off); rbp(m.rebuild_n, off);
     if (m.host_flags) m.host_flags += 2 * b;
     m.se.B = 1; m.sel = 0;
     return m;
   }
   float4* registered = nullptr;  // full-resolution cloud in the map frame, on request
   long long* assoc_cyc = nullptr;  // [2][8] debug: phase cycle sums of k_map_assoc per outer round
+  long long* ts_log = nullptr;     // [1024][2] VLOAM_TS_LOG=1: constant-rate (100 MHz) clock at the start of k_map_prepare / end of k_map_finalize of sweep k % 1024
   int max_points = 0;
   float inv_leaf[2] = {0, 0};
 };

@@ -124,8 +124,9 @@ __device__ __forceinline__ void dquat_rot(const double* q, const double* v, doub
 // ---------------------------------------------------------------------------------------------- prepare
 __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr, const LOState* lo, int* cube_cnt, int skip_frame,
                                                      double* traj_row14, StackInfo* si, int* deferred0, int* deferred1, const int* newraw0,
-                                                     const int* newraw1, size_t ss) {
-  VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si); RB(deferred0); RB(deferred1); RB(newraw0); RB(newraw1);
+                                                     const int* newraw1, long long* ts_log, size_t ss) {
+  VL_SESSION(ss); RB(ms); RB(fr); RB(lo); RB(cube_cnt); RB(traj_row14); RB(si); RB(deferred0); RB(deferred1); RB(newraw0); RB(newraw1); RB(ts_log);
+  const long long ts_begin = ts_log ? (long long)wall_clock64() : 0;
   __shared__ int shift[3], s_cen[3];
   const int tid = threadIdx.x;
   // Every load that does not depend on another one is issued up front (one memory round trip for the lot): this launch is a single
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
       ms->n_corner_stack = nst[0]; ms->n_surf_stack = nst[1];
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
       ms->sweep_no = sweep_no + 1;
+      if (ts_log) ts_log[2 * (sweep_no & 1023)] = ts_begin;
     }
     fr->rolled = rolled;
   }
@@ -1078,9 +1080,10 @@ __global__ __launch_bounds__(256) void k_map_finalize(const float4* __restrict__
                                                       VoxelTable T1, MapState* ms, MapFrame* fr,
                                                       const int* __restrict__ touched0, const int* __restrict__ touched1,
                                                       int* __restrict__ deferred0, int* __restrict__ deferred1, int* __restrict__ newraw0,
-                                                      int* __restrict__ newraw1, int* __restrict__ cube_cnt, int* host_flags, size_t ss) {
+                                                      int* __restrict__ newraw1, int* __restrict__ cube_cnt, int* host_flags, long long* ts_log, size_t ss) {
   VL_SESSION(ss); RB(smap0); RB(smap1); T0.rebase(so_); T1.rebase(so_); RB(ms); RB(fr); RB(touched0); RB(touched1); RB(deferred0); RB(deferred1);
-  RB(newraw0); RB(newraw1); RB(cube_cnt);
+  RB(newraw0); RB(newraw1); RB(cube_cnt); RB(ts_log);
+  if (ts_log && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_log[2 * ((ms->sweep_no - 1) & 1023) + 1] = (long long)wall_clock64();   // START of the sweep's last launch
   if (host_flags) host_flags += 2 * blockIdx.z;   // host-mapped, one pair per session (not part of the arenas)
   const int kind = blockIdx.y;
   const VoxelTable T = kind ? T1 : T0;
@@ -1294,7 +1297,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
   ok = ok && A.take(&m->cbox, 2 * (size_t)kMapFactorCap) && A.take(&m->ccand, (size_t)kMapFactorCap * kCandCache);
   m->rebuild_cap = (int)(slots / 2);
   ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 1);
-  ok = ok && A.take(&m->registered, (size_t)cfg.max_points) && A.take(&m->assoc_cyc, 16);
+  ok = ok && A.take(&m->registered, (size_t)cfg.max_points) && A.take(&m->assoc_cyc, 16) && A.take(&m->ts_log, 2048);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
   m->inv_leaf[0] = 1.0f / cfg.mapping_line_resolution;   // inverse_leaf_size_ of downSizeFilterCorner (LM:100)
@@ -1359,6 +1362,7 @@ vloam_status map_force_rebuild(MapContext* m, hipStream_t st) {
   return VLOAM_OK;
 }
 
+static const bool g_ts_log = getenv("VLOAM_TS_LOG") != nullptr;   // debug: device-side time stamps of the mapping stage (tools/map_stream_gaps.py)
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
                          bool skip_frame, int set, ProfHook* ph, hipEvent_t done) {
   (void)cur;
@@ -1381,7 +1385,7 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   }
   // `done` (mapping of this sweep finished) rides on the sweep's last dispatch: a marker packet behind it costs ~5 us of idle stream
   VLOAM_LAUNCH_EV(ph, kKMapPrepare, st, skip_frame ? done : nullptr, k_map_prepare, dim3(1, 1, Z), dim3(256), 0, st, ms, fr, lo, m->cube_cnt,
-                  skip_frame ? 1 : 0, traj_row14, m->stack_info[set], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], ss);
+                  skip_frame ? 1 : 0, traj_row14, m->stack_info[set], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], g_ts_log ? m->ts_log : (long long*)nullptr, ss);
   if (skip_frame) return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
   for (int outer = 0; outer < 2; outer++) {  // LM:458
     // lanes per query of the 5-NN search: a batch fills the chip with 16-lane groups (four queries per wavefront); a single sequence
@@ -1406,7 +1410,7 @@ vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st,
   VLOAM_LAUNCH(ph, kKMapInsert, st, k_map_insert, dim3(64, 2, Z), dim3(256), 0, st, m->stack[0], m->stack[1], m->stack_map[0], m->stack_map[1],
                m->tab[0], m->tab[1], m->inv_leaf[0], m->inv_leaf[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], traj_row14, ss);
   VLOAM_LAUNCH_EV(ph, kKMapFinalize, st, done, k_map_finalize, dim3(kStackCapSurf / 256, 2, Z), dim3(256), 0, st, m->stack_map[0], m->stack_map[1],
-                  m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], m->cube_cnt, m->host_flags, ss);
+                  m->tab[0], m->tab[1], ms, fr, m->touched[0], m->touched[1], m->deferred[0], m->deferred[1], m->newraw[0], m->newraw[1], m->cube_cnt, m->host_flags, g_ts_log ? m->ts_log : (long long*)nullptr, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
@@ -1544,6 +1548,7 @@ vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, l
     if (buf && c) memcpy(buf, rows.data(), c);
     return VLOAM_OK;
   }
+  if (item == 72) return copy_dev(m->ts_log, sizeof(long long) * 2048, buf, cap, n);   // VLOAM_TS_LOG=1: [sweep % 1024][prepare start, finalize start], 100 MHz ticks
   if (item == 71) return copy_dev(m->assoc_cyc, sizeof(long long) * 16, buf, cap, n);   // k_map_assoc phase cycles (debug handles): [outer][6 phases, spare, wavefronts]
   if (item == 69) {  // table health: {keys, purged, block keys, spare} x {corner, surf}, rebuilds, largest candidate list
     int out[12] = {0};
