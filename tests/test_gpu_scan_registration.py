@@ -173,9 +173,10 @@ def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
 
 
 def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
-    """k_sr_ring runs as a 2176-point tier (two rings per CU) plus, only while needed, the 4096-point tier: always during the first 8
-    sweeps, afterwards once a ring has come within 32 points of the small tier's capacity (host-mapped watch word).  Rings that grow
-    from 1 792 over 2 160 to 2 300 points across the 8-sweep mark must come out of the right tier: features equal the oracle's."""
+    """k_sr_ring runs as a 2176-point tier (two rings per CU) plus the 4096-point tier: its full grid during the first 8 sweeps and once a
+    ring has come within 32 points of the small tier's capacity (host-mapped watch word), otherwise one catch-all workgroup that only
+    works on rings the small tier had to leave.  Rings that grow from 1 792 over 2 160 to 2 300 points across the 8-sweep mark must come
+    out of the right tier: features equal the oracle's."""
     def sweep(n_az, k):
         return synth.SynthSequence(n_rings=64, n_azimuth=n_az, n_sweeps=k + 1).sweep(k)
     h = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
@@ -199,3 +200,28 @@ def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
             h2.process_scan(sweep(1024 if k < 10 else 2300, k))
         h2.sync()
     assert e.value.status == vl.ERR_CAPACITY
+    # ... unless the handle was created with the catch-all workgroup of the big tier (VLOAM_SR_CATCHALL=1: every sweep pays a launch
+    # for it): then such a ring is processed, features equal the oracle's
+    import os
+    os.environ["VLOAM_SR_CATCHALL"] = "1"
+    try:
+        h3 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+        h4 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+    finally:
+        del os.environ["VLOAM_SR_CATCHALL"]
+    for k in range(13):
+        cloud = sweep(1024 if k < 10 else 2300, k)
+        h3.reset_frame()
+        h3.scan_registration(cloud)
+        if k >= 9:
+            o = orc.Oracle(with_mapping=False)
+            assert o.scan_registration(cloud) == 0
+            sc = o.sr_scalars()
+            flips = check_cloud(h3.features(0), o.cloud(0), "laserCloud sweep %d" % k, unwrap_bounds(sc["startOri"], sc["endOri"]))
+            for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+                check_cloud(h3.features(which), o.cloud(which), "%s sweep %d (jump without warning)" % (name, k), max_flips=flips)
+        h3.laser_odometry()
+    h3.sync()
+    for k in range(14):   # streamed: the host runs ahead of the kernels and of the watch word
+        h4.process_scan(sweep(1024 if k < 10 else 2300, k))
+    h4.sync()

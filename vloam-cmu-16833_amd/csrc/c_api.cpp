@@ -71,6 +71,7 @@ struct vloam_handle {
   Sess se;
   int sel = 0;          // session the getters read (vloam_select_session)
   double* sync_pool = nullptr;
+  bool ring_catchall = false;  // VLOAM_SR_CATCHALL=1 at create: a catch-all workgroup of the big ring tier behind the small tier on every sweep (sr_launch)
   int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
@@ -270,6 +271,7 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   vloam_handle* h = new vloam_handle;
   h->cfg = *cfg;
   h->device = device;
+  h->ring_catchall = getenv("VLOAM_SR_CATCHALL") && atoi(getenv("VLOAM_SR_CATCHALL")) != 0;
   *out = nullptr;
   vloam_status st = VLOAM_OK;
   do {
@@ -456,7 +458,7 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   bool big_tier = k < 8;   // nothing is known about the ring lengths yet
   for (int b = 0; b < h->se.B; b++) big_tier = big_tier || __atomic_load_n(&h->ring_watch[b], __ATOMIC_RELAXED) != 0;
   HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug, &h->prof,
-                   h->ev_sr[cur], h->ring_watch, big_tier));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
+                   h->ev_sr[cur], h->ring_watch, big_tier, h->ring_catchall));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
   lo_grid_build_launch(h->stream, h->se, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);

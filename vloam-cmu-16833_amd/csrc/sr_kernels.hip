@@ -455,7 +455,10 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   int* s_zone = s_leak_hi + 8;                                       // [kSectors] incoming spill the sector was computed with
   int* s_any = s_zone + 8;
 
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // One workgroup per ring (gridDim.x == kMaxRings) — or, as the catch-all behind the small tier on sweeps for which the host has
+  // not launched the full big tier, ONE workgroup per session that walks the rings and works on the (normally zero) oversized ones.
+  auto one_ring = [&](const int r) {
   long long tstamp[8];
   int nstamp = 0;
 #define SR_STAMP() do { if (dbg_cyc) tstamp[nstamp] = clock64(); nstamp++; } while (0)
@@ -466,9 +469,10 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   if (tid < kSectors * 3) (&S->sect_cnt[r][0][0])[tid] = 0;
   if (tid == 0) S->ring_ds_cnt[r] = 0;
   // The big tier asks for 146 KB of LDS just to start, which on a busy chip (batches) costs tens of microseconds even when it has
-  // nothing to do: the host only launches it while rings near the small tier's capacity have been seen (ring_watch, a host-mapped
-  // word it polls without synchronising) or during the first sweeps.  A ring that outgrows the small tier without that warning
-  // (it would have to jump from < kRingWatch to > kRingCapSmall points between two sweeps) is reported, not dropped silently.
+  // nothing to do: the host only launches its full grid while rings near the small tier's capacity have been seen (ring_watch, a
+  // host-mapped word it polls without synchronising) or during the first sweeps; otherwise a single catch-all workgroup per session
+  // follows the small tier, so that a ring which outgrows the small tier without that warning is still processed (slowly: the rings
+  // one after the other, until the host has seen the watch word).
   if (!BIG_TIER && tid == 0 && len > kRingWatch && ring_watch) __hip_atomic_store(&ring_watch[blockIdx.z], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (len > CAP) { if ((BIG_TIER || !big_follows) && tid == 0) atomicOr(&S->error, kErrRingTooLong); return; }   // small tier: left to the big tier
   if (end - start < 6) return;  // SR:314
@@ -919,6 +923,23 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     dbg_cyc[r * 8 + 7] = (long long)nrun | ((long long)nvox << 16) | ((long long)len << 32) | ((long long)ncand << 48);
   }
 #undef SR_STAMP
+  };
+  // one workgroup per ring — or the catch-all: which rings are oversized (one load per lane, the same answer in every wavefront; normally
+  // none, and the launch ends here).  ONE call site: a second copy of the ring body costs the small tier 50 VGPRs, i.e. its second
+  // workgroup per CU.
+  static_assert(kMaxRings == 64, "one ring per lane");
+  if constexpr (!BIG_TIER) {
+    one_ring((int)blockIdx.x);   // (straight-line: a loop around the body costs this tier 50 VGPRs, i.e. its second workgroup per CU)
+  } else {
+    unsigned long long todo = 1ull << (blockIdx.x & 63);
+    if (gridDim.x != kMaxRings) todo = __ballot(S->ring_count[lane] > kRingCapSmall);
+    while (todo != 0ull) {
+      const int r = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      one_ring(r);
+      if (todo != 0ull) __syncthreads();   // the ring's LDS is no longer read
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1003,7 +1024,7 @@ hipError_t sr_init() {
 }
 
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, int debug_level, ProfHook* ph, hipEvent_t done,
-                     int* ring_watch, bool big_tier) {
+                     int* ring_watch, bool big_tier, bool catchall) {
   const bool debug = debug_level == 1, stamps = debug_level != 0;   // debug = 2: only the ring kernel's phase stamps (no reference-order debug sort)
   int n = 0;
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
@@ -1016,12 +1037,16 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
                slice, nslice, blk, se.ss);
   VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  // catchall (VLOAM_SR_CATCHALL=1 at vloam_create): one workgroup of the big tier follows the small tier on every sweep, so that a ring that
+  // outgrows the small tier without the watch word's warning is processed instead of reported.  Off by default: the launch does nothing on
+  // ordinary sweeps and still costs 13 - 16 us of single-sweep latency (its 146 KB LDS request) and 1.4 % of the B = 8 throughput.
   VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, big_tier ? 1 : 0, se.ss);
-  if (big_tier)
-    VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
+               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, (big_tier || catchall) ? 1 : 0, se.ss);
+  // the full big tier while rings near the small tier's capacity are around, else its one-workgroup catch-all
+  if (big_tier || catchall)
+  VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(big_tier ? kMaxRings : 1, 1, Z), dim3(kRingThreads),
                  (sr_ring_smem_bytes<kMaxRingLen, kSectCap>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                  b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                  debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
