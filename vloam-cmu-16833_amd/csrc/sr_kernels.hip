@@ -46,11 +46,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
-// LDS hand-over between lanes of one wavefront without waiting for the wavefront's global stores (a workgroup-scope fence does)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // SR:157 removeNaNFromPointCloud + SR:100-129 removeClosedPointCloud
 __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float thres) {
