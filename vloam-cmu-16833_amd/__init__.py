@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libvloam_hip.so")
+# VLOAM_HIP_LIB: another build of the SAME library (A/B runs of kernel variants, stamp builds); never a different implementation
+LIB_PATH = os.environ.get("VLOAM_HIP_LIB") or os.path.join(_DIR, "libvloam_hip.so")
 
 VLOAM_OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY, ERR_NO_DEVICE, ERR_ORDER = 0, -1, -2, -3, -4, -5, -6
 

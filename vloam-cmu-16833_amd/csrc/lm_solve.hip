@@ -107,6 +107,18 @@ __device__ void angle_axis_rotate(const Dual6* w_, const Dual6* pt, Dual6* out) 
 }
 
 
+// Cooperative solves of a single sequence are launched 8 x wide and every eighth workgroup works: the dispatcher deals workgroups to the
+// eight XCDs round-robin, so the NB working ones share ONE XCD and an exchange of partial sums costs 1 350 / 1 600 cycles (NB = 4 / 6)
+// instead of 2 200 / 3 100 across XCDs (tools/microbench/solver_limits.hip, profiles/r04_solver_limits.txt) — same arithmetic, same
+// results.  The scan-to-scan and the scan-to-map solves, which overlap in time, sit on different XCDs (2 and 6).  Returns the index of this
+// workgroup among the working ones, -1: nothing to do.  (Round 3 tried this for batches too: there it crowds all solves of a session
+// into one XCD's 32 compute units and loses; a batch keeps the plain launch, where session s already owns XCD s % 8.)
+template <int NB, int MODE>
+__device__ __forceinline__ int lm_coop_block() {
+  const int b = (int)blockIdx.x;
+  if (NB > 1 && (int)gridDim.x == NB * 8) { const int xcd = MODE == 1 ? 2 : 6; return (b & 7) != xcd ? -1 : (b >> 3); }
+  return b;
+}
 __device__ __forceinline__ double wave_sum(double v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
@@ -418,7 +430,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   static_assert(NB == 1 || QUAT, "the cooperative form exists for the quaternion problems");
   constexpr bool DIRECT = MODE == kLmDirect;
   const int tid = threadIdx.x;
-  const int blk = NB > 1 ? (int)blockIdx.x : 0;
+  const int blk = NB > 1 ? lm_coop_block<NB, MODE>() : 0;
   const int vt = blk * kLmThreads + tid;     // lane of the virtual workgroup
   constexpr int VT = NB * kLmThreads;
   const long long tf0 = clock64();
@@ -821,9 +833,10 @@ template <bool QUAT, int MODE, int NB>
 __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
   VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
+  if (NB > 1 && lm_coop_block<NB, MODE>() < 0) return;   // single sequence: only the workgroups of the solve's XCD work (lm_coop_block)
   __shared__ LmShared sh;
   const int tid = threadIdx.x;
-  const bool lead = NB == 1 || blockIdx.x == 0;  // the workgroup that owns every global side effect other than its factors' residuals
+  const bool lead = NB == 1 || lm_coop_block<NB, MODE>() == 0;  // the workgroup that owns every global side effect other than its factors' residuals
   constexpr int na = QUAT ? 7 : 6;
   // the gate word, the parameters, this lane's first row counter and the solve generation are fetched in ONE round trip (a branch on
   // the gate first would put a dependent ~1.5 us memory trip in front of everything else the solve reads)
@@ -1241,9 +1254,11 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
   static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
   const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1);
   if (!direct && !rowmask) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
+  static const int one_xcd = getenv("VLOAM_LM_ONE_XCD") ? atoi(getenv("VLOAM_LM_ONE_XCD")) : 1;   // A/B switch, see lm_coop_block
+  const unsigned spread = (one_xcd && se.B == 1) ? 8u : 1u;
 #define VL_SOLVE(Q, M, N)                                                                                                                   \
-  VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<Q, M, N>), dim3(N, 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, d_rec, max_iters, \
-                  huber_a, d_enable, fin_lo, fin_traj, se.ss)
+  VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<Q, M, N>), dim3((N) > 1 ? (N) * spread : (N), 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, \
+                  d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj, se.ss)
   if (direct && coop) VL_SOLVE(true, kLmDirect, kCoop);
   else if (direct) VL_SOLVE(true, kLmDirect, 1);
   else if (rowmask && coop) {

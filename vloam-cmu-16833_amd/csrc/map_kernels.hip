@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
   // voxels that turned raw in the previous sweep join the list of raw voxels (k_map_finalize could not append to the list it compacts)
   if (nn0 > 0) for (int e = tid; e < nn0; e += 256) { if (nd0 + e < kStackCapCorner) deferred0[nd0 + e] = newraw0[e]; }
   if (nn1 > 0) for (int e = tid; e < nn1; e += 256) { if (nd1 + e < kStackCapSurf) deferred1[nd1 + e] = newraw1[e]; }
+  // every wavefront holds its copy of the four counters (and has issued its share of the merge) before thread 0 rewrites them below:
+  // the barrier's fence completes the loads above, so a wavefront that starts late can neither see the zeroed n_newraw nor the bumped n_deferred
+  __syncthreads();
   if (tid == 0) {
     if (nd0 + nn0 > kStackCapCorner || nd1 + nn1 > kStackCapSurf) { atomicOr(&fr->error, kErrMapFull); fr_err |= kErrMapFull; }
     if (nn0 | nn1) {
