@@ -221,7 +221,11 @@ void Problem::Solve(const SolveOptions& opt, double* p0, double* p1, SolveSummar
     if (!it.step_is_valid) {
       // ---- HandleInvalidStep
       if (++num_consecutive_invalid >= opt.max_num_consecutive_invalid_steps) { S.termination = 2; break; }
-      radius *= 0.5;  // LevenbergMarquardtStrategy::StepInvalid
+      // LevenbergMarquardtStrategy::StepIsInvalid (levenberg_marquardt_strategy.h) is "StepRejected(0.0)": the radius is divided by
+      // decrease_factor — which DOUBLES — not halved.  (Until round 4 this was a plain radius *= 0.5; the second transcription,
+      // tests/ceres_transcription.py, disagreed.  Identical for a first invalid step behind an accepted one; no test reaches the path.)
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
       reuse_diagonal = true;
       it.cost = x_cost; it.cost_change = 0; it.gradient_max_norm = S.iterations.back().gradient_max_norm;
       it.step_norm = 0; it.relative_decrease = 0; it.step_is_successful = false;

@@ -196,3 +196,152 @@ def test_kdtree_exact_vs_brute_force_and_scipy(orc):
     dup = np.concatenate([pts[:100], pts[:100]])
     it, _ = orc.knn(dup, pts[:100, :3], 1, use_tree=True)
     assert np.array_equal(it[:, 0], np.arange(100))
+
+
+# ---------------------------------------------------------------------------------------------------------------- second transcription of the LM loop
+def _rand_rot(rng, angle):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    h = 0.5 * angle
+    return np.concatenate([np.sin(h) * ax, [np.cos(h)]])      # (x, y, z, w)
+
+
+def _qrot(q, v):
+    u = q[:3]
+    uv = 2.0 * np.cross(u, v)
+    return v + q[3] * uv + np.cross(u, uv)
+
+
+def _random_se3_problem(rng, case):
+    """Edge + plane (+ plane-norm) factors around a true pose.  Eight classes: ordinary scan-matching problems (noise, 5-30 % gross outliers:
+    the Huber corrector is active), noise-free ones (they end on the gradient / parameter tolerances), outlier-heavy ones, and THIN ones — a
+    handful of factors with long lever arms started ~pi away — which are what makes Levenberg-Marquardt steps get rejected."""
+    cls = case % 8
+    # far_rot, far_t, noise, outlier share, outlier size, edges, planes, plane-norms, spread
+    cfg = [(rng.uniform(0.01, 0.6), 1.0, 2e-2, rng.uniform(0.05, 0.30), rng.uniform(0.5, 3.0), int(rng.integers(6, 30)), int(rng.integers(10, 50)), int(rng.integers(0, 20)), 20.0),
+           (rng.uniform(0.5, 1.6), 5.0, 5e-2, rng.uniform(0.05, 0.50), rng.uniform(0.5, 30.0), int(rng.integers(6, 30)), int(rng.integers(10, 50)), int(rng.integers(0, 20)), 20.0),
+           (0.3, 1.0, 0.0, 0.0, 0.0, 10, 20, 5, 20.0),
+           (3.0, 40.0, 0.0, 0.0, 0.0, 6, 12, 0, 20.0),
+           (3.1, 50.0, 0.0, 0.0, 0.0, 2, 3, 0, 100.0),
+           (3.1, 50.0, 0.02, 0.1, 2.0, 2, 3, 0, 100.0),
+           (3.1, 200.0, 0.01, 0.0, 0.0, 0, 8, 0, 100.0),
+           (3.1, 100.0, 0.05, 0.2, 5.0, 2, 4, 0, 100.0)][cls]
+    far_rot, far_t, noise, outlier_share, outlier_size, n_edge, n_plane, n_pn, spread = cfg
+    qt, tt = _rand_rot(rng, rng.uniform(0.0, 0.3)), rng.normal(size=3) * 0.5
+    rows = []
+    for k in range(n_edge + n_plane + n_pn):
+        p = rng.uniform(-spread, spread, size=3)
+        lp = _qrot(qt, p) + tt + rng.normal(size=3) * noise
+        if rng.uniform() < outlier_share:
+            lp = lp + rng.normal(size=3) * outlier_size
+        if k < n_edge:
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            rows.append([0, *p, *(lp + 0.5 * u), *(lp - 0.7 * u)])
+        elif k < n_edge + n_plane:
+            n = rng.normal(size=3); n /= np.linalg.norm(n)
+            e1 = np.cross(n, [1.0, 0.3, -0.2]); e1 /= np.linalg.norm(e1)
+            e2 = np.cross(n, e1)
+            rows.append([1, *p, *(lp + 0.4 * e1), *(lp - 0.5 * e1 + 0.6 * e2), *(lp - 0.3 * e1 - 0.7 * e2)])
+        else:
+            n = rng.normal(size=3); n /= np.linalg.norm(n)
+            rows.append([2, *p, *n, -float(np.dot(n, lp))])
+    q0 = _rand_rot(rng, far_rot)
+    # compose the start from the truth so that "far" means far from the minimiser
+    x1, y1, z1, w1 = q0; x2, y2, z2, w2 = qt
+    qs = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2,
+                   w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+    ts = tt + rng.normal(size=3) * far_t
+    return rows, qs, ts
+
+
+def _random_vo_problem(rng, case):
+    """CostFunctor32 / CostFunctor22 blocks (angle-axis + translation, identity parameterisation)."""
+    n32, n22 = int(rng.integers(8, 40)), int(rng.integers(0, 25))
+    noise = [0.0, 1e-4, 2e-3][case % 3]
+    w = rng.normal(size=3) * 0.05
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+    t = rng.normal(size=3) * 0.3
+    rows = []
+    for k in range(n32 + n22):
+        X0 = np.array([rng.uniform(-8, 8), rng.uniform(-3, 3), rng.uniform(4, 40)])
+        X1 = R @ X0 + t
+        obs = X1[:2] / X1[2] + rng.normal(size=2) * noise
+        if rng.uniform() < 0.15:
+            obs = obs + rng.normal(size=2) * 0.2
+        if k < n32:
+            rows.append([3, *X0, *obs])
+        else:
+            rows.append([4, X0[0] / X0[2], X0[1] / X0[2], *obs])
+    far = [0.0, 0.05, 0.4][(case // 3) % 3]
+    return rows, w + rng.normal(size=3) * far * 0.3, t + rng.normal(size=3) * far * 2.0
+
+
+def test_lm_trace_vs_python_transcription(orc):
+    """The trust-region loop twice: oracle/orc_ceres.cpp (C++, DENSE_QR on the stacked Jacobian, Jets) against tests/ceres_transcription.py — a
+    literal Python transcription of Ceres 2.0's TrustRegionMinimizer + LevenbergMarquardtStrategy + TrustRegionStepEvaluator + Corrector +
+    EigenQuaternionParameterization written from the published sources, not from the C++ file.  288 randomised problems (SE3 with edge /
+    plane / plane-norm factors and angle-axis problems with the visual-odometry functors; 5-30 % gross outliers so that the Huber corrector is
+    active; starts far enough away that steps get REJECTED; max_num_iterations 4 like the LiDAR solves and 100 like the visual odometry):
+    the whole iteration table — cost, cost change, gradient max-norm, step norm, relative decrease, radius, valid / successful flags — and
+    the termination must agree: flags and termination exactly, the numbers to 1e-11 relative over the first five rows (all a 4-iteration
+    solve produces) on the well-posed classes, see the tolerance comments below for longer runs and for the deliberately ill-conditioned
+    classes that provoke the rejections; parameters to 1e-10.  The case mix is asserted: >= 20 % contain a
+    rejected step, every termination rule fires at least once."""
+    import ceres_transcription as ct
+    rng = np.random.default_rng(20260927)
+    n_rejected, seen, n_cases = 0, set(), 0
+    worst = 0.0
+    for case in range(288):
+        quaternion = case % 6 != 5
+        max_iters = 4 if (case // 8) % 2 == 0 else 100
+        if quaternion and case % 8 >= 4 and max_iters == 100:
+            max_iters = 10   # (the ill-conditioned classes: two round-off-different runs eventually take a different accept / reject decision)
+        if quaternion:
+            rows, p0, p1 = _random_se3_problem(rng, case)
+        else:
+            rows, p0, p1 = _random_vo_problem(rng, case)
+        a = orc.solve(rows, p0, p1, quaternion=quaternion, huber_a=0.1, max_iters=max_iters)
+        b = ct.solve(rows, p0, p1, quaternion=quaternion, huber_a=0.1, max_iters=max_iters)
+        ta, tb = a["trace"], b["trace"]
+        assert ta.shape == tb.shape, (case, ta.shape, tb.shape, a["termination"], b["message"])
+        assert a["termination"] == b["termination"], (case, a["termination"], b["message"])
+        assert np.array_equal(ta[:, 6:8], tb[:, 6:8]), (case, ta[:, 6:8], tb[:, 6:8])
+        # per column: relative 1e-11 for the rows a 4-iteration solve can reach (every LiDAR solve of the reference; a quadratically converging
+        # noise-free problem turns one ulp of x into 1e-12 of its cost, so 1e-12 itself is not reachable by two correct programs); two round-off-level
+        # different trajectories of a THIN problem drift apart once steps get rejected (each accept / reject decision is a discontinuity), so
+        # rows beyond the fifth may differ 4x more per row, never more than 1e-6 — the flags and the termination must still be identical.
+        # Absolute floors for quantities that are DIFFERENCES of O(1) numbers in both implementations: a cost at round-off level (noise-free
+        # problems converge to ~1e-25), cost change = cost - cost, gradient max-norm and step norm = |x - Plus(x, .)| (one ulp of |x| is
+        # 1e-16 whatever the result's size; the gradient itself is a sum of ~100 terms J r of mixed sign), relative decrease = cost change /
+        # model cost change.
+        nrow = tb.shape[0]
+        rel = np.minimum(1e-11 * 4.0 ** np.maximum(0, np.arange(nrow) - 4), 1e-6)[:, None]
+        if quaternion and case % 8 >= 4:   # the THIN classes: 5 - 8 factors, 100 m lever arms, started ~pi away — every step amplifies round-off ~100x (two Householder QRs of an ill-conditioned 15 x 6 system agree to 1e-16 x condition number)
+            rel = np.minimum(1e-12 * 100.0 ** np.arange(nrow), 1e-6)[:, None]
+        pm = max(abs(v) for r in rows for v in r[1:])
+        xmag = max(1.0, float(np.max(np.abs(np.concatenate([p0, p1])))))
+        cost_floor = len(rows) * (2e-13 * (1.0 + pm + xmag)) ** 2
+        cost = np.abs(tb[:, 0])
+        prev = np.maximum(cost, np.abs(np.roll(tb[:, 0], 1)))
+        d = np.abs(ta[:, :6] - tb[:, :6])
+        tol = rel * np.abs(tb[:, :6])
+        # one ulp of x moves a cost 0.5 sum r^2 by |r| |J| |x| 1e-16: dominant once a noise-free problem converges quadratically
+        amp = np.sqrt(2.0 * cost * len(rows)) * 2.0 * (1.0 + pm) * 1e-16 * (1.0 + pm + xmag) * (rel[:, 0] / 1e-11)
+        amp_prev = np.maximum(amp, np.roll(amp, 1))
+        tol[:, 0] += cost_floor + amp
+        tol[:, 1] += 4e-15 * prev + cost_floor + rel[:, 0] * prev + amp_prev
+        tol[:, 2] += 4e-15 * xmag + 2e-13 * tb[0, 2] + len(rows) * 2.0 * (1.0 + pm) * 4e-15 * (1.0 + pm + xmag)   # (last term: J^T r with every r at round-off level)
+        tol[:, 3] += 4e-15 * xmag
+        mcc = np.abs(tb[:, 1]) / np.maximum(np.abs(tb[:, 4]), 1e-300)       # model cost change of the row
+        tol[:, 4] += (8e-15 * prev + cost_floor + rel[:, 0] * prev + amp_prev) / np.maximum(mcc, 1e-300)
+        excess = d / np.maximum(tol, 1e-300)
+        worst = max(worst, float(excess.max()))
+        assert excess.max() <= 1.0, (case, b["message"], float(excess.max()), np.unravel_index(excess.argmax(), excess.shape), ta, tb)
+        assert np.allclose(np.concatenate([a["p0"], a["p1"]]), np.concatenate([b["p0"], b["p1"]]), rtol=0, atol=1e-10 if nrow <= 5 and not (quaternion and case % 8 >= 4) else 1e-6 * xmag), case
+        n_cases += 1
+        n_rejected += int(np.any(tb[1:, 7] == 0.0))
+        seen.add(b["message"])
+    assert n_rejected >= 0.2 * n_cases, (n_rejected, n_cases)
+    for msg in ("Maximum number of iterations reached.", "Gradient tolerance reached.", "Parameter tolerance reached.", "Function tolerance reached."):
+        assert msg in seen, (msg, seen)

@@ -1036,7 +1036,8 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
         if (!it_valid) {
           // ---- HandleInvalidStep
           if (++num_invalid >= 5) { termination = 2; go = 0; break; }
-          radius *= 0.5;
+          radius = radius * (1.0 / decrease_factor);   // LevenbergMarquardtStrategy::StepIsInvalid == StepRejected(0.0): divide by decrease_factor, which doubles (oracle/orc_ceres.cpp)
+          decrease_factor *= 2.0;
           it_cost = x_cost; it_cost_change = 0; it_step_norm = 0; it_rho = 0; it_success = false;
           continue;
         }
