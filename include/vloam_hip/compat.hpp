@@ -8,8 +8,9 @@
 //   vloam::VisualOdometry     visual_odometry.h:36-58     init / reset / processImage / setUpPointCloud / processPointCloud / solveNlsAll
 //                             (optical_flow_match = true; shares a Session with the LiDAR stages or owns one)
 // Same method names, argument meaning and call order.  Clouds are a PCL-free POD vector by default; define
-// VLOAM_HIP_WITH_PCL (and have PCL on the include path) to get overloads taking pcl::PointCloud — that adapter is
-// compile-guarded and untested here because PCL / ROS are absent from this image.  Errors: the reference aborts
+// VLOAM_HIP_WITH_PCL (and have PCL on the include path) to get overloads with the reference's own signatures — ScanRegistration::input
+// taking pcl::PointCloud<pcl::PointXYZ>, and the pcl::PointCloud<PointType>::Ptr forms of ScanRegistration::output, LaserOdometry::input /
+// output and LaserMapping::input; that adapter is compile-guarded and untested here because PCL / ROS are absent from this image.  Errors: the reference aborts
 // (ROS_BREAK) or returns void; here a failing ABI call throws std::runtime_error carrying vloam_last_error().
 //
 // What stays in HBM: the reference hands clouds from stage to stage by value (LaserOdometry::input deep-copies the five
@@ -56,6 +57,25 @@ inline bool same_cloud(const Cloud& a, const Cloud& b) {  // cheap identity chec
   return eq(a.front(), b.front()) && eq(a.back(), b.back());
 }
 
+#ifdef VLOAM_HIP_WITH_PCL
+// pcl::PointCloud<pcl::PointXYZI> <-> Cloud (the reference's PointType, common.h:42).  Compile-guarded and UNTESTED here: PCL is absent
+// from this image.  The Ptr overloads below give the three stage classes the exact signatures of scan_registration.h:74-76,
+// laser_odometry.h:76-84 and laser_mapping.h:88-91, so that a caller that drives them one by one (lidar_odometry_mapping.cpp:73-154) links
+// unchanged.
+typedef pcl::PointCloud<pcl::PointXYZI> PclCloud;
+inline void to_pcl(const Cloud& c, PclCloud::Ptr& out) {
+  if (!out) out.reset(new PclCloud());
+  out->points.resize(c.size());
+  for (size_t i = 0; i < c.size(); i++) { out->points[i].x = c[i].x; out->points[i].y = c[i].y; out->points[i].z = c[i].z; out->points[i].intensity = c[i].intensity; }
+  out->width = static_cast<uint32_t>(c.size()); out->height = 1; out->is_dense = true;
+}
+inline Cloud from_pcl(const PclCloud::Ptr& in) {
+  Cloud c(in ? in->points.size() : 0);
+  for (size_t i = 0; i < c.size(); i++) { c[i].x = in->points[i].x; c[i].y = in->points[i].y; c[i].z = in->points[i].z; c[i].intensity = in->points[i].intensity; }
+  return c;
+}
+#endif
+
 class Session {  // one vloam_handle == one sequence on one GPU; shared by the three stage objects
  public:
   explicit Session(int device = 0, const vloam_config* cfg = nullptr) {
@@ -97,6 +117,13 @@ class ScanRegistration {
     laserCloud = s_->features(0); cornerPointsSharp = s_->features(1); cornerPointsLessSharp = s_->features(2);
     surfPointsFlat = s_->features(3); surfPointsLessFlat = s_->features(4);
   }
+#ifdef VLOAM_HIP_WITH_PCL
+  void output(PclCloud::Ptr& laserCloud_, PclCloud::Ptr& cornerPointsSharp_, PclCloud::Ptr& cornerPointsLessSharp_, PclCloud::Ptr& surfPointsFlat_,
+              PclCloud::Ptr& surfPointsLessFlat_) {   // scan_registration.h:75-77
+    PclCloud::Ptr* out[5] = {&laserCloud_, &cornerPointsSharp_, &cornerPointsLessSharp_, &surfPointsFlat_, &surfPointsLessFlat_};
+    for (int k = 0; k < 5; k++) to_pcl(s_->features(k), *out[k]);
+  }
+#endif
 
  private:
   std::shared_ptr<Session> s_;
@@ -117,6 +144,18 @@ class LaserOdometry {
                                     "clouds on the device; substituted clouds are not uploaded)");
   }
   void input() {}
+#ifdef VLOAM_HIP_WITH_PCL
+  void input(const PclCloud::Ptr& laserCloud_, const PclCloud::Ptr& cornerPointsSharp_, const PclCloud::Ptr& cornerPointsLessSharp_,
+             const PclCloud::Ptr& surfPointsFlat_, const PclCloud::Ptr& surfPointsLessFlat_) {   // laser_odometry.h:76-80
+    input(from_pcl(laserCloud_), from_pcl(cornerPointsSharp_), from_pcl(cornerPointsLessSharp_), from_pcl(surfPointsFlat_), from_pcl(surfPointsLessFlat_));
+  }
+  void output(Quaterniond& q_w_curr_, Vector3d& t_w_curr_, PclCloud::Ptr& laserCloudCornerLast_, PclCloud::Ptr& laserCloudSurfLast_,
+              PclCloud::Ptr& laserCloudFullRes_, bool& skip_frame) {   // laser_odometry.h:82-84 (the pose as (x, y, z, w) / (x, y, z) arrays: Eigen is not a dependency of this header)
+    Cloud a, b, c;
+    output(q_w_curr_, t_w_curr_, a, b, c, skip_frame);
+    to_pcl(a, laserCloudCornerLast_); to_pcl(b, laserCloudSurfLast_); to_pcl(c, laserCloudFullRes_);
+  }
+#endif
   void setVOPrior(const Quaterniond& q, const Vector3d& t) { check(vloam_set_lo_prior(s_->get(), q.data(), t.data())); }  // vloam_tf->velo_last_VOT_velo_curr
   void solveLO() {
     check(vloam_laser_odometry(s_->get(), q_w_curr.data(), t_w_curr.data(), q_last_curr.data(), t_last_curr.data()));
@@ -150,6 +189,12 @@ class LaserMapping {
       throw std::invalid_argument("vloam_hip: LaserMapping::input: skip_frame differs from frameCount % mapping_skip_frame (laser_odometry.cpp:618)");
   }
   void input() {}
+#ifdef VLOAM_HIP_WITH_PCL
+  void input(const PclCloud::Ptr& laserCloudCornerLast_, const PclCloud::Ptr& laserCloudSurfLast_, const PclCloud::Ptr& laserCloudFullRes_,
+             const Quaterniond& q_wodom_curr_, const Vector3d& t_wodom_curr_, const bool& skip_frame_) {   // laser_mapping.h:88-91
+    input(from_pcl(laserCloudCornerLast_), from_pcl(laserCloudSurfLast_), from_pcl(laserCloudFullRes_), q_wodom_curr_, t_wodom_curr_, skip_frame_);
+  }
+#endif
   void solveMapping() { check(vloam_laser_mapping(s_->get(), q_w_curr.data(), t_w_curr.data())); }
   Cloud map() {   // /laser_cloud_map (laser_mapping.cpp:778-793)
     long long n = 0;

@@ -9,11 +9,15 @@
 // T must support + - * / < >, sqrt, sin, cos, acos, abs (found by ADL, as for ceres::Jet).  The interpolation ratio s is honoured
 // exactly like the reference (lidarFactor.hpp:26-33: q_last_curr = Identity.slerp(s, q), t_last_curr = s * t); the GPU path runs with
 // s == 1 (DISTORTION == false, laser_odometry.h:90), where the slerp returns q itself.
-// Not provided: the static Create(...) factories (lidarFactor.hpp:47-52, 94-101, 132-134) — they return ceres::CostFunction*, i.e. need
-// Ceres; with Ceres at hand they are the one-liners quoted above.
+// The static Create(...) factories (lidarFactor.hpp:47-52, 95-101, 129-134; ceres_cost_function.h:87-92, 176-181) return
+// ceres::CostFunction*, i.e. need Ceres: they are compiled with -DVLOAM_HIP_WITH_CERES (which includes <ceres/ceres.h>) and are UNTESTED
+// here — Ceres is absent from this image.  Points are passed as const double[3] instead of Eigen::Vector3d (v.data() at the call site).
 #pragma once
 #include <cmath>
 #include <limits>
+#ifdef VLOAM_HIP_WITH_CERES
+#include <ceres/ceres.h>
+#endif
 
 namespace vloam {
 namespace factors {
@@ -64,6 +68,12 @@ struct LidarEdgeFactor {
     residual[0] = nu.x / n; residual[1] = nu.y / n; residual[2] = nu.z / n;
     return true;
   }
+#ifdef VLOAM_HIP_WITH_CERES
+  // lidarFactor.hpp:47-52
+  static ceres::CostFunction* Create(const double* curr_point_, const double* last_point_a_, const double* last_point_b_, const double s_) {
+    return (new ceres::AutoDiffCostFunction<LidarEdgeFactor, 3, 4, 3>(new LidarEdgeFactor(curr_point_, last_point_a_, last_point_b_, s_)));
+  }
+#endif
   double cp[3], lpa[3], lpb[3], s;
 };
 
@@ -84,6 +94,12 @@ struct LidarPlaneFactor {
     residual[0] = dot(sub(lp, j), n);
     return true;
   }
+#ifdef VLOAM_HIP_WITH_CERES
+  // lidarFactor.hpp:95-101
+  static ceres::CostFunction* Create(const double* curr_point_, const double* last_point_j_, const double* last_point_l_, const double* last_point_m_, const double s_) {
+    return (new ceres::AutoDiffCostFunction<LidarPlaneFactor, 1, 4, 3>(new LidarPlaneFactor(curr_point_, last_point_j_, last_point_l_, last_point_m_, s_)));
+  }
+#endif
   double cp[3], lpj[3], ljm[3], s;
 };
 
@@ -96,6 +112,12 @@ struct LidarPlaneNormFactor {
     residual[0] = dot(n, w) + T(d);
     return true;
   }
+#ifdef VLOAM_HIP_WITH_CERES
+  // lidarFactor.hpp:129-134
+  static ceres::CostFunction* Create(const double* curr_point_, const double* plane_unit_norm_, const double negative_OA_dot_norm_) {
+    return (new ceres::AutoDiffCostFunction<LidarPlaneNormFactor, 1, 4, 3>(new LidarPlaneNormFactor(curr_point_, plane_unit_norm_, negative_OA_dot_norm_)));
+  }
+#endif
   double cp[3], nrm[3], d;
 };
 
@@ -125,6 +147,12 @@ struct CostFunctor32 {  // 3D - 2D
     residuals[1] = X1[1] - X1[2] * T(y1_bar);
     return true;
   }
+#ifdef VLOAM_HIP_WITH_CERES
+  // ceres_cost_function.h:87-92
+  static ceres::CostFunction* Create(const double observed_x0, const double observed_y0, const double observed_z0, const double observed_x1_bar, const double observed_y1_bar) {
+    return (new ceres::AutoDiffCostFunction<CostFunctor32, 2, 3, 3>(new CostFunctor32(observed_x0, observed_y0, observed_z0, observed_x1_bar, observed_y1_bar)));
+  }
+#endif
   double x0, y0, z0, x1_bar, y1_bar;
 };
 
@@ -137,6 +165,12 @@ struct CostFunctor22 {  // 2D - 2D epipolar
     residuals[0] = T(x1_bar) * c[0] + T(y1_bar) * c[1] + c[2];
     return true;
   }
+#ifdef VLOAM_HIP_WITH_CERES
+  // ceres_cost_function.h:176-181
+  static ceres::CostFunction* Create(const double observed_x0_bar, const double observed_y0_bar, const double observed_x1_bar, const double observed_y1_bar) {
+    return (new ceres::AutoDiffCostFunction<CostFunctor22, 1, 3, 3>(new CostFunctor22(observed_x0_bar, observed_y0_bar, observed_x1_bar, observed_y1_bar)));
+  }
+#endif
   double x0_bar, y0_bar, x1_bar, y1_bar;
 };
 
