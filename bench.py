@@ -239,8 +239,11 @@ def main():
     vl = conftest.load_pkg()
     synth = conftest.load_synth()
     multi = importlib.import_module("vloam_amd.multi")
+    # N > 1: this rank's enqueue thread and its ray-casting workers stay on the NUMA node of its GPU (an even slice of it per rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    affinity = multi.pin_host_threads(local_rank, local_world)
     cores = os.cpu_count() or 1
-    procs = args.synth_procs or max(1, min(cores // max(world, 1), 16))
+    procs = args.synth_procs or max(1, min(affinity["cpus"] if world > 1 else cores, 16))
     g0 = time.perf_counter()
     seq, host = make_sweeps(synth, T, args.rings, args.azimuth, multi.rank_sequence_seeds(rank), procs)
     n_img = 0 if (args.no_extras or args.rings != 64 or world != 1) else min(max(args.image_frames, 0), T - 1)
@@ -312,7 +315,9 @@ def main():
     t1 = time.perf_counter()
 
     elapsed = t1 - t0
+    per_rank_s = [elapsed]
     if dist is not None:
+        per_rank_s = multi.gather_seconds(dist, elapsed, device=coll_dev)
         elapsed = multi.max_over_ranks(dist, elapsed, device=coll_dev)
     counts = h.counts()
     traj = h.trajectory()
@@ -591,13 +596,15 @@ def main():
         achieved = kb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "scans/sec end-to-end odometry on 64x2048 cloud", "value": value, "unit": "scans/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "warmup": W, "ms_per_step": 1e3 * elapsed / K, "per_rank_ms_per_step": [1e3 * s_ / K for s_ in per_rank_s],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 points / f64 poses+residuals", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "points_per_sweep": int(n_pts), "sequences": world,
                        "map_warmup_sweeps": M0, "map_points_at_last_sweep": counts["M"],
                        "sharding": "one independent sequence per GPU, no data-path collective; all_gather of trajectories after the run",
                        "gathered_trajectories": {"ranks": len(trajectories), "frames": [int(t.shape[0]) for t in trajectories],
                                                  "last_map_position": [[float(v) for v in t[-1, 11:14]] for t in trajectories]},
+                       "host_affinity_rank0": affinity,
                        "pipelining": "SR / LO / mapping of consecutive sweeps overlap on their own HIP streams (one sequence, one GPU)"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -59,3 +59,43 @@ def test_aggregate_and_seeds():
     assert multi.aggregate_throughput(64, 8, 0.5) == 64 * 8 / 0.5
     assert multi.rank_sequence_seeds(0) == dict(seed_scene=1234, seed_traj=42, seed_noise=5678)   # SURVEY.md §8d seeds
     assert len({tuple(multi.rank_sequence_seeds(r).values()) for r in range(8)}) == 8
+
+
+def test_rank_host_affinity_follows_the_gpu_numa_node(tmp_path):
+    """multi.host_cpus_for_rank on a fake sysfs: 8 GPUs, 2 NUMA nodes of 64 CPUs (a CPU agent node in front, as KFD lists them) — every rank
+    gets a quarter of ITS node's CPUs, disjoint from its neighbours'; without the topology files the allowed CPUs are split evenly."""
+    import importlib
+    import conftest
+    conftest.load_pkg()
+    multi = importlib.import_module("vloam_amd.multi")
+    root = tmp_path
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    for n in range(10):       # nodes 0, 1: the two CPU sockets; 2..9: GPUs
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        if n < 2:
+            (d / "properties").write_text("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+        else:
+            (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (128 + n - 2))
+            dev = root / ("class/drm/renderD%d/device" % (128 + n - 2))
+            dev.mkdir(parents=True)
+            (dev / "numa_node").write_text("%d\n" % (0 if n - 2 < 4 else 1))
+    for node, lst in ((0, "0-63"), (1, "64-127")):
+        d = root / ("devices/system/node/node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(lst + "\n")
+    assert multi.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert multi.gpu_numa_cpus(5, str(root)) == (1, list(range(64, 128)))
+    allowed = set(range(128))
+    shares = [multi.host_cpus_for_rank(r, 8, allowed, str(root)) for r in range(8)]
+    assert all(how == "numa" for _, how in shares)
+    assert [len(c) for c, _ in shares] == [16] * 8
+    assert shares[0][0] == list(range(0, 16)) and shares[3][0] == list(range(48, 64)) and shares[4][0] == list(range(64, 80))
+    flat = [c for cs, _ in shares for c in cs]
+    assert len(flat) == len(set(flat)) == 128
+    # a container that hides half of the CPUs: the share is cut from what is allowed
+    half, how = multi.host_cpus_for_rank(1, 8, set(range(0, 32)), str(root))
+    assert how == "numa" and half == list(range(8, 16))
+    # no topology: an even split
+    even = [multi.host_cpus_for_rank(r, 8, allowed, str(tmp_path / "nothing")) for r in range(8)]
+    assert all(how == "even-split" for _, how in even) and [len(c) for c, _ in even] == [16] * 8

@@ -40,3 +40,28 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     a, b = g["last_map_position"]
     assert a != b and all(abs(v) < 1e3 for v in a + b), (a, b)   # two different sequences, both gathered on rank 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert len(d["per_rank_ms_per_step"]) == 2 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-9
+
+
+def test_bench_eight_ranks_the_drivers_own_command_line():
+    """configs[4] as the driver launches it on the 8-GPU node — `--gpus 8`, eight ranks — here sharing GPU 0 over gloo: eight different
+    sequences, eight gathered trajectories, the aggregate over the slowest rank, every rank's own time in the line (a straggler shows),
+    and every rank pinned to its own slice of the host's cores (NUMA node of its GPU on the node; an even split here)."""
+    env = dict(os.environ, VLOAM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2",
+           "--map-warmup", "4", "--no-extras", "--no-cpu-baseline", "--no-kernel-timer"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["sequences"] == 8
+    assert len(d["per_rank_ms_per_step"]) == 8 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-9
+    assert abs(d["value"] - 8 * 4 / (d["ms_per_step"] * 4 / 1e3)) < 1e-6 * d["value"]
+    g = d["config"]["gathered_trajectories"]
+    assert g["ranks"] == 8 and g["frames"] == [10] * 8
+    ends = [tuple(round(v, 6) for v in p) for p in g["last_map_position"]]
+    assert len(set(ends)) == 8, ends                                  # eight different sequences
+    aff = d["config"]["host_affinity_rank0"]
+    assert aff["how"] in ("numa", "even-split") and 1 <= aff["cpus"] <= (os.cpu_count() or 1)

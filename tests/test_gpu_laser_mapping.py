@@ -406,3 +406,31 @@ def test_long_drive_purges_and_rebuilds_the_tables(vl, orc, synth):
     got, ref = h.get_map(), oracle_published_map(o)
     assert got.shape == ref.shape and same_cloud(got, ref)
     assert hl["keys"][0] + hl["keys"][1] < 2.5 * got.shape[0], hl   # the tables hold the live map plus a bounded number of tombstones
+
+
+def test_dense_scan_voxels_take_the_wavefront_rank_path(vl, orc, sweeps):
+    """A coarse surf leaf (3.2 m instead of 0.8 m) puts far more than 256 sweep points into single voxels of the scan-feature VoxelGrid:
+    k_map_ds_reduce's third path — the whole wavefront ranks the members by counting, chunk by chunk through LDS — must still add them
+    in input order (pcl::VoxelGrid's f32 centroid is order dependent): down-sampled scan features, poses and map against the oracle."""
+    h = vl.Handle(0, with_mapping=1, mapping_plane_resolution=3.2, mapping_line_resolution=1.6)
+    o = orc.Oracle(with_mapping=True, line_res=1.6, plane_res=3.2)
+    big = 0
+    for k in range(4):
+        cloud = sweeps(64, 2048, k)
+        h.reset_frame()
+        h.scan_registration(cloud)
+        h.laser_odometry()
+        qm, tm = h.laser_mapping()
+        assert o.process(cloud) == 0
+        lf = o.cloud(4)   # surfPointsLessFlat: what the 3.2 m grid bins
+        keys = np.floor(lf[:, :3] / np.float32(3.2)).astype(np.int64)
+        big = max(big, int(np.unique(keys, axis=0, return_counts=True)[1].max()))
+        for which in (7, 8):
+            dv, rf = h.features(which), o.cloud(which)
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+        oq, ot, _, _ = o.map_pose()
+        assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, k
+    assert big > 256, big   # the case is what it claims to be
+    h.sync()
+    got, want = h.get_map(), oracle_published_map(o)
+    assert got.shape == want.shape and same_cloud(got, want)

@@ -173,55 +173,52 @@ def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
 
 
 def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
-    """k_sr_ring runs as a 2176-point tier (two rings per CU) plus the 4096-point tier: its full grid during the first 8 sweeps and once a
-    ring has come within 32 points of the small tier's capacity (host-mapped watch word), otherwise one catch-all workgroup that only
-    works on rings the small tier had to leave.  Rings that grow from 1 792 over 2 160 to 2 300 points across the 8-sweep mark must come
-    out of the right tier: features equal the oracle's."""
+    """k_sr_ring runs as a 2176-point tier (two rings per CU) followed by the 4096-point tier: its full grid once a ring has come within 32
+    points of the small tier's capacity (host-mapped watch word), otherwise one catch-all workgroup that only works on rings the small tier
+    had to leave.  A DEFAULT handle must take any ring of up to 4096 points on any sweep, like the reference's 400 000-point scratch takes
+    any ring (scan_registration.h:90): rings that grow gradually (1 792 -> 2 160 -> 2 300 points), and rings that jump from ~2 000 to ~3 000
+    points between two sweeps at sweep 12, long after the start and without any warning — stage-wise and streamed (the host runs ahead of
+    the kernels and of the watch word): features equal the oracle's on every sweep."""
     def sweep(n_az, k):
         return synth.SynthSequence(n_rings=64, n_azimuth=n_az, n_sweeps=k + 1).sweep(k)
+
+    def check(h, cloud, what):
+        o = orc.Oracle(with_mapping=False)
+        assert o.scan_registration(cloud) == 0
+        sc = o.sr_scalars()
+        flips = check_cloud(h.features(0), o.cloud(0), "laserCloud " + what, unwrap_bounds(sc["startOri"], sc["endOri"]))
+        for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+            check_cloud(h.features(which), o.cloud(which), "%s %s" % (name, what), max_flips=flips)
+
     h = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
     plan = [1792] * 10 + [2160] * 2 + [2300] * 3 + [1792] * 2
     for k, n_az in enumerate(plan):
         cloud = sweep(n_az, k)
         h.reset_frame()
         h.scan_registration(cloud)
-        o = orc.Oracle(with_mapping=False)
-        assert o.scan_registration(cloud) == 0
-        sc = o.sr_scalars()
-        flips = check_cloud(h.features(0), o.cloud(0), "laserCloud sweep %d" % k, unwrap_bounds(sc["startOri"], sc["endOri"]))
-        for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
-            check_cloud(h.features(which), o.cloud(which), "%s sweep %d (%d columns)" % (name, k, n_az), max_flips=flips)
+        check(h, cloud, "sweep %d (%d columns)" % (k, n_az))
         h.laser_odometry()
     h.sync()
-    # without the warning (a jump from far below the watch threshold to beyond the small tier after the first sweeps): reported, not dropped
-    h2 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+    # the jump without a warning: 2 000 -> 3 000 points per ring at sweep 12, and back
+    jump = [2000] * 12 + [3000] * 3 + [2000] * 2
+    h2 = vl.Handle(0, with_mapping=0, max_points=64 * 3072)
+    for k, n_az in enumerate(jump):
+        cloud = sweep(n_az, k)
+        h2.reset_frame()
+        h2.scan_registration(cloud)
+        if k >= 10:
+            check(h2, cloud, "sweep %d (jump to %d columns)" % (k, n_az))
+        h2.laser_odometry()
+    h2.sync()
+    h3 = vl.Handle(0, with_mapping=0, max_points=64 * 3072)
+    clouds = [sweep(n_az, k) for k, n_az in enumerate(jump)]
+    for c in clouds:        # streamed
+        h3.process_scan(c)
+    h3.sync()               # (raises if any sweep was reported instead of processed)
+    check(h3, clouds[-1], "last sweep of the streamed run")
+    # beyond the big tier's capacity (4096 points per ring) the handle still says so
+    h4 = vl.Handle(0, with_mapping=0, max_points=64 * 4400)
     with pytest.raises(vl.VloamError) as e:
-        for k in range(12):
-            h2.process_scan(sweep(1024 if k < 10 else 2300, k))
-        h2.sync()
+        h4.process_scan(sweep(4300, 0))
+        h4.sync()
     assert e.value.status == vl.ERR_CAPACITY
-    # ... unless the handle was created with the catch-all workgroup of the big tier (VLOAM_SR_CATCHALL=1: every sweep pays a launch
-    # for it): then such a ring is processed, features equal the oracle's
-    import os
-    os.environ["VLOAM_SR_CATCHALL"] = "1"
-    try:
-        h3 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
-        h4 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
-    finally:
-        del os.environ["VLOAM_SR_CATCHALL"]
-    for k in range(13):
-        cloud = sweep(1024 if k < 10 else 2300, k)
-        h3.reset_frame()
-        h3.scan_registration(cloud)
-        if k >= 9:
-            o = orc.Oracle(with_mapping=False)
-            assert o.scan_registration(cloud) == 0
-            sc = o.sr_scalars()
-            flips = check_cloud(h3.features(0), o.cloud(0), "laserCloud sweep %d" % k, unwrap_bounds(sc["startOri"], sc["endOri"]))
-            for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
-                check_cloud(h3.features(which), o.cloud(which), "%s sweep %d (jump without warning)" % (name, k), max_flips=flips)
-        h3.laser_odometry()
-    h3.sync()
-    for k in range(14):   # streamed: the host runs ahead of the kernels and of the watch word
-        h4.process_scan(sweep(1024 if k < 10 else 2300, k))
-    h4.sync()

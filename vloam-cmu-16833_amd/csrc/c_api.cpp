@@ -71,7 +71,6 @@ struct vloam_handle {
   Sess se;
   int sel = 0;          // session the getters read (vloam_select_session)
   double* sync_pool = nullptr;
-  bool ring_catchall = false;  // VLOAM_SR_CATCHALL=1 at create: a catch-all workgroup of the big ring tier behind the small tier on every sweep (sr_launch)
   int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
@@ -249,9 +248,19 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   }
   // A handle drives four or five HIP streams that must run side by side (scan registration | scan-feature VoxelGrid | odometry | mapping
   // [| images]); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two stages sharing a queue serialise —
-  // measured: 214 us per sweep instead of 164.  Only effective when this is the process's first HIP call; hosts that initialise HIP
-  // earlier (PyTorch, ROS nodelets) export GPU_MAX_HW_QUEUES=8 themselves.
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // measured: 214 us per sweep instead of 164.  The variable is read when the HIP runtime initialises, so it belongs to the HOST's
+  // environment (the Python package and bench.py export it before they load the runtime): a library must not setenv()
+  // behind a multi-threaded host's back (not thread-safe against a concurrent getenv, and silently without effect once HIP is up).
+  // Said once per process instead.
+  {
+    static bool warned = false;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (!warned && (!q || atoi(q) < 5)) {
+      warned = true;
+      fprintf(stderr, "libvloam_hip: GPU_MAX_HW_QUEUES is %s: the stage streams of a handle will share hardware queues and a sweep takes ~30 %% longer; "
+                      "export GPU_MAX_HW_QUEUES=8 before the process initialises HIP\n", q ? q : "unset (runtime default 4)");
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device visible: libvloam_hip has no CPU fallback");
@@ -271,7 +280,6 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   vloam_handle* h = new vloam_handle;
   h->cfg = *cfg;
   h->device = device;
-  h->ring_catchall = getenv("VLOAM_SR_CATCHALL") && atoi(getenv("VLOAM_SR_CATCHALL")) != 0;
   *out = nullptr;
   vloam_status st = VLOAM_OK;
   do {
@@ -455,10 +463,13 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   if (k >= kS && h->cfg.with_mapping) HIPCHK(hipEventSynchronize(h->ev_map[set_of(k - kS)]));
   if (g_host_prof) h->host_s[0] += now_s() - tw0;
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  bool big_tier = k < 8;   // nothing is known about the ring lengths yet
+  // the full grid of the big ring tier only while long rings are around (watch word of an earlier sweep: plain read of host-mapped memory);
+  // whatever the host knows or does not know, ONE catch-all workgroup of the big tier follows the small tier on every sweep, so any ring of up
+  // to kMaxRingLen points is processed (sr_launch)
+  bool big_tier = false;
   for (int b = 0; b < h->se.B; b++) big_tier = big_tier || __atomic_load_n(&h->ring_watch[b], __ATOMIC_RELAXED) != 0;
   HIPCHK(sr_launch(h->stream, h->sr[cur], bi, h->se, h->cfg.scan_line, (float)h->cfg.minimum_range, h->cfg.debug, &h->prof,
-                   h->ev_sr[cur], h->ring_watch, big_tier, h->ring_catchall));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
+                   h->ev_sr[cur], h->ring_watch, big_tier));  // the odometry of THIS sweep needs the feature clouds only (its NN grids were built with the previous sweep)
   // == kdtreeCornerLast / kdtreeSurfLast->setInputCloud (laser_odometry.cpp:525-526): index this sweep's clouds for the next one
   // (the next sweep's ev_sr is recorded behind this on the same stream, so its odometry sees the finished grids)
   lo_grid_build_launch(h->stream, h->se, h->sr[cur].less_sharp, h->sr[cur].less_flat, h->sr[cur].S, h->grid[cur], &h->prof);
@@ -894,6 +905,7 @@ vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz
 
 vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, int n, const unsigned char* gray, int width, int height, int stride) {
   if (!h || !xyz_pad4 || !gray) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);   // before anything is enqueued: VLOAM_ERR_INVALID has no side effects (c_api.h)
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
@@ -901,7 +913,6 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
-  SINGLE_SESSION_ONLY(h);
   { const int* none = nullptr; const int zero = 0;
     const unsigned char* g = h->img.staging;
     return process_frame_common(h, one_sweep(h->d_in, n), &none, &none, &zero, &g, width, height, width); }

@@ -1175,39 +1175,42 @@ __global__ __launch_bounds__(64) void k_lm_compact(FactorTable F, int quat, cons
   }
 }
 
-// ---- placement of the cooperative solve's sync words.  The grid barrier is a handful of agent-scope atomics and loads on ONE
-// cache line, and on MI355X their round trip depends on which memory channel the line maps to: 1.5 us at most addresses, 2.3 us
-// at some (measured; same answer from one XCD or four).  Five barriers per solve, four solves per sweep: worth choosing.  The
-// probe replays the solver's exact exchange (publish kAcc partials, barrier, read all partials) on a candidate slot.
+// ---- placement of the cooperative solve's sync words.  The workgroups exchange their partial sums as tagged 8-byte granules on a
+// handful of cache lines, and on MI355X that round trip depends on which memory channel the lines map to (1.5 us at most addresses,
+// 2.3 us at some; five exchanges per solve, four solves per sweep: worth choosing).  The probe replays the solver's exchange as it is
+// today (lm_evaluate): kAcc lanes per workgroup publish {32 payload bits, tag} pairs at gran[blk * 64 (+ 32) + lane] of the parity buffer
+// and poll the 2 x NB granules of their column — same layout, same loads, same polling loop.
 constexpr int kCoop = 4;     // workgroups of the cooperative form (see lm_evaluate): the odometry table (<= 2 304 factors) ...
 constexpr int kCoopMap = 6;  // ... and the scan-to-map problems (4-5 000 factors; 4: 4 227, 6: 4 300, 8: 4 298 scans/s on one box)
 static_assert(kCoop <= kLmMaxBlocks && kCoopMap <= kLmMaxBlocks, "partial-sum buffer");
 __global__ __launch_bounds__(kLmThreads) void k_lm_sync_probe(double* gsync, int iters, double* sink) {
   const int tid = threadIdx.x, blk = blockIdx.x;
-  unsigned* bar = reinterpret_cast<unsigned*>(gsync);
+  u64* gw = reinterpret_cast<u64*>(gsync);
   double acc = 0.0;
   for (int it = 0; it < iters; it++) {
-    double* gpart = gsync + 8 + (size_t)(it & 1) * kLmMaxBlocks * 32;
-    if (tid < kAcc) __hip_atomic_store(&gpart[blk * 32 + tid], (double)(it + blk + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (unsigned)(it + 1) * (unsigned)kCoop;
-      int spins = 0;
-      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) break;
-      }
-    }
     __syncthreads();
     if (tid < kAcc) {
+      u64* gran = gw + 8 + (size_t)(it & 1) * kLmMaxBlocks * 64;
+      const u64 tag = (u64)(unsigned)(it + 1) << 32;
+      const u64 bits = (u64)__double_as_longlong((double)(it + blk + tid));
+      __hip_atomic_store(&gran[blk * 64 + tid], (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gran[blk * 64 + 32 + tid], (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 lo[kCoop], hi[kCoop];
+      for (int spins = 0; spins < (1 << 16); spins++) {
 #pragma unroll
-      for (int q = 0; q < kCoop; q++) acc += __hip_atomic_load(&gpart[q * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < kCoop; q++) {
+          lo[q] = __hip_atomic_load(&gran[q * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[q] = __hip_atomic_load(&gran[q * 64 + 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < kCoop; q++) all = all && (lo[q] >> 32 << 32) == tag && (hi[q] >> 32 << 32) == tag;
+        if (all) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < kCoop; q++) acc += __longlong_as_double((long long)((hi[q] << 32) | (lo[q] & 0xffffffffull)));
     }
-  }
-  if (tid == 0 && __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)kCoop - 1u) {
-    __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid < kAcc && blk == 0) sink[tid] = acc;
 }

@@ -423,13 +423,34 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
         const float4 p = lane < m ? pts[s_sorted[wave][c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
       }
-    } else {  // more sweep points than that in one voxel: serial fallback in global memory
-      int* b = D.seg + b0;
-      if (lane == 0) {
-        for (int a = 1; a < cnt; a++) { const int v = b[a]; int c = a - 1; while (c >= 0 && b[c] > v) { b[c + 1] = b[c]; c--; } b[c + 1] = v; }
-        for (int a = 0; a < cnt; a++) { const float4 p = pts[b[a]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
+    } else {
+      // More sweep points than that in one voxel (a dense near-range or stationary scene at the 0.8 m leaf): the whole wavefront ranks the
+      // members by counting, chunk by chunk through LDS — cnt^2 / 64 LDS reads per lane: ~30 us at 1 000 points where a single lane's
+      // insertion sort in global memory took milliseconds — and leaves them in input order in the (by now unused) point -> slot array;
+      // then the same in-order fold as above.
+      const int* seg = D.seg + b0;
+      int* sorted = D.point_slot + b0;
+      for (int j0 = 0; j0 < cnt; j0 += 64) {
+        const int j = j0 + lane;
+        const int mine = j < cnt ? seg[j] : INT_MAX;
+        int rank = 0;
+        for (int c0 = 0; c0 < cnt; c0 += kBigVoxel) {
+          const int m = min(kBigVoxel, cnt - c0);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          for (int q = lane; q < m; q += 64) s_idx[wave][q] = seg[c0 + q];
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          for (int q = 0; q < m; q++) rank += s_idx[wave][q] < mine;
+        }
+        if (j < cnt) sorted[rank] = mine;   // (point indices are distinct: the ranks are a permutation)
       }
-      sx = rl(sx, 0); sy = rl(sy, 0); sz = rl(sz, 0); si = rl(si, 0);
+      __threadfence();
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int m = min(64, cnt - c0);
+        const float4 p = lane < m ? pts[sorted[c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
+      }
     }
     if (lane == 0) {
       const float nn = (float)cnt;

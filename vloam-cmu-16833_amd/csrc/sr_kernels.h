@@ -38,6 +38,6 @@ hipError_t sr_init();
 // bi: the sweeps of the B sessions (device pointers + point counts); `done`: recorded when the feature clouds are complete
 // ring_watch: host-mapped [sessions], set by the small ring tier when a ring nears its capacity; big_tier: also launch the 4096-point tier
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, int debug_level, ProfHook* ph = nullptr,
-                     hipEvent_t done = nullptr, int* ring_watch = nullptr, bool big_tier = true, bool catchall = false);
+                     hipEvent_t done = nullptr, int* ring_watch = nullptr, bool big_tier = true);
 
 }  // namespace vloam

@@ -1019,7 +1019,7 @@ hipError_t sr_init() {
 }
 
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, int debug_level, ProfHook* ph, hipEvent_t done,
-                     int* ring_watch, bool big_tier, bool catchall) {
+                     int* ring_watch, bool big_tier) {
   const bool debug = debug_level == 1, stamps = debug_level != 0;   // debug = 2: only the ring kernel's phase stamps (no reference-order debug sort)
   int n = 0;
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
@@ -1032,15 +1032,17 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
                slice, nslice, blk, se.ss);
   VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
-  // catchall (VLOAM_SR_CATCHALL=1 at vloam_create): one workgroup of the big tier follows the small tier on every sweep, so that a ring that
-  // outgrows the small tier without the watch word's warning is processed instead of reported.  Off by default: the launch does nothing on
-  // ordinary sweeps and still costs 13 - 16 us of single-sweep latency (its 146 KB LDS request) and 1.4 % of the B = 8 throughput.
+  // Behind the small tier ALWAYS comes the big tier: its full grid while the host has seen long rings (watch word), otherwise ONE catch-all
+  // workgroup per session that looks at the ring lengths and works on the (normally zero) rings the small tier had to leave.  Any ring of up
+  // to kMaxRingLen points is therefore processed on any sweep, like the reference's 400 000-point scratch (scan_registration.h:90) takes any
+  // ring; the catch-all costs 13 - 16 us of single-sweep latency (a 146 KB LDS request) and 1.4 % of the B = 8 throughput on ordinary sweeps.
+  // (Rounds 2 - 3 made it optional and REPORTED a ring that outgrew the small tier without the watch word's warning: a results gap on
+  // reachable input.)
   VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, (big_tier || catchall) ? 1 : 0, se.ss);
+               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
   // the full big tier while rings near the small tier's capacity are around, else its one-workgroup catch-all
-  if (big_tier || catchall)
   VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(big_tier ? kMaxRings : 1, 1, Z), dim3(kRingThreads),
                  (sr_ring_smem_bytes<kMaxRingLen, kSectCap>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                  b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
