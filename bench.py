@@ -100,14 +100,19 @@ def algorithmic_bytes(kernel, c):
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_summary.py wrote the table).
-    A PMC pass cannot run inside this process, so the number is read from profiles/ (latest round) — None when missing."""
+    A PMC pass cannot run inside this process, so the number is read from profiles/ (latest round) — None when missing, and None when
+    the table was measured on OTHER kernel sources than the ones being timed: the table's header carries the content hash of csrc/
+    (tools/pmc_summary.py: csrc_sha256) and a table without a matching hash is named as stale instead of being quoted."""
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_hbm_traffic.txt" % workload)))
     if not cands:
         return None, None
     path = cands[-1]
-    tot, cnt = 0.0, 0
+    rel = os.path.relpath(path, ROOT)
+    tot, cnt, sha = 0.0, 0, None
     try:
         for line in open(path):
+            if line.startswith("# csrc_sha256:"):
+                sha = line.split(":", 1)[1].strip()
             name = line.split("<")[0].split()[:1]
             f = line.split()
             if name and name[0] == kernel and len(f) >= 5:  # every instantiation of the kernel, weighted by its launches
@@ -115,9 +120,14 @@ def pmc_traffic(workload, kernel):
                 cnt += int(f[-4])
     except (OSError, ValueError):
         return None, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    now = pmc_summary.csrc_sha256(ROOT)
+    if sha != now:
+        return None, "%s is STALE (measured on csrc %s, timing csrc %s): not quoted" % (rel, sha or "without a hash", now)
     if cnt == 0:
         return None, None
-    return tot / cnt, os.path.relpath(path, ROOT)
+    return tot / cnt, rel
 
 
 def sweep_bytes(c, with_mapping):

@@ -36,3 +36,33 @@ def test_points_on_an_unwrap_threshold_are_counted():
     junk = np.full((10, 4), np.nan, dtype=np.float32)
     assert m.unwrap_boundary_points(np.vstack([junk, cloud])) == 0
     assert m.unwrap_boundary_points(junk) == 0
+
+
+def test_bench_refuses_a_traffic_table_of_other_kernels(tmp_path, monkeypatch):
+    """bench.py quotes roofline.traffic from the committed PMC table only if the table's csrc hash is the hash of the kernels it times."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import pmc_summary
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    csrc = tmp_path / "vloam-cmu-16833_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "a.hip").write_text("__global__ void k() {}\n")
+    (tmp_path / "profiles").mkdir()
+    sha = pmc_summary.csrc_sha256(str(tmp_path))
+    table = "# HBM traffic\n# csrc_sha256: %s\nkernel launches fetch write total\nk_lm_solve<true, 2, 6>   10   100   50   150\nk_lm_solve<true, 1, 4>   30   10   40   50\n"
+    (tmp_path / "profiles" / "r09_map_hbm_traffic.txt").write_text(table % sha)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(pmc_summary, "csrc_sha256", lambda root=None, _f=pmc_summary.csrc_sha256: _f(str(tmp_path)))
+    val, src = bench.pmc_traffic("map", "k_lm_solve")
+    assert abs(val - (150 * 10 + 50 * 30) / 40.0) < 1e-9 and src.endswith("r09_map_hbm_traffic.txt")
+    (csrc / "a.hip").write_text("__global__ void k() { }\n")          # the kernels changed after the PMC pass
+    val, src = bench.pmc_traffic("map", "k_lm_solve")
+    assert val is None and "STALE" in src
+    (tmp_path / "profiles" / "r09_map_hbm_traffic.txt").write_text(table.replace("# csrc_sha256: %s\n", ""))   # an old table without a hash
+    val, src = bench.pmc_traffic("map", "k_lm_solve")
+    assert val is None and "STALE" in src

@@ -7,7 +7,22 @@ the calibration is unknown).  WRITE_SIZE is taken as is (uncalibrated).  Output:
 """
 import csv
 import collections
+import glob
+import hashlib
+import os
 import sys
+
+
+def csrc_sha256(root=None):
+    """Content hash of the kernel sources (csrc/*.hip, *.h, *.cpp, file names included): written into every PMC table so that bench.py can
+    refuse to quote a traffic figure measured on other kernels than the ones it is timing (there is no .git on the GPU box)."""
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(root, "vloam-cmu-16833_amd", "csrc", "*"))):
+        if os.path.isfile(path) and path.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(path, counter):
@@ -25,6 +40,7 @@ def main(fetch_csv, write_csv, out_path):
     ft, fc = load(fetch_csv, "FETCH_SIZE")
     wt, wc = load(write_csv, "WRITE_SIZE")
     lines = ["# HBM traffic per launch from rocprofv3 --pmc (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE raw), bytes",
+             "# csrc_sha256: %s" % csrc_sha256(),
              "%-28s %8s %16s %16s %16s" % ("kernel", "launches", "fetch_B/launch", "write_B/launch", "total_B/launch")]
     for k in sorted(ft, key=lambda k: -(ft[k] + wt.get(k, 0))):
         f = 2.0 * 1024.0 * ft[k] / max(fc[k], 1)
