@@ -1263,10 +1263,22 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
 #define VL_SOLVE(Q, M, N)                                                                                                                   \
   VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<Q, M, N>), dim3((N) > 1 ? (N) * spread : (N), 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, \
                   d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj, se.ss)
-  if (direct && coop) VL_SOLVE(true, kLmDirect, kCoop);
+  // Workgroups of a cooperative solve.  A single sequence: 8 for both problems — with the exchange inside one XCD (1 350 - 1 900 cycles
+  // whatever the count) more compute units shorten the factor loops for free: 6 440 scans/s against 6 250 with 4 / 6 (four alternating
+  // runs each, profiles/r04_solver_workgroups_ab.txt).  Batches keep 4 / 6: B = 8 loses 5 % with 8 / 8 (128 compute units pinned by
+  // one-wavefront-per-SIMD workgroups).  The partial sums are added in workgroup order, so the count is part of the summation order:
+  // a batched session agrees with the same sequence run alone to round-off (1e-13 on the poses), not bit for bit (tests/test_gpu_batch.py).
+  if (direct && coop) {
+    static const int lo_env = getenv("VLOAM_LM_LO_WGS") ? atoi(getenv("VLOAM_LM_LO_WGS")) : 0;   // A/B override
+    const int lo_wgs = lo_env ? lo_env : (se.B == 1 ? 8 : kCoop);
+    if (lo_wgs == 8) VL_SOLVE(true, kLmDirect, 8);
+    else if (lo_wgs == 6) VL_SOLVE(true, kLmDirect, 6);
+    else VL_SOLVE(true, kLmDirect, kCoop);
+  }
   else if (direct) VL_SOLVE(true, kLmDirect, 1);
   else if (rowmask && coop) {
-    static const int wgs_env = getenv("VLOAM_LM_MAP_WGS") ? atoi(getenv("VLOAM_LM_MAP_WGS")) : kCoopMap;   // A/B: workgroups of a scan-to-map solve
+    static const int map_env = getenv("VLOAM_LM_MAP_WGS") ? atoi(getenv("VLOAM_LM_MAP_WGS")) : 0;   // A/B override
+    const int wgs_env = map_env ? map_env : (se.B == 1 ? 8 : kCoopMap);
     if (wgs_env == 8) VL_SOLVE(true, kLmRowMask, 8);
     else if (wgs_env == 4) VL_SOLVE(true, kLmRowMask, 4);
     else VL_SOLVE(true, kLmRowMask, kCoopMap);
