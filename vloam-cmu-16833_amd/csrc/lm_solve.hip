@@ -119,6 +119,14 @@ __device__ __forceinline__ int lm_coop_block() {
   if (NB > 1 && (int)gridDim.x == NB * 8) { const int xcd = MODE == 1 ? 2 : 6; return (b & 7) != xcd ? -1 : (b >> 3); }
   return b;
 }
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also waits for every global store
+// the wavefront has in flight — thread 0's trace rows, the residual hook of the first evaluation, the tagged granules — a memory round
+// trip in front of barriers that only hand LDS data over.  Used where nothing but LDS crosses the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ double wave_sum(double v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
@@ -566,7 +574,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     };
     // ---- edge factors (compact order == slot order: they come first).  Cached slots in packets of kPkE, streamed ones too.
     // (with NB workgroups a lane rarely owns more than one edge factor: packets of one instead of evaluating padding)
-    constexpr int kPkE = NB > 1 ? 1 : 3, kPkP = 2;
+    constexpr int kPkE = NB > 1 ? 1 : 3, kPkP = (DIRECT && NB * kLmThreads >= kMaxFlat) ? 1 : 2;   // (scan-to-scan with >= 6 workgroups: a lane owns at most ONE plane slot — a packet of two would evaluate padding; zeros add exactly nothing, so the sums are the same bits)
     auto edge_packet = [&](const double (&p)[kPkE][3], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], const double (&d1)[kPkE],
                            const double (&d2)[kPkE], int k0 /* compact index of lane's first factor */, int kstride) {
       double c1[kPkE], c2[kPkE];
@@ -661,7 +669,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
 #pragma unroll
   for (int i = 0; i < kAcc; i++) sh.red[i * kRedStride + tid] = acc[i];
-  __syncthreads();
+  lds_barrier();
   if (tid < 8 * kAcc) {
     const int i = tid >> 3, sub = tid & 7;
     const double* col = sh.red + i * kRedStride + sub;
@@ -670,7 +678,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     for (int j = 0; j < kLmThreads / 8; j++) s += col[8 * j];
     sh.part[sub * kAcc + i] = s;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < kAcc) {
     double s = 0.0;
 #pragma unroll
@@ -721,7 +729,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       s_out[tid] = tot;
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
@@ -962,7 +970,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   refresh_normal_equations(sh.acc2[0], true, 0);
   if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.acc2[0]);
   if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
-  __syncthreads();
+  lds_barrier();
   const bool failed_at_start = NB > 1 && sh.failed;  // (uniform: written before the barrier that ends lm_evaluate)
   if (tid == 0) {
     const double* cur = sh.acc2[0];
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       }
       sh.go = go;
     }
-    __syncthreads();
+    lds_barrier();
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
@@ -1107,7 +1115,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
       sh.go2 = stop ? 0 : 1;
       LM_STAMP(7);   // acceptance test
     }
-    __syncthreads();
+    lds_barrier();
     if (accepted) { gmax = sh.gmax_c; x_norm = sh.xnorm_c; }
     cyc_serial += clock64() - t_mark;
     if (sh.go2 == 0) break;
