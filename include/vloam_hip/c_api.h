@@ -75,14 +75,18 @@ vloam_status vloam_destroy(vloam_handle* h);
 /* ---- Batched execution: one handle, n_sessions independent sequences advanced in lock step.  Every kernel of the sweep chain is
  * launched once per sweep for ALL sessions (session index in blockIdx.z), so n_sessions sequences cost one launch chain — the way to
  * fill the chip with a path whose single-sequence form is a latency chain.  Each session owns an identical arena of
- * device state; results are bit-identical to running the sequence alone.  vloam_create == vloam_create_batch(…, 1, …).
+ * device state; integer / index / f32 point results (feature clouds, picks, down-sampled scan features, image key points) are bit-identical
+ * to running the sequence alone, the f64 poses agree to round-off (~1e-13: a batch adds the partial sums of its solves over 4 / 6
+ * workgroups, a single sequence over 8).  vloam_create == vloam_create_batch(…, 1, …).
  * vloam_batch_process_scan[_device]: session b gets sweep xyz_pad4[b] with n[b] points (arrays of n_sessions entries).
  * vloam_select_session: which session the getters below (trajectory, features, counts, map, parity hooks) read; 0 after creation.
  * The single-sequence entry points (vloam_scan_registration*, vloam_laser_*, vloam_process_scan*, vloam_process_frame*) return
  * VLOAM_ERR_INVALID on a handle with more than one session.
- * Co-residency bound: the Levenberg-Marquardt solves of a sweep run as cooperating workgroups (4 for the odometry, 6 for the mapping,
- * one compute unit's worth of registers each) that exchange partial sums INSIDE one launch, so all workgroups of a solve must be
- * resident together; a session can have one odometry and one mapping solve in flight, i.e. 10 such workgroups.  vloam_create_batch
+ * Co-residency bound: the Levenberg-Marquardt solves of a sweep run as cooperating workgroups (batch: 4 for the odometry, 6 for the
+ * mapping; a single sequence: 8 + 8, all eight of a solve on ONE XCD — odometry on XCD 2, mapping on XCD 6 — for the first two
+ * single-sequence handles alive in a process, spread over the XCDs for further ones; one compute unit's worth of registers each) that
+ * exchange partial sums INSIDE one launch, so all workgroups of a solve must be
+ * resident together; a session of a batch can have one odometry and one mapping solve in flight, i.e. 10 such workgroups.  vloam_create_batch
  * refuses (VLOAM_ERR_CAPACITY) when 10 * n_sessions exceeds the device's compute-unit count (256 on MI355X, so n_sessions <= 16 is
  * always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  A
  * workgroup that still waits for its partners after ~0.5 s abandons the solve (pose unchanged) and vloam_sync reports VLOAM_ERR_HIP. */

@@ -7,6 +7,7 @@
 #include "../../include/vloam_hip/c_api.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -71,6 +72,7 @@ struct vloam_handle {
   Sess se;
   int sel = 0;          // session the getters read (vloam_select_session)
   double* sync_pool = nullptr;
+  bool counted_single = false; // this handle is in g_single_handles
   int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
@@ -197,6 +199,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   return VLOAM_OK;
 }
 
+static std::atomic<int> g_single_handles{0};   // single-sequence handles alive in this process (Sess::crowd)
 #define SINGLE_SESSION_ONLY(h) do { if ((h)->se.B != 1) { set_err("this entry point drives one sequence: the handle has %d sessions (use the vloam_batch_* calls)", (h)->se.B); return VLOAM_ERR_INVALID; } } while (0)
 
 // session-relative pointer for the host-side getters
@@ -321,6 +324,10 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       const size_t ss = (dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // 2 MB granules: every session sees the same address bits below
       h->se.B = n_sessions;
       h->se.ss = ss;
+      // The cooperative solves of a single sequence are placed on ONE XCD each (lm_solve.hip: lm_coop_block): 8 + 8 compute units of XCDs 2 and
+      // 6.  Several single-sequence handles in one process would crowd those two XCDs (and their solves wait for each other's compute
+      // units): only the first two alive get the placement, the others launch spread over the XCDs like before round 4.  Same arithmetic.
+      if (n_sessions == 1) { h->se.crowd = g_single_handles.fetch_add(1); h->counted_single = true; }
       h->arena_bytes = ss * (size_t)n_sessions;
       if (hipMalloc((void**)&h->arena, h->arena_bytes) != hipSuccess) {
         set_err("hipMalloc of %zu MB for %d session(s) failed", h->arena_bytes >> 20, n_sessions); h->arena = nullptr; return VLOAM_ERR_HIP;
@@ -400,6 +407,7 @@ vloam_status vloam_select_session(vloam_handle* h, int session) {
 
 vloam_status vloam_destroy(vloam_handle* h) {
   if (!h) return VLOAM_OK;
+  if (h->counted_single) g_single_handles.fetch_sub(1);
   if (g_host_prof && h->host_calls > 0)
     fprintf(stderr, "[vloam host prof] %lld sweeps: per sweep %.1f us in the buffer-set throttle, %.1f us enqueueing SR (incl. throttle), %.1f us LO, %.1f us mapping\n",
             h->host_calls, 1e6 * h->host_s[0] / h->host_calls, 1e6 * h->host_s[1] / h->host_calls, 1e6 * h->host_s[2] / h->host_calls, 1e6 * h->host_s[3] / h->host_calls);

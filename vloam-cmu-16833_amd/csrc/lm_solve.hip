@@ -1267,7 +1267,7 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, 
   const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1);
   if (!direct && !rowmask) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
   static const int one_xcd = getenv("VLOAM_LM_ONE_XCD") ? atoi(getenv("VLOAM_LM_ONE_XCD")) : 1;   // A/B switch, see lm_coop_block
-  const unsigned spread = (one_xcd && se.B == 1) ? 8u : 1u;
+  const unsigned spread = (one_xcd && se.B == 1 && se.crowd < 2) ? 8u : 1u;   // (crowd: the third and later single-sequence handles of a process stay spread, c_api.cpp)
 #define VL_SOLVE(Q, M, N)                                                                                                                   \
   VLOAM_LAUNCH_EV(ph, kKLmSolve, st, done, (k_lm_solve<Q, M, N>), dim3((N) > 1 ? (N) * spread : (N), 1, Z), dim3(kLmThreads), 0, st, F, edge_rows, d_x, \
                   d_rec, max_iters, huber_a, d_enable, fin_lo, fin_traj, se.ss)

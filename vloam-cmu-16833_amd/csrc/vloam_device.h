@@ -21,7 +21,7 @@ constexpr int kMaxBatch = 16;
 // with only one mapping stage queued behind the running one, and every stream idled 60-75 us per 214 us period
 // (profiles/r03_critical_path_4_sets.txt); 8 sets keep several sweeps queued on every stream, so the period is the longest stage again.
 constexpr int kBufferSets = 8;
-struct Sess { int B = 1; size_t ss = 0; };
+struct Sess { int B = 1; size_t ss = 0; int crowd = 0; };   // crowd: single-sequence handles alive in this process when the handle was created (lm_launch: one-XCD placement only for the first two)
 struct BatchIn { const float4* in[kMaxBatch]; int n[kMaxBatch]; };   // the one thing that is not in the arenas: the callers' sweeps
 template <class T>
 __host__ __device__ inline void rbp(T*& p, size_t off) { if (p) p = (T*)((char*)p + off); }   // pointer arithmetic, NOT an integer round trip:
