@@ -44,17 +44,17 @@ def pct(x, name, unit="cycles"):
 
 
 cyc = h.debug_raw(0, 11, np.int64).reshape(-1, 8)[:64]
-names = ["load ring -> LDS", "gaps / reach (+ debug sort)", "greedy picks (6 wavefronts)", "bbox, voxel ids, run keys", "bitonic sort of runs",
-         "voxel heads + centroids"]
+names = ["load ring -> LDS", "gaps / reach (+ debug sort)", "greedy picks, all sectors at once", "picks: boundary rounds (redone sectors)",
+         "bbox, voxel ids, run keys", "bitonic sort of runs", "voxel heads + centroids"]
 print("k_sr_ring: cycles per phase over the %d scan lines of the last sweep (debug level %d)" % (cyc.shape[0], a.debug_level))
-tot = cyc[:, :6].sum(axis=1)
+tot = cyc[:, :7].sum(axis=1)
 for r in np.argsort(-tot)[:6]:
     m = int(cyc[r, 7])
     print("  slowest: ring %2d  total %7d  phases %s   len %4d  lessFlat candidates %4d  runs %4d  voxels %4d" %
-          (r, tot[r], " ".join("%6d" % v for v in cyc[r, :6]), (m >> 32) & 0xffff, (m >> 48) & 0xffff, m & 0xffff, (m >> 16) & 0xffff))
+          (r, tot[r], " ".join("%6d" % v for v in cyc[r, :7]), (m >> 32) & 0xffff, (m >> 48) & 0xffff, m & 0xffff, (m >> 16) & 0xffff))
 for q, n in enumerate(names):
     pct(cyc[:, q], n)
-pct(cyc[:, :6].sum(axis=1), "whole workgroup")
+pct(cyc[:, :7].sum(axis=1), "whole workgroup")
 
 for outer in (0, 1):
     raw = h.debug_raw(1, outer * 16 + 4, np.int64).reshape(-1, 4)

@@ -19,6 +19,7 @@ import conftest  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweeps", type=int, default=400)
 ap.add_argument("--resident", type=int, default=96)
+ap.add_argument("--serial", action="store_true", help="sync after every sweep: the chain without the other streams' kernels of the next sweeps beside it")
 a = ap.parse_args()
 synth = conftest.load_synth()
 _SEQ = synth.SynthSequence(n_rings=64, n_azimuth=2048, n_sweeps=a.resident + 1)
@@ -45,6 +46,8 @@ h = vl.Handle(0, with_mapping=1, max_frames=a.sweeps + 8)
 t0 = time.perf_counter()
 for k in order:
     h.process_scan_device(d.data_ptr() + k * npts * 16, npts)
+    if a.serial:
+        h.sync()
 h.sync()
 dt = time.perf_counter() - t0
 ts = h.debug_raw(2, 72, np.int64).reshape(1024, 2).astype(np.float64) * 0.01   # microseconds

@@ -565,11 +565,17 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       for (int l = sp_l + lane; l <= ep_l; l += 64) { picked[l] = (l <= in_hi) ? 1 : 0; label[l] = 0; }
       lds_fence_wave();
     }
+    // A pick is a chain of dependent instructions on a wavefront that is (almost) alone on its SIMD — ~8 cycles each —, so the walk is
+    // written for few instructions per pick: the lane's candidates are kept PRE-MASKED (an ineligible slot holds the walk's neutral
+    // value: the lane's best is a max3 / min3 tree), the winner's local index travels with its suppression reach in one word (no LDS
+    // round trip for the reach), the lane that owns the winner is found by ballot (a second reduction only when two lanes tie), and the
+    // picks stay in registers (lane k: pick k) until the walk is over — labels, index lists and the pick list are written once, in parallel.
     unsigned cb[kQ];                      // curvature bits of point sp_l + q * 64 + lane
+    unsigned pay[kQ];                     // its local index << 8 | reach byte
     unsigned sharp_bits = 0, flat_bits = 0, elig = 0, inside = 0;
 #pragma unroll
     for (int q = 0; q < kQ; q++) {
-      cb[q] = 0;
+      cb[q] = 0; pay[q] = 0;
       if (q * 64 < seclen) {
         const int t = q * 64 + lane;
         if (t < seclen) {
@@ -583,6 +589,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
             cb[q] = __float_as_uint(c0);   // c >= 0: the bit pattern orders like the value
             cbits[i] = cb[q];
           }
+          pay[q] = ((unsigned)i << 8) | (unsigned)reachb[i];
           const float c = __uint_as_float(cb[q]);
           if ((double)c > 0.1) sharp_bits |= 1u << q;
           if ((double)c < 0.1) flat_bits |= 1u << q;
@@ -593,27 +600,35 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     int* o_sharp = sharp_idx + (r * kSectors + s) * kMaxSharpPerSect;
     int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
     int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
-    int n_sharp = 0, n_less = 0, n_flat = 0;
+    int n_less = 0, n_flat = 0;
+    int my_sharp = 0, my_flat = 0;        // lane k: pick k of the sharp / flat walk (local index)
     int leak_lo = INT_MAX, leak_hi = -1;
-    auto suppress = [&](int lf) {  // SR:353-376 around local index lf
-      const int rb = reachb[lf];
-      const int lo_m = lf - (rb & 15), hi_m = lf + (rb >> 4);
+    unsigned v[kQ];                       // the running walk's pre-masked candidates
+    auto suppress = [&](unsigned pw, unsigned neutral) {  // SR:353-376 around the winner (local index << 8 | reach)
+      const int lf = (int)(pw >> 8);
+      const int lo_m = lf - (int)(pw & 15u), hi_m = lf + (int)((pw >> 4) & 15u);
       const int l = lo_m + lane;  // at most 11 marks
       if (l <= hi_m && l >= sp_l && l <= ep_l) picked[l] = 1;
       leak_lo = min(leak_lo, lo_m); leak_hi = max(leak_hi, hi_m);
       const int tlo = max(lo_m - sp_l, 0), thi = min(hi_m - sp_l, seclen - 1);
-      for (int q = tlo >> 6; q <= (thi >> 6); q++) {  // one or two slots
-        const int t = q * 64 + lane;
-        if (t >= tlo && t <= thi) elig &= ~(1u << q);
-      }
+      const unsigned d = (unsigned)(lane - tlo), span = (unsigned)(thi - tlo);
+#pragma unroll
+      for (int q = 0; q < kQ; q++)
+        if (d + (unsigned)(q * 64) <= span) v[q] = neutral;
     };
-    // kept picks [first, first + n) of the pick list: lane k marks around pick k (labels, marks, extents), then every lane re-reads
-    // which of its points are still eligible
+    // which of the lane's points no pick has marked (the walks themselves only keep v[] current)
+    auto refresh_elig = [&]() {
+      lds_fence_wave();
+#pragma unroll
+      for (int q = 0; q < kQ; q++)
+        if (((inside >> q) & 1u) && picked[sp_l + q * 64 + lane]) elig &= ~(1u << q);
+    };
+    // kept picks [first, first + n) of the pick list: lane k marks around pick k (marks, extents) and takes the pick back into its register
     auto replay = [&](int first, int n, int n_marking, int sharp_walk) {
       int lo_m = INT_MAX, hi_m = -1;
       if (lane < n) {
         const int lf = plist[first + lane];
-        label[lf] = sharp_walk ? (lane < kMaxSharpPerSect ? 2 : 1) : -1;
+        if (sharp_walk) my_sharp = lf; else my_flat = lf;
         if (lane < n_marking) {
           const int rb = reachb[lf];
           lo_m = lf - (rb & 15); hi_m = lf + (rb >> 4);
@@ -622,56 +637,58 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       }
       leak_lo = min(leak_lo, (int)wave_min_u32((unsigned)lo_m));
       leak_hi = max(leak_hi, (int)wave_max_u32((unsigned)(hi_m + 1)) - 1);
-      lds_fence_wave();
-#pragma unroll
-      for (int q = 0; q < kQ; q++)
-        if (((inside >> q) & 1u) && picked[sp_l + q * 64 + lane]) elig &= ~(1u << q);
     };
     // SR:327-378, descending curvature
-    if (keep_sharp > 0) {
-      replay(0, keep_sharp, keep_sharp, 1);
-      n_sharp = min(keep_sharp, kMaxSharpPerSect); n_less = keep_sharp;
-    }
-    if (!sharp_final)
-    for (int picks = keep_sharp + 1;; picks++) {
-      const unsigned m = elig & sharp_bits;
-      unsigned bh = 0, bl = 0;
+    if (keep_sharp > 0) { replay(0, keep_sharp, keep_sharp, 1); n_less = keep_sharp; }
+    if (!sharp_final) {
+      if (redo) refresh_elig();
 #pragma unroll
-      for (int q = 0; q < kQ; q++)
-        if (q * 64 < seclen && ((m >> q) & 1u) && cb[q] >= bh) { bh = cb[q]; bl = (unsigned)(sp_l + q * 64 + lane); }  // >=: higher index wins ties
-      const unsigned mh = wave_max_u32(bh);  // candidates have c > 0.1, i.e. non-zero bits
-      if (mh == 0) break;
-      const int lf = (int)wave_max_u32(bh == mh ? bl : 0u);
-      if (picks <= 2) {
-        if (lane == 0) { label[lf] = 2; o_sharp[n_sharp] = off + lf; o_less[n_less] = off + lf; plist[n_less] = lf; }
-        n_sharp++; n_less++;
-      } else if (picks <= 20) {
-        if (lane == 0) { label[lf] = 1; o_less[n_less] = off + lf; plist[n_less] = lf; }
+      for (int q = 0; q < kQ; q++) v[q] = ((elig & sharp_bits) >> q) & 1u ? cb[q] : 0u;   // candidates have c > 0.1, i.e. non-zero bits
+      for (int picks = keep_sharp + 1; picks <= kMaxLessSharpPerSect; picks++) {
+        unsigned lb = v[0];
+#pragma unroll
+        for (int q = 1; q < kQ; q++) lb = max(lb, v[q]);
+        const unsigned mh = wave_max_u32(lb);
+        if (mh == 0) break;
+        unsigned pl = 0;
+#pragma unroll
+        for (int q = 0; q < kQ; q++) if (v[q] == mh) pl = pay[q];   // ascending: the higher index wins ties
+        const u64 tie = __ballot(lb == mh);
+        const unsigned pw = (tie & (tie - 1ull)) == 0ull ? (unsigned)__builtin_amdgcn_readlane((int)pl, __ffsll((long long)tie) - 1) : wave_max_u32(pl);
+        if (lane == n_less) my_sharp = (int)(pw >> 8);
         n_less++;
-      } else {
-        break;
+        suppress(pw, 0u);
       }
-      suppress(lf);
     }
     // SR:380-422, ascending curvature
-    if (keep_flat > 0) {
-      replay(kMaxLessSharpPerSect, keep_flat, min(keep_flat, kMaxFlatPerSect - 1), 0);
-      n_flat = keep_flat;
-    }
-    for (int picks = keep_flat + 1;; picks++) {
-      const unsigned m = elig & flat_bits;
-      unsigned bh = 0xffffffffu, bl = 0xffffffffu;
+    if (keep_flat > 0) { replay(kMaxLessSharpPerSect, keep_flat, min(keep_flat, kMaxFlatPerSect - 1), 0); n_flat = keep_flat; }
+    refresh_elig();
 #pragma unroll
-      for (int q = 0; q < kQ; q++)
-        if (q * 64 < seclen && ((m >> q) & 1u) && (bl == 0xffffffffu || cb[q] < bh)) { bh = cb[q]; bl = (unsigned)(sp_l + q * 64 + lane); }  // <: lower index wins ties
-      if (__ballot(bl != 0xffffffffu) == 0ull) break;
-      const unsigned mh = wave_min_u32(bl != 0xffffffffu ? bh : 0xffffffffu);
-      const int lf = (int)wave_min_u32((bl != 0xffffffffu && bh == mh) ? bl : 0xffffffffu);
-      if (lane == 0) { label[lf] = -1; o_flat[n_flat] = off + lf; plist[kMaxLessSharpPerSect + n_flat] = lf; }
+    for (int q = 0; q < kQ; q++) v[q] = ((elig & flat_bits) >> q) & 1u ? cb[q] : 0xffffffffu;   // (c < 0.1: never all ones)
+    for (int picks = keep_flat + 1;; picks++) {
+      unsigned lb = v[0];
+#pragma unroll
+      for (int q = 1; q < kQ; q++) lb = min(lb, v[q]);
+      const unsigned mh = wave_min_u32(lb);
+      if (mh == 0xffffffffu) break;
+      unsigned pl = 0xffffffffu;
+#pragma unroll
+      for (int q = kQ - 1; q >= 0; q--) if (v[q] == mh) pl = pay[q];   // descending: the lower index wins ties
+      const u64 tie = __ballot(lb == mh);
+      const unsigned pw = (tie & (tie - 1ull)) == 0ull ? (unsigned)__builtin_amdgcn_readlane((int)pl, __ffsll((long long)tie) - 1) : wave_min_u32(pl);
+      if (lane == n_flat) my_flat = (int)(pw >> 8);
       n_flat++;
-      if (picks >= 4) break;  // the 4th flat point is emitted but not suppressed (SR:390-394)
-      suppress(lf);
+      if (picks >= kMaxFlatPerSect) break;  // the 4th flat point is emitted but not suppressed (SR:390-394)
+      suppress(pw, 0xffffffffu);
     }
+    // labels, index lists, pick list: one lane per pick
+    const int n_sharp = min(n_less, kMaxSharpPerSect);
+    if (lane < n_less) {
+      label[my_sharp] = lane < kMaxSharpPerSect ? 2 : 1;
+      o_less[lane] = off + my_sharp; plist[lane] = my_sharp;
+      if (lane < n_sharp) o_sharp[lane] = off + my_sharp;
+    }
+    if (lane < n_flat) { label[my_flat] = -1; o_flat[lane] = off + my_flat; plist[kMaxLessSharpPerSect + lane] = my_flat; }
     lds_fence_wave();
     if (lane == 0) {
       S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
@@ -686,6 +703,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   };
   if (wave < kSectors) run_sector(wave, -1, false, 0, false, 0);
   __syncthreads();
+  SR_STAMP();
   // fixed point over the boundaries: a sector is redone when the spill it was computed with differs from its predecessors'
   // current spill in a way that can matter.  Sector 0 never changes, so after round k sectors 0..k are final.
   for (int round = 0; round < kSectors - 1; round++) {
@@ -913,8 +931,7 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   if (tid == 0) S->ring_ds_cnt[r] = nvox;
   SR_STAMP();
   if (dbg_cyc && tid == 0) {
-    for (int q = 0; q < 6; q++) dbg_cyc[r * 8 + q] = q + 1 < nstamp ? tstamp[q + 1] - tstamp[q] : 0;
-    dbg_cyc[r * 8 + 6] = 0;
+    for (int q = 0; q < 7; q++) dbg_cyc[r * 8 + q] = q + 1 < nstamp ? tstamp[q + 1] - tstamp[q] : 0;
     dbg_cyc[r * 8 + 7] = (long long)nrun | ((long long)nvox << 16) | ((long long)len << 32) | ((long long)ncand << 48);
   }
 #undef SR_STAMP
