@@ -558,7 +558,8 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   int* s_pcnt = s_plist + kSectors * kPickSlots;        // [kSectors][2] picks of the sharp / flat walk
   auto run_sector_q = [&](auto kq_tag, int s, int in_hi, bool redo, int keep_sharp, bool sharp_final, int keep_flat) {
     constexpr int kQ = decltype(kq_tag)::value;   // register slots per lane: sector length <= 64 kQ
-    const int sp_l = s_sp[s] - off, ep_l = s_ep[s] - off;
+    // (the same in every lane: in scalar registers, so that what derives from them — the lane masks of suppress() — is scalar too)
+    const int sp_l = __builtin_amdgcn_readfirstlane(s_sp[s] - off), ep_l = __builtin_amdgcn_readfirstlane(s_ep[s] - off);
     const int seclen = ep_l - sp_l + 1;
     int* plist = s_plist + s * kPickSlots;
     if (redo) {  // forget the previous result, then apply the predecessor's spill
@@ -601,20 +602,30 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     int* o_less = less_sharp_idx + (r * kSectors + s) * kMaxLessSharpPerSect;
     int* o_flat = flat_idx + (r * kSectors + s) * kMaxFlatPerSect;
     int n_less = 0, n_flat = 0;
-    int my_sharp = 0, my_flat = 0;        // lane k: pick k of the sharp / flat walk (local index)
+    unsigned my_sharp = 0, my_flat = 0;   // lane k: pick k of the sharp / flat walk (local index << 8 | reach)
     int leak_lo = INT_MAX, leak_hi = -1;
     unsigned v[kQ];                       // the running walk's pre-masked candidates
-    auto suppress = [&](unsigned pw, unsigned neutral) {  // SR:353-376 around the winner (local index << 8 | reach)
+    // SR:353-376 around the winner, as far as the walk itself needs it: the (at most 11) covered points of the sector leave the
+    // candidates.  The marks themselves (cloudNeighborPicked) are written after the walk, by one lane per pick.
+    auto suppress = [&](unsigned pw, unsigned neutral) {
       const int lf = (int)(pw >> 8);
       const int lo_m = lf - (int)(pw & 15u), hi_m = lf + (int)((pw >> 4) & 15u);
-      const int l = lo_m + lane;  // at most 11 marks
-      if (l <= hi_m && l >= sp_l && l <= ep_l) picked[l] = 1;
-      leak_lo = min(leak_lo, lo_m); leak_hi = max(leak_hi, hi_m);
       const int tlo = max(lo_m - sp_l, 0), thi = min(hi_m - sp_l, seclen - 1);
       const unsigned d = (unsigned)(lane - tlo), span = (unsigned)(thi - tlo);
 #pragma unroll
       for (int q = 0; q < kQ; q++)
         if (d + (unsigned)(q * 64) <= span) v[q] = neutral;
+    };
+    // the marks (clipped to the sector) and extents of picks [from, to) of a walk: lane k marks around pick k
+    auto apply_marks = [&](unsigned my, int from, int to) {
+      int lo_m = INT_MAX, hi_m = -1;
+      if (lane >= from && lane < to) {
+        const int lf = (int)(my >> 8);
+        lo_m = lf - (int)(my & 15u); hi_m = lf + (int)((my >> 4) & 15u);
+        for (int l = max(lo_m, sp_l); l <= min(hi_m, ep_l); l++) picked[l] = 1;
+      }
+      leak_lo = min(leak_lo, (int)wave_min_u32((unsigned)lo_m));
+      leak_hi = max(leak_hi, (int)wave_max_u32((unsigned)(hi_m + 1)) - 1);
     };
     // which of the lane's points no pick has marked (the walks themselves only keep v[] current)
     auto refresh_elig = [&]() {
@@ -623,20 +634,12 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       for (int q = 0; q < kQ; q++)
         if (((inside >> q) & 1u) && picked[sp_l + q * 64 + lane]) elig &= ~(1u << q);
     };
-    // kept picks [first, first + n) of the pick list: lane k marks around pick k (marks, extents) and takes the pick back into its register
+    // kept picks [first, first + n) of the pick list come back into the registers (lane k: pick k); the first n_marking of them mark
     auto replay = [&](int first, int n, int n_marking, int sharp_walk) {
-      int lo_m = INT_MAX, hi_m = -1;
-      if (lane < n) {
-        const int lf = plist[first + lane];
-        if (sharp_walk) my_sharp = lf; else my_flat = lf;
-        if (lane < n_marking) {
-          const int rb = reachb[lf];
-          lo_m = lf - (rb & 15); hi_m = lf + (rb >> 4);
-          for (int l = max(lo_m, sp_l); l <= min(hi_m, ep_l); l++) picked[l] = 1;
-        }
-      }
-      leak_lo = min(leak_lo, (int)wave_min_u32((unsigned)lo_m));
-      leak_hi = max(leak_hi, (int)wave_max_u32((unsigned)(hi_m + 1)) - 1);
+      unsigned my = 0;
+      if (lane < n) { const int lf = plist[first + lane]; my = ((unsigned)lf << 8) | (unsigned)reachb[lf]; }
+      if (sharp_walk) my_sharp = my; else my_flat = my;
+      apply_marks(my, 0, n_marking);
     };
     // SR:327-378, descending curvature
     if (keep_sharp > 0) { replay(0, keep_sharp, keep_sharp, 1); n_less = keep_sharp; }
@@ -655,10 +658,11 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
         for (int q = 0; q < kQ; q++) if (v[q] == mh) pl = pay[q];   // ascending: the higher index wins ties
         const u64 tie = __ballot(lb == mh);
         const unsigned pw = (tie & (tie - 1ull)) == 0ull ? (unsigned)__builtin_amdgcn_readlane((int)pl, __ffsll((long long)tie) - 1) : wave_max_u32(pl);
-        if (lane == n_less) my_sharp = (int)(pw >> 8);
+        if (lane == n_less) my_sharp = pw;
         n_less++;
         suppress(pw, 0u);
       }
+      apply_marks(my_sharp, keep_sharp, n_less);
     }
     // SR:380-422, ascending curvature
     if (keep_flat > 0) { replay(kMaxLessSharpPerSect, keep_flat, min(keep_flat, kMaxFlatPerSect - 1), 0); n_flat = keep_flat; }
@@ -676,19 +680,21 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       for (int q = kQ - 1; q >= 0; q--) if (v[q] == mh) pl = pay[q];   // descending: the lower index wins ties
       const u64 tie = __ballot(lb == mh);
       const unsigned pw = (tie & (tie - 1ull)) == 0ull ? (unsigned)__builtin_amdgcn_readlane((int)pl, __ffsll((long long)tie) - 1) : wave_min_u32(pl);
-      if (lane == n_flat) my_flat = (int)(pw >> 8);
+      if (lane == n_flat) my_flat = pw;
       n_flat++;
       if (picks >= kMaxFlatPerSect) break;  // the 4th flat point is emitted but not suppressed (SR:390-394)
       suppress(pw, 0xffffffffu);
     }
+    apply_marks(my_flat, keep_flat, min(n_flat, kMaxFlatPerSect - 1));
     // labels, index lists, pick list: one lane per pick
     const int n_sharp = min(n_less, kMaxSharpPerSect);
     if (lane < n_less) {
-      label[my_sharp] = lane < kMaxSharpPerSect ? 2 : 1;
-      o_less[lane] = off + my_sharp; plist[lane] = my_sharp;
-      if (lane < n_sharp) o_sharp[lane] = off + my_sharp;
+      const int lf = (int)(my_sharp >> 8);
+      label[lf] = lane < kMaxSharpPerSect ? 2 : 1;
+      o_less[lane] = off + lf; plist[lane] = lf;
+      if (lane < n_sharp) o_sharp[lane] = off + lf;
     }
-    if (lane < n_flat) { label[my_flat] = -1; o_flat[lane] = off + my_flat; plist[kMaxLessSharpPerSect + lane] = my_flat; }
+    if (lane < n_flat) { const int lf = (int)(my_flat >> 8); label[lf] = -1; o_flat[lane] = off + lf; plist[kMaxLessSharpPerSect + lane] = lf; }
     lds_fence_wave();
     if (lane == 0) {
       S->sect_cnt[r][s][0] = n_sharp; S->sect_cnt[r][s][1] = n_less; S->sect_cnt[r][s][2] = n_flat;
