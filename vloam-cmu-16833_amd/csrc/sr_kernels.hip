@@ -46,6 +46,33 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+// The same steps for f32 min / max (finite values) and an integer sum; lanes without a source combine with themselves (min / max) or 0 (sum).
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ float dpp_fminmax_step(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  return MAX ? fmaxf(o, v) : fminf(o, v);
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_fminmax(float v) {
+  v = dpp_fminmax_step<0xB1, 0xf, MAX>(v);
+  v = dpp_fminmax_step<0x4E, 0xf, MAX>(v);
+  v = dpp_fminmax_step<0x124, 0xf, MAX>(v);
+  v = dpp_fminmax_step<0x128, 0xf, MAX>(v);
+  v = dpp_fminmax_step<0x142, 0xa, MAX>(v);
+  v = dpp_fminmax_step<0x143, 0xc, MAX>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_step(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v = dpp_add_step<0xB1, 0xf>(v);
+  v = dpp_add_step<0x4E, 0xf>(v);
+  v = dpp_add_step<0x124, 0xf>(v);
+  v = dpp_add_step<0x128, 0xf>(v);
+  v = dpp_add_step<0x142, 0xa>(v);
+  v = dpp_add_step<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
 
 // SR:157 removeNaNFromPointCloud + SR:100-129 removeClosedPointCloud
 __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float thres) {
@@ -485,21 +512,31 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   SR_STAMP();
 
   // ---- neighbour-suppression reach of every point, computed once in parallel (SR:353-376 walks outwards while consecutive
-  // points are closer than sqrt(0.05) m): gap[l] = 1 when dist2(p[l+1], p[l]) > 0.05; reach[l] = (how many of l-1..l-5) |
-  // (how many of l+1..l+5) << 4 a pick at l would mark.
-  for (int l = tid; l < len; l += kRingThreads) {
-    unsigned char g = 1;
+  // points are closer than sqrt(0.05) m): gap bit l = 1 when dist2(p[l+1], p[l]) > 0.05; reach[l] = (how many of l-1..l-5) |
+  // (how many of l+1..l+5) << 4 a pick at l would mark.  The gap bits of 64 consecutive points are one ballot word; a point then
+  // reads its five bits forward and five bits backward out of three words (count of trailing / leading zeros) instead of walking up to
+  // ten bytes, each a dependent LDS round trip.
+  u64* gapw = (u64*)gap;   // [CAP / 64 + 1] ballot words (the byte array's place)
+  for (int base = wave * 64; base < len; base += kRingThreads) {   // wavefront-uniform
+    const int l = base + lane;
+    bool g = true;
     if (l + 1 < len) {
       const float dx = px[l + 1] - px[l], dy = py[l + 1] - py[l], dz = pz[l + 1] - pz[l];
-      g = ((double)(dx * dx + dy * dy + dz * dz) > 0.05) ? 1 : 0;
+      g = (double)(dx * dx + dy * dy + dz * dz) > 0.05;
     }
-    gap[l] = g;
+    const u64 m = __ballot(g);
+    if (lane == 0) gapw[base >> 6] = m;
   }
   __syncthreads();
   for (int l = 5 + tid; l < len - 5; l += kRingThreads) {  // picks are >= 5 away from both ring ends
-    int f = 0, k = 0;
-    while (f < 5 && gap[l + f] == 0) f++;       // SR:353-364
-    while (k < 5 && gap[l - 1 - k] == 0) k++;   // SR:365-376
+    const int c = l >> 6, b = l & 63;
+    const u64 w0 = gapw[c], wn = gapw[c + 1], wp = c > 0 ? gapw[c - 1] : 0ull;
+    // forward: bits l .. l+4 (SR:353-364 stops at the first gap)
+    const unsigned fw = (unsigned)(((w0 >> b) | ((wn << 1) << (63 - b))) & 31ull);
+    const int f = min(5, (int)__builtin_ctz(fw | 32u));
+    // backward: bits l-1 .. l-5, bit l-1 on top (SR:365-376)
+    const unsigned bw = b >= 5 ? (unsigned)((w0 >> (b - 5)) & 31ull) : (unsigned)(((wp >> (59 + b)) | (w0 << (5 - b))) & 31ull);
+    const int k = min(5, (int)__builtin_clz((bw << 27) | (1u << 26)));
     reachb[l] = (unsigned char)(k | (f << 4));
   }
 
@@ -776,9 +813,8 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
       mn[2] = fminf(mn[2], pz[l]); mx[2] = fmaxf(mx[2], pz[l]);
       mycnt++;
     }
-  for (int a = 0; a < 3; a++)
-    for (int d = 32; d > 0; d >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], d)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d)); }
-  for (int d = 32; d > 0; d >>= 1) mycnt += __shfl_xor(mycnt, d);
+  for (int a = 0; a < 3; a++) { mn[a] = wave_fminmax<false>(mn[a]); mx[a] = wave_fminmax<true>(mx[a]); }   // (DPP row steps: no LDS crossbar)
+  mycnt = wave_sum_i32(mycnt);
   float* wred = (float*)scan_tmp;  // [8 waves][6] + counts
   if (lane == 0) {
     for (int a = 0; a < 3; a++) { wred[wave * 8 + a] = mn[a]; wred[wave * 8 + 3 + a] = mx[a]; }
