@@ -353,15 +353,15 @@ __device__ __forceinline__ void bitonic_reg_stages(u64* a, int P, int k_lo, int 
     for (int k = k_lo; k <= k_hi; k <<= 1) {
       const bool up0 = ((base + lane) & k) == 0, up1 = ((base + 64 + lane) & k) == 0;
       if (k > 64) {  // stride 64 (both elements see the same direction: bit k lies above bit 6)
-        const u64 hi = a0 > a1 ? a0 : a1, lo = a0 > a1 ? a1 : a0;
-        a0 = up0 ? lo : hi; a1 = up0 ? hi : lo;
+        const bool swap = (a0 > a1) == up0;
+        const u64 t0 = swap ? a1 : a0, t1 = swap ? a0 : a1;
+        a0 = t0; a1 = t1;
       }
       for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
         const u64 b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
-        const bool lower = (lane & j) == 0;
-        const u64 mx0 = a0 > b0 ? a0 : b0, mn0 = a0 > b0 ? b0 : a0, mx1 = a1 > b1 ? a1 : b1, mn1 = a1 > b1 ? b1 : a1;
-        a0 = (up0 == lower) ? mn0 : mx0;
-        a1 = (up1 == lower) ? mn1 : mx1;
+        const bool lower = (lane & j) == 0;   // the lower lane of an ascending pair keeps the smaller key: one compare, one exchange decision
+        a0 = ((a0 > b0) == (up0 == lower)) ? b0 : a0;
+        a1 = ((a1 > b1) == (up1 == lower)) ? b1 : a1;
       }
     }
     a[base + lane] = a0; a[base + 64 + lane] = a1;
@@ -386,16 +386,16 @@ __device__ __forceinline__ void bitonic_reg_stages4(u64* a, int P, int k_lo, int
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const u64 x = v[e], y = v[e + 2];
-          const u64 hi = x > y ? x : y, lo = x > y ? y : x;
-          v[e] = up[e] ? lo : hi; v[e + 2] = up[e] ? hi : lo;
+          const bool swap = (x > y) == up[e];
+          v[e] = swap ? y : x; v[e + 2] = swap ? x : y;
         }
       }
       if (k > 64) {   // stride 64: (0, 1) and (2, 3)
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const u64 x = v[e], y = v[e + 1];
-          const u64 hi = x > y ? x : y, lo = x > y ? y : x;
-          v[e] = up[e] ? lo : hi; v[e + 1] = up[e] ? hi : lo;
+          const bool swap = (x > y) == up[e];
+          v[e] = swap ? y : x; v[e + 1] = swap ? x : y;
         }
       }
       for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
@@ -403,8 +403,7 @@ __device__ __forceinline__ void bitonic_reg_stages4(u64* a, int P, int k_lo, int
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const u64 b = __shfl_xor(v[e], j);
-          const u64 mx = v[e] > b ? v[e] : b, mn = v[e] > b ? b : v[e];
-          v[e] = (up[e] == lower) ? mn : mx;
+          v[e] = ((v[e] > b) == (up[e] == lower)) ? b : v[e];
         }
       }
     }
