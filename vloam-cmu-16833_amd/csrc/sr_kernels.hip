@@ -627,9 +627,11 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
             cbits[i] = cb[q];
           }
           pay[q] = ((unsigned)i << 8) | (unsigned)reachb[i];
+          // SR:330 / SR:383 compare the f32 curvature with the double 0.1, which lies between two neighbouring floats (0.099999994 and
+          // 0.1f = 0.100000001): (double)c > 0.1 <=> c >= 0.1f and (double)c < 0.1 <=> c < 0.1f — no f64 convert and compare per point
           const float c = __uint_as_float(cb[q]);
-          if ((double)c > 0.1) sharp_bits |= 1u << q;
-          if ((double)c < 0.1) flat_bits |= 1u << q;
+          if (c >= 0.1f) sharp_bits |= 1u << q;
+          if (c < 0.1f) flat_bits |= 1u << q;
           if (i > in_hi) elig |= 1u << q;
         }
       }
@@ -820,21 +822,15 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
     ((int*)wred)[wave * 8 + 6] = mycnt;
   }
   __syncthreads();
-  if (tid == 0) {
-    int tot = 0;
-    for (int a = 0; a < 3; a++) { mn[a] = wred[a]; mx[a] = wred[3 + a]; }
-    for (int w = 0; w < kRingThreads / 64; w++) {
-      for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], wred[w * 8 + a]); mx[a] = fmaxf(mx[a], wred[w * 8 + 3 + a]); }
-      tot += ((int*)wred)[w * 8 + 6];
-    }
-    for (int a = 0; a < 3; a++) { s_red[a] = mn[a]; s_red[3 + a] = mx[a]; }
-    *s_ncand_p = tot;
+  // (every lane folds the eight wavefronts' results itself — broadcast reads — instead of waiting for one lane behind a second barrier)
+  int ncand = 0;
+  for (int a = 0; a < 3; a++) { mn[a] = wred[a]; mx[a] = wred[3 + a]; }
+  for (int w = 0; w < kRingThreads / 64; w++) {
+    for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], wred[w * 8 + a]); mx[a] = fmaxf(mx[a], wred[w * 8 + 3 + a]); }
+    ncand += ((int*)wred)[w * 8 + 6];
   }
-  __syncthreads();
-  const int ncand = *s_ncand_p;
   if (ncand == 0) return;
   const float inv = 1.0f / 0.2f;  // inverse_leaf_size_
-  for (int a = 0; a < 3; a++) { mn[a] = s_red[a]; mx[a] = s_red[3 + a]; }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   float4* out = ring_ds + (size_t)r * kMaxRingLen;
   if (dx * dy * dz > (long long)INT_MAX) {
@@ -856,37 +852,68 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   // consecutive candidates sharing a voxel), not points: key = (voxel index, first point of the run).  Sorted runs of one
   // voxel are in input order and so are the points inside a run, hence summing run after run reproduces the
   // input-order f32 sums of pcl::VoxelGrid exactly, with a network several times smaller.
+  // run key = voxel index : first point : last point (32 : 20 : 12 bits; a run is known by its first point, so the order is (voxel,
+  // first point)).  The run's head writes the voxel and its own position, the point behind its last point ORs in where the run ended:
+  // the centroid pass below then walks [first, last] without testing every point's voxel (a dependent LDS trip per point otherwise).
+  //
+  // Every wavefront takes a CONTIGUOUS stretch of the ring, 64 consecutive points per trip: a point's predecessor sits in the lane
+  // below, the run heads of a trip are one ballot word and a head's run number is a population count — no voxel array, no flag array,
+  // no workgroup scan (that was five passes over LDS behind five barriers; this is two passes behind two).
   u64* K2 = keys;                      // [<= CAP] run keys
-  int* vox = (int*)(keys + CAP);       // [CAP] voxel index of every covered point (-1: not a candidate)
-  for (int l = tid; l < len; l += kRingThreads) {
-    int idx = -1;
-    if (l >= c_lo && l <= c_hi && label[l] <= 0) {
-      const int ijk0 = (int)(floorf(px[l] * inv) - (float)min_b[0]);
-      const int ijk1 = (int)(floorf(py[l] * inv) - (float)min_b[1]);
-      const int ijk2 = (int)(floorf(pz[l] * inv) - (float)min_b[2]);
-      idx = ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1];
+  unsigned* K2w = (unsigned*)K2;       // [2 t] low word, [2 t + 1] high word
+  constexpr int kTrips = (CAP + kRingThreads - 1) / kRingThreads;
+  const int seg = ((len + kRingThreads - 1) / kRingThreads) * 64;   // points per wavefront (<= 64 kTrips)
+  const int seg0 = wave * seg;
+  auto voxel_of = [&](int l) -> int {  // -1: not a lessFlat candidate
+    if (l < c_lo || l > c_hi || label[l] > 0) return -1;
+    const int ijk0 = (int)(floorf(px[l] * inv) - (float)min_b[0]);
+    const int ijk1 = (int)(floorf(py[l] * inv) - (float)min_b[1]);
+    const int ijk2 = (int)(floorf(pz[l] * inv) - (float)min_b[2]);
+    return ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1];
+  };
+  int vidx[kTrips];
+  u64 headm[kTrips], pcandm[kTrips];   // trip's run heads / lanes whose predecessor is a candidate
+  int nheads = 0;
+  {
+    int carry = seg0 > 0 && seg0 - 1 < len ? voxel_of(seg0 - 1) : -2;   // the point in front of the stretch (-2: none)
+    carry = __builtin_amdgcn_readfirstlane(carry);
+#pragma unroll
+    for (int it = 0; it < kTrips; it++) {
+      vidx[it] = -1; headm[it] = 0ull; pcandm[it] = 0ull;
+      if (it * 64 < seg) {
+        const int l = seg0 + it * 64 + lane;
+        const int v = l < len ? voxel_of(l) : -1;
+        int pv = __shfl_up(v, 1);
+        if (lane == 0) pv = carry;
+        carry = __builtin_amdgcn_readlane(v, 63);
+        vidx[it] = v;
+        headm[it] = __ballot(v >= 0 && pv != v);
+        pcandm[it] = __ballot(pv >= 0);
+        nheads += __popcll(headm[it]);
+        if (l < CAP) K2[l] = 0ull;   // (run numbers never exceed point numbers: every key that will be ORed together starts from zero)
+      }
     }
-    vox[l] = idx;
   }
+  int* s_heads = scan_tmp + 64;        // [8] (behind the bounding-box slots: a slow wavefront may still be reading those)
+  if (lane == 0) s_heads[wave] = nheads;
   __syncthreads();
-  for (int l = tid; l < len; l += kRingThreads) iscratch[l] = (vox[l] >= 0 && (l == 0 || vox[l - 1] != vox[l])) ? 1 : 0;
-  __syncthreads();
-  const int nrun = block_exclusive_scan(iscratch, len, scan_tmp);
+  int nrun = 0, running = 0;
+  for (int w = 0; w < kRingThreads / 64; w++) { const int t = s_heads[w]; running += w < wave ? t : 0; nrun += t; }
   int P2 = 2;
   while (P2 < nrun) P2 <<= 1;
-  // run key = voxel index : first point : last point (32 : 20 : 12 bits; a run is known by its first point, so the order is (voxel,
-  // first point)).  The run's head writes the voxel and its own position, its last point ORs in where the run ends: the centroid
-  // pass below then walks [first, last] without testing every point's voxel (a dependent LDS trip per point otherwise).
-  unsigned* K2w = (unsigned*)K2;   // [2 t] low word, [2 t + 1] high word
-  for (int t = tid; t < P2 && t < CAP; t += kRingThreads) K2[t] = t < nrun ? 0ull : ~0ull;
-  __syncthreads();
-  for (int l = tid; l < len; l += kRingThreads) {
-    const int v = vox[l];
-    if (v < 0) continue;
-    const bool head = l == 0 || vox[l - 1] != v, tail = l + 1 == len || vox[l + 1] != v;
-    const int run = iscratch[l] - (head ? 0 : 1);   // iscratch[l] = heads before l: a later point of a run counts its own head
-    if (head) { K2w[2 * run + 1] = (unsigned)v; atomicOr(&K2w[2 * run], (unsigned)l << 12); }
-    if (tail) atomicOr(&K2w[2 * run], (unsigned)l);
+  for (int t = nrun + tid; t < P2 && t < CAP; t += kRingThreads) K2[t] = ~0ull;   // the sorting network's padding
+#pragma unroll
+  for (int it = 0; it < kTrips; it++) {
+    if (it * 64 < seg) {
+      const int l = seg0 + it * 64 + lane;
+      const int v = vidx[it];
+      const u64 hm = headm[it];
+      const bool head = (hm >> lane) & 1ull;
+      const int run = running + __popcll(hm & ((1ull << lane) - 1ull));   // heads in front of l
+      if (head) { K2w[2 * run + 1] = (unsigned)v; atomicOr(&K2w[2 * run], (unsigned)l << 12); }
+      if (((pcandm[it] >> lane) & 1ull) && (head || v < 0)) atomicOr(&K2w[2 * (run - 1)], (unsigned)(l - 1));   // l - 1 closed its run
+      running += __popcll(hm);
+    }
   }
   __syncthreads();
   SR_STAMP();
@@ -946,27 +973,55 @@ __global__ __launch_bounds__(kRingThreads) void k_sr_ring(const float4* __restri
   }
   __syncthreads();
   SR_STAMP();
-  // voxel heads -> output rank
-  for (int t = tid; t < nrun; t += kRingThreads) iscratch[t] = (t == 0 || (K2[t] >> 32) != (K2[t - 1] >> 32)) ? 1 : 0;
-  __syncthreads();
-  const int nvox = block_exclusive_scan(iscratch, nrun, scan_tmp);
-  for (int t = tid; t < nrun; t += kRingThreads) {
-    const u64 k0 = K2[t];
-    const unsigned vid = (unsigned)(k0 >> 32);
-    if (t == 0 || vid != (unsigned)(K2[t - 1] >> 32)) {
-      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in input order
-      int npt = 0;
-      u64 k = k0;
-      for (int u = t;;) {
-        const int l0 = (int)((k >> 12) & 0xfffu), l1 = (int)(k & 0xfffu);
-        for (int l = l0; l <= l1; l++) { sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l]; }
-        npt += l1 - l0 + 1;
-        if (++u >= nrun) break;
-        k = K2[u];
-        if ((unsigned)(k >> 32) != vid) break;
+  // voxel heads -> output rank, the same way (contiguous stretches of the sorted keys, ballot words, population counts), then the centroids
+  int nvox = 0;
+  {
+    const int qseg = ((nrun + kRingThreads - 1) / kRingThreads) * 64, q0 = wave * qseg;
+    u64 kreg[kTrips], hm[kTrips];
+    unsigned carry = q0 > 0 && q0 - 1 < nrun ? (unsigned)(K2[q0 - 1] >> 32) : 0xffffffffu;   // (no voxel has that index: idx <= INT_MAX)
+    int mine = 0;
+#pragma unroll
+    for (int it = 0; it < kTrips; it++) {
+      kreg[it] = 0ull; hm[it] = 0ull;
+      if (it * 64 < qseg) {
+        const int t = q0 + it * 64 + lane;
+        const u64 k0 = t < nrun ? K2[t] : ~0ull;
+        const unsigned vid = (unsigned)(k0 >> 32);
+        unsigned pv = (unsigned)__shfl_up((int)vid, 1);
+        if (lane == 0) pv = carry;
+        carry = (unsigned)__builtin_amdgcn_readlane((int)vid, 63);
+        kreg[it] = k0;
+        hm[it] = __ballot(t < nrun && vid != pv);
+        mine += __popcll(hm[it]);
       }
-      const float cnt = (float)npt;
-      out[iscratch[t]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    }
+    int* s_vox = scan_tmp + 72;   // [8]
+    if (lane == 0) s_vox[wave] = mine;
+    __syncthreads();
+    int running = 0;
+    for (int w = 0; w < kRingThreads / 64; w++) { const int c = s_vox[w]; running += w < wave ? c : 0; nvox += c; }
+#pragma unroll
+    for (int it = 0; it < kTrips; it++) {
+      if (it * 64 < qseg) {
+        const int t = q0 + it * 64 + lane;
+        if ((hm[it] >> lane) & 1ull) {
+          const unsigned vid = (unsigned)(kreg[it] >> 32);
+          float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: f32 sums in input order
+          int npt = 0;
+          u64 k = kreg[it];
+          for (int u = t;;) {
+            const int l0 = (int)((k >> 12) & 0xfffu), l1 = (int)(k & 0xfffu);
+            for (int l = l0; l <= l1; l++) { sx += px[l]; sy += py[l]; sz += pz[l]; si += pi[l]; }
+            npt += l1 - l0 + 1;
+            if (++u >= nrun) break;
+            k = K2[u];
+            if ((unsigned)(k >> 32) != vid) break;
+          }
+          const float cnt = (float)npt;
+          out[running + __popcll(hm[it] & ((1ull << lane) - 1ull))] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+        }
+        running += __popcll(hm[it]);
+      }
     }
   }
   if (tid == 0) S->ring_ds_cnt[r] = nvox;
