@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--image-frames", type=int, default=24, help="extra leg: frames of the coupled loop driven from raw images (rendered on the host before the GPU work starts; 0 = skip)")
     ap.add_argument("--sessions", type=int, default=int(os.environ.get("VLOAM_BENCH_SESSIONS", "8")),
                     help="extra leg: batched execution, this many independent sequences per launch chain on ONE GPU (vloam_create_batch); 0 = skip")
+    ap.add_argument("--map-capacity-log2", type=int, default=0, help="voxel-hash slots per feature kind = 2^n (0: the library's default, 22); A/B runs of the table footprint")
     ap.add_argument("--sustain-seconds", type=float, default=float(os.environ.get("VLOAM_BENCH_SUSTAIN_S", "6")),
                     help="extra leg: stream the headline workload for about this long (sweeps replayed back and forth; 0 = skip)")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
@@ -300,8 +301,10 @@ def main():
     d_clouds = torch.from_numpy(host).to(torch.device("cuda", local_rank))
     base_ptr, stride = d_clouds.data_ptr(), n_pts * 16
 
+    cap_kw = {"map_capacity_log2": args.map_capacity_log2} if args.map_capacity_log2 > 0 else {}
+
     def new_handle(mapping=with_mapping, frames=T + 8):
-        return vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(mapping), max_points=max(n_pts, 1024), max_frames=frames)
+        return vl.Handle(local_rank, scan_line=args.rings, with_mapping=int(mapping), max_points=max(n_pts, 1024), max_frames=frames, **cap_kw)
 
     def stream(hh, lo, hi):
         for kk in range(lo, hi):
@@ -374,7 +377,7 @@ def main():
     batched = None
     if extras and args.sessions > 1:
         B = args.sessions
-        hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8)
+        hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8, **cap_kw)
 
         def bstream(lo, hi):
             for kk in range(lo, hi):
@@ -395,7 +398,7 @@ def main():
         hb.close()
         bk = {}
         if not args.no_kernel_timer:   # per-kernel durations of the batched launches (separate replay, like the single-sequence table)
-            hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8)
+            hb = vl.Handle(local_rank, n_sessions=B, scan_line=args.rings, with_mapping=int(with_mapping), max_points=max(n_pts, 1024), max_frames=T + 8, **cap_kw)
             bstream(0, M0 + W)
             hb.sync()
             hb.profile_kernel("*", 48 * K + 64)
