@@ -7,7 +7,8 @@
 //   vloam::LidarOdometryMapping  lidar_odometry_mapping.cpp:65-154  reset / scanRegistrationIO / laserOdometryIO / laserMappingIO
 //   vloam::VisualOdometry     visual_odometry.h:36-58     init / reset / processImage / setUpPointCloud / processPointCloud / solveNlsAll
 //                             (optical_flow_match = true; shares a Session with the LiDAR stages or owns one)
-// Same method names, argument meaning and call order.  Clouds are a PCL-free POD vector by default; define
+// Same method names, argument meaning and call order; the stage classes are default-constructible like the reference's (they then share
+// Session::get_default()), or take the Session they work on.  Clouds are a PCL-free POD vector by default; define
 // VLOAM_HIP_WITH_PCL (and have PCL on the include path) to get overloads with the reference's own signatures — ScanRegistration::input
 // taking pcl::PointCloud<pcl::PointXYZ>, and the pcl::PointCloud<PointType>::Ptr forms of ScanRegistration::output, LaserOdometry::input /
 // output and LaserMapping::input; that adapter is compile-guarded and untested here because PCL / ROS are absent from this image.  Errors: the reference aborts
@@ -88,6 +89,17 @@ class Session {  // one vloam_handle == one sequence on one GPU; shared by the t
   Session(const Session&) = delete;
   Session& operator=(const Session&) = delete;
   vloam_handle* get() const { return h_; }
+  // The session behind DEFAULT-CONSTRUCTED stage objects (the reference's classes are default-constructible, laser_odometry.h:66-68, and
+  // its façade holds them as plain members): created with the launch-file defaults on device 0 the first time one is needed; bind another
+  // one (other device / config) with set_default() before the stage objects are constructed, and release it with set_default(nullptr)
+  // before main() returns (the HIP runtime's own static destructors may otherwise run first).
+  static std::shared_ptr<Session>& default_slot() { static std::shared_ptr<Session> s; return s; }
+  static void set_default(std::shared_ptr<Session> s) { default_slot() = std::move(s); }
+  static std::shared_ptr<Session> get_default() {
+    auto& s = default_slot();
+    if (!s) s = std::make_shared<Session>();
+    return s;
+  }
   Cloud features(int which) const {
     int n = 0;
     check(vloam_get_features(h_, which, nullptr, 0, &n));
@@ -102,6 +114,7 @@ class Session {  // one vloam_handle == one sequence on one GPU; shared by the t
 
 class ScanRegistration {
  public:
+  ScanRegistration() : s_(Session::get_default()) {}   // like the reference's: the stages of a process share Session::get_default()
   explicit ScanRegistration(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}                                   // parameters were bound at vloam_create
   template <class TF> void init(std::shared_ptr<TF>&) {}
@@ -131,6 +144,7 @@ class ScanRegistration {
 
 class LaserOdometry {
  public:
+  LaserOdometry() : s_(Session::get_default()) {}   // like the reference's: the stages of a process share Session::get_default()
   explicit LaserOdometry(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}
   template <class TF> void init(std::shared_ptr<TF>&) {}   // laser_odometry.h:70 takes the vloam_tf blackboard
@@ -176,6 +190,7 @@ class LaserOdometry {
 
 class LaserMapping {
  public:
+  LaserMapping() : s_(Session::get_default()) {}   // like the reference's: the stages of a process share Session::get_default()
   explicit LaserMapping(std::shared_ptr<Session> s) : s_(std::move(s)) {}
   void init() {}
   template <class TF> void init(std::shared_ptr<TF>&) {}   // laser_mapping.h:85

@@ -56,6 +56,20 @@ int main(int argc, char** argv) {
     }
   }
   std::printf("map %zu registered %zu\n", LOAM.laser_mapping.map().size(), LOAM.laser_mapping.registeredCloud().size());
+  {   // default-constructed stage objects (laser_odometry.h:66-68) share Session::get_default(): a fresh sequence, first sweep again
+    vloam::ScanRegistration sr; vloam::LaserOdometry lo; vloam::LaserMapping lm;
+    sr.init(); lo.init(); lm.init();
+    std::rewind(f);
+    vloam::Cloud in((size_t)n_pts);
+    if (std::fread(in.data(), sizeof(vloam::PointXYZI), (size_t)n_pts, f) != (size_t)n_pts) return 2;
+    sr.input(in);
+    vloam::Cloud full, sharp, lessSharp, flat, lessFlat;
+    sr.output(full, sharp, lessSharp, flat, lessFlat);
+    lo.input(full, sharp, lessSharp, flat, lessFlat);
+    lo.solveLO();
+    std::printf("default %zu %zu %zu %zu %zu\n", full.size(), sharp.size(), lessSharp.size(), flat.size(), lessFlat.size());
+  }
+  vloam::Session::set_default(nullptr);   // release the device before the runtime's own static destructors run
   return 0;
 }
 '''
@@ -77,7 +91,7 @@ def test_cpp_facade_runs_on_the_gpu_and_matches_the_oracle(tmp_path, orc, sweeps
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lvloam_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe), str(data), str(n), str(clouds[0].shape[0]), str(skip)]).decode().strip().split("\n")
-    assert len(out) == n + 1
+    assert len(out) == n + 2
     o = orc.Oracle(with_mapping=True, mapping_skip_frame=skip)
     for k in range(n):
         f = out[k].split()
@@ -93,6 +107,8 @@ def test_cpp_facade_runs_on_the_gpu_and_matches_the_oracle(tmp_path, orc, sweeps
     last = out[n].split()
     info = o.map_info()
     assert int(last[1]) == info["total_corner"] + info["total_surf"] and int(last[3]) == o.cloud(0).shape[0]
+    # default-constructed stage objects: a fresh sequence on the process-wide default session, the first sweep's feature clouds again
+    assert out[n + 1].split()[0] == "default" and out[n + 1].split()[1:] == out[0].split()[1:6]
 
 
 VO_PROBE = r'''
