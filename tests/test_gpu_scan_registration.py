@@ -146,6 +146,50 @@ def test_rings_with_a_voxel_for_almost_every_point(vl, orc, synth):
         check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
 
 
+def test_equal_curvatures_are_picked_in_the_canonical_order(vl, orc, synth):
+    """Ties.  std::sort leaves points of equal curvature in an unspecified order (scan_registration.cpp:323); the oracle's canonical order
+    is (curvature, index), walked from the top for the sharp picks and from the bottom for the flat picks.  The device never sorts: a pick is
+    a wavefront arg-max over pre-masked candidates, the lane that owns the winner is found by ballot and a second reduction only runs when
+    two lanes tie (k_sr_ring, run_sector_q).  Every ring of this cloud holds two stretches of points TWICE — the same coordinates 80 columns
+    apart (twins in different lanes: the second reduction) and 128 columns apart (twins in the same lane, two register slots apart: the
+    slot order of the lane's own search) — so that every candidate inside them has a twin with the same curvature bits."""
+    n_az = 2048
+    el = np.deg2rad(synth.beam_elevations_deg(64))[:, None]
+    az = (-2 * np.pi * np.arange(n_az) / n_az)[None, :]
+    rng = np.random.default_rng(11)
+    rad = 18.0 + 4.0 * np.sin(3 * az) + 0.05 * rng.standard_normal((64, n_az))
+    rad += 1.2 * ((np.arange(n_az) // 37) % 2)[None, :]          # range steps: sharp candidates
+    cloud = np.zeros((64, n_az, 4), dtype=np.float32)
+    cloud[..., 0] = rad * np.cos(el) * np.cos(az)
+    cloud[..., 1] = rad * np.cos(el) * np.sin(az)
+    cloud[..., 2] = rad * np.sin(el)
+    cloud[:, 100:180] = cloud[:, 20:100]      # sector 0 of every ring: twins 80 points apart
+    cloud[:, 528:656] = cloud[:, 400:528]     # sector 1: twins 128 points apart
+    cloud = cloud.transpose(1, 0, 2).reshape(-1, 4).copy()   # firing order
+    o = orc.Oracle(with_mapping=False)
+    assert o.scan_registration(cloud) == 0
+    cur, start, end = o.sr_curvature(), o.sr_ints(3), o.sr_ints(4)
+    twins = rings = 0
+    for r in range(64):   # the construction works: interior points of the copies carry the same curvature bits as their originals
+        if end[r] - start[r] < 2000:
+            continue      # (the reference drops the lasers it maps to scan ids above 50, scan_registration.cpp:218-221)
+        rings += 1
+        a = cur[start[r] - 5 + 110:start[r] - 5 + 170].view(np.uint32)
+        b = cur[start[r] - 5 + 30:start[r] - 5 + 90].view(np.uint32)
+        twins += int(np.count_nonzero(a == b))
+    assert rings >= 48 and twins == rings * 60, "the cloud must contain exact curvature ties (%d of %d)" % (twins, rings * 60)
+    for debug in (0, 1):   # the production kernel and the debug build (which also emits the sort order)
+        h = vl.Handle(0, with_mapping=0, debug=debug)
+        h.scan_registration(cloud)
+        for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+            dev, ref = h.features(which), o.cloud(which)
+            assert dev.shape == ref.shape, name
+            assert np.array_equal(dev[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)), "%s: picks among equal curvatures differ (debug=%d)" % (name, debug)
+        if debug:
+            d = h.sr_debug()
+            assert np.array_equal(d["sharpInd"], o.sr_ints(5)) and np.array_equal(d["lessSharpInd"], o.sr_ints(6)) and np.array_equal(d["flatInd"], o.sr_ints(7))
+
+
 def test_scan_registration_errors_of_a_burst_are_not_lost(vl, sweeps):
     """vloam_process_scan bursts rotate four buffer sets and rewrite each set's error word every sweep: an empty sweep (all NaN) or a
     dropped over-long ring in the MIDDLE of a burst must still be reported by the vloam_sync that ends it — once."""
