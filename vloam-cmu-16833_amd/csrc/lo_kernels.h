@@ -9,7 +9,7 @@ namespace vloam {
 // pcl::KdTreeFLANN::setInputCloud calls at laser_odometry.cpp:525-526): a 1 m grid for the expanding exact search and a 5 m
 // grid whose 27-cell neighbourhood covers DISTANCE_SQ_THRESHOLD = 25 for the rare queries without a close neighbour.
 // Grid index g = kind + 2 * level (kind 0 corner / 1 surf, level 0 = 1 m / 1 = 5 m); bucket = hash(cell) & mask.
-constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 12, 1 << 14};
+constexpr int kGridBuckets[4] = {1 << 13, 1 << 15, 1 << 14, 1 << 15};   // 5 m level: 1 024 / 2 048 cell slots x 16 ring groups (contiguous per cell, lo_kernels.hip coarse_bucket)
 constexpr int kStopLen = kMaxRings + 4;
 constexpr int kGridMaxBuckets = 1 << 15;
 struct LoGrid {

@@ -52,7 +52,14 @@ __device__ __forceinline__ int coarse_cell(float v) { return (int)floor((double)
 // The 5 m level is keyed by (cell, group of 4 scan lines): the second / third neighbour searches only want points within two
 // scan lines of the closest point, i.e. at most two groups, instead of every line crossing those 15 m.
 constexpr int kRingGroupShift = 2;
-__device__ __forceinline__ unsigned coarse_hash(int ix, int iy, int iz, int grp) { return grid_hash(ix, iy, iz) ^ ((unsigned)grp * 0x9E3779B1u); }
+// The kRingGroups buckets of one cell are NEIGHBOURS in the table (bucket = cell slot * kRingGroups + group), so a cell's points of the groups
+// [g0, g0 + ng) are ONE contiguous range of the bucket-ordered copy: every search of the 5 m level — all groups for the closest point, the
+// one or two groups around its scan line for the second / third point — fetches 27 ranges, one per lane, whatever the group count
+// (keyed by a hash of (cell, group) the closest-point search walked 27 x 16 buckets: seven per lane, staged through LDS).
+constexpr int kRingGroups = kMaxRings >> kRingGroupShift;
+static_assert((kRingGroups & (kRingGroups - 1)) == 0, "group count is a power of two");
+__device__ __forceinline__ unsigned coarse_slot(int ix, int iy, int iz, unsigned mask) { return (grid_hash(ix, iy, iz) & (mask / kRingGroups)) * kRingGroups; }
+__device__ __forceinline__ unsigned coarse_bucket(int ix, int iy, int iz, int grp, unsigned mask) { return coarse_slot(ix, iy, iz, mask) + (unsigned)grp; }
 // bucket-ordered copies carry (point index, ring id) in .w: one fetch per candidate instead of index -> point
 __device__ __forceinline__ unsigned pack_tag(int j, int ring) { return (unsigned)j | ((unsigned)ring << 24); }
 __device__ __forceinline__ int tag_index(unsigned t) { return (int)(t & 0xffffffu); }
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void k_lo_grid_count(const float4* __restrict_
     if (i < n) {
       const float4 p = pts[i];
       bf = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
-      bc = coarse_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift) & (unsigned)G.mask[kind + 2];
+      bc = coarse_bucket(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift, (unsigned)G.mask[kind + 2]);
       line = (int)p.w;
     }
     int hl, off, len;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void k_lo_grid_scatter(const float4* __restric
     if (i < n) {
       const float4 p = pts[i];
       bf = grid_hash((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (unsigned)G.mask[kind];
-      bc = coarse_hash(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift) & (unsigned)G.mask[kind + 2];
+      bc = coarse_bucket(coarse_cell(p.x), coarse_cell(p.y), coarse_cell(p.z), (int)p.w >> kRingGroupShift, (unsigned)G.mask[kind + 2]);
       packed = make_float4(p.x, p.y, p.z, __uint_as_float(pack_tag(i, (int)p.w)));
     }
     int hl, off, len, pos = 0;
@@ -202,25 +209,26 @@ constexpr unsigned kBack = 0x40000000u;
 // A block holding more than max_total points is not visited at all (*skipped = true).
 // KC: cells per lane; UB: points per lane and trip (all of a trip's loads are in flight together — a cold neighbourhood costs
 // a full HBM round trip per trip); R / Rin are compile-time so the cell decoding divides by constants.
-template <int KC, int UB, int R, int Rin, class V>
+template <int KC, int UB, int R, int Rin, bool GROUPS = false, class V = void>
 __device__ __forceinline__ V for_each_candidate(const int* __restrict__ gstart, const float4* __restrict__ gpts, unsigned gmask, int cx,
                                                 int cy, int cz, int g0, int ng, int lane, V v, int max_total, bool* skipped,
                                                 int* s_inc, int* s_rel, long long* tm = nullptr) {
   if (tm) tm[0] = clock64();
   constexpr int w = 2 * R + 1, w3 = w * w * w;
-  const int ncell = w3 * ng;  // ng ring groups per cell (1 with g0 = 0 on the 1 m level)
+  // GROUPS: the 5 m level — one range per cell covers its ring groups [g0, g0 + ng) (coarse_bucket); otherwise the 1 m level (g0 = 0, ng = 1)
+  const int ncell = w3;
   int bs[KC], cnt[KC], mine = 0;
 #pragma unroll
   for (int q = 0; q < KC; q++) {
     const int cc = q * 64 + lane;
     bs[q] = 0; cnt[q] = 0;
     if (cc < ncell) {
-      const int ci = cc % w3, grp = g0 + cc / w3;
+      const int ci = cc;
       const int ox = ci % w - R, oy = (ci / w) % w - R, oz = ci / (w * w) - R;
       if (!(abs(ox) <= Rin && abs(oy) <= Rin && abs(oz) <= Rin)) {  // the block of radius Rin was scanned by an earlier stage
-        const unsigned b = coarse_hash(cx + ox, cy + oy, cz + oz, grp) & gmask;
+        const unsigned b = GROUPS ? coarse_slot(cx + ox, cy + oy, cz + oz, gmask) + (unsigned)g0 : grid_hash(cx + ox, cy + oy, cz + oz) & gmask;
         bs[q] = gstart[b];
-        cnt[q] = gstart[b + 1] - bs[q];
+        cnt[q] = gstart[b + (GROUPS ? ng : 1)] - bs[q];
       }
     }
     mine += cnt[q];
@@ -459,7 +467,7 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
     // VGPRs = 3 wavefronts per SIMD, so that all ~1 800 queries stay resident in one round even while the scan-registration
     // ring kernel (one 146 KB-LDS workgroup per scan line) holds 51 of the 256 compute units
     constexpr int kSparseUB = 8;
-    constexpr int kGroups = kMaxRings >> kRingGroupShift;
+    constexpr int kGroups = kRingGroups;
     auto stage_bound = [](int stage) { return stage == 0 ? 1.0f * 0.999999f : (stage == 2 ? 4.0f * 0.999999f : (stage == 3 ? 9.0f * 0.999999f : 3.0e38f)); };
     // walk stops of this kind's cloud, one table entry per lane (ringA indexes them through a cross-lane read below)
     const int* stops = is_corner ? G.stops : G.stops + 2 * kStopLen;
@@ -508,12 +516,12 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
       if (stage == 0) vn = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
       else if (stage == 1) {
         long long tm[5] = {0, 0, 0, 0, 0};
-        vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
+        vn = for_each_candidate<1, kSparseUB, 1, -1, true>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kSparse, &skipped, s_inc, s_rel, dbg_cyc ? tm : nullptr);
         if (dbg_cyc) tdbg = ((tm[1] - tm[0]) & 0xffff) | (((tm[2] - tm[1]) & 0xffff) << 16) | (((tm[3] - tm[2]) & 0xffff) << 32) | ((tm[4] & 0xffff) << 48);
       }
       else if (stage == 2) continue;  // (the closest point: both shells in one pass, the few queries that get here are the kernel's tail)
       else if (stage == 3) vn = for_each_candidate<6, 4, 3, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, vn, kAll, &skipped, s_inc, s_rel);
-      else vn = for_each_candidate<(27 * kGroups + 63) / 64, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
+      else vn = for_each_candidate<1, kSparseUB, 1, -1, true>(cstart, cpts, cmask, ccx, ccy, ccz, 0, kGroups, lane, vn, kAll, &skipped, s_inc, s_rel);
       if (skipped) continue;
       const u64 loc = wave_min_u64(vn.loc);
       best = loc < best ? loc : best;
@@ -542,10 +550,10 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
         va.l2 = ~0ull; va.l3 = ~0ull; va.visited = 0;
         bool skipped = false;
         if (stage == 0) va = for_each_candidate<1, 4, 1, -1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
-        else if (stage == 1) va = for_each_candidate<1, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups x 27 cells
+        else if (stage == 1) va = for_each_candidate<1, kSparseUB, 1, -1, true>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kSparse, &skipped, s_inc, s_rel);  // <= 2 groups of 27 cells
         else if (stage == 2) va = for_each_candidate<2, 4, 2, 1>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
         else if (stage == 3) va = for_each_candidate<6, 4, 3, 2>(fstart, fpts, fmask, fcx, fcy, fcz, 0, 1, lane, va, kAll, &skipped, s_inc, s_rel);
-        else va = for_each_candidate<1, kSparseUB, 1, -1>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kAll, &skipped, s_inc, s_rel);
+        else va = for_each_candidate<1, kSparseUB, 1, -1, true>(cstart, cpts, cmask, ccx, ccy, ccz, glo, ghi - glo + 1, lane, va, kAll, &skipped, s_inc, s_rel);
         if (skipped) continue;
         cand_dbg += va.visited;
         const u64 l2 = wave_min_u64(va.l2);
