@@ -49,7 +49,7 @@ REFERENCE_TIMERS = {
     "laser odometry: data association (laser_odometry.cpp:453)": ["k_lo_assoc"],
     "laser odometry / mapping: solver time (laser_odometry.cpp:465, laser_mapping.cpp:618)": ["k_lm_compact", "k_lm_solve"],
     "laser odometry: build tree -> NN grids (laser_odometry.cpp:525-526)": ["k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter"],
-    "laser mapping: filter time (laser_mapping.cpp:432-446)": ["k_map_ds_count", "k_map_ds_rank", "k_map_ds_scatter", "k_map_ds_reduce"],
+    "laser mapping: filter time (laser_mapping.cpp:432-446)": ["k_map_ds_bin", "k_map_ds_reduce"],
     "laser mapping: shift + build tree (laser_mapping.cpp:422,453) -> none needed: persistent voxel hash": ["k_map_prepare"],
     "laser mapping: mapping data assosiation (laser_mapping.cpp:606)": ["k_map_assoc", "k_map_fit"],
     "laser mapping: add points + filter (laser_mapping.cpp:686,705)": ["k_map_insert", "k_map_finalize"],
@@ -82,10 +82,10 @@ def algorithmic_bytes(kernel, c):
         return 32 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"] + c["n_lessFlat"])
     if kernel in ("k_lo_grid_count", "k_lo_grid_scatter"):  # the two less-clouds in; scatter also writes the bucket-ordered copies (2 levels)
         return 16 * n_less + (2 * 16 * n_less if kernel == "k_lo_grid_scatter" else 0)
-    if kernel in ("k_map_ds_count", "k_map_ds_scatter"):
-        return 16 * n_less + 4 * n_less
-    if kernel == "k_map_ds_reduce":
-        return 16 * n_less + 16 * nn
+    if kernel == "k_map_ds_bin":      # the two less-clouds in, one 8-byte sort key (cell index | point index) per point out
+        return 16 * n_less + 8 * n_less
+    if kernel == "k_map_ds_reduce":   # the keys back in, every point fetched once, one centroid per occupied cell out
+        return 8 * n_less + 16 * n_less + 16 * nn
     if kernel == "k_map_assoc":   # stack point in, 5 neighbour voxels (32-byte records) looked at, 5 slot ids out
         return nn * (16 + 5 * 32 + 20)
     if kernel == "k_map_fit":     # 5 neighbours in, one 76-byte factor record out
@@ -287,7 +287,9 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()  # identity on a full node; lets the gloo path share one GPU in tests
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # VLOAM_BENCH_FORCE_DIST=1: take the N > 1 path with WORLD_SIZE 1 as well (tests/test_gpu_bench_multi.py initialises RCCL — process group,
+    # device binding, barrier, the all_gather of the trajectory, the MAX all-reduce — on a single GPU, before the first 8-GPU run does)
+    if world > 1 or os.environ.get("VLOAM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VLOAM_BENCH_BACKEND", "nccl")  # "nccl" == RCCL; "gloo" only to exercise this path on a 1-GPU box
@@ -618,6 +620,8 @@ def main():
                        "gathered_trajectories": {"ranks": len(trajectories), "frames": [int(t.shape[0]) for t in trajectories],
                                                  "last_map_position": [[float(v) for v in t[-1, 11:14]] for t in trajectories]},
                        "host_affinity_rank0": affinity,
+                       "collective": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                                "rccl_version": list(torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None},
                        "pipelining": "SR / LO / mapping of consecutive sweeps overlap on their own HIP streams (one sequence, one GPU)"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

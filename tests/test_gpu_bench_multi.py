@@ -65,3 +65,26 @@ def test_bench_eight_ranks_the_drivers_own_command_line():
     assert len(set(ends)) == 8, ends                                  # eight different sequences
     aff = d["config"]["host_affinity_rank0"]
     assert aff["how"] in ("numa", "even-split") and 1 <= aff["cpus"] <= (os.cpu_count() or 1)
+
+
+def test_bench_initialises_rccl_on_one_gpu():
+    """The real collective backend, once: `torchrun --nproc-per-node 1 bench.py --gpus 1` with VLOAM_BENCH_FORCE_DIST=1 takes the N > 1 path
+    with backend "nccl" (= RCCL on ROCm) and world_size 1 — init_process_group with the device bound, the barriers around the timed
+    region, the all_gather of the [frames, 14] f64 trajectory out of device memory and the MAX all-reduce of the elapsed time.  No scaling
+    number comes out of it; it proves the RCCL import, the device binding and the environment (HSA_ENABLE_IPC_MODE_LEGACY=0, MASTER_ADDR)
+    before the driver's 8-GPU run has to."""
+    env = dict(os.environ, VLOAM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VLOAM_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--map-warmup", "8", "--no-extras", "--no-cpu-baseline", "--synth-procs", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["rccl_version"] and c["rccl_version"][0] >= 2, c
+    g = d["config"]["gathered_trajectories"]
+    assert g["ranks"] == 1 and g["frames"] == [16]
+    assert d["n_gpus"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and abs(d["per_rank_ms_per_step"][0] - d["ms_per_step"]) < 1e-9

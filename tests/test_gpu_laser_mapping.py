@@ -410,7 +410,7 @@ def test_long_drive_purges_and_rebuilds_the_tables(vl, orc, synth):
 
 def test_dense_scan_voxels_take_the_wavefront_rank_path(vl, orc, sweeps):
     """A coarse surf leaf (3.2 m instead of 0.8 m) puts far more than 256 sweep points into single voxels of the scan-feature VoxelGrid:
-    k_map_ds_reduce's third path — the whole wavefront ranks the members by counting, chunk by chunk through LDS — must still add them
+    k_map_ds_reduce hands cells of more than 32 points to a whole wavefront (64 points fetched at once) — and must still add them one by one
     in input order (pcl::VoxelGrid's f32 centroid is order dependent): down-sampled scan features, poses and map against the oracle."""
     h = vl.Handle(0, with_mapping=1, mapping_plane_resolution=3.2, mapping_line_resolution=1.6)
     o = orc.Oracle(with_mapping=True, line_res=1.6, plane_res=3.2)
@@ -431,6 +431,34 @@ def test_dense_scan_voxels_take_the_wavefront_rank_path(vl, orc, sweeps):
         oq, ot, _, _ = o.map_pose()
         assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, k
     assert big > 256, big   # the case is what it claims to be
+    h.sync()
+    got, want = h.get_map(), oracle_published_map(o)
+    assert got.shape == want.shape and same_cloud(got, want)
+
+
+def test_scan_voxel_bins_overflow(vl, orc, sweeps):
+    """A very coarse leaf (25.6 m / 12.8 m) puts thousands of sweep points into ONE cell: the bin that holds it outgrows its region
+    (4 096 keys, csrc/map_kernels.h kDsBinCap) however the splitters fall, the rest goes through the overflow list and the reduce pass's
+    slow path (gather + rank by counting in global memory).  Same stacks, bit for bit incl. order, same poses and map as the oracle."""
+    h = vl.Handle(0, with_mapping=1, mapping_plane_resolution=25.6, mapping_line_resolution=12.8)
+    o = orc.Oracle(with_mapping=True, line_res=12.8, plane_res=25.6)
+    big = 0
+    for k in range(3):
+        cloud = sweeps(64, 2048, k)
+        h.reset_frame()
+        h.scan_registration(cloud)
+        h.laser_odometry()
+        qm, tm = h.laser_mapping()
+        assert o.process(cloud) == 0
+        lf = o.cloud(4)
+        keys = np.floor(lf[:, :3] / np.float32(25.6)).astype(np.int64)
+        big = max(big, int(np.unique(keys, axis=0, return_counts=True)[1].max()))
+        for which in (7, 8):
+            dv, rf = h.features(which), o.cloud(which)
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+        oq, ot, _, _ = o.map_pose()
+        assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, k
+    assert big > 4096, big   # more points in one cell than a bin's region holds
     h.sync()
     got, want = h.get_map(), oracle_published_map(o)
     assert got.shape == want.shape and same_cloud(got, want)

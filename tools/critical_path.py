@@ -20,7 +20,7 @@ def short(n):
     return n.split('(')[0].replace('vloam::', '').replace('void ', '').split('<')[0]
 
 
-FIRST = {'sr': 'k_sr_first_last', 'ds': 'k_map_ds_count', 'lo': 'k_lo_assoc', 'map': 'k_map_prepare'}
+FIRST = {'sr': 'k_sr_first_last', 'ds': 'k_map_ds_bin', 'lo': 'k_lo_assoc', 'map': 'k_map_prepare'}
 LAST = {'sr': 'k_lo_grid_scatter', 'ds': 'k_map_ds_reduce', 'lo': 'k_lm_solve', 'map': 'k_map_finalize'}
 ev = collections.defaultdict(list)   # stage -> list of [start, end, busy]
 by_stream = collections.defaultdict(list)

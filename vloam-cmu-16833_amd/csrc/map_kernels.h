@@ -20,7 +20,6 @@ constexpr int kStackCapCorner = 8192;   // >= kMaxLessSharp
 constexpr int kStackCapSurf = 16384;    // voxels of one sweep's lessFlat cloud at the plane resolution
 constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
 constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
-constexpr int kDsHashCorner = 1 << 15, kDsHashSurf = 1 << 16;
 
 // One map voxel == one 32-byte record, so that a candidate of the 5-NN search, an insert and a finalize each touch ONE cache line
 // (round 1 kept keys / sums / counts in three arrays: three scattered lines per candidate, 27x the algorithmic traffic).
@@ -47,28 +46,28 @@ constexpr int kMaxProbe = 128;  // a longer chain means the table is overloaded:
 constexpr int kCandChunk = 256; // candidate lists longer than this are reported in MapFrame::max_candidates (the 5-NN search takes them in several passes, exactly)
 constexpr int kCandCache = 128; // entries per stack point in the second outer round's candidate cache (>= the pass size of every lane count of k_map_assoc)
 
+// scan-feature VoxelGrid (k_map_ds_bin / k_map_ds_reduce): the cell-index space of a sweep's cloud is cut into bins of ~kDsBinTarget points
+constexpr int kDsMaxBins = 256;      // bins per cloud (a cloud of more than 256 x 512 points gets fuller bins)
+constexpr int kDsBinTarget = 512;    // points per bin aimed at
+constexpr int kDsBinCap = 4096;      // keys a bin's region holds == keys the reduce pass sorts in LDS; a fuller bin spills into the overflow list
+constexpr int kDsBigCell = 32;       // cells with more points than this are folded by a whole wavefront
+constexpr int kDsBigCap = 128;       // such cells per bin (4 096 / 33)
+
 struct DsScratch {        // per-sweep VoxelGrid of the scan features (laser_mapping.cpp:432-440)
-  unsigned long long* keys;  // [hash] packed global voxel coords (iz, iy, ix), 0 = empty
-  int* cnt;                  // [hash] points per voxel (pass 1)
-  int* fill;                 // [hash] fill cursor of pass 3
-  int* suidx;                // [hash] index of the slot's voxel in uniq
-  unsigned long long* uniq;  // [stack_cap] keys of occupied voxels (arrival order)
-  int* uslot;                // [stack_cap] hash slot of uniq[i]
-  int* rank;                 // [stack_cap] output rank of uniq[i] (pass 2; zero between sweeps)
-  int* off;                  // [stack_cap] start of uniq[i]'s segment in seg (pass 2; zero between sweeps)
-  int* point_slot;           // [max_points] hash slot of every sweep point
-  int* seg;                  // [max_points] point indices grouped by voxel
-  int* rank_slot;            // [stack_cap] hash slot of the t-th voxel in VoxelGrid output order
-  int* rank_off;             // [stack_cap + 1] segment bounds in output order
-  int hash_mask, stack_cap;
+  unsigned long long* region;     // [kDsMaxBins][kDsBinCap] sort keys (cell index << 24 | point index) by bin, arrival order inside a bin
+  unsigned long long* over;       // [max_points] keys that found their bin's region full
+  unsigned long long* tmp;        // [max_points] slow path: an over-full bin gathered from its region + the overflow list ...
+  unsigned long long* sorted;     // [max_points] ... and ranked
+  unsigned long long* splitters;  // [kDsMaxBins] this sweep's bin boundaries (cell indices)
+  int* cursor;                    // [kDsMaxBins] keys per bin | [kDsMaxBins] overflow entries | [+1] ticket of the reduce pass | [+2] slow-path scratch in use
+  unsigned long long* done;       // [kDsMaxBins] look-back words: sweep generation << 32 | cells of the bin
+  int stack_cap;
   __host__ __device__ void rebase(size_t off) {
-    rbp(keys, off); rbp(cnt, off); rbp(fill, off); rbp(suidx, off); rbp(uniq, off); rbp(uslot, off); rbp(rank, off); rbp(this->off, off);
-    rbp(point_slot, off); rbp(seg, off); rbp(rank_slot, off); rbp(rank_off, off);
+    rbp(region, off); rbp(over, off); rbp(tmp, off); rbp(sorted, off); rbp(splitters, off); rbp(cursor, off); rbp(done, off);
   }
 };
 
-struct StackInfo {        // per stack set: counters of the scan-feature VoxelGrid (written on the scan-registration stream)
-  int n_uniq[2];          // occupied voxels while counting (returns to 0 when the set is consumed)
+struct StackInfo {        // per stack set: counters of the scan-feature VoxelGrid (written on its own stream)
   int n_stack[2];         // laserCloudCornerStackNum / laserCloudSurfStackNum
   int error;
 };
@@ -91,6 +90,7 @@ struct MapContext {
   VoxelTable tab[2];       // 0 corner, 1 surf
   int* cube_cnt = nullptr; // [2][kCubeNum] points per cube, window-relative index (== the reference's array index)
   DsScratch ds[2];
+  unsigned ds_gen = 0;      // scan-feature VoxelGrids enqueued so far (tags the look-back words of k_map_ds_reduce)
   static constexpr int kSets = kBufferSets;   // == the SR buffer sets of the handle (same rotation)
   float4* stack_sets[kSets][2] = {};          // laserCloudCornerStack / laserCloudSurfStack (sensor frame), one pair per set
   StackInfo* stack_info[kSets] = {};

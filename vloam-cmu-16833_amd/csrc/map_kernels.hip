@@ -30,6 +30,7 @@
 #include "lm_solve.h"
 #include "map_kernels.h"
 #include "subwave.h"
+#include "bitonic.h"
 
 namespace vloam {
 
@@ -252,214 +253,291 @@ __device__ void map_purge(const VoxelTable& T, const MapState* ms, int first, in
 }
 
 // ---------------------------------------------------------------------------------------------- scan VoxelGrid
-// pcl::VoxelGrid<PointXYZI> (voxel_grid.hpp applyFilter): cell = floor(p * inverse_leaf) on the global lattice, output sorted
-// by the linearised cell index (x fastest) == lexicographic (iz, iy, ix), centroid = f32 sum in input order / n.
-__device__ __forceinline__ u64 ds_key(float4 p, float inv) {
-  const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv), iz = (int)floorf(p.z * inv);
-  return ((u64)(unsigned)(iz + (1 << 20)) << 42) | ((u64)(unsigned)(iy + (1 << 20)) << 21) | (u64)(unsigned)(ix + (1 << 20));
+// pcl::VoxelGrid<PointXYZI> (PCL 1.10 filters/impl/voxel_grid.hpp applyFilter) of laserCloudCornerLast / laserCloudSurfLast, LM:432-440:
+// getMinMax3D -> the overflow guard (more than INT_MAX cells in the bounding box: a warning and output = input) -> cell index
+// idx = ijk0 + ijk1 * div0 + ijk2 * div0 * div1 with ijk = floor(p * inverse_leaf) - min_b -> sort by idx -> one centroid per cell, f32
+// sums in the order of the sorted index vector (std::sort leaves the order inside a cell open; canonical here and in the oracle: input order).
+//
+// Two launches, no global hash, no whole-chip ranking (rounds 1 - 4 hashed the points into a table, ranked the occupied cells by counting
+// — u^2 compares — and folded one wavefront per cell: 80 k of the 227 k wavefront-microseconds a sweep cost at B = 8, 14 MB of traffic for
+// 0.6 MB of points):
+//   k_map_ds_bin     cuts the key space into P = ceil(n / 512) bins at the quantiles of a sample of the cloud (every workgroup sorts the same
+//                    <= 2 048 sampled keys in LDS: same splitters everywhere, no exchange), and appends every point's sort key
+//                    (cell index << 24 | point index) to its bin's region — one device-scope atomic per run of equal bins in a wavefront;
+//   k_map_ds_reduce  one workgroup per bin: bitonic sort of the bin's keys in LDS, cell heads, the bin's cell count published for the bins
+//                    behind it (look-back over the lower bins, in ticket order: a workgroup only ever waits for workgroups that started
+//                    before it), centroids in input order, written at their final place in VoxelGrid's output order.
+// A bin is a contiguous range of cell indices, so bin order == output order.  Correctness never rests on the sample: a bin that outgrows
+// its region (kDsBinCap keys, e.g. thousands of points in ONE cell with a coarse leaf) spills into an overflow list and takes the slow path
+// (gather, rank by counting in global memory); test_scan_voxel_bins_overflow drives it.
+struct DsGrid { float mnb[3]; int div0, div1; bool overflow; };
+
+// getMinMax3D + the guard + min_b / div_b (voxel_grid.hpp), from the per-scan-line boxes k_sr_compact left; every lane gets the result
+__device__ __forceinline__ DsGrid ds_grid(const FrameScalars* __restrict__ S, int kind, float inv) {
+  const int lane = threadIdx.x & 63;
+  float mn[3], mx[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { mn[a] = S->less_bbox[kind][lane][a]; mx[a] = S->less_bbox[kind][lane][3 + a]; }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+    for (int d = 32; d > 0; d >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], d)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d)); }
+  DsGrid g;
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  g.overflow = dx * dy * dz > (long long)INT_MAX;
+  int minb[3], maxb[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { minb[a] = (int)floorf(mn[a] * inv); maxb[a] = (int)floorf(mx[a] * inv); g.mnb[a] = (float)minb[a]; }
+  g.div0 = maxb[0] - minb[0] + 1; g.div1 = maxb[1] - minb[1] + 1;
+  return g;
+}
+__device__ __forceinline__ u64 ds_cell(float4 p, float inv, const DsGrid& g) {
+  const int i0 = (int)(floorf(p.x * inv) - g.mnb[0]), i1 = (int)(floorf(p.y * inv) - g.mnb[1]), i2 = (int)(floorf(p.z * inv) - g.mnb[2]);
+  return (u64)(unsigned)i0 + (u64)(unsigned)g.div0 * ((u64)(unsigned)i1 + (u64)(unsigned)g.div1 * (u64)(unsigned)i2);
+}
+constexpr int kDsIdxBits = 24;   // point index in the low bits of a sort key (max_points <= 2^24, vloam_create); the cell index (< 2^33) above
+__device__ __forceinline__ int ds_num_bins(int n) { const int p = (n + kDsBinTarget - 1) / kDsBinTarget; return p < 1 ? 1 : (p > kDsMaxBins ? kDsMaxBins : p); }
+__device__ __forceinline__ int ds_num_samples(int P) { return P <= 32 ? 256 : (P <= 64 ? 512 : (P <= 128 ? 1024 : 2048)); }
+// bin of a cell: the number of splitters <= cell (upper bound; equal cells always share a bin)
+__device__ __forceinline__ int ds_bin_of(const u64* split, int P, u64 cell) {
+  int lo = 0, hi = P - 1;   // answer in [0, P - 1]
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (split[mid] <= cell) lo = mid + 1; else hi = mid; }
+  return lo;
 }
 
-// pass 1: voxel membership + per-voxel counts
-__global__ __launch_bounds__(256) void k_map_ds_count(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
-                                                      const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0,
-                                                      float inv1, StackInfo* fr, size_t ss) {
-  VL_SESSION(ss); RB(corner_last); RB(surf_last); RB(S); D0.rebase(so_); D1.rebase(so_); RB(fr);
-  const int kind = blockIdx.y;
+constexpr int kDsTile = 2048;   // points a workgroup of the binning pass takes per trip
+__global__ __launch_bounds__(256) void k_map_ds_bin(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
+                                                    const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0, float inv1,
+                                                    float4* __restrict__ stack0, float4* __restrict__ stack1, StackInfo* fr, size_t ss) {
+  VL_SESSION(ss); RB(corner_last); RB(surf_last); RB(S); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
+  __shared__ __attribute__((aligned(16))) u64 s_key[2048];
+  __shared__ u64 s_split[kDsMaxBins];
+  const int kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const DsScratch D = kind ? D1 : D0;
   const float inv = kind ? inv1 : inv0;
   const float4* pts = kind ? surf_last : corner_last;
+  float4* stack = kind ? stack1 : stack0;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
-  // The feature clouds are ring / sector ordered: consecutive points often share a voxel.  One find-or-insert and one counter update per RUN
-  // of equal keys inside a wavefront instead of one per point (device-scope atomics are memory-side transactions on this chip: they were
-  // 4.2 of the kernel's 4.8 MB of traffic).
-  const int lane = threadIdx.x & 63;
-  for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += gridDim.x * 256) {   // wavefront-uniform
-    const int i = i0 + lane;
-    const bool act = i < n;
-    const u64 key = act ? ds_key(pts[i], inv) : ~0ull;   // (bit 63 is never set in a real key)
-    const u64 prev = __shfl_up(key, 1);
-    const u64 H = __ballot(lane == 0 || prev != key);
-    const int hl = 63 - __clzll((long long)(H & ((2ull << lane) - 1ull)));
-    const u64 rest = hl == 63 ? 0ull : (H >> (hl + 1));
-    const int len = (rest ? hl + __ffsll((long long)rest) : 64) - hl;
-    int found = -1;
-    bool fresh = false;   // this lane's run opened a new voxel
-    if (act && lane == hl) {
-      unsigned s = (unsigned)mix64(key) & D.hash_mask;
-      for (int probe = 0; probe <= D.hash_mask; probe++, s = (s + 1) & D.hash_mask) {
-        const u64 old = atomicCAS(&D.keys[s], 0ull, key);
-        if (old == 0ull || old == key) { atomicAdd(&D.cnt[s], len); found = (int)s; fresh = old == 0ull; break; }
-      }
-      if (found < 0) atomicOr(&fr->error, kErrStackFull);
-    }
-    // arrival numbers of the new voxels: one counter update per wavefront, not one per voxel on the same word
-    const u64 fm = __ballot(fresh);
-    if (fm != 0ull) {
-      const int leader = __ffsll((long long)fm) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&fr->n_uniq[kind], __popcll(fm));
-      base = __shfl(base, leader);
-      if (fresh) {
-        const int u = base + __popcll(fm & ((1ull << lane) - 1ull));
-        if (u < D.stack_cap) { D.uniq[u] = key; D.uslot[u] = found; D.suidx[found] = u; } else atomicOr(&fr->error, kErrStackFull);
-      }
-    }
-    found = __shfl(found, hl);
-    if (act) D.point_slot[i] = found;
+  if (n <= 0) { if (blockIdx.x == 0 && tid == 0) fr->n_stack[kind] = 0; return; }
+  if ((int)blockIdx.x * kDsTile >= n) return;
+  const DsGrid g = ds_grid(S, kind, inv);
+  if (g.overflow) {   // "Leaf size is too small for the input dataset. Integer indices would overflow." — output = *input_
+    for (int t0 = blockIdx.x * kDsTile; t0 < n; t0 += gridDim.x * kDsTile)   // (only the workgroups whose first tile exists are here)
+      for (int i = t0 + tid; i < min(t0 + kDsTile, n); i += 256) if (i < D.stack_cap) stack[i] = pts[i];
+    if (blockIdx.x == 0 && tid == 0) { fr->n_stack[kind] = min(n, D.stack_cap); if (n > D.stack_cap) atomicOr(&fr->error, kErrStackFull); }
+    return;
   }
-}
-
-// pass 2: output order.  VoxelGrid emits voxels sorted by key; with only a few thousand occupied voxels the whole chip ranks
-// them by counting: tile (256 keys) x (512 entries), rank = #keys below mine, off = #points in voxels below mine (which is the
-// voxel's segment start, so no scan pass is needed).  Partial results are added up with integer atomics (order-free).
-constexpr int kRankKeys = 256, kRankChunk = 512;
-__global__ __launch_bounds__(kRankKeys) void k_map_ds_rank(DsScratch D0, DsScratch D1, const StackInfo* __restrict__ fr, size_t ss) {
-  VL_SESSION(ss); D0.rebase(so_); D1.rebase(so_); RB(fr);
-  __shared__ __attribute__((aligned(16))) u64 s_key[kRankChunk];
-  __shared__ __attribute__((aligned(16))) int s_cnt[kRankChunk];
-  const int kind = blockIdx.y, tid = threadIdx.x;
-  const DsScratch D = kind ? D1 : D0;
-  const int u = min(fr->n_uniq[kind], D.stack_cap);
-  const int nkg = (u + kRankKeys - 1) / kRankKeys, nch = (u + kRankChunk - 1) / kRankChunk;
-  for (int tile = blockIdx.x; tile < nkg * nch; tile += gridDim.x) {
-    const int kg = tile / nch, ch = tile % nch;
+  const int P = ds_num_bins(n);
+  if (P > 1) {
+    // the splitters: P - 1 quantiles of Sn evenly spaced sample points; every workgroup computes the same ones
+    const int Sn = ds_num_samples(P);
+    for (int j = tid; j < Sn; j += 256) s_key[j] = ds_cell(pts[(int)(((long long)j * n) / Sn)], inv, g);
     __syncthreads();
-    for (int e = tid; e < kRankChunk; e += kRankKeys) {
-      const int j = ch * kRankChunk + e;
-      s_key[e] = j < u ? D.uniq[j] : ~0ull;
-      s_cnt[e] = j < u ? D.cnt[D.uslot[j]] : 0;
+    block_bitonic_sort_u64(s_key, Sn, tid, 256);
+    for (int j = tid; j < P - 1; j += 256) {
+      const u64 sp = s_key[(int)(((long long)(j + 1) * Sn) / P)];
+      s_split[j] = sp;
+      if (blockIdx.x == 0) D.splitters[j] = sp;   // the reduce pass's slow path tells the bins of the overflow list by them
     }
     __syncthreads();
-    const int i = kg * kRankKeys + tid;
-    const u64 mine = i < u ? D.uniq[i] : 0ull;  // 0 is below every key: contributes nothing
-    int rank = 0, off = 0;
-#pragma unroll 4
-    for (int e = 0; e < kRankChunk; e += 2) {
-      const ulonglong2 k2 = *(const ulonglong2*)&s_key[e];
-      const int2 c2 = *(const int2*)&s_cnt[e];
-      const bool l0 = k2.x < mine, l1 = k2.y < mine;
-      rank += (int)l0 + (int)l1;
-      off += (l0 ? c2.x : 0) + (l1 ? c2.y : 0);
+  }
+  for (int t0 = blockIdx.x * kDsTile; t0 < n; t0 += gridDim.x * kDsTile) {
+    for (int e = 0; e < kDsTile / 256; e++) {
+      const int i = t0 + ((tid >> 6) * (kDsTile / 256) + e) * 64 + lane;   // a wavefront takes 64 CONSECUTIVE points: neighbours in the cloud mostly share a bin
+      const bool act = i < n;
+      u64 cell = 0ull;
+      int bin = -1;
+      if (act) { cell = ds_cell(pts[i], inv, g); bin = P > 1 ? ds_bin_of(s_split, P, cell) : 0; }
+      // one cursor update per distinct bin of the wavefront
+      u64 todo = __ballot(act);
+      int pos = 0;
+      while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader);
+        const u64 mine = __ballot(act && bin == b);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&D.cursor[b], __popcll(mine));
+        base = __shfl(base, leader);
+        if (act && bin == b) pos = base + __popcll(mine & ((1ull << lane) - 1ull));
+        todo &= ~mine;
+      }
+      if (act) {
+        const u64 key = (cell << kDsIdxBits) | (u64)(unsigned)i;
+        if (pos < kDsBinCap) D.region[(size_t)bin * kDsBinCap + pos] = key;
+        else { const int o = atomicAdd(&D.cursor[kDsMaxBins], 1); D.over[o] = key; }   // (o < n <= max_points: every point is written exactly once)
+      }
     }
-    if (rank) { atomicAdd(&D.rank[i], rank); atomicAdd(&D.off[i], off); }
   }
 }
 
-// pass 3: group the point indices by voxel (segment start = off of the voxel); the same launch publishes the output order
-__global__ __launch_bounds__(256) void k_map_ds_scatter(const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, StackInfo* fr, size_t ss) {
-  VL_SESSION(ss); RB(S); D0.rebase(so_); D1.rebase(so_); RB(fr);
-  const int kind = blockIdx.y;
-  const DsScratch D = kind ? D1 : D0;
-  const int n = kind ? S->n_less_flat : S->n_less_sharp;
-  const int lane = threadIdx.x & 63;
-  for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += gridDim.x * 256) {   // wavefront-uniform; one cursor update per run of equal slots
-    const int i = i0 + lane;
-    const int s = i < n ? D.point_slot[i] : -1;
-    const int prev = __shfl_up(s, 1);
-    const u64 H = __ballot(lane == 0 || prev != s);
-    const int hl = 63 - __clzll((long long)(H & ((2ull << lane) - 1ull)));
-    const u64 rest = hl == 63 ? 0ull : (H >> (hl + 1));
-    const int len = (rest ? hl + __ffsll((long long)rest) : 64) - hl;
-    int base = 0;
-    if (s >= 0 && lane == hl) base = D.off[D.suidx[s]] + atomicAdd(&D.fill[s], len);
-    base = __shfl(base, hl);
-    if (s >= 0) D.seg[base + (lane - hl)] = i;
-  }
-  const int u = min(fr->n_uniq[kind], D.stack_cap);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < u; i += gridDim.x * 256) {
-    const int r = D.rank[i], o = D.off[i], s = D.uslot[i];
-    D.rank_slot[r] = s;
-    D.rank_off[r] = o;
-    if (r == u - 1) D.rank_off[u] = o + D.cnt[s];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_stack[kind] = u;
-}
-
-// pass 4: one wavefront per output voxel.  The atomics of pass 3 appended the members in arbitrary order; VoxelGrid sums in
-// input order, so each lane ranks its member by counting (readlane loop, cnt is ~4 on average), the member points are
-// fetched in parallel and then folded one by one in rank order (f32, exactly like CentroidPoint).
 __device__ __forceinline__ float rl(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
+// heads / look-back / centroids of one bin whose keys lie sorted in `key` (LDS on the fast path, global memory on the slow one)
+template <bool LDS_KEYS>
+__device__ __forceinline__ void ds_reduce_sorted(const u64* key, int m, int bin, int P, const float4* __restrict__ pts, float4* __restrict__ stack,
+                                                 const DsScratch& D, StackInfo* fr, int kind, unsigned gen, int* s_cnt /* [256 + 8] */, int* s_big /* [3 * kDsBigCap + 1] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // contiguous chunks: thread t owns keys [t * per, t * per + per)
+  const int per = (m + 255) / 256;
+  const int c0 = min(tid * per, m), c1 = min(c0 + per, m);
+  int heads = 0;
+  for (int i = c0; i < c1; i++) heads += (i == 0 || (key[i] >> kDsIdxBits) != (key[i - 1] >> kDsIdxBits)) ? 1 : 0;
+  // block exclusive scan of the head counts
+  int inc = heads;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) s_cnt[256 + wave] = inc;
+  if (tid == 0) s_big[0] = 0;
+  __syncthreads();
+  int wbase = 0, u = 0;
+  for (int w = 0; w < 4; w++) { const int t = s_cnt[256 + w]; wbase += w < wave ? t : 0; u += t; }
+  const int rank0 = wbase + inc - heads;   // output rank (inside the bin) of this thread's first head
+  // publish this bin's cell count, then add up the bins in front (look-back; every one of them started before this workgroup took its ticket)
+  u64* done = D.done;
+  if (tid == 0) __hip_atomic_store(&done[bin], ((u64)gen << 32) | (u64)(unsigned)u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  int before = 0;
+  if (wave == 0) {
+    bool bad = false;
+    for (int b = lane; b < bin; b += 64) {
+      u64 v = 0ull;
+      int spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(&done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == gen) break;
+        if (++spins > (1 << 22)) { bad = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      before += (int)(unsigned)(v & 0xffffffffull);
+    }
+    for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&fr->error, kErrSolverSync);   // (never seen: a bounded wait instead of a hang)
+    if (lane == 0) s_cnt[0] = before;
+  }
+  __syncthreads();
+  before = s_cnt[0];
+  // centroids: the thread that owns a head walks the cell (its points in input order: the sort key ends in the point index); cells of more
+  // than kDsBigCell points are left to a whole wavefront each
+  int r = rank0;
+  for (int i = c0; i < c1; i++) {
+    const u64 ci = key[i] >> kDsIdxBits;
+    if (!(i == 0 || ci != (key[i - 1] >> kDsIdxBits))) continue;
+    int e = i + 1;
+    while (e < m && (key[e] >> kDsIdxBits) == ci) e++;
+    const int out = before + r;
+    r++;
+    if (out >= D.stack_cap) continue;   // reported by the last bin
+    if (e - i > kDsBigCell) {
+      const int q = atomicAdd(&s_big[0], 1);
+      if (q < kDsBigCap) { s_big[1 + 3 * q] = i; s_big[2 + 3 * q] = e; s_big[3 + 3 * q] = out; }
+      else {   // (more big cells than the list holds: this thread folds it after all)
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (int j = i; j < e; j++) { const float4 p = pts[(int)(key[j] & ((1ull << kDsIdxBits) - 1ull))]; sx += p.x; sy += p.y; sz += p.z; si += p.w; }
+        const float nn = (float)(e - i);
+        stack[out] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
+      }
+      continue;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (int j = i; j < e; j += 4) {   // four loads in flight, added in order
+      float4 p[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (j + q < e) p[q] = pts[(int)(key[j + q] & ((1ull << kDsIdxBits) - 1ull))];
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (j + q < e) { sx += p[q].x; sy += p[q].y; sz += p[q].z; si += p[q].w; }
+    }
+    const float nn = (float)(e - i);
+    stack[out] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
+  }
+  __syncthreads();
+  const int nbig = min(s_big[0], kDsBigCap);
+  for (int q = wave; q < nbig; q += 4) {   // a wavefront per big cell: 64 points fetched at once, folded one by one (f32, CentroidPoint's order)
+    const int i = s_big[1 + 3 * q], e = s_big[2 + 3 * q], out = s_big[3 + 3 * q];
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (int j0 = i; j0 < e; j0 += 64) {
+      const int mm = min(64, e - j0);
+      const float4 p = lane < mm ? pts[(int)(key[j0 + lane] & ((1ull << kDsIdxBits) - 1ull))] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < mm; t++) { sx += rl(p.x, t); sy += rl(p.y, t); sz += rl(p.z, t); si += rl(p.w, t); }
+    }
+    if (lane == 0) { const float nn = (float)(e - i); stack[out] = make_float4(sx / nn, sy / nn, sz / nn, si / nn); }
+  }
+  if (bin == P - 1 && tid == 0) {
+    // the last bin has seen every other bin's count, i.e. every workgroup of this pass is done with the region counters, the overflow list
+    // and the ticket: hand them back clean for the next sweep
+    const int total = before + u;
+    fr->n_stack[kind] = min(total, D.stack_cap);
+    if (total > D.stack_cap) atomicOr(&fr->error, kErrStackFull);
+    D.cursor[kDsMaxBins] = 0; D.cursor[kDsMaxBins + 1] = 0; D.cursor[kDsMaxBins + 2] = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
-                                                       DsScratch D0, DsScratch D1, float4* __restrict__ stack0, float4* __restrict__ stack1,
-                                                       StackInfo* __restrict__ fr, size_t ss) {
-  VL_SESSION(ss); RB(corner_last); RB(surf_last); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
-  constexpr int kBigVoxel = 256;   // sweep points of one voxel sorted in LDS (above: the serial fallback); 8 KB per workgroup, so that LDS does not cap the occupancy of the common (<= 64 points, registers only) case
-  __shared__ int s_idx[4][kBigVoxel];
-  __shared__ int s_sorted[4][kBigVoxel];
-  const int kind = blockIdx.y;
+                                                       const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0, float inv1,
+                                                       float4* __restrict__ stack0, float4* __restrict__ stack1, StackInfo* __restrict__ fr, unsigned gen,
+                                                       size_t ss) {
+  VL_SESSION(ss); RB(corner_last); RB(surf_last); RB(S); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
+  __shared__ __attribute__((aligned(16))) u64 s_key[kDsBinCap];
+  __shared__ u64 s_split[kDsMaxBins];
+  __shared__ int s_cnt[256 + 8];
+  __shared__ int s_big[3 * kDsBigCap + 1];
+  __shared__ int s_bin;
+  const int kind = blockIdx.y, tid = threadIdx.x;
   const DsScratch D = kind ? D1 : D0;
+  const float inv = kind ? inv1 : inv0;
   const float4* pts = kind ? surf_last : corner_last;
   float4* stack = kind ? stack1 : stack0;
-  const int u = min(fr->n_stack[kind], D.stack_cap);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) fr->n_uniq[kind] = 0;  // this set's arrival counter, ready for its next sweep
-  for (int t = blockIdx.x * 4 + wave; t < u; t += gridDim.x * 4) {
-    const int b0 = D.rank_off[t], cnt = D.rank_off[t + 1] - b0;
-    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    if (cnt <= 64) {
-      const int idx = lane < cnt ? D.seg[b0 + lane] : INT_MAX;
-      const float4 p = lane < cnt ? pts[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-      int rank = 0;
-      for (int j = 0; j < cnt; j++) rank += __builtin_amdgcn_readlane(idx, j) < idx;
-      for (int r = 0; r < cnt; r++) {
-        const int src = __ffsll((long long)__ballot(rank == r && lane < cnt)) - 1;
-        sx += rl(p.x, src); sy += rl(p.y, src); sz += rl(p.z, src); si += rl(p.w, src);
-      }
-    } else if (cnt <= kBigVoxel) {
-      for (int j = lane; j < cnt; j += 64) s_idx[wave][j] = D.seg[b0 + j];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      for (int j = lane; j < cnt; j += 64) {
-        const int mine = s_idx[wave][j];
-        int rank = 0;
-        for (int q = 0; q < cnt; q++) rank += s_idx[wave][q] < mine;
-        s_sorted[wave][rank] = mine;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int m = min(64, cnt - c0);
-        const float4 p = lane < m ? pts[s_sorted[wave][c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
-      }
-    } else {
-      // More sweep points than that in one voxel (a dense near-range or stationary scene at the 0.8 m leaf): the whole wavefront ranks the
-      // members by counting, chunk by chunk through LDS — cnt^2 / 64 LDS reads per lane: ~30 us at 1 000 points where a single lane's
-      // insertion sort in global memory took milliseconds — and leaves them in input order in the (by now unused) point -> slot array;
-      // then the same in-order fold as above.
-      const int* seg = D.seg + b0;
-      int* sorted = D.point_slot + b0;
-      for (int j0 = 0; j0 < cnt; j0 += 64) {
-        const int j = j0 + lane;
-        const int mine = j < cnt ? seg[j] : INT_MAX;
-        int rank = 0;
-        for (int c0 = 0; c0 < cnt; c0 += kBigVoxel) {
-          const int m = min(kBigVoxel, cnt - c0);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-          for (int q = lane; q < m; q += 64) s_idx[wave][q] = seg[c0 + q];
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-          for (int q = 0; q < m; q++) rank += s_idx[wave][q] < mine;
-        }
-        if (j < cnt) sorted[rank] = mine;   // (point indices are distinct: the ranks are a permutation)
-      }
-      __threadfence();
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int m = min(64, cnt - c0);
-        const float4 p = lane < m ? pts[sorted[c0 + lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = 0; r < m; r++) { sx += rl(p.x, r); sy += rl(p.y, r); sz += rl(p.z, r); si += rl(p.w, r); }
-      }
-    }
-    if (lane == 0) {
-      const float nn = (float)cnt;
-      stack[t] = make_float4(sx / nn, sy / nn, sz / nn, si / nn);
-      const int s = D.rank_slot[t];
-      D.keys[s] = 0ull; D.cnt[s] = 0; D.fill[s] = 0;  // leave the scratch clean for the next sweep
-      D.rank[t] = 0; D.off[t] = 0;
-    }
+  const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  if (n <= 0) return;
+  const int P = ds_num_bins(n);
+  if ((int)blockIdx.x >= P) return;
+  if (ds_grid(S, kind, inv).overflow) return;   // the binning pass copied the cloud (voxel_grid.hpp's guard)
+  // bins are taken in ticket order, not in blockIdx order: the look-back below then only waits for workgroups that are already running
+  if (tid == 0) s_bin = atomicAdd(&D.cursor[kDsMaxBins + 1], 1);
+  __syncthreads();
+  const int bin = s_bin;
+  const int m_raw = D.cursor[bin];
+  __syncthreads();
+  if (tid == 0) D.cursor[bin] = 0;   // this bin's region counter, clean for the next sweep
+  if (m_raw <= kDsBinCap) {
+    int P2 = 256;
+    while (P2 < m_raw) P2 <<= 1;
+    const u64* reg = D.region + (size_t)bin * kDsBinCap;
+    for (int i = tid; i < P2; i += 256) s_key[i] = i < m_raw ? reg[i] : ~0ull;
+    __syncthreads();
+    block_bitonic_sort_u64(s_key, P2, tid, 256);
+    ds_reduce_sorted<true>(s_key, m_raw, bin, P, pts, stack, D, fr, kind, gen, s_cnt, s_big);
+    return;
   }
+  // ---- slow path: the bin outgrew its region.  Gather region + this bin's share of the overflow list, rank by counting (keys are unique:
+  // they end in the point index), continue from global memory.
+  const int n_over = D.cursor[kDsMaxBins];
+  for (int j = tid; j < P - 1; j += 256) s_split[j] = D.splitters[j];
+  __syncthreads();
+  int mine = 0;
+  for (int j = tid; j < n_over; j += 256) mine += (P > 1 ? ds_bin_of(s_split, P, D.over[j] >> kDsIdxBits) : 0) == bin ? 1 : 0;
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if ((tid & 63) == 0) s_cnt[256 + (tid >> 6)] = mine;
+  __syncthreads();
+  const int m = kDsBinCap + s_cnt[256] + s_cnt[257] + s_cnt[258] + s_cnt[259];
+  __syncthreads();
+  if (tid == 0) { s_cnt[1] = atomicAdd(&D.cursor[kDsMaxBins + 2], m); s_cnt[2] = kDsBinCap; }
+  __syncthreads();
+  u64* raw = D.tmp + s_cnt[1];
+  u64* srt = D.sorted + s_cnt[1];
+  const u64* reg = D.region + (size_t)bin * kDsBinCap;
+  for (int i = tid; i < kDsBinCap; i += 256) raw[i] = reg[i];
+  for (int j = tid; j < n_over; j += 256) {
+    const u64 k = D.over[j];
+    if ((P > 1 ? ds_bin_of(s_split, P, k >> kDsIdxBits) : 0) == bin) raw[atomicAdd(&s_cnt[2], 1)] = k;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) {
+    const u64 k = raw[i];
+    int rank = 0;
+    for (int j = 0; j < m; j++) rank += raw[j] < k ? 1 : 0;
+    srt[rank] = k;
+  }
+  __threadfence();
+  __syncthreads();
+  ds_reduce_sorted<false>(srt, m, bin, P, pts, stack, D, fr, kind, gen, s_cnt, s_big);
 }
 
 // ---------------------------------------------------------------------------------------------- data association
@@ -1298,13 +1376,10 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
     T.bslots_mask = (unsigned)(bslots - 1);
     DsScratch& D = m->ds[k];
     if (k == 0) for (int c = 0; c < MapContext::kSets; c++) ok = ok && A.take(&m->stack_info[c], 1);
-    D.hash_mask = (k ? kDsHashSurf : kDsHashCorner) - 1;
     D.stack_cap = k ? kStackCapSurf : kStackCapCorner;
-    const size_t hs = (size_t)D.hash_mask + 1;
-    ok = ok && A.take(&D.keys, hs) && A.take(&D.cnt, hs) && A.take(&D.fill, hs) && A.take(&D.suidx, hs) &&
-         A.take(&D.uslot, (size_t)D.stack_cap) && A.take(&D.rank, (size_t)D.stack_cap) && A.take(&D.off, (size_t)D.stack_cap) &&
-         A.take(&D.uniq, (size_t)D.stack_cap) && A.take(&D.point_slot, (size_t)cfg.max_points) &&
-         A.take(&D.seg, (size_t)cfg.max_points) && A.take(&D.rank_slot, (size_t)D.stack_cap) && A.take(&D.rank_off, (size_t)D.stack_cap + 1);
+    ok = ok && A.take(&D.region, (size_t)kDsMaxBins * kDsBinCap) && A.take(&D.over, (size_t)cfg.max_points) && A.take(&D.tmp, (size_t)cfg.max_points) &&
+         A.take(&D.sorted, (size_t)cfg.max_points) && A.take(&D.splitters, (size_t)kDsMaxBins) && A.take(&D.cursor, (size_t)kDsMaxBins + 4) &&
+         A.take(&D.done, (size_t)kDsMaxBins);
     for (int c = 0; c < MapContext::kSets; c++) ok = ok && A.take(&m->stack_sets[c][k], (size_t)D.stack_cap);
     m->stack[k] = m->stack_sets[0][k];
     ok = ok && A.take(&m->stack_map[k], (size_t)D.stack_cap) && A.take(&m->touched[k], (size_t)D.stack_cap) && A.take(&m->deferred[k], (size_t)D.stack_cap) &&
@@ -1348,13 +1423,12 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
   StackInfo* si = m->stack_info[set];
   const unsigned Z = (unsigned)m->se.B;
   const size_t ss = m->se.ss;
-  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_count, dim3(128, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
-               m->inv_leaf[0], m->inv_leaf[1], si, ss);
-  VLOAM_LAUNCH(ph, kKMapDsRank, st, k_map_ds_rank, dim3(256, 2, Z), dim3(kRankKeys), 0, st, m->ds[0], m->ds[1], si, ss);
-  VLOAM_LAUNCH(ph, kKMapDsScatter, st, k_map_ds_scatter, dim3(128, 2, Z), dim3(256), 0, st, cur.S, m->ds[0], m->ds[1], si, ss);
+  m->ds_gen++;   // tags the per-bin cell counts of this sweep's reduce pass (look-back words are never reset)
+  VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_bin, dim3(32, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+               m->inv_leaf[0], m->inv_leaf[1], m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
   // `done` (the stack of this sweep is complete) is bound to the last dispatch instead of a marker packet behind it
-  VLOAM_LAUNCH_EV(ph, kKMapDsReduce, st, done, k_map_ds_reduce, dim3(1024, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, m->ds[0], m->ds[1],
-                  m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
+  VLOAM_LAUNCH_EV(ph, kKMapDsReduce, st, done, k_map_ds_reduce, dim3(kDsMaxBins, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+                  m->inv_leaf[0], m->inv_leaf[1], m->stack_sets[set][0], m->stack_sets[set][1], si, m->ds_gen, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 

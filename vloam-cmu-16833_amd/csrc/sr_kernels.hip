@@ -14,9 +14,11 @@
 //   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <float.h>
 #include <type_traits>
 #include <math.h>
 #include "sr_kernels.h"
+#include "bitonic.h"
 
 namespace vloam {
 
@@ -319,97 +321,6 @@ __device__ int block_exclusive_scan(int* a, int n, int* scratch /* kRingThreads 
   for (int k = lo; k < hi; k++) { int v = a[k]; a[k] = run; run += v; }
   __syncthreads();
   return total;
-}
-
-// One stage of the network for `nthreads` cooperating lanes: each lane fetches both operands of up to four compare-exchanges
-// before writing any of them back (the exchanges of a stage touch disjoint pairs), so the LDS round trips overlap.
-__device__ __forceinline__ void bitonic_stage(u64* a, int P, int j, int k, int tid, int nthreads) {
-  for (int t0 = tid; t0 < P / 2; t0 += 4 * nthreads) {
-    u64 x[4], y[4];
-    int ii[4], ll[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int t = t0 + u * nthreads;
-      ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-      ll[u] = ii[u] | j;
-      if (t < P / 2) { x[u] = a[ii[u]]; y[u] = a[ll[u]]; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int t = t0 + u * nthreads;
-      if (t < P / 2 && ((x[u] > y[u]) == ((ii[u] & k) == 0))) { a[ii[u]] = y[u]; a[ll[u]] = x[u]; }
-    }
-  }
-}
-
-// Merge levels k_lo .. k_hi (doubling) of an ASCENDING bitonic network, strides min(k / 2, 64) .. 1, on 128-element blocks held in
-// registers: wavefront w of the workgroup owns blocks w, w + nwaves, ...; lane l holds elements l and l + 64 of its block, so a stride
-// below 64 is a cross-lane exchange and stride 64 the lane's own pair — no LDS round trip, no barrier between these stages.
-__device__ __forceinline__ void bitonic_reg_stages(u64* a, int P, int k_lo, int k_hi, int tid, int nthreads) {
-  const int lane = tid & 63, wv = tid >> 6, nwaves = nthreads >> 6;
-  for (int blk = wv; blk * 128 < P; blk += nwaves) {
-    const int base = blk * 128;
-    u64 a0 = a[base + lane], a1 = a[base + 64 + lane];
-    for (int k = k_lo; k <= k_hi; k <<= 1) {
-      const bool up0 = ((base + lane) & k) == 0, up1 = ((base + 64 + lane) & k) == 0;
-      if (k > 64) {  // stride 64 (both elements see the same direction: bit k lies above bit 6)
-        const bool swap = (a0 > a1) == up0;
-        const u64 t0 = swap ? a1 : a0, t1 = swap ? a0 : a1;
-        a0 = t0; a1 = t1;
-      }
-      for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
-        const u64 b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
-        const bool lower = (lane & j) == 0;   // the lower lane of an ascending pair keeps the smaller key: one compare, one exchange decision
-        a0 = ((a0 > b0) == (up0 == lower)) ? b0 : a0;
-        a1 = ((a1 > b1) == (up1 == lower)) ? b1 : a1;
-      }
-    }
-    a[base + lane] = a0; a[base + 64 + lane] = a1;
-  }
-}
-
-// The same with 256-element blocks, four keys per lane (elements l, l + 64, l + 128, l + 192): strides 128 and 64 are the lane's own pairs,
-// anything below a cross-lane exchange.  2 048 run keys are then eight blocks — one per wavefront — and only the strides >= 256 (6 of
-// the 66 stages) go through LDS behind a workgroup barrier.
-__device__ __forceinline__ void bitonic_reg_stages4(u64* a, int P, int k_lo, int k_hi, int tid, int nthreads) {
-  const int lane = tid & 63, wv = tid >> 6, nwaves = nthreads >> 6;
-  for (int blk = wv; blk * 256 < P; blk += nwaves) {
-    const int base = blk * 256;
-    u64 v[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = a[base + e * 64 + lane];
-    for (int k = k_lo; k <= k_hi; k <<= 1) {
-      bool up[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) up[e] = ((base + e * 64 + lane) & k) == 0;
-      if (k > 128) {  // stride 128: (0, 2) and (1, 3); both ends of a pair see the same direction (bit k lies above bit 7)
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const u64 x = v[e], y = v[e + 2];
-          const bool swap = (x > y) == up[e];
-          v[e] = swap ? y : x; v[e + 2] = swap ? x : y;
-        }
-      }
-      if (k > 64) {   // stride 64: (0, 1) and (2, 3)
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const u64 x = v[e], y = v[e + 1];
-          const bool swap = (x > y) == up[e];
-          v[e] = swap ? y : x; v[e + 1] = swap ? x : y;
-        }
-      }
-      for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
-        const bool lower = (lane & j) == 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const u64 b = __shfl_xor(v[e], j);
-          v[e] = ((v[e] > b) == (up[e] == lower)) ? b : v[e];
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) a[base + e * 64 + lane] = v[e];
-  }
 }
 
 __device__ __forceinline__ void bitonic_step(u64* a, int t, int j, int k) {
@@ -1061,7 +972,13 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
   RB(dbg_feat_idx); RB(sticky_err);
   __shared__ int base[4];
   __shared__ int soff[kSectors][3];
+  __shared__ float s_box[4][12];
   const int r = blockIdx.x, tid = threadIdx.x;
+  float bmn[2][3], bmx[2][3];   // this thread's share of the line's lessSharp [0] / lessFlat [1] bounding boxes
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bmn[c][a] = FLT_MAX; bmx[c][a] = -FLT_MAX; }
   // last launch of the sweep's scan registration: its error bits (S->error is per buffer set and rewritten every sweep) go into the
   // handle's sticky word, so that a burst of vloam_process_scan calls cannot lose them
   if (r == 0 && tid == 0 && sticky_err && S->error) atomicOr(sticky_err, S->error);
@@ -1098,7 +1015,10 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
       const int qq = q - kMaxSharpPerSect;
       if (qq < S->sect_cnt[r][s][1]) {
         int src = less_sharp_idx[(r * kSectors + s) * kMaxLessSharpPerSect + qq];
-        less_sharp[soff[s][1] + qq] = cloud[src];
+        const float4 p = cloud[src];
+        less_sharp[soff[s][1] + qq] = p;
+        bmn[0][0] = fminf(bmn[0][0], p.x); bmn[0][1] = fminf(bmn[0][1], p.y); bmn[0][2] = fminf(bmn[0][2], p.z);
+        bmx[0][0] = fmaxf(bmx[0][0], p.x); bmx[0][1] = fmaxf(bmx[0][1], p.y); bmx[0][2] = fmaxf(bmx[0][2], p.z);
         if (dbg_feat_idx) dbg_feat_idx[kMaxLessSharp + soff[s][1] + qq] = src;
       }
     } else {
@@ -1112,7 +1032,27 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
   }
   const int nds = S->ring_ds_cnt[r];
   const float4* src = ring_ds + (size_t)r * kMaxRingLen;
-  for (int k = tid; k < nds; k += 256) less_flat[base[3] + k] = src[k];
+  for (int k = tid; k < nds; k += 256) {
+    const float4 p = src[k];
+    less_flat[base[3] + k] = p;
+    bmn[1][0] = fminf(bmn[1][0], p.x); bmn[1][1] = fminf(bmn[1][1], p.y); bmn[1][2] = fminf(bmn[1][2], p.z);
+    bmx[1][0] = fmaxf(bmx[1][0], p.x); bmx[1][1] = fmaxf(bmx[1][1], p.y); bmx[1][2] = fmaxf(bmx[1][2], p.z);
+  }
+  // the line's two boxes: wavefront reductions, then the four wavefronts' results by twelve lanes
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float lo = wave_fminmax<false>(bmn[c][a]), hi = wave_fminmax<true>(bmx[c][a]);
+      if ((tid & 63) == 0) { s_box[tid >> 6][c * 6 + a] = lo; s_box[tid >> 6][c * 6 + 3 + a] = hi; }
+    }
+  __syncthreads();
+  if (tid < 12) {
+    const bool is_max = (tid % 6) >= 3;
+    float v = s_box[0][tid];
+    for (int w = 1; w < 4; w++) v = is_max ? fmaxf(v, s_box[w][tid]) : fminf(v, s_box[w][tid]);
+    S->less_bbox[tid / 6][r][tid % 6] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ namespace vloam {
 // All device state of a session lives in ONE arena; session b's arena is the byte-for-byte layout of session 0's, `ss` bytes
 // further on.  Hosts and kernels therefore hold session 0's pointers only and kernels rebase them by blockIdx.z * ss on entry —
 // one extra kernel argument instead of B copies of every argument.
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 24;   // 10 cooperating solver workgroups per session must be co-resident: 10 * 24 <= 256 compute units (c_api.h)
 // Rotating buffer sets of everything one stage hands to a later stage (set = sweep mod kBufferSets): scan-registration output, NN grids,
 // mapping stack clouds, VO depth maps.  3 suffice for correctness; the host may enqueue scan registration kBufferSets - 1 sweeps ahead of
 // the odometry it waits for and kBufferSets ahead of the mapping.  With 4 sets the host blocked (hipEventSynchronize, ~50-100 us to wake up)
@@ -60,13 +60,13 @@ constexpr int kMaxLoFactors = kMaxSharp + kMaxFlat;                         // 2
 enum KernelId : int {
   kKNone = 0, kKSrFirstLast, kKSrLabel, kKSrScan, kKSrScatter, kKSrRing, kKSrCompact, kKLoAssoc, kKLmSolve, kKLoFinish,
   kKMapPrepare, kKMapStack, kKMapAssoc, kKMapInsert, kKMapFinalize, kKVoProject, kKVoMatch,
-  kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsRank, kKMapDsScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig,
+  kKLoGridCount, kKLoGridScan, kKLoGridScatter, kKMapDsReduce, kKMapFit, kKLmCompact, kKVoFold, kKSrRingBig,
   kKImgSobel, kKImgEig, kKImgLocalMax, kKImgNeighbours, kKImgSelect, kKImgPyrDown, kKImgScharr, kKImgLk, kKLoAssocFast, kKCount
 };
 static const char* const kKernelNames[kKCount] = {"", "k_sr_first_last", "k_sr_label", "k_sr_scan", "k_sr_scatter", "k_sr_ring",
-  "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_ds_count", "k_map_assoc", "k_map_insert",
-  "k_map_finalize", "k_vo_project", "k_vo_match", "k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter", "k_map_ds_rank",
-  "k_map_ds_scatter", "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier",
+  "k_sr_compact", "k_lo_assoc", "k_lm_solve", "k_lo_finish", "k_map_prepare", "k_map_ds_bin", "k_map_assoc", "k_map_insert",
+  "k_map_finalize", "k_vo_project", "k_vo_match", "k_lo_grid_count", "k_lo_grid_scan", "k_lo_grid_scatter",
+  "k_map_ds_reduce", "k_map_fit", "k_lm_compact", "k_vo_fold", "k_sr_ring_big_tier",
   "k_img_sobel", "k_img_eig", "k_img_localmax", "k_img_neighbours", "k_img_select", "k_img_pyrdown", "k_img_scharr", "k_img_lk", "k_lo_assoc_fast"};
 constexpr int kKAll = -1;  // ProfHook::id: bracket every launch, whichever kernel
 
@@ -92,9 +92,15 @@ struct ProfHook {
 // kernels `blockIdx` / `gridDim` are redirected to the logical coordinates (the two accessors below are defined BEFORE the macros, so
 // they read the hardware values); host code passes logical grids to the launch macros, which transpose them.
 struct VlDim3 { unsigned x, y, z; };
+#ifdef VLOAM_SPREAD_GEOMETRY   // A/B build (make spread): the plain grid (x, y, session) — every session's workgroups dealt over all eight XCDs (profiles/r05_batch_scaling.txt)
+__device__ __forceinline__ VlDim3 vl_block_idx() { VlDim3 r; r.x = blockIdx.x; r.y = blockIdx.y; r.z = blockIdx.z; return r; }
+__device__ __forceinline__ VlDim3 vl_grid_dim() { VlDim3 r; r.x = gridDim.x; r.y = gridDim.y; r.z = gridDim.z; return r; }
+inline dim3 vl_hw_grid(dim3 g) { return g; }
+#else
 __device__ __forceinline__ VlDim3 vl_block_idx() { VlDim3 r; r.x = blockIdx.y; r.y = blockIdx.z; r.z = blockIdx.x; return r; }
 __device__ __forceinline__ VlDim3 vl_grid_dim() { VlDim3 r; r.x = gridDim.y; r.y = gridDim.z; r.z = gridDim.x; return r; }
 inline dim3 vl_hw_grid(dim3 g) { return dim3(g.z, g.x, g.y); }
+#endif
 #define blockIdx (::vloam::vl_block_idx())
 #define gridDim (::vloam::vl_grid_dim())
 #define VL_RAW_LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, ::vloam::vl_hw_grid(grid), __VA_ARGS__)
@@ -142,6 +148,9 @@ struct FrameScalars {
   int sect_cnt[kMaxRings][kSectors][3];  // sharp, lessSharp, flat picks per sector
   int ring_ds_cnt[kMaxRings];            // per-ring VoxelGrid(0.2) output size
   int n_sharp, n_less_sharp, n_flat, n_less_flat;
+  // bounding box (min x, y, z, max x, y, z) of the points every scan line contributes to cornerPointsLessSharp [0] / surfPointsLessFlat [1]
+  // (k_sr_compact; an empty line holds +FLT_MAX / -FLT_MAX): getMinMax3D of the clouds pcl::VoxelGrid is run on in the mapping stage
+  float less_bbox[2][kMaxRings][6];
 };
 
 // ---------------------------------------------------------------- Levenberg–Marquardt
