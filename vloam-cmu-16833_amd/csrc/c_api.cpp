@@ -321,7 +321,11 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       Arena dry;
       vloam_status s = handle_layout(h, dry);
       if (s != VLOAM_OK) return s;
-      const size_t ss = (dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // 2 MB granules: every session sees the same address bits below
+      // 2 MB granules + a skew: with arenas exactly 2 MB-aligned every session's hot words (bucket counters, cursors, table heads) share
+      // their low address bits, i.e. ALL sessions of a batch hit the same memory channels at the same time (k_lo_grid_count's atomics:
+      // 2 150 cycles of vector-memory latency alone, 8 160 at B = 16, profiles/r05_batch_pmc.txt); the skew walks the sessions over the channels
+      static const size_t skew = getenv("VLOAM_ARENA_SKEW") ? (size_t)atol(getenv("VLOAM_ARENA_SKEW")) & ~(size_t)255 : 0;
+      const size_t ss = ((dry.off + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) + (n_sessions > 1 ? skew : 0);
       h->se.B = n_sessions;
       h->se.ss = ss;
       // The cooperative solves of a single sequence are placed on ONE XCD each (lm_solve.hip: lm_coop_block): 8 + 8 compute units of XCDs 2 and
@@ -1211,6 +1215,7 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
       case 1: return copy_out(SEL(h, h->lo_corr[outer]) + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
       case 2: return copy_out(SEL(h, h->lo_rec) + outer, sizeof(LMRecord), buf, cap, n);
       case 3: return copy_out(SEL(h, h->lo_resid[outer]), sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
+      case 5: return copy_out(SEL(h, h->lo_queue_n), sizeof(int) * 2, buf, cap, n);   // queries k_lo_assoc_fast left to the wave-per-query pass (last launch pair of a batch)
       case 4: if (!h->lo_cyc[outer]) return VLOAM_ERR_INVALID;
               return copy_out(SEL(h, h->lo_cyc[outer]), sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);
     }

@@ -305,6 +305,7 @@ __device__ __forceinline__ int ds_bin_of(const u64* split, int P, u64 cell) {
 }
 
 constexpr int kDsTile = 2048;   // points a workgroup of the binning pass takes per trip
+constexpr int kDsReduceGrid = 64;   // workgroups of the reduce pass per cloud (each keeps drawing bins)
 __global__ __launch_bounds__(256) void k_map_ds_bin(const float4* __restrict__ corner_last, const float4* __restrict__ surf_last,
                                                     const FrameScalars* __restrict__ S, DsScratch D0, DsScratch D1, float inv0, float inv1,
                                                     float4* __restrict__ stack0, float4* __restrict__ stack1, StackInfo* fr, size_t ss) {
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void k_map_ds_bin(const float4* __restrict__ c
   const float4* pts = kind ? surf_last : corner_last;
   float4* stack = kind ? stack1 : stack0;
   const int n = kind ? S->n_less_flat : S->n_less_sharp;
+  if (blockIdx.x == 0 && tid == 0) D.cursor[kDsMaxBins + 1] = 0;   // the reduce pass's ticket counter (nothing of the previous sweep draws from it any more)
   if (n <= 0) { if (blockIdx.x == 0 && tid == 0) fr->n_stack[kind] = 0; return; }
   if ((int)blockIdx.x * kDsTile >= n) return;
   const DsGrid g = ds_grid(S, kind, inv);
@@ -464,7 +466,7 @@ __device__ __forceinline__ void ds_reduce_sorted(const u64* key, int m, int bin,
     const int total = before + u;
     fr->n_stack[kind] = min(total, D.stack_cap);
     if (total > D.stack_cap) atomicOr(&fr->error, kErrStackFull);
-    D.cursor[kDsMaxBins] = 0; D.cursor[kDsMaxBins + 1] = 0; D.cursor[kDsMaxBins + 2] = 0;
+    D.cursor[kDsMaxBins] = 0; D.cursor[kDsMaxBins + 2] = 0;   // (the ticket counter is reset by the next sweep's binning pass: workgroups still draw from it)
   }
 }
 
@@ -488,10 +490,18 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
   const int P = ds_num_bins(n);
   if ((int)blockIdx.x >= P) return;
   if (ds_grid(S, kind, inv).overflow) return;   // the binning pass copied the cloud (voxel_grid.hpp's guard)
-  // bins are taken in ticket order, not in blockIdx order: the look-back below then only waits for workgroups that are already running
+  // Bins are taken in ticket order, not in blockIdx order: the look-back then only waits for workgroups that are already running.  The
+  // grid is a fraction of kDsMaxBins (a capacity): a workgroup keeps taking tickets until the bins are gone — workgroups that only
+  // find out that there is nothing for them cost a wave slot for a memory round trip each, and on a chip full of sessions that adds up
+  // (8 192 such workgroups per launch at B = 16 were 85 % of this kernel's wave-microseconds).
+  for (;;) {
+  __syncthreads();   // (the previous bin's LDS is no longer read)
   if (tid == 0) s_bin = atomicAdd(&D.cursor[kDsMaxBins + 1], 1);
   __syncthreads();
   const int bin = s_bin;
+  if (bin >= P) {
+    return;   // every ticket is out (the counter is reset by the next sweep's binning pass)
+  }
   const int m_raw = D.cursor[bin];
   __syncthreads();
   if (tid == 0) D.cursor[bin] = 0;   // this bin's region counter, clean for the next sweep
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
     __syncthreads();
     block_bitonic_sort_u64(s_key, P2, tid, 256);
     ds_reduce_sorted<true>(s_key, m_raw, bin, P, pts, stack, D, fr, kind, gen, s_cnt, s_big);
-    return;
+    continue;
   }
   // ---- slow path: the bin outgrew its region.  Gather region + this bin's share of the overflow list, rank by counting (keys are unique:
   // they end in the point index), continue from global memory.
@@ -538,6 +548,7 @@ __global__ __launch_bounds__(256) void k_map_ds_reduce(const float4* __restrict_
   __threadfence();
   __syncthreads();
   ds_reduce_sorted<false>(srt, m, bin, P, pts, stack, D, fr, kind, gen, s_cnt, s_big);
+  }   // next ticket
 }
 
 // ---------------------------------------------------------------------------------------------- data association
@@ -1427,7 +1438,7 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
   VLOAM_LAUNCH(ph, kKMapStack, st, k_map_ds_bin, dim3(32, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
                m->inv_leaf[0], m->inv_leaf[1], m->stack_sets[set][0], m->stack_sets[set][1], si, ss);
   // `done` (the stack of this sweep is complete) is bound to the last dispatch instead of a marker packet behind it
-  VLOAM_LAUNCH_EV(ph, kKMapDsReduce, st, done, k_map_ds_reduce, dim3(kDsMaxBins, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
+  VLOAM_LAUNCH_EV(ph, kKMapDsReduce, st, done, k_map_ds_reduce, dim3(kDsReduceGrid, 2, Z), dim3(256), 0, st, cur.less_sharp, cur.less_flat, cur.S, m->ds[0], m->ds[1],
                   m->inv_leaf[0], m->inv_leaf[1], m->stack_sets[set][0], m->stack_sets[set][1], si, m->ds_gen, ss);
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }

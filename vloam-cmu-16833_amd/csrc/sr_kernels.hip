@@ -122,6 +122,8 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 // 256-lane workgroups: small enough to slip onto CUs whose register file is mostly taken by the previous sweep's odometry
 // kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
 constexpr int kFLThreads = 256;
+constexpr int kFLPoints = 1024;   // points per slice: four per lane — a wavefront that looks at 64 points lives as long as one that looks at 256 (one
+                                  // memory round trip), and on a chip full of sessions it is wave-microseconds, not launches, that are short
 __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float thres, int2* __restrict__ slice, size_t ss) {
   VL_SESSION(ss); RB(slice);
   const float4* __restrict__ in = bi.in[blockIdx.z];
@@ -130,14 +132,25 @@ __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float 
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
-  const int i = blockIdx.x * kFLThreads + tid;
-  bool v = false;
-  if (i < n) { const float4 p = in[i]; v = sr_survives_s1(p.x, p.y, p.z, thres); }
-  const unsigned long long m = __ballot(v);
-  if (m != 0ull) {
-    if (lane == __ffsll((long long)m) - 1) atomicMin(&s_first, i);
-    if (lane == 63 - __clzll((long long)m)) atomicMax(&s_last, i);
+  float4 p[kFLPoints / kFLThreads];
+#pragma unroll
+  for (int e = 0; e < kFLPoints / kFLThreads; e++) {
+    const int i = blockIdx.x * kFLPoints + e * kFLThreads + tid;
+    p[e] = i < n ? in[i] : make_float4(NAN, NAN, NAN, 0.f);
   }
+  int first = INT_MAX, last = -1;
+#pragma unroll
+  for (int e = 0; e < kFLPoints / kFLThreads; e++) {
+    const int i = blockIdx.x * kFLPoints + e * kFLThreads + tid;
+    const bool v = i < n && sr_survives_s1(p[e].x, p[e].y, p[e].z, thres);
+    const unsigned long long m = __ballot(v);
+    if (m != 0ull) {
+      const int base = i - lane;
+      first = min(first, base + __ffsll((long long)m) - 1);
+      last = max(last, base + 63 - __clzll((long long)m));
+    }
+  }
+  if (lane == 0 && last >= 0) { atomicMin(&s_first, first); atomicMax(&s_last, last); }
   __syncthreads();
   if (tid == 0) slice[blockIdx.x] = make_int2(s_first, s_last);
 }
@@ -145,10 +158,12 @@ __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float 
 // ------------------------------------------------------------------------------------------------
 // blk: per-workgroup results for k_sr_scatter — [0, nblk): candidate pivot (SR:246-249) or INT_MAX, [nblk, 2 nblk): points
 // surviving S1.  Plain stores, no counters to re-arm between sweeps.
-__global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thres, int N_SCANS,
-                                                          FrameScalars* S, signed char* __restrict__ sid,
-                                                          float* __restrict__ ori_raw, int* __restrict__ blockhist,
-                                                          const int2* __restrict__ slice, int nslice, int* __restrict__ blk, size_t ss) {
+constexpr int kLabelThreads = 256;                       // lanes of a label / scatter workgroup ...
+constexpr int kLabelPer = kLabelBlock / kLabelThreads;   // ... each takes this many of the workgroup's kLabelBlock points (chunk e = points e * 256 .. e * 256 + 255)
+__global__ __launch_bounds__(kLabelThreads) void k_sr_label(BatchIn bi, float thres, int N_SCANS,
+                                                           FrameScalars* S, signed char* __restrict__ sid,
+                                                           float* __restrict__ ori_raw, int* __restrict__ blockhist,
+                                                           const int2* __restrict__ slice, int nslice, int* __restrict__ blk, size_t ss) {
   VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(slice); RB(blk);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
@@ -156,12 +171,19 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thre
   __shared__ int s_istar, s_cnt, s_first, s_last;
   __shared__ float s_start;
   const int tid = threadIdx.x, lane = tid & 63;
+  // this workgroup's points first: their loads are in flight while the slice records are folded
+  float4 p[kLabelPer];
+#pragma unroll
+  for (int e = 0; e < kLabelPer; e++) {
+    const int i = blockIdx.x * kLabelBlock + e * kLabelThreads + tid;
+    p[e] = i < n ? in[i] : make_float4(NAN, NAN, NAN, 0.f);
+  }
   if (tid < kMaxRings) hist[tid] = 0;
   if (tid == 0) { s_istar = INT_MAX; s_cnt = 0; s_first = INT_MAX; s_last = -1; }
   __syncthreads();
   {
     int f = INT_MAX, l = -1;
-    for (int b = tid; b < nslice; b += kLabelBlock) { const int2 fl = slice[b]; f = min(f, fl.x); l = max(l, fl.y); }
+    for (int b = tid; b < nslice; b += kLabelThreads) { const int2 fl = slice[b]; f = min(f, fl.x); l = max(l, fl.y); }
     for (int d = 32; d > 0; d >>= 1) { f = min(f, __shfl_xor(f, d)); l = max(l, __shfl_xor(l, d)); }
     if (lane == 0) { atomicMin(&s_first, f); atomicMax(&s_last, l); }
   }
@@ -184,27 +206,31 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thre
     }
   }
   __syncthreads();
-  const int i = blockIdx.x * kLabelBlock + tid;
   const float startOri = s_start;
-  int id = -1;
-  bool v1 = false;
-  if (i < n) {
-    float4 p = in[i];
-    v1 = sr_survives_s1(p.x, p.y, p.z, thres);
-    if (v1) {
-      id = sr_scan_id(p.x, p.y, p.z, N_SCANS);
-      float ori = -atan2f(p.y, p.x);  // SR:234
-      ori_raw[i] = ori;
-      if (id >= 0) {
-        atomicAdd(&hist[id], 1);
-        float o = sr_ori_first_half(ori, startOri);
-        if ((double)(o - startOri) > M_PI) atomicMin(&s_istar, i);  // SR:246-249 candidate pivot
+  int nv = 0, istar = INT_MAX;
+#pragma unroll
+  for (int e = 0; e < kLabelPer; e++) {
+    const int i = blockIdx.x * kLabelBlock + e * kLabelThreads + tid;
+    int id = -1;
+    bool v1 = false;
+    if (i < n) {
+      v1 = sr_survives_s1(p[e].x, p[e].y, p[e].z, thres);
+      if (v1) {
+        id = sr_scan_id(p[e].x, p[e].y, p[e].z, N_SCANS);
+        float ori = -atan2f(p[e].y, p[e].x);  // SR:234
+        ori_raw[i] = ori;
+        if (id >= 0) {
+          atomicAdd(&hist[id], 1);
+          float o = sr_ori_first_half(ori, startOri);
+          if ((double)(o - startOri) > M_PI) istar = min(istar, i);  // SR:246-249 candidate pivot
+        }
       }
+      sid[i] = (signed char)id;
     }
-    sid[i] = (signed char)id;
+    nv += __popcll(__ballot(v1));
   }
-  unsigned long long mv = __ballot(v1);
-  if ((tid & 63) == 0 && mv) atomicAdd(&s_cnt, __popcll(mv));
+  if (istar != INT_MAX) atomicMin(&s_istar, istar);
+  if (lane == 0 && nv) atomicAdd(&s_cnt, nv);
   __syncthreads();
   if (tid < kMaxRings) blockhist[blockIdx.x * kMaxRings + tid] = hist[tid];
   if (tid == 0) { blk[blockIdx.x] = s_istar; blk[gridDim.x + blockIdx.x] = s_cnt; }
@@ -214,32 +240,44 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_label(BatchIn bi, float thre
 // Stable scatter into the ring-major cloud.  Every workgroup first derives, from the per-WG ring histograms of k_sr_label,
 // the ring offsets (SR:276-281) and its own base inside every ring — 32 KB of L2 reads per WG instead of a separate
 // single-workgroup scan kernel on the critical path.
-__global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(BatchIn bi, FrameScalars* S,
-                                                            const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
-                                                            const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud,
-                                                            const int* __restrict__ blk, size_t ss) {
+__global__ __launch_bounds__(kLabelThreads) void k_sr_scatter(BatchIn bi, FrameScalars* S,
+                                                             const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
+                                                             const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud,
+                                                             const int* __restrict__ blk, size_t ss) {
   VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(cloud); RB(blk);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
-  __shared__ int wcnt[kLabelBlock / 64][kMaxRings];
+  constexpr int kChunks = kLabelBlock / 64, kWaves = kLabelThreads / 64;   // 64-point chunks of the workgroup's points, in input order: chunk c = e * kWaves + wave
+  __shared__ int wcnt[kChunks][kMaxRings];
   __shared__ int s_istar, s_nvalid;
-  __shared__ int part_before[kLabelBlock / 64][kMaxRings], part_all[kLabelBlock / 64][kMaxRings];
+  __shared__ int part_before[kWaves][kMaxRings], part_all[kWaves][kMaxRings];
   __shared__ int ring_base[kMaxRings];   // ring offset + points of this ring in earlier workgroups
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < (kLabelBlock / 64) * kMaxRings; k += kLabelBlock) (&wcnt[0][0])[k] = 0;
+  // this workgroup's points, ring ids and raw azimuths first (in flight during the prologue)
+  float4 p[kLabelPer];
+  float oraw[kLabelPer];
+  int ids[kLabelPer];
+#pragma unroll
+  for (int e = 0; e < kLabelPer; e++) {
+    const int i = blockIdx.x * kLabelBlock + e * kLabelThreads + tid;
+    ids[e] = (i < n) ? (int)sid[i] : -1;
+    p[e] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    oraw[e] = i < n ? ori_raw[i] : 0.f;
+  }
+  for (int k = tid; k < kChunks * kMaxRings; k += kLabelThreads) (&wcnt[0][0])[k] = 0;
   if (tid == 0) { s_istar = INT_MAX; s_nvalid = 0; }
   __syncthreads();
   {
     // the pivot of the sweep = the smallest candidate of any label workgroup; the S1 survivor count is a debug scalar
     int mi = INT_MAX, cnt = 0;
-    for (int b = tid; b < nblk; b += kLabelBlock) { mi = min(mi, blk[b]); cnt += blk[nblk + b]; }
+    for (int b = tid; b < nblk; b += kLabelThreads) { mi = min(mi, blk[b]); cnt += blk[nblk + b]; }
     for (int d = 32; d > 0; d >>= 1) { mi = min(mi, __shfl_xor(mi, d)); cnt += __shfl_xor(cnt, d); }
     if (lane == 0) { atomicMin(&s_istar, mi); atomicAdd(&s_nvalid, cnt); }
   }
   {
-    // wavefront w sums blocks w, w + 16, ... for ring = lane
+    // wavefront w sums blocks w, w + kWaves, ... for ring = lane
     int before = 0, all = 0;
-    for (int b = wave; b < nblk; b += kLabelBlock / 64) {
+    for (int b = wave; b < nblk; b += kWaves) {
       const int h = blockhist[b * kMaxRings + lane];
       all += h;
       if (b < (int)blockIdx.x) before += h;
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(BatchIn bi, FrameSca
   __syncthreads();
   if (tid < kMaxRings) {
     int before = 0, all = 0;
-    for (int w = 0; w < kLabelBlock / 64; w++) { before += part_before[w][tid]; all += part_all[w][tid]; }
+    for (int w = 0; w < kWaves; w++) { before += part_before[w][tid]; all += part_all[w][tid]; }
     // exclusive prefix of the ring totals across the 64 rings of this wavefront
     int inc = all;
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (tid >= d) inc += t; }
@@ -264,37 +302,44 @@ __global__ __launch_bounds__(kLabelBlock) void k_sr_scatter(BatchIn bi, FrameSca
       if (tid == kMaxRings - 1) { S->N2 = inc; S->ring_off[kMaxRings] = inc; S->istar = s_istar; S->n_after_s1 = s_nvalid; }
     }
   }
-  const int i = blockIdx.x * kLabelBlock + tid;
-  int id = (i < n) ? (int)sid[i] : -1;
-  // stable rank of this point among same-ring points of its wavefront
-  int rank = 0;
-  bool pending = id >= 0;
-  while (true) {
-    u64 act = __ballot(pending);
-    if (act == 0) break;
-    int leader = __ffsll((long long)act) - 1;
-    int lid = __shfl(id, leader);
-    u64 same = __ballot(pending && id == lid);
-    if (pending && id == lid) {
-      rank = __popcll(same & ((1ull << lane) - 1ull));
-      pending = false;
+  // stable rank of every point among the same-ring points of its 64-point chunk
+  int rank[kLabelPer];
+#pragma unroll
+  for (int e = 0; e < kLabelPer; e++) {
+    const int id = ids[e];
+    rank[e] = 0;
+    bool pending = id >= 0;
+    while (true) {
+      u64 act = __ballot(pending);
+      if (act == 0) break;
+      int leader = __ffsll((long long)act) - 1;
+      int lid = __shfl(id, leader);
+      u64 same = __ballot(pending && id == lid);
+      if (pending && id == lid) {
+        rank[e] = __popcll(same & ((1ull << lane) - 1ull));
+        pending = false;
+      }
+      if (lane == leader) wcnt[e * kWaves + wave][lid] = __popcll(same);
     }
-    if (lane == leader) wcnt[wave][lid] = __popcll(same);
   }
   __syncthreads();
-  if (id >= 0) {
+  const float startOri = S->startOri, endOri = S->endOri;
+  const int istar = s_istar;
+#pragma unroll
+  for (int e = 0; e < kLabelPer; e++) {
+    const int id = ids[e];
+    if (id < 0) continue;
+    const int i = blockIdx.x * kLabelBlock + e * kLabelThreads + tid;
     int base = ring_base[id];
-    for (int w = 0; w < wave; w++) base += wcnt[w][id];
-    const float startOri = S->startOri, endOri = S->endOri;
-    float ori = ori_raw[i];
-    if (i <= s_istar) ori = sr_ori_first_half(ori, startOri);
+    for (int c = 0; c < e * kWaves + wave; c++) base += wcnt[c][id];
+    float ori = oraw[e];
+    if (i <= istar) ori = sr_ori_first_half(ori, startOri);
     else ori = sr_ori_second_half(ori, endOri);
     float relTime = (ori - startOri) / (endOri - startOri);  // SR:264
-    float4 p = in[i];
     float4 o;
-    o.x = p.x; o.y = p.y; o.z = p.z;
+    o.x = p[e].x; o.y = p[e].y; o.z = p[e].z;
     o.w = (float)((double)id + 0.1 * (double)relTime);  // SR:265, scanPeriod = 0.1 (scan_registration.h:84)
-    cloud[base + rank] = o;
+    cloud[base + rank[e]] = o;
   }
 }
 
@@ -1078,13 +1123,13 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  const int nslice = (n + kFLThreads - 1) / kFLThreads;
+  const int nslice = (n + kFLPoints - 1) / kFLPoints;
   int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
   int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
   VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice, 1, Z), dim3(kFLThreads), 0, st, bi, min_range, slice, se.ss);
-  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
+  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelThreads), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
                slice, nslice, blk, se.ss);
-  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelBlock), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelThreads), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
   // Behind the small tier ALWAYS comes the big tier: its full grid while the host has seen long rings (watch word), otherwise ONE catch-all
   // workgroup per session that looks at the ring lengths and works on the (normally zero) rings the small tier had to leave.  Any ring of up
   // to kMaxRingLen points is therefore processed on any sweep, like the reference's 400 000-point scratch (scan_registration.h:90) takes any
