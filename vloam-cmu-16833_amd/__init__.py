@@ -159,6 +159,10 @@ class Handle:
         cloud = np.ascontiguousarray(cloud, dtype=np.float32)
         self._chk(self.L.vloam_process_scan(self.h, _fp(cloud), cloud.shape[0]))
 
+    def process_scan_host_ptr(self, hptr, n):
+        """vloam_process_scan on a raw HOST address (e.g. a pinned torch tensor's data_ptr()): n packed float4."""
+        self._chk(self.L.vloam_process_scan(self.h, C.c_void_p(hptr), int(n)))
+
     def process_scan_device(self, dptr, n):
         self._chk(self.L.vloam_process_scan_device(self.h, C.c_void_p(dptr), int(n)))
 

@@ -80,7 +80,17 @@ struct vloam_handle {
   int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
   int nblk_max = 0;
   // scan registration
-  float4* d_in = nullptr;
+  // Host sweeps (vloam_process_scan and the other host-pointer entry points) are staged through a ring of kInRing device input buffers per
+  // session on a copy stream of their own: the H2D copy of sweep k + 1 runs (on a DMA engine) while sweep k's scan registration still reads
+  // its buffer, instead of sitting behind it on the scan-registration stream.  ev_in_copied: the copy has landed (the SR stream waits for it);
+  // ev_in_free: the last reader of the slot on the SR stream is through (the next copy into the slot waits for it).
+  static constexpr int kInRing = 4;
+  float4* d_in = nullptr;         // [kInRing][max_points]
+  hipStream_t s_copy = nullptr;   // created by the first host-pointer call
+  hipEvent_t ev_in_copied[kInRing] = {}, ev_in_free[kInRing] = {};
+  hipEvent_t in_reader[kInRing] = {};   // the event that marks the slot's last reader done: the sweep's own "scan registration finished" / "VO depth map
+                                        // built" event when the slot fed a whole-sweep call (no extra marker packet), else ev_in_free[slot]
+  int in_next = 0, in_slot = -1;  // next ring slot; the slot being staged by the call in progress
   SRBuffers sr[kSets];  // rotating sets: S, cloud and the feature clouds are per set, the scratch arrays are shared (SR stream only)
   // laser odometry
   LOState* lo = nullptr;
@@ -146,7 +156,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   const vloam_config* cfg = &h->cfg;
   const int P = cfg->max_points;
   h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
-  TAKE(h->d_in, (size_t)P);
+  TAKE(h->d_in, (size_t)vloam_handle::kInRing * (size_t)P);
   SRBuffers& a = h->sr[0];
   TAKE(a.sid, (size_t)P);
   TAKE(a.ori, (size_t)P);
@@ -416,13 +426,14 @@ vloam_status vloam_destroy(vloam_handle* h) {
     fprintf(stderr, "[vloam host prof] %lld sweeps: per sweep %.1f us in the buffer-set throttle, %.1f us enqueueing SR (incl. throttle), %.1f us LO, %.1f us mapping\n",
             h->host_calls, 1e6 * h->host_s[0] / h->host_calls, 1e6 * h->host_s[1] / h->host_calls, 1e6 * h->host_s[2] / h->host_calls, 1e6 * h->host_s[3] / h->host_calls);
   (void)hipSetDevice(h->device);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : {h->s_copy, h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamSynchronize(st);
   if (h->arena) (void)hipFree(h->arena);
+  for (int k = 0; k < vloam_handle::kInRing; k++) for (hipEvent_t e : {h->ev_in_copied[k], h->ev_in_free[k]}) if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
     for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k], h->ev_img[k]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-  for (hipStream_t st : {h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : {h->s_copy, h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamDestroy(st);
   map_destroy(&h->map);
   if (h->ring_watch) (void)hipHostFree(h->ring_watch);
   delete h;
@@ -588,6 +599,53 @@ static vloam_status finish_frame(vloam_handle* h) {
   return VLOAM_OK;
 }
 
+// ------------------------------------------------------------------ host sweeps -> the input ring
+// stage_begin picks the ring slot of this call and makes the copy stream wait for the slot's previous readers; stage_sweep enqueues session
+// b's copy and returns the device address; stage_end makes the scan-registration stream wait for the copies; stage_release (after the
+// call's readers — scan registration, the VO depth map — are enqueued on the scan-registration stream) marks the slot reusable.
+// Pageable source memory: hipMemcpyAsync has taken its copy when it returns (the caller may reuse the buffer at once).  Pinned source
+// memory (hipHostMalloc / hipHostRegister) is read by DMA later: it must stay unchanged until the next vloam_sync() (c_api.h).
+static vloam_status stage_begin(vloam_handle* h) {
+  if (!h->s_copy) {
+    HIPCHK(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
+    for (int k = 0; k < vloam_handle::kInRing; k++) {
+      HIPCHK(hipEventCreateWithFlags(&h->ev_in_copied[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_in_free[k], hipEventDisableTiming));
+    }
+  }
+  h->in_slot = h->in_next % vloam_handle::kInRing;
+  h->in_next++;
+  if (h->in_reader[h->in_slot]) HIPCHK(hipStreamWaitEvent(h->s_copy, h->in_reader[h->in_slot], 0));
+  return VLOAM_OK;
+}
+static vloam_status stage_sweep(vloam_handle* h, int b, const float* xyz_pad4, int n, const float4** d_out) {
+  float4* dst = (float4*)((char*)(h->d_in + (size_t)h->in_slot * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
+  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->s_copy));
+  *d_out = dst;
+  return VLOAM_OK;
+}
+static vloam_status stage_end(vloam_handle* h) {
+  HIPCHK(hipEventRecord(h->ev_in_copied[h->in_slot], h->s_copy));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in_copied[h->in_slot], 0));
+  return VLOAM_OK;
+}
+static vloam_status stage_release(vloam_handle* h, vloam_status call_status, hipEvent_t last_reader = nullptr) {
+  // last_reader: an event the call already recorded behind the slot's last reader (a whole-sweep call: the sweep's ev_sr / ev_vo — with
+  // kInRing < kSets it still belongs to that sweep when the slot comes round again); otherwise a marker on the scan-registration stream
+  // (also after a refused call: the wait on ev_in_copied was enqueued there, the record behind it is harmless)
+  if (h->in_slot >= 0) {
+    if (last_reader && call_status == VLOAM_OK) h->in_reader[h->in_slot] = last_reader;
+    else { HIPCHK(hipEventRecord(h->ev_in_free[h->in_slot], h->stream)); h->in_reader[h->in_slot] = h->ev_in_free[h->in_slot]; }
+    h->in_slot = -1;
+  }
+  return call_status;
+}
+static_assert(vloam_handle::kInRing < vloam_handle::kSets, "a slot's reader event (per buffer set) must not be re-recorded before the slot is reused");
+#define STAGE_ONE(h, xyz, n, dptr)                                                                              \
+  const float4* dptr = nullptr;                                                                                 \
+  { vloam_status s_ = stage_begin(h); if (s_ == VLOAM_OK) s_ = stage_sweep(h, 0, xyz, n, &dptr);               \
+    if (s_ == VLOAM_OK) s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+
 // ------------------------------------------------------------------ stage-wise API (façade order)
 vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
   if (!h || !d_xyz_pad4) return VLOAM_ERR_INVALID;
@@ -602,9 +660,10 @@ vloam_status vloam_scan_registration(vloam_handle* h, const float* xyz_pad4, int
   if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  return vloam_scan_registration_device(h, h->d_in, n);
+  STAGE_ONE(h, xyz_pad4, n, d);
+  return stage_release(h, vloam_scan_registration_device(h, d, n));
 }
 
 static vloam_status read_sr_error(vloam_handle* h, int cur) {
@@ -754,20 +813,27 @@ vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_p
     if (!xyz_pad4[b]) return VLOAM_ERR_INVALID;
     if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
     if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
-    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
-    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    bi.in[b] = dst; bi.n[b] = n[b];
   }
-  return process_scan_batch(h, bi);
+  { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
+  for (int b = 0; b < h->se.B; b++) {
+    vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &bi.in[b]);
+    if (s_ != VLOAM_OK) return s_;
+    bi.n[b] = n[b];
+  }
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  const vloam_status st = process_scan_batch(h, bi);
+  return stage_release(h, st, (st == VLOAM_OK && !h->cfg.timing) ? h->ev_sr[set_of(h->frame - 1)] : nullptr);
 }
 
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
   if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  return vloam_process_scan_device(h, h->d_in, n);
+  STAGE_ONE(h, xyz_pad4, n, d);
+  const vloam_status st = vloam_process_scan_device(h, d, n);
+  return stage_release(h, st, (st == VLOAM_OK && !h->cfg.timing) ? h->ev_sr[set_of(h->frame - 1)] : nullptr);
 }
 
 // ------------------------------------------------------------------ coupled VLOAM frame (configs[3])
@@ -891,20 +957,26 @@ vloam_status vloam_batch_process_frame(vloam_handle* h, const float* const* xyz_
     if (!xyz_pad4[b]) return VLOAM_ERR_INVALID;
     if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
     if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
-    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
-    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    bi.in[b] = dst; bi.n[b] = n[b];
   }
-  return process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0);
+  { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
+  for (int b = 0; b < h->se.B; b++) {
+    vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &bi.in[b]);
+    if (s_ != VLOAM_OK) return s_;
+    bi.n[b] = n[b];
+  }
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  return stage_release(h, process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0));
 }
 
 vloam_status vloam_process_frame(vloam_handle* h, const float* xyz_pad4, int n, const int* prev_uv, const int* curr_uv, int n_match) {
   if (!h || !xyz_pad4) return VLOAM_ERR_INVALID;
   if (n > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n, h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
+  SINGLE_SESSION_ONLY(h);
+  if (n_match < 0 || (n_match > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  return vloam_process_frame_device(h, h->d_in, n, prev_uv, curr_uv, n_match);
+  STAGE_ONE(h, xyz_pad4, n, d);
+  return stage_release(h, vloam_process_frame_device(h, d, n, prev_uv, curr_uv, n_match));
 }
 
 vloam_status vloam_process_frame_image_device(vloam_handle* h, const void* d_xyz_pad4, int n, const void* d_gray, int width, int height, int stride) {
@@ -923,11 +995,11 @@ vloam_status vloam_process_frame_image(vloam_handle* h, const float* xyz_pad4, i
   if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
   if (width <= 0 || height <= 0 || stride < width || width > h->img.max_w || height > h->img.max_h) { set_err("bad image size (%d x %d; the handle was created for at most %d x %d)", width, height, h->img.max_w, h->img.max_h); return VLOAM_ERR_INVALID; }
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return s_; }
+  STAGE_ONE(h, xyz_pad4, n, d);
+  { vloam_status s_ = upload_image(h, gray, width, height, stride); if (s_ != VLOAM_OK) return stage_release(h, s_); }
   { const int* none = nullptr; const int zero = 0;
     const unsigned char* g = h->img.staging;
-    return process_frame_common(h, one_sweep(h->d_in, n), &none, &none, &zero, &g, width, height, width); }
+    return stage_release(h, process_frame_common(h, one_sweep(d, n), &none, &none, &zero, &g, width, height, width)); }
 }
 
 // Batched coupled frames from raw inputs: session b gets sweep d_xyz_pad4[b] and the 8-bit grey image d_gray[b] (all images of one size).
@@ -955,12 +1027,16 @@ vloam_status vloam_batch_process_frame_image(vloam_handle* h, const float* const
     if (!xyz_pad4[b] || !gray[b]) return VLOAM_ERR_INVALID;
     if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
     if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
-    float4* dst = (float4*)((char*)h->d_in + (size_t)b * h->se.ss);
-    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  }
+  { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
+  for (int b = 0; b < h->se.B; b++) {
+    const float4* dst = nullptr;
+    { vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &dst); if (s_ != VLOAM_OK) return s_; }
     { vloam_status s_ = upload_image(h, gray[b], width, height, stride, b); if (s_ != VLOAM_OK) return s_; }
     d_in[b] = dst; d_img[b] = h->img.staging + (size_t)b * h->se.ss;
   }
-  return vloam_batch_process_frame_image_device(h, d_in, n, d_img, width, height, width);
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  return stage_release(h, vloam_batch_process_frame_image_device(h, d_in, n, d_img, width, height, width));
 }
 
 // ---- the image front-end on its own (VisualOdometry::processImage, optical_flow_match = true)
@@ -1155,8 +1231,8 @@ vloam_status vloam_vo_process_point_cloud(vloam_handle* h, const float* xyz_pad4
   SINGLE_SESSION_ONLY(h);
   if (n > h->cfg.max_points) return VLOAM_ERR_CAPACITY;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(h->d_in, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  return vo_process_point_cloud(&h->vo, h->stream, h->d_in, n) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP;
+  STAGE_ONE(h, xyz_pad4, n, d);
+  return stage_release(h, vo_process_point_cloud(&h->vo, h->stream, d, n) == VLOAM_OK ? VLOAM_OK : VLOAM_ERR_HIP);
 }
 vloam_status vloam_vo_solve(vloam_handle* h, const int* prev_uv, const int* curr_uv, int n_match, double aa[3], double t[3], int counters[2]) {
   if (!h || !prev_uv || !curr_uv || !aa || !t || n_match < 0) return VLOAM_ERR_INVALID;
