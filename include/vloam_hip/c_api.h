@@ -88,8 +88,11 @@ vloam_status vloam_destroy(vloam_handle* h);
  * exchange partial sums INSIDE one launch, so all workgroups of a solve must be
  * resident together; a session of a batch can have one odometry and one mapping solve in flight, i.e. 10 such workgroups.  vloam_create_batch
  * refuses (VLOAM_ERR_CAPACITY) when 10 * n_sessions exceeds the device's compute-unit count (256 on MI355X, so n_sessions <= 16 is
- * always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  A
- * workgroup that still waits for its partners after ~0.5 s abandons the solve (pose unchanged) and vloam_sync reports VLOAM_ERR_HIP. */
+ * always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  The one-XCD
+ * placement of a single sequence's solves holds at most 4 solves per XCD (32 compute units, 8 per solve).  When the workgroups of a solve
+ * are NOT resident together after all (another process on the GPU, a CU-masked queue, a partitioned device), the solve does not fail: a
+ * workgroup that still waits for its partners after ~0.5 s gives up, the lead workgroup runs the whole solve on its own, vloam_get_health
+ * counts it, and from the next vloam_sync on the handle launches one-workgroup solves only (slower per solve, no co-residency needed). */
 vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessions, vloam_handle** out);
 vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions);
 vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n);
@@ -250,6 +253,12 @@ vloam_status vloam_profile_read(vloam_handle* h, double* total_ms, int* launches
 vloam_status vloam_profile_read_table(vloam_handle* h, int n_kernels, double* ms, int* launches);
 int vloam_profile_kernel_count(void);
 const char* vloam_profile_kernel_name(int k);
+
+/* Health counters (synchronises): out8[0] cooperative Levenberg-Marquardt solves that found their partner workgroups missing and finished on ONE
+ * workgroup instead (same factors, same trust-region loop; the pose agrees with the cooperative form to round-off, the solve is ~0.5 s late
+ * because the workgroup first waited for its partners), summed over the sessions; out8[1] 1 once the handle has reacted to that by launching
+ * one-workgroup solves only (vloam_sync does, see the co-residency note at vloam_create_batch); out8[2] voxel-table rebuilds; out8[3..7] 0. */
+vloam_status vloam_get_health(vloam_handle* h, long long out8[8]);
 
 /* Timing of the last vloam_sync()ed scans: HIP-event milliseconds accumulated per stage
  * {scanRegistration, laserOdometry, laserMapping, vo} and number of scans covered. */

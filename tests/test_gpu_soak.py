@@ -75,3 +75,46 @@ def test_concurrent_sessions_are_bit_reproducible(vl, synth):
         a = lexsort_rows(alone.map_dump(kind)[1])
         for h in hs:
             assert np.array_equal(lexsort_rows(h.map_dump(kind)[1]).view(np.uint32), a.view(np.uint32))
+
+
+def test_cooperative_solve_degrades_to_one_workgroup(vl, orc, synth, monkeypatch):
+    """The Levenberg-Marquardt solves of a sweep run as workgroups that exchange partial sums inside ONE launch and therefore have to be
+    resident together.  When they are not (another process holding the compute units, a CU-masked queue, a partitioned device) a
+    workgroup gives up waiting — forced here by VLOAM_LM_SPIN_LIMIT=1: three polls instead of ~0.5 s — and the solve must DEGRADE, not
+    fail: the lead workgroup runs it on its own, poses stay within 1e-8 of the oracle, vloam_get_health counts it, vloam_sync raises
+    no error and switches the handle to one-workgroup launches (after which nothing degrades any more).  One sequence and a batch."""
+    monkeypatch.setenv("VLOAM_LM_SPIN_LIMIT", "1")
+    n = 14
+    seqs = [synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=n + 1, seed_scene=50 + 7 * b, seed_traj=3 + b) for b in range(3)]
+    clouds = [[np.ascontiguousarray(s.sweep(k), dtype=np.float32) for k in range(n)] for s in seqs]
+    hs = vl.Handle(0, with_mapping=1)
+    hb = vl.Handle(0, n_sessions=2, with_mapping=1)
+    oracles = [orc.Oracle(with_mapping=True) for _ in range(3)]
+
+    def check(k):
+        for name, tj, b in (("single", hs.trajectory(), 0), ("batch 0", hb.select(0).trajectory(), 1), ("batch 1", hb.select(1).trajectory(), 2)):
+            qw, tw, _, _ = oracles[b].lo_pose()
+            qm, tm = oracles[b].map_published_pose()
+            tol = 1e-8 * (k + 1)
+            assert qdist(tj[k, 0:4], qw) < tol and np.linalg.norm(tj[k, 4:7] - tw) < tol, (name, k)
+            assert qdist(tj[k, 7:11], qm) < tol and np.linalg.norm(tj[k, 11:14] - tm) < tol, (name, k)
+
+    for k in range(8):
+        hs.process_scan(clouds[0][k])
+        hb.batch_process_scan([clouds[1][k], clouds[2][k]])
+        for b in range(3):
+            assert oracles[b].process(clouds[b][k]) == 0
+    hs.sync(); hb.sync()   # no error: nothing failed, solves only degraded
+    check(7)
+    h1, h2 = hs.health(), hb.health()
+    assert h1["fallback_solves"] > 0 and h2["fallback_solves"] > 0, (h1, h2)
+    assert h1["one_workgroup_solves"] and h2["one_workgroup_solves"]      # vloam_sync reacted
+    for k in range(8, n):
+        hs.process_scan(clouds[0][k])
+        hb.batch_process_scan([clouds[1][k], clouds[2][k]])
+        for b in range(3):
+            assert oracles[b].process(clouds[b][k]) == 0
+    hs.sync(); hb.sync()
+    check(n - 1)
+    assert hs.health()["fallback_solves"] == h1["fallback_solves"] and hb.health()["fallback_solves"] == h2["fallback_solves"]   # one-workgroup launches have no partners to miss
+    hs.close(); hb.close()

@@ -235,6 +235,12 @@ class Handle:
                  "n_s", "K_m", "E_m", "M"]
         return dict(zip(names, [int(v) for v in c]))
 
+    def health(self):
+        """vloam_get_health: cooperative solves that degraded to one workgroup, whether the handle switched to one-workgroup solves, table rebuilds."""
+        v = np.zeros(8, dtype=np.int64)
+        self._chk(self.L.vloam_get_health(self.h, _fp(v)))
+        return dict(fallback_solves=int(v[0]), one_workgroup_solves=bool(v[1]), rebuilds=int(v[2]))
+
     # ---- VO
     def vo_set_calib(self, cam_T_velo, rect0_T_cam, P_rect0):
         c = Calib()

@@ -74,6 +74,7 @@ struct vloam_handle {
   double* sync_pool = nullptr;
   bool counted_single = false; // this handle is in g_single_handles
   int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
+  long long fallback_solves = 0;   // cooperative solves that degraded to one workgroup, as of the last vloam_sync
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
   int map_done = 0;     // sweeps whose laser mapping has been enqueued
@@ -144,6 +145,7 @@ static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
   F->rowmask = nullptr;  // the odometry / VO tables use the per-row counters
   F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated
   F->err = nullptr;    // set once the mapping context (owner of the sticky error word) exists
+  F->fallbacks = nullptr; F->gen = 0; F->spin_limit = 1 << 18;
   return VLOAM_OK;
 }
 
@@ -205,6 +207,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   if (vo_layout(&h->vo, h->cfg, A) != VLOAM_OK) { set_err("vo_layout failed"); return VLOAM_ERR_HIP; }
   if (img_layout(&h->img, h->cfg, A) != VLOAM_OK) { set_err("img_layout failed"); return VLOAM_ERR_HIP; }
   h->lo_F.err = &h->map.frame->error;
+  h->lo_F.fallbacks = &h->map.frame->fallback_solves;
   for (int k = 0; k < vloam_handle::kSets; k++) h->sr[k].sticky_err = &h->map.frame->error;
   return VLOAM_OK;
 }
@@ -342,6 +345,13 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       // 6.  Several single-sequence handles in one process would crowd those two XCDs (and their solves wait for each other's compute
       // units): only the first two alive get the placement, the others launch spread over the XCDs like before round 4.  Same arithmetic.
       if (n_sessions == 1) { h->se.crowd = g_single_handles.fetch_add(1); h->counted_single = true; }
+      {
+        // ... and only on the device the placement was measured on: 256 compute units dealt round-robin to 8 XCDs (SPX mode).  Anything else
+        // (a CPX / NPS partition, a CU-masked context, another part) keeps the plain spread launch; and whatever the placement, a solve
+        // whose workgroups do not end up resident together degrades to one workgroup instead of failing (lm_solve.hip).
+        hipDeviceProp_t prop2;
+        if (hipGetDeviceProperties(&prop2, device) != hipSuccess || prop2.multiProcessorCount != 256) h->se.crowd = 1 << 20;
+      }
       h->arena_bytes = ss * (size_t)n_sessions;
       if (hipMalloc((void**)&h->arena, h->arena_bytes) != hipSuccess) {
         set_err("hipMalloc of %zu MB for %d session(s) failed", h->arena_bytes >> 20, n_sessions); h->arena = nullptr; return VLOAM_ERR_HIP;
@@ -1179,14 +1189,22 @@ vloam_status vloam_sync(vloam_handle* h) {
     // surface sticky device-side errors: scan-registration bits of ANY sweep since the last vloam_sync (k_sr_compact folds every
     // sweep's word into the handle's sticky word; reported once, then cleared), map / solver bits for good
     int merr = 0;
-    vloam_status s = map_error(&h->map, &merr, kErrEmpty | kErrRingTooLong);
+    long long fb = 0;
+    vloam_status s = map_error(&h->map, &merr, kErrEmpty | kErrRingTooLong, &fb);
     if (s != VLOAM_OK) return s;
+    if (fb > h->fallback_solves) {
+      // a cooperative solve found its partner workgroups missing and finished on one workgroup (lm_solve.hip): same answer, ~0.5 s late.
+      // Whatever kept them apart (a CU-masked or partitioned device, another process' solves holding the compute units) is likely to last:
+      // this handle launches one-workgroup solves from now on.
+      h->se.no_coop = 1; h->map.se.no_coop = 1; h->vo.se.no_coop = 1;
+    }
+    h->fallback_solves = fb;
     if (merr & kErrEmpty) { set_err("no point survived NaN / minimum_range removal in at least one sweep since the last vloam_sync"); return VLOAM_ERR_EMPTY; }
     if (merr & kErrRingTooLong) { set_err("a ring held more than %d points (dropped) in at least one sweep since the last vloam_sync", kMaxRingLen); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrMapFull) { set_err("voxel hash full (map_capacity_log2=%d)", h->cfg.map_capacity_log2); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrStackFull) { set_err("mapping factor table full"); return VLOAM_ERR_CAPACITY; }
     if (merr & kErrMapDeferred) { set_err("raw-point capacity of the map exceeded (more than 255 un-merged points in a voxel of a cube outside the valid block, or more than 64 raw voxels around one query)"); return VLOAM_ERR_CAPACITY; }
-    if (merr & kErrSolverSync) { set_err("a cooperative LM solve timed out at its grid barrier"); return VLOAM_ERR_HIP; }
+    if (merr & kErrSolverSync) { set_err("a workgroup of the scan-feature VoxelGrid gave up waiting for the bins in front of it"); return VLOAM_ERR_HIP; }
     if (merr & kErrVoDegenerate) { set_err("a VO solve returned a zero rotation angle: poses are NaN from that frame on, as in the reference (visual_odometry.cpp:427-430)"); return VLOAM_ERR_INVALID; }
   }
   if (h->img.max_w != 0 && h->img.count >= 0) {
@@ -1364,6 +1382,20 @@ vloam_status vloam_profile_read_table(vloam_handle* h, int n_kernels, double* ms
 }
 int vloam_profile_kernel_count(void) { return kKCount; }
 const char* vloam_profile_kernel_name(int k) { return (k >= 0 && k < kKCount) ? kKernelNames[k] : ""; }
+
+// {cooperative solves that degraded to one workgroup (all sessions), 1 if the handle has switched to one-workgroup solves, voxel-table
+// rebuilds, 0 ...}
+vloam_status vloam_get_health(vloam_handle* h, long long out8[8]) {
+  if (!h || !out8) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  int merr = 0;
+  long long fb = 0;
+  if (h->frame > 0) { vloam_status s = map_error(&h->map, &merr, 0, &fb); if (s != VLOAM_OK) return s; }
+  out8[0] = fb; out8[1] = h->se.no_coop; out8[2] = h->map.rebuilds;
+  return VLOAM_OK;
+}
 
 vloam_status vloam_get_stage_ms(vloam_handle* h, double ms4[4], int* scans) {
   if (!h || !ms4) return VLOAM_ERR_INVALID;

@@ -18,6 +18,7 @@
 #include <float.h>
 #include <math.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -714,9 +715,8 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         for (int q = 0; q < NB; q++) all = all && (lo[q] >> 32 << 32) == tag && (hi[q] >> 32 << 32) == tag;
         if (all) break;
         if (__hip_atomic_load(&gw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == poison) { bad = true; break; }
-        if (spins > (1 << 18)) {
+        if (spins > F.spin_limit) {   // (~0.5 s by default; k_lm_solve then degrades to a one-workgroup solve)
           __hip_atomic_store(&gw[1], poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (F.err) atomicOr(F.err, kErrSolverSync);
           bad = true;
           break;
         }
@@ -837,38 +837,23 @@ __device__ void lo_integrate(LOState* lo, const double* x, double* traj_row14) {
   }
 }
 
-template <bool QUAT, int MODE, int NB>
-__global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
-                                                         double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
-  VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
-  if (NB > 1 && lm_coop_block<NB, MODE>() < 0) return;   // single sequence: only the workgroups of the solve's XCD work (lm_coop_block)
-  __shared__ LmShared sh;
-  const int tid = threadIdx.x;
-  const bool lead = NB == 1 || lm_coop_block<NB, MODE>() == 0;  // the workgroup that owns every global side effect other than its factors' residuals
-  constexpr int na = QUAT ? 7 : 6;
-  // the gate word, the parameters, this lane's first row counter and the solve generation are fetched in ONE round trip (a branch on
-  // the gate first would put a dependent ~1.5 us memory trip in front of everything else the solve reads)
-  const int enabled = enable_flag ? *enable_flag : 1;
-  const double x_first = tid < na ? x_io[tid] : 0.0;
-  int row_first = 0;
-  ulonglong2 mask_first = make_ulonglong2(0ull, 0ull);   // kLmRowMask: the accepted-slot masks of rows 2 tid, 2 tid + 1
-  if constexpr (MODE == kLmRowMask) { if (2 * tid < (F.cap >> 6)) mask_first = *reinterpret_cast<const ulonglong2*>(F.rowmask + 2 * tid); }
-  else row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
-  // generation of this table's cooperative solves: tags the partial sums every workgroup publishes (lm_evaluate); bumped by the lead
-  // workgroup on its way out — every workgroup has read it by then, because the lead needed their first partial sums
-  u64 gen = 0;
-  if constexpr (NB > 1) gen = __hip_atomic_load(reinterpret_cast<u64*>(F.gsync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned tag_base = (unsigned)(gen & 0xffffffull) << 8;
-  if (enabled == 0) {
-    if (MODE != kLmRowMask && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
-    return;
-  }
-  if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
-  if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
+// What one attempt at a solve leaves behind for the kernel's epilogue.
+struct LmRun {
+  double minimum_cost;
+  int termination, n_rec, n_evals;
+  bool failed;          // cooperative form only: a workgroup gave up waiting for its partners
+  long long cyc_fac, cyc_eval, cyc_serial;
+};
 
+// One attempt: prologue (factor counts / self-compaction tables), first evaluation, the trust-region loop.  NB workgroups cooperate
+// (NB == 1: this workgroup alone).  sh.x / sh.x0 hold the start point; on return sh.best holds the answer unless the attempt failed.
+template <bool QUAT, int MODE, int NB>
+__device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMRecord* rec, int max_iters, double huber_a, LmShared& sh, bool lead,
+                                              int row_first, ulonglong2 mask_first, unsigned tag_base) {
+  const int tid = threadIdx.x;
+  constexpr int na = QUAT ? 7 : 6;
   // ---- prologue: count the factors.  Packed / direct: per-row counters (released for the next solve); row-mask form: scan the row
   // masks into row offsets and stage both in LDS for the self-compaction of the first evaluation (lm_evaluate)
-  const long long t_start = clock64();
   if constexpr (MODE == kLmRowMask) {
     static_assert(kLmThreads == 256, "two rows per lane cover tables of up to 512 rows");
     int* rowoff = reinterpret_cast<int*>(sh.red);            // [513]
@@ -912,7 +897,6 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
   int eval_idx = 0;
   lm_evaluate<QUAT, MODE, NB>(F, n_edge, n_valid, sh.x, huber_a, sh, sh.acc2[0], true, cache, &cyc_fac, eval_idx++, tag_base);
   cyc_eval += clock64() - t_mark;
-  if (MODE != kLmRowMask && NB > 1 && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // everyone has published its first partial sums, i.e. is past its prologue
 
 #ifdef VLOAM_LM_STAMPS   // debug build only: where thread 0's serial sections spend their cycles (sums over the iterations -> trace rows 100, 101)
   long long lm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lm_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1122,12 +1106,64 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     curidx = sh.curidx;   // accepted (uniform): the candidate's accumulators and its prepared normal equations become the current point's
   }
 
-  if (tid == 0 && lead) {
-    if (NB > 1 && sh.failed) {  // abandoned: the solve degrades to "no update" (x unchanged) instead of corrupting the state
-#pragma unroll
-      for (int i = 0; i < 7; i++) sh.best[i] = i < na ? sh.x0[i] : 0.0;
-      termination = 3;
+  LmRun R;
+  R.minimum_cost = minimum_cost; R.termination = termination; R.n_rec = n_rec; R.n_evals = n_evals;
+  R.failed = NB > 1 && sh.failed != 0;
+  R.cyc_fac = cyc_fac; R.cyc_eval = cyc_eval; R.cyc_serial = cyc_serial;
+  (void)t_pro;
+  return R;
+}
+
+template <bool QUAT, int MODE, int NB>
+__global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
+                                                         double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
+  VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
+  if (NB > 1 && lm_coop_block<NB, MODE>() < 0) return;   // single sequence: only the workgroups of the solve's XCD work (lm_coop_block)
+  __shared__ LmShared sh;
+  const int tid = threadIdx.x;
+  const bool lead = NB == 1 || lm_coop_block<NB, MODE>() == 0;  // the workgroup that owns every global side effect other than its factors' residuals
+  constexpr int na = QUAT ? 7 : 6;
+  // the gate word, the parameters and this lane's first row counter are fetched in ONE round trip (a branch on the gate first would put a
+  // dependent ~1.5 us memory trip in front of everything else the solve reads)
+  const int enabled = enable_flag ? *enable_flag : 1;
+  const double x_first = tid < na ? x_io[tid] : 0.0;
+  int row_first = 0;
+  ulonglong2 mask_first = make_ulonglong2(0ull, 0ull);   // kLmRowMask: the accepted-slot masks of rows 2 tid, 2 tid + 1
+  if constexpr (MODE == kLmRowMask) { if (2 * tid < (F.cap >> 6)) mask_first = *reinterpret_cast<const ulonglong2*>(F.rowmask + 2 * tid); }
+  else row_first = tid < (F.cap >> 6) ? F.rowcnt[tid] : 0;
+  // generation of this launch (a host-side counter, lm_launch): tags the partial sums the workgroups of a cooperative solve publish
+  // (lm_evaluate), so that nothing an earlier solve left in the exchange buffer — or a straggler of an abandoned attempt — can be taken
+  // for this solve's data
+  const unsigned tag_base = (F.gen & 0xffffffu) << 8;
+  if (enabled == 0) {
+    if (MODE != kLmRowMask && lead) for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;
+    return;
+  }
+  if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
+  if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
+  const long long t_start = clock64();
+  LmRun R = lm_solve_run<QUAT, MODE, NB>(F, edge_rows, rec, max_iters, huber_a, sh, lead, row_first, mask_first, tag_base);
+  if constexpr (NB > 1) {
+    if (R.failed) {
+      // A partner never showed up (not co-resident: a CU-masked queue, a partitioned device, a chip held by another process' spinning
+      // solves) or gave up itself.  The solve DEGRADES instead of failing: the lead workgroup starts over on its own — same factors, same
+      // trust-region loop, the partial sums added in one workgroup's order (poses agree with the cooperative form to round-off) — and
+      // counts it (vloam_get_health); the host then stops launching cooperative solves on this handle (vloam_sync).  Every other
+      // workgroup just leaves; a straggler that arrives later finds the poison word of ITS generation and leaves as well.
+      if (!lead) return;
+      __syncthreads();
+      if (tid < na) sh.x[tid] = sh.x0[tid];
+      if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
+      R = lm_solve_run<QUAT, MODE, 1>(F, edge_rows, rec, max_iters, huber_a, sh, true, row_first, mask_first, tag_base);
+      if (tid == 0 && F.fallbacks) atomicAdd(F.fallbacks, 1);
+    } else if (MODE != kLmRowMask && lead) {
+      for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // every workgroup published its partial sums, i.e. is past its prologue's reads
     }
+  }
+  const double minimum_cost = R.minimum_cost;
+  const int termination = R.termination, n_rec = R.n_rec, n_evals = R.n_evals;
+  const long long cyc_fac = R.cyc_fac, cyc_eval = R.cyc_eval, cyc_serial = R.cyc_serial;
+  if (tid == 0 && lead) {
 #pragma unroll
     for (int i = 0; i < na; i++) x_io[i] = sh.best[i];
 #pragma unroll
@@ -1138,12 +1174,11 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     rec->termination = termination;
     rec->n_evals = n_evals;
     rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
-    (void)t_pro; rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
+    rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
     rec->cyc[3] = (double)(clock64() - t_start);
 #ifdef VLOAM_LM_STAMPS
     for (int k = 0; k < 8; k++) rec->trace[100][k] = (double)lm_sum[k];
 #endif
-    if constexpr (NB > 1) __hip_atomic_store(reinterpret_cast<u64*>(F.gsync), gen + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next solve, next generation
   }
 }
 
@@ -1254,17 +1289,24 @@ int lm_sync_calibrate(hipStream_t st, double* pool, int n_cand, size_t stride_by
   return 0;
 }
 
-void lm_launch(hipStream_t st, Sess se, const FactorTable& F, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
+void lm_launch(hipStream_t st, Sess se, const FactorTable& F_in, int n_edge_slots, double* d_x, LMRecord* d_rec, int max_iters, double huber_a, bool quat,
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
   const unsigned Z = (unsigned)se.B;
+  // every launch gets a generation of its own (process-wide counter: a sync slot only has to tell its own successive solves apart) and the
+  // patience of its workgroups (VLOAM_LM_SPIN_LIMIT: tests force the degraded path with 1)
+  static std::atomic<unsigned> g_gen{1};
+  FactorTable Fg = F_in;
+  Fg.gen = g_gen.fetch_add(1);
+  { const char* e = getenv("VLOAM_LM_SPIN_LIMIT"); Fg.spin_limit = e ? atoi(e) : (1 << 18); }
+  const FactorTable& F = Fg;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   const bool rowmask = quat && !direct && F.rowmask != nullptr && (F.cap >> 6) <= 2 * kLmThreads;   // the fit kernel left row masks: the solve compacts on its own
   // Batches keep the cooperative form: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured only 3 % faster at
   // B = 8 (10 785 vs 10 435 scans/s) and gives up the bit-identity of a batched session with the same sequence run alone (the f64
   // sums of the normal equations would be added in a different order).
   static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
-  const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1);
+  const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1) && !se.no_coop;   // no_coop: a solve of this handle had to degrade once (vloam_sync)
   if (!direct && !rowmask) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);
   static const int one_xcd = getenv("VLOAM_LM_ONE_XCD") ? atoi(getenv("VLOAM_LM_ONE_XCD")) : 1;   // A/B switch, see lm_coop_block
   const unsigned spread = (one_xcd && se.B == 1 && se.crowd < 2) ? 8u : 1u;   // (crowd: the third and later single-sequence handles of a process stay spread, c_api.cpp)

@@ -82,6 +82,7 @@ struct MapFrame {         // per-sweep device counters
   int error;
   int n_factors[2][2];    // [outer][corner, surf] accepted factors
   int max_candidates;     // largest 5-NN candidate list seen (diagnostic; lists beyond kCandChunk take extra passes)
+  int fallback_solves;    // cooperative Levenberg-Marquardt solves of this session that degraded to one workgroup (lm_solve.hip)
 };
 
 struct MapContext {
@@ -138,7 +139,7 @@ vloam_status map_stack_enqueue(MapContext* m, hipStream_t st, const SRBuffers& c
 vloam_status map_enqueue(MapContext* m, const vloam_config& cfg, hipStream_t st, const SRBuffers& cur, LOState* lo, double* traj_row14,
                          bool skip_frame, int set, ProfHook* ph, hipEvent_t done = nullptr);
 vloam_status map_get_cloud(MapContext* m, hipStream_t st, int which, const SRBuffers& cur, float* xyzi4, int cap, int* n);
-vloam_status map_error(MapContext* m, int* err_bits, int clear_mask = 0);
+vloam_status map_error(MapContext* m, int* err_bits, int clear_mask = 0, long long* fallback_solves = nullptr);
 vloam_status map_debug_get(MapContext* m, int item, void* buf, long long cap, long long* n);
 // == /laser_cloud_map (laser_mapping.cpp:778-793): every cube's corner cloud then surf cloud, cube index ascending
 vloam_status map_export(MapContext* m, hipStream_t st, float* xyzi4, long long cap, long long* n);

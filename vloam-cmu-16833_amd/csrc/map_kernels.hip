@@ -1402,11 +1402,13 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
          A.take(&F.rowcnt, (size_t)F.cap / 64 + 1) && A.take(&F.rowmask, (size_t)F.cap / 64 + 2);
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
+    F.fallbacks = ok ? &m->frame->fallback_solves : nullptr;
+    F.gen = 0; F.spin_limit = 1 << 18;
   }
   ok = ok && A.take(&m->rec, 2) && A.take(&m->nbr, 5 * (size_t)kMapFactorCap);
   ok = ok && A.take(&m->cbox, 2 * (size_t)kMapFactorCap) && A.take(&m->ccand, (size_t)kMapFactorCap * kCandCache);
   m->rebuild_cap = (int)(slots / 2);
-  ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 1);
+  ok = ok && A.take(&m->rebuild_tmp, (size_t)m->rebuild_cap) && A.take(&m->rebuild_n, 2);
   ok = ok && A.take(&m->registered, (size_t)cfg.max_points) && A.take(&m->assoc_cyc, 16) && A.take(&m->ts_log, 2048);
   if (!ok) return VLOAM_ERR_HIP;
   m->max_points = cfg.max_points;
@@ -1606,18 +1608,20 @@ vloam_status map_get_cloud(MapContext* m0, hipStream_t st, int which, const SRBu
   return VLOAM_OK;
 }
 
-__global__ void k_map_error_fetch(MapFrame* fr, int clear_mask, int* out) { *out = atomicAnd(&fr->error, ~clear_mask); }
+__global__ void k_map_error_fetch(MapFrame* fr, int clear_mask, int* out) { out[0] = atomicAnd(&fr->error, ~clear_mask); out[1] = fr->fallback_solves; }
 
 // the sticky error words of all sessions OR-ed; the bits of clear_mask are reported once and cleared (transient per-sweep conditions)
-vloam_status map_error(MapContext* m, int* e, int clear_mask) {
+vloam_status map_error(MapContext* m, int* e, int clear_mask, long long* fallback_solves) {
   *e = 0;
+  if (fallback_solves) *fallback_solves = 0;
   for (int b = 0; b < m->se.B; b++) {
     const MapContext mb = m->for_session(b);
-    int* d_out = mb.rebuild_n;  // scratch int (no rebuild can be in flight: the caller has synchronised the streams)
+    int* d_out = mb.rebuild_n;  // scratch ints (no rebuild can be in flight: the caller has synchronised the streams)
     VL_RAW_LAUNCH(k_map_error_fetch, dim3(1), dim3(1), 0, 0, mb.frame, clear_mask, d_out);
-    int v = 0;
-    if (hipMemcpy(&v, d_out, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
-    *e |= v;
+    int v[2] = {0, 0};
+    if (hipMemcpy(v, d_out, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return VLOAM_ERR_HIP;
+    *e |= v[0];
+    if (fallback_solves) *fallback_solves += v[1];
   }
   return VLOAM_OK;
 }

@@ -21,7 +21,7 @@ constexpr int kMaxBatch = 24;   // 10 cooperating solver workgroups per session 
 // with only one mapping stage queued behind the running one, and every stream idled 60-75 us per 214 us period
 // (profiles/r03_critical_path_4_sets.txt); 8 sets keep several sweeps queued on every stream, so the period is the longest stage again.
 constexpr int kBufferSets = 8;
-struct Sess { int B = 1; size_t ss = 0; int crowd = 0; };   // crowd: single-sequence handles alive in this process when the handle was created (lm_launch: one-XCD placement only for the first two)
+struct Sess { int B = 1; size_t ss = 0; int crowd = 0; int no_coop = 0; };   // crowd: single-sequence handles alive in this process when the handle was created (lm_launch: one-XCD placement only for the first two); no_coop: a cooperative solve of this handle had to degrade once — one-workgroup solves from now on (vloam_sync)
 struct BatchIn { const float4* in[kMaxBatch]; int n[kMaxBatch]; };   // the one thing that is not in the arenas: the callers' sweeps
 template <class T>
 __host__ __device__ inline void rbp(T*& p, size_t off) { if (p) p = (T*)((char*)p + off); }   // pointer arithmetic, NOT an integer round trip:
@@ -188,11 +188,14 @@ struct FactorTable {
   unsigned long long* rowmask;  // optional [cap / 64 (+ 2)]: accepted slots of every 64-slot row as a bit mask, rewritten in full by the producer
                                // (k_map_fit) for every solve: the solve then compacts on its own and k_lm_compact is not launched (lm_solve.hip, kLmRowMask)
   int cap;
-  double* gsync;  // optional [kLmSyncDoubles]: solve generation + the tagged partial sums the workgroups of a cooperative solve exchange (null: one workgroup)
+  double* gsync;  // optional [kLmSyncDoubles]: poison word + the tagged partial sums the workgroups of a cooperative solve exchange (null: one workgroup)
   int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
+  int* fallbacks; // optional counter: cooperative solves that degraded to one workgroup (k_lm_solve; vloam_get_health)
+  unsigned gen;   // generation of the launch (lm_launch): the tag of everything the solve's workgroups exchange
+  int spin_limit; // polls a workgroup of a cooperative solve waits for its partners before it gives up (lm_launch; VLOAM_LM_SPIN_LIMIT)
   __host__ __device__ void rebase(size_t off) {
     rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off);
-    rbp(rowcnt, off); rbp(rowmask, off); rbp(gsync, off); rbp(err, off);
+    rbp(rowcnt, off); rbp(rowmask, off); rbp(gsync, off); rbp(err, off); rbp(fallbacks, off);
   }
 };
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
