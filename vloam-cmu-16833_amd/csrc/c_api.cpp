@@ -1309,6 +1309,7 @@ vloam_status vloam_debug_get(vloam_handle* h, int stage, int item, void* buf, lo
       case 1: return copy_out(SEL(h, h->lo_corr[outer]) + 4 * kMaxSharp, sizeof(int) * 4 * kMaxFlat, buf, cap, n);
       case 2: return copy_out(SEL(h, h->lo_rec) + outer, sizeof(LMRecord), buf, cap, n);
       case 3: return copy_out(SEL(h, h->lo_resid[outer]), sizeof(double) * 3 * kMaxLoFactors, buf, cap, n);
+      case 6: return copy_out(SEL(h, h->lo_queue), sizeof(int) * kMaxLoFactors, buf, cap, n);   // the queue itself: slot | reason << 16 (1 block over capacity, 2 closest point beyond 1 m, 3 dense 5 m neighbourhood)
       case 5: return copy_out(SEL(h, h->lo_queue_n), sizeof(int) * 2, buf, cap, n);   // queries k_lo_assoc_fast left to the wave-per-query pass (last launch pair of a batch)
       case 4: if (!h->lo_cyc[outer]) return VLOAM_ERR_INVALID;
               return copy_out(SEL(h, h->lo_cyc[outer]), sizeof(long long) * 4 * kMaxLoFactors, buf, cap, n);

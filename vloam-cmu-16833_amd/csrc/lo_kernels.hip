@@ -426,7 +426,7 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
     if (blockIdx.x == 0 && threadIdx.x == 0) queue_n[parity ^ 1] = 0;   // the next launch pair's counter (its last readers finished a launch ago)
     const int qi_ = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (qi_ >= qn) return;
-    slot = queue[qi_];
+    slot = queue[qi_] & 0xffff;
   }
   if (slot >= kMaxLoFactors) return;
   const bool is_corner = slot < kMaxSharp;
@@ -686,9 +686,44 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
       cnt[k] = fstart[b + 1] - bs[k];
     }
   }
-  const int inc0 = grp_scan_incl<G>(cnt[0]), tot0 = grp_sum<G>(cnt[0]);
-  const int inc1 = tot0 + grp_scan_incl<G>(cnt[1]);
-  const int total = tot0 + grp_sum<G>(cnt[1]);
+  int inc0 = grp_scan_incl<G>(cnt[0]), tot0 = grp_sum<G>(cnt[0]);
+  int inc1 = tot0 + grp_scan_incl<G>(cnt[1]);
+  int total = tot0 + grp_sum<G>(cnt[1]);
+  // A block too full for the group's LDS list (> kFastCap points: the rule for plane features on the dense ground near the sensor — 90 % of
+  // what used to be left to the wave-per-query pass) is cut down to the cells that can hold a point within HALF a metre of the query: a
+  // cell at offset o is at least dmin(o) away (the query's position inside its own cell decides), cells with dmin^2 > 0.25 are dropped,
+  // and every result is then only final within that smaller bound — in a neighbourhood this dense it practically always is.
+  const bool crowded = act && total > kFastCap;
+  float bound0 = 1.0f * 0.999999f;   // every point outside the radius-1 block is farther than 1 m
+  if (__ballot(crowded) != 0ull) {
+    const float fx = sel.x - (float)fcx, fy = sel.y - (float)fcy, fz = sel.z - (float)fcz;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int c = gl + 16 * k;
+      const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
+      const float ax = ox < 0 ? fx : (ox > 0 ? 1.0f - fx : 0.f), ay = oy < 0 ? fy : (oy > 0 ? 1.0f - fy : 0.f), az = oz < 0 ? fz : (oz > 0 ? 1.0f - fz : 0.f);
+      if (crowded && (ax * ax + ay * ay) + az * az > 0.25f) cnt[k] = 0;
+    }
+    inc0 = grp_scan_incl<G>(cnt[0]); tot0 = grp_sum<G>(cnt[0]);
+    inc1 = tot0 + grp_scan_incl<G>(cnt[1]);
+    total = tot0 + grp_sum<G>(cnt[1]);
+    if (crowded) bound0 = 0.25f * 0.9999f;
+    // ... and once more at a quarter of a metre where even those cells hold too many
+    const bool crowded2 = crowded && total > kFastCap;
+    if (__ballot(crowded2) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int c = gl + 16 * k;
+        const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
+        const float ax = ox < 0 ? fx : (ox > 0 ? 1.0f - fx : 0.f), ay = oy < 0 ? fy : (oy > 0 ? 1.0f - fy : 0.f), az = oz < 0 ? fz : (oz > 0 ? 1.0f - fz : 0.f);
+        if (crowded2 && (ax * ax + ay * ay) + az * az > 0.0625f) cnt[k] = 0;
+      }
+      inc0 = grp_scan_incl<G>(cnt[0]); tot0 = grp_sum<G>(cnt[0]);
+      inc1 = tot0 + grp_scan_incl<G>(cnt[1]);
+      total = tot0 + grp_sum<G>(cnt[1]);
+      if (crowded2) bound0 = 0.0625f * 0.9999f;
+    }
+  }
   s_inc[qi][gl] = inc0; s_inc[qi][16 + gl] = inc1;                      // inclusive sums in (k, lane) order
   s_rel[qi][gl] = bs[0] - (inc0 - cnt[0]); s_rel[qi][16 + gl] = bs[1] - (inc1 - cnt[1]);   // item i of a cell lives at rel + i
   sw_lds_sync();
@@ -726,7 +761,7 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
     }
   }
   const u64 best = grp_min_u64<G>(loc);
-  constexpr float kBound0 = 1.0f * 0.999999f;   // every point outside the radius-1 block is farther than 1 m
+  const float kBound0 = bound0;
   const bool fastq = kept && best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= kBound0;
   if (fastq && loc == best) s_ring[qi] = ring;   // the index part makes the key unique: one owner
   sw_lds_sync();
@@ -751,17 +786,89 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
       if (ok && to3) l3 = key < l3 ? key : l3;
     }
   }
-  const u64 b2 = grp_min_u64<G>(l2);
-  const u64 b3 = grp_min_u64<G>(l3);
+  u64 b2 = grp_min_u64<G>(l2);
+  u64 b3 = grp_min_u64<G>(l3);
   const bool done2 = b2 != ~0ull && __uint_as_float((unsigned)(b2 >> 32)) <= kBound0;
   const bool done3 = is_corner || (b3 != ~0ull && __uint_as_float((unsigned)(b3 >> 32)) <= kBound0);
-  const bool resolved = !act || (fastq && done2 && done3);
+  // ---- stage 1 of the second / third point plan (k_lo_assoc), also by the group: the closest point is settled (within 1 m) but its partner
+  // on a neighbouring scan line is farther than the radius-1 block reaches — the rule on the ground beyond ~15 m, where the lines lie
+  // metres apart (44 % of all queries of a 64 x 2048 sweep went to the wave-per-query pass for this, at eleven times the instructions).
+  // The 27 cells of the 5 m level hold every point within DISTANCE_SQ_THRESHOLD; restricted to the one or two groups of four scan lines
+  // around the closest point's line they are the search's FINAL stage whenever they hold no more than kSparse2 points (the same rule and
+  // the same bound as stage 1 of k_lo_assoc, so the answers are the same); a denser neighbourhood goes to the queue as before.
+  constexpr int kSparse2 = 1024;
+  const bool need2 = act && fastq && !(done2 && done3);
+  bool final2 = false;
+  if (__ballot(need2) != 0ull) {
+    const int* cstart = is_corner ? Gd.start[2] : Gd.start[3];
+    const float4* cpts = is_corner ? Gd.pts[2] : Gd.pts[3];
+    const unsigned cmask = (unsigned)(is_corner ? Gd.mask[2] : Gd.mask[3]);
+    const int ccx = coarse_cell(sel.x), ccy = coarse_cell(sel.y), ccz = coarse_cell(sel.z);
+    const int glo = max(ringA - 2, 0) >> kRingGroupShift, ghi = min(ringA + 2, kMaxRings - 1) >> kRingGroupShift;
+    const int ng = ghi - glo + 1;
+    int bs2[2] = {0, 0}, cn2[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int c = gl + 16 * k;
+      if (need2 && c < 27) {
+        const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
+        const unsigned b = coarse_slot(ccx + ox, ccy + oy, ccz + oz, cmask) + (unsigned)glo;
+        bs2[k] = cstart[b];
+        cn2[k] = cstart[b + ng] - bs2[k];
+      }
+    }
+    const int i0 = grp_scan_incl<G>(cn2[0]), t0 = grp_sum<G>(cn2[0]);
+    const int i1 = t0 + grp_scan_incl<G>(cn2[1]);
+    const int total2 = t0 + grp_sum<G>(cn2[1]);
+    sw_lds_sync();   // (the radius-1 block's prefix sums are no longer read)
+    s_inc[qi][gl] = i0; s_inc[qi][16 + gl] = i1;
+    s_rel[qi][gl] = bs2[0] - (i0 - cn2[0]); s_rel[qi][16 + gl] = bs2[1] - (i1 - cn2[1]);
+    sw_lds_sync();
+    final2 = need2 && total2 <= kSparse2;
+    u64 m2 = ~0ull, m3 = ~0ull;
+    constexpr int CHK2 = 8;   // (up to 64 candidates per lane here: eight loads in flight per trip)
+    for (int u0 = 0; __ballot(final2 && u0 * G < total2) != 0ull; u0 += CHK2) {
+      int addr[CHK2];
+      float4 c4[CHK2];
+#pragma unroll
+      for (int u = 0; u < CHK2; u++) {
+        const int item = (u0 + u) * G + gl;
+        addr[u] = -1;
+        if (final2 && item < total2) {
+          int pos = 0;
+#pragma unroll
+          for (int step = 16; step > 0; step >>= 1) if (s_inc[qi][pos + step - 1] <= item) pos += step;
+          addr[u] = s_rel[qi][pos & 31] + item;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CHK2; u++) c4[u] = cpts[addr[u] >= 0 ? addr[u] : 0];
+#pragma unroll
+      for (int u = 0; u < CHK2; u++) {
+        if (addr[u] >= 0) {
+          const float d = sqdist(c4[u], sel);
+          const unsigned tag = __float_as_uint(c4[u].w);
+          const int j = tag_index(tag), rj = tag_ring(tag);
+          const bool fwd = j > idx;
+          const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
+          const bool ok = d < 25.0f && j != idx && j < stop_f && j > stop_b;
+          const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : (fwd ? rj <= ringA : rj >= ringA);
+          const bool to3 = !is_corner && !to2;
+          if (ok && to2) m2 = key < m2 ? key : m2;
+          if (ok && to3) m3 = key < m3 ? key : m3;
+        }
+      }
+    }
+    const u64 g2 = grp_min_u64<G>(m2), g3 = grp_min_u64<G>(m3);
+    if (final2) { b2 = g2 < b2 ? g2 : b2; b3 = g3 < b3 ? g3 : b3; }
+  }
+  const bool resolved = !act || (fastq && done2 && done3) || final2;
   if (gl == 0) {
     if (!resolved) {
-      queue[atomicAdd(&queue_n[parity], 1)] = slot;   // k_lo_assoc takes it from scratch
+      queue[atomicAdd(&queue_n[parity], 1)] = slot | ((!kept ? 1 : (!fastq ? 2 : 3)) << 16);   // k_lo_assoc takes it from scratch (bits 16+: why — a diagnostic, vloam_debug_get(1, 6))
     } else {
       int type = 0, ia = -1, ib = -1, ic = -1;
-      if (act) {
+      if (act && (is_corner ? b2 != ~0ull : (b2 != ~0ull && b3 != ~0ull))) {   // (after the final stage a partner may simply not exist: no factor, LO:326 / LO:419)
         auto decode = [&](u64 k) {
           const unsigned o = (unsigned)(k & 0xffffffffu);
           return o >= kBack ? idx - (int)(o - kBack) : idx + (int)o;
