@@ -122,37 +122,46 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 // 256-lane workgroups: small enough to slip onto CUs whose register file is mostly taken by the previous sweep's odometry
 // kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
 constexpr int kFLThreads = 256;
-constexpr int kFLPoints = 1024;   // points per slice: four per lane — a wavefront that looks at 64 points lives as long as one that looks at 256 (one
-                                  // memory round trip), and on a chip full of sessions it is wave-microseconds, not launches, that are short
+constexpr int kFLPoints = 4096;   // points a workgroup looks at per trip (sixteen loads in flight per lane: a cloud that opens with a few thousand dropped returns is still one trip)
+// Two workgroups per session: workgroup 0 walks the cloud from the front until it meets a surviving point, workgroup 1 from the back.  On a
+// real sweep that is one trip each (32 KB of the 2 MB cloud: rounds 1 - 4 read all of it for these two indices); a cloud that opens or
+// closes with a long stretch of dropped returns just takes more trips.  slice[0] = (first, -1), slice[1] = (INT_MAX, last).
 __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float thres, int2* __restrict__ slice, size_t ss) {
   VL_SESSION(ss); RB(slice);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
   __shared__ int s_first, s_last;
   const int tid = threadIdx.x, lane = tid & 63;
+  const bool back = blockIdx.x != 0;
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
-  float4 p[kFLPoints / kFLThreads];
+  const int ntrip = (n + kFLPoints - 1) / kFLPoints;
+  for (int trip = 0; trip < ntrip; trip++) {
+    const int t0 = (back ? ntrip - 1 - trip : trip) * kFLPoints;
+    float4 p[kFLPoints / kFLThreads];
 #pragma unroll
-  for (int e = 0; e < kFLPoints / kFLThreads; e++) {
-    const int i = blockIdx.x * kFLPoints + e * kFLThreads + tid;
-    p[e] = i < n ? in[i] : make_float4(NAN, NAN, NAN, 0.f);
-  }
-  int first = INT_MAX, last = -1;
-#pragma unroll
-  for (int e = 0; e < kFLPoints / kFLThreads; e++) {
-    const int i = blockIdx.x * kFLPoints + e * kFLThreads + tid;
-    const bool v = i < n && sr_survives_s1(p[e].x, p[e].y, p[e].z, thres);
-    const unsigned long long m = __ballot(v);
-    if (m != 0ull) {
-      const int base = i - lane;
-      first = min(first, base + __ffsll((long long)m) - 1);
-      last = max(last, base + 63 - __clzll((long long)m));
+    for (int e = 0; e < kFLPoints / kFLThreads; e++) {
+      const int i = t0 + e * kFLThreads + tid;
+      p[e] = i < n ? in[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
+    int first = INT_MAX, last = -1;
+#pragma unroll
+    for (int e = 0; e < kFLPoints / kFLThreads; e++) {
+      const int i = t0 + e * kFLThreads + tid;
+      const bool v = i < n && sr_survives_s1(p[e].x, p[e].y, p[e].z, thres);
+      const unsigned long long m = __ballot(v);
+      if (m != 0ull) {
+        const int base = i - lane;
+        first = min(first, base + __ffsll((long long)m) - 1);
+        last = max(last, base + 63 - __clzll((long long)m));
+      }
+    }
+    if (lane == 0 && last >= 0) { atomicMin(&s_first, first); atomicMax(&s_last, last); }
+    __syncthreads();
+    if (s_last >= 0) break;   // (uniform: read behind the barrier)
+    __syncthreads();
   }
-  if (lane == 0 && last >= 0) { atomicMin(&s_first, first); atomicMax(&s_last, last); }
-  __syncthreads();
-  if (tid == 0) slice[blockIdx.x] = make_int2(s_first, s_last);
+  if (tid == 0) slice[blockIdx.x] = back ? make_int2(INT_MAX, s_last) : make_int2(s_first, -1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1123,7 +1132,7 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  const int nslice = (n + kFLPoints - 1) / kFLPoints;
+  const int nslice = 2;   // (first, last) from the two ends
   int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
   int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
   VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice, 1, Z), dim3(kFLThreads), 0, st, bi, min_range, slice, se.ss);
