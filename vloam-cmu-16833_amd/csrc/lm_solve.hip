@@ -1114,8 +1114,11 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
   return R;
 }
 
+#ifndef VLOAM_LM_WPE
+#define VLOAM_LM_WPE 1   // wavefronts per SIMD the solve is compiled for (1: the whole register file; A/B builds: 2)
+#endif
 template <bool QUAT, int MODE, int NB>
-__global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
+__global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(VLOAM_LM_WPE, VLOAM_LM_WPE))) void k_lm_solve(FactorTable F, int edge_rows, double* x_io, LMRecord* rec, int max_iters,
                                                          double huber_a, const int* enable_flag, LOState* fin_lo, double* fin_traj, size_t ss) {
   VL_SESSION(ss); F.rebase(so_); RB(x_io); RB(rec); RB(enable_flag); RB(fin_lo); RB(fin_traj);
   if (NB > 1 && lm_coop_block<NB, MODE>() < 0) return;   // single sequence: only the workgroups of the solve's XCD work (lm_coop_block)
@@ -1176,6 +1179,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(1, 1
     rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
     rec->cyc[1] = (double)cyc_eval; rec->cyc[2] = (double)cyc_serial;
     rec->cyc[3] = (double)(clock64() - t_start);
+    rec->trace[kLmMaxTrace - 1][0] += rec->cyc[3]; rec->trace[kLmMaxTrace - 1][1] += 1.0;   // running sum / count over the handle's life (row 103 is never a real iteration: tools read the average in-kernel time of a solve under load from it)
 #ifdef VLOAM_LM_STAMPS
     for (int k = 0; k < 8; k++) rec->trace[100][k] = (double)lm_sum[k];
 #endif

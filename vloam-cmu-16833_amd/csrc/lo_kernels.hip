@@ -650,7 +650,6 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
   static_assert(kMaxSharp % (8 * QW) == 0 && kMaxFlat % (8 * QW) == 0, "bijective remap");
   __shared__ int s_stops[2 * kStopLen];
   __shared__ int s_inc[QW][32], s_rel[QW][32];
-  __shared__ u64 s_item[QW][kFastCap];
   __shared__ int s_ring[QW];
   const int tid = threadIdx.x, lane = tid & 63, gl = lane & (G - 1), qi = (tid >> 6) * Q + lane / G;
   const int bq = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
@@ -752,7 +751,6 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
       if (addr[u] >= 0) {
         const float d = sqdist(c4[u], sel);
         const unsigned tag = __float_as_uint(c4[u].w);
-        s_item[qi][(u0 + u) * G + gl] = ((u64)__float_as_uint(d) << 32) | tag;
         const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)tag_index(tag);
         const bool better = key < loc;
         loc = better ? key : loc;
@@ -769,21 +767,39 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
   const int idx = (int)(best & 0xffffffffu);
   const int ringA = fastq ? s_ring[qi] : 0;
   const int stop_f = s_stops[ringA + 3], stop_b = s_stops[kStopLen + ringA];
+  // (the candidates are fetched a second time — they sit in this CU's cache — instead of being parked in LDS between the passes: 32 KB of
+  // LDS per workgroup held the kernel at four workgroups per CU, and this kernel's duration is rounds x per-workgroup latency)
   u64 l2 = ~0ull, l3 = ~0ull;
-  for (int u = 0; __ballot(fastq && u * G < total) != 0ull; u++) {
-    const int item = u * G + gl;
-    if (fastq && item < total) {
-      const u64 v = s_item[qi][item];
-      const float d = __uint_as_float((unsigned)(v >> 32));
-      const unsigned tag = (unsigned)v;
-      const int j = tag_index(tag), rj = tag_ring(tag);
-      const bool fwd = j > idx;
-      const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
-      const bool ok = d < 25.0f && j != idx && j < stop_f && j > stop_b;
-      const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : (fwd ? rj <= ringA : rj >= ringA);
-      const bool to3 = !is_corner && !to2;
-      if (ok && to2) l2 = key < l2 ? key : l2;
-      if (ok && to3) l3 = key < l3 ? key : l3;
+  for (int u0 = 0; __ballot(fastq && u0 * G < total) != 0ull; u0 += CHK) {
+    int addr[CHK];
+    float4 c4[CHK];
+#pragma unroll
+    for (int u = 0; u < CHK; u++) {
+      const int item = (u0 + u) * G + gl;
+      addr[u] = -1;
+      if (fastq && item < total) {
+        int pos = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) if (s_inc[qi][pos + step - 1] <= item) pos += step;
+        addr[u] = s_rel[qi][pos & 31] + item;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CHK; u++) c4[u] = fpts[addr[u] >= 0 ? addr[u] : 0];
+#pragma unroll
+    for (int u = 0; u < CHK; u++) {
+      if (addr[u] >= 0) {
+        const float d = sqdist(c4[u], sel);
+        const unsigned tag = __float_as_uint(c4[u].w);
+        const int j = tag_index(tag), rj = tag_ring(tag);
+        const bool fwd = j > idx;
+        const u64 key = ((u64)__float_as_uint(d) << 32) | (fwd ? (unsigned)(j - idx) : 0x40000000u + (unsigned)(idx - j));
+        const bool ok = d < 25.0f && j != idx && j < stop_f && j > stop_b;
+        const bool to2 = is_corner ? (fwd ? rj > ringA : rj < ringA) : (fwd ? rj <= ringA : rj >= ringA);
+        const bool to3 = !is_corner && !to2;
+        if (ok && to2) l2 = key < l2 ? key : l2;
+        if (ok && to3) l3 = key < l3 ? key : l3;
+      }
     }
   }
   u64 b2 = grp_min_u64<G>(l2);
