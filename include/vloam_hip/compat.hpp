@@ -24,6 +24,7 @@
 #pragma once
 #include <array>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -91,11 +92,15 @@ class Session {  // one vloam_handle == one sequence on one GPU; shared by the t
   vloam_handle* get() const { return h_; }
   // The session behind DEFAULT-CONSTRUCTED stage objects (the reference's classes are default-constructible, laser_odometry.h:66-68, and
   // its façade holds them as plain members): created with the launch-file defaults on device 0 the first time one is needed; bind another
-  // one (other device / config) with set_default() before the stage objects are constructed, and release it with set_default(nullptr)
-  // before main() returns (the HIP runtime's own static destructors may otherwise run first).
-  static std::shared_ptr<Session>& default_slot() { static std::shared_ptr<Session> s; return s; }
-  static void set_default(std::shared_ptr<Session> s) { default_slot() = std::move(s); }
+  // one (other device / config) with set_default() before the stage objects are constructed.  The slot itself is never destroyed (a
+  // heap object that outlives static destruction): a process that forgets set_default(nullptr) leaves the handle to the operating system
+  // instead of calling vloam_destroy after the HIP runtime's own static destructors have run; release it with set_default(nullptr) for a
+  // clean shutdown.  Access is serialised (several threads may default-construct stage objects at once).
+  static std::shared_ptr<Session>& default_slot() { static std::shared_ptr<Session>* s = new std::shared_ptr<Session>(); return *s; }
+  static std::mutex& default_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+  static void set_default(std::shared_ptr<Session> s) { std::lock_guard<std::mutex> g(default_mutex()); default_slot() = std::move(s); }
   static std::shared_ptr<Session> get_default() {
+    std::lock_guard<std::mutex> g(default_mutex());
     auto& s = default_slot();
     if (!s) s = std::make_shared<Session>();
     return s;

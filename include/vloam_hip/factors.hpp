@@ -11,16 +11,22 @@
 // s == 1 (DISTORTION == false, laser_odometry.h:90), where the slerp returns q itself.
 // The static Create(...) factories (lidarFactor.hpp:47-52, 95-101, 129-134; ceres_cost_function.h:87-92, 176-181) return
 // ceres::CostFunction*, i.e. need Ceres: they are compiled with -DVLOAM_HIP_WITH_CERES (which includes <ceres/ceres.h>) and are UNTESTED
-// here — Ceres is absent from this image.  Points are passed as const double[3] instead of Eigen::Vector3d (v.data() at the call site).
+// here — Ceres is absent from this image.  Points are taken as const double[3] OR as any vector class with operator[] — an
+// Eigen::Vector3d as the reference's call sites pass (laser_odometry.cpp:337-347, laser_mapping.cpp:507-510): `Vec3Like` overloads,
+// no Eigen include needed (tests/test_cpp_headers.py drives them with a stand-in).
 #pragma once
 #include <cmath>
 #include <limits>
+#include <type_traits>
 #ifdef VLOAM_HIP_WITH_CERES
 #include <ceres/ceres.h>
 #endif
 
 namespace vloam {
 namespace factors {
+
+// "anything indexable that is a class": Eigen::Vector3d, std::array<double, 3>, ... (plain arrays / pointers take the const double[3] overloads)
+template <class V> using Vec3Like = typename std::enable_if<std::is_class<V>::value && std::is_convertible<decltype(std::declval<const V&>()[0]), double>::value, int>::type;
 
 template <class T> struct V3 { T x, y, z; };
 template <class T> inline V3<T> sub(const V3<T>& a, const V3<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -55,6 +61,8 @@ template <class T> inline void slerp_from_identity(const T& s, const T* q, T* ou
 
 struct LidarEdgeFactor {
   LidarEdgeFactor(const double c[3], const double a[3], const double b[3], double s_) : s(s_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; lpa[i] = a[i]; lpb[i] = b[i]; } }
+  template <class V, Vec3Like<V> = 0>   // LidarEdgeFactor(Eigen::Vector3d curr_point_, Eigen::Vector3d last_point_a_, Eigen::Vector3d last_point_b_, double s_), lidarFactor.hpp:16-19
+  LidarEdgeFactor(const V& c, const V& a, const V& b, double s_) : s(s_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; lpa[i] = a[i]; lpb[i] = b[i]; } }
   template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
     using std::sqrt;
     V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, a{T(lpa[0]), T(lpa[1]), T(lpa[2])}, b{T(lpb[0]), T(lpb[1]), T(lpb[2])};
@@ -70,6 +78,10 @@ struct LidarEdgeFactor {
   }
 #ifdef VLOAM_HIP_WITH_CERES
   // lidarFactor.hpp:47-52
+  template <class V, Vec3Like<V> = 0>
+  static ceres::CostFunction* Create(const V& curr_point_, const V& last_point_a_, const V& last_point_b_, const double s_) {   // lidarFactor.hpp:47-52
+    return (new ceres::AutoDiffCostFunction<LidarEdgeFactor, 3, 4, 3>(new LidarEdgeFactor(curr_point_, last_point_a_, last_point_b_, s_)));
+  }
   static ceres::CostFunction* Create(const double* curr_point_, const double* last_point_a_, const double* last_point_b_, const double s_) {
     return (new ceres::AutoDiffCostFunction<LidarEdgeFactor, 3, 4, 3>(new LidarEdgeFactor(curr_point_, last_point_a_, last_point_b_, s_)));
   }
@@ -85,6 +97,11 @@ struct LidarPlaneFactor {
     double nn = std::sqrt(dot(n, n));
     ljm[0] = n.x / nn; ljm[1] = n.y / nn; ljm[2] = n.z / nn;
   }
+  template <class V, Vec3Like<V> = 0>   // LidarPlaneFactor(Eigen::Vector3d curr_point_, last_point_j_, last_point_l_, last_point_m_, double s_), lidarFactor.hpp:60-70
+  LidarPlaneFactor(const V& c, const V& j, const V& l, const V& m, double s_) : s(s_) {
+    const double cc[3] = {c[0], c[1], c[2]}, jj[3] = {j[0], j[1], j[2]}, ll[3] = {l[0], l[1], l[2]}, mm[3] = {m[0], m[1], m[2]};
+    *this = LidarPlaneFactor(cc, jj, ll, mm, s_);
+  }
   template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
     V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, j{T(lpj[0]), T(lpj[1]), T(lpj[2])}, n{T(ljm[0]), T(ljm[1]), T(ljm[2])};
     T qs[4];
@@ -96,6 +113,10 @@ struct LidarPlaneFactor {
   }
 #ifdef VLOAM_HIP_WITH_CERES
   // lidarFactor.hpp:95-101
+  template <class V, Vec3Like<V> = 0>
+  static ceres::CostFunction* Create(const V& curr_point_, const V& last_point_j_, const V& last_point_l_, const V& last_point_m_, const double s_) {
+    return (new ceres::AutoDiffCostFunction<LidarPlaneFactor, 1, 4, 3>(new LidarPlaneFactor(curr_point_, last_point_j_, last_point_l_, last_point_m_, s_)));
+  }
   static ceres::CostFunction* Create(const double* curr_point_, const double* last_point_j_, const double* last_point_l_, const double* last_point_m_, const double s_) {
     return (new ceres::AutoDiffCostFunction<LidarPlaneFactor, 1, 4, 3>(new LidarPlaneFactor(curr_point_, last_point_j_, last_point_l_, last_point_m_, s_)));
   }
@@ -105,6 +126,8 @@ struct LidarPlaneFactor {
 
 struct LidarPlaneNormFactor {
   LidarPlaneNormFactor(const double c[3], const double n[3], double d_) : d(d_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; nrm[i] = n[i]; } }
+  template <class V, Vec3Like<V> = 0>   // LidarPlaneNormFactor(Eigen::Vector3d curr_point_, Eigen::Vector3d plane_unit_norm_, double negative_OA_dot_norm_), lidarFactor.hpp:110-113
+  LidarPlaneNormFactor(const V& c, const V& n, double d_) : d(d_) { for (int i = 0; i < 3; i++) { cp[i] = c[i]; nrm[i] = n[i]; } }
   template <typename T> bool operator()(const T* q, const T* t, T* residual) const {
     V3<T> p{T(cp[0]), T(cp[1]), T(cp[2])}, n{T(nrm[0]), T(nrm[1]), T(nrm[2])};
     V3<T> r = rotate(q, p);
@@ -114,6 +137,10 @@ struct LidarPlaneNormFactor {
   }
 #ifdef VLOAM_HIP_WITH_CERES
   // lidarFactor.hpp:129-134
+  template <class V, Vec3Like<V> = 0>
+  static ceres::CostFunction* Create(const V& curr_point_, const V& plane_unit_norm_, const double negative_OA_dot_norm_) {
+    return (new ceres::AutoDiffCostFunction<LidarPlaneNormFactor, 1, 4, 3>(new LidarPlaneNormFactor(curr_point_, plane_unit_norm_, negative_OA_dot_norm_)));
+  }
   static ceres::CostFunction* Create(const double* curr_point_, const double* plane_unit_norm_, const double negative_OA_dot_norm_) {
     return (new ceres::AutoDiffCostFunction<LidarPlaneNormFactor, 1, 4, 3>(new LidarPlaneNormFactor(curr_point_, plane_unit_norm_, negative_OA_dot_norm_)));
   }

@@ -26,6 +26,12 @@ int main() {
   vloam::factors::LidarPlaneFactor p2(c, a, b, m, 0.4); p2(q, t, r); std::printf("%.17g\n", r[0]);
   double qn[4] = {-0.3, 0.2, -0.1, -0.9273618495495703};   // w < 0: the sign branch of Eigen's slerp
   vloam::factors::LidarEdgeFactor e3(c, a, b, 0.7); e3(qn, t, r); std::printf("%.17g %.17g %.17g\n", r[0], r[1], r[2]);
+  // the reference's call sites pass Eigen::Vector3d (lidarFactor.hpp:16-19,60-63,110-113): any class with operator[] is taken (no Eigen here: a stand-in)
+  struct Vec3d { double v[3]; double operator[](int i) const { return v[i]; } };
+  const Vec3d vc{{1.5, -2.0, 0.7}}, va{{1.0, 0.5, 0.2}}, vb{{1.2, 0.1, 1.4}}, vm{{-0.4, 2.0, 0.3}}, vn{{0.0, 0.6, 0.8}};
+  vloam::factors::LidarEdgeFactor ev(vc, va, vb, 1.0); ev(q, t, r); std::printf("%.17g %.17g %.17g\n", r[0], r[1], r[2]);
+  vloam::factors::LidarPlaneFactor pv(vc, va, vb, vm, 1.0); pv(q, t, r); std::printf("%.17g\n", r[0]);
+  vloam::factors::LidarPlaneNormFactor pnv(vc, vn, 0.25); pnv(q, t, r); std::printf("%.17g\n", r[0]);
   return 0;
 }
 '''
@@ -56,6 +62,8 @@ def test_headers_compile_and_functors_match_oracle(tmp_path, orc, vl):
     e3 = np.array([float(x) for x in out[6].split()])
     r5, _ = orc.eval_lidar_factor(0, curr, a + b, [-0.3, 0.2, -0.1, -0.9273618495495703], t, s=0.7)
     assert np.allclose(e3, r5, rtol=1e-13, atol=1e-14)
+    # vector-class overloads == the array overloads
+    assert out[7] == out[0] and out[8] == out[1] and out[9] == out[2]
     # c_api.h is plain C
     csrc = tmp_path / "c.c"
     csrc.write_text('#include "vloam_hip/c_api.h"\nint main(void) { vloam_config c; vloam_default_config(&c); return c.scan_line != 64; }\n')
