@@ -50,9 +50,10 @@ def _w(job):
 
 jobs = [(s, k) for s in range(n_seq) for k in range(a.sweeps)]
 t0 = time.perf_counter()
-if a.cache and os.path.exists(a.cache) and np.load(a.cache, mmap_mode="r").shape[:2] == (n_seq, a.sweeps):
+_c = np.load(a.cache, mmap_mode="r") if (a.cache and os.path.exists(a.cache)) else None
+if _c is not None and _c.shape[0] >= n_seq and _c.shape[1] == a.sweeps:
     flat = None
-    host = np.load(a.cache)
+    host = np.ascontiguousarray(_c[:n_seq])
 elif a.procs > 1:
     with mp.get_context("fork").Pool(min(a.procs, os.cpu_count() or 1)) as pool:   # before the HIP runtime loads
         flat = pool.map(_w, jobs, chunksize=2)

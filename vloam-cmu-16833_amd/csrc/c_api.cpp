@@ -615,7 +615,9 @@ static vloam_status finish_frame(vloam_handle* h) {
 // call's readers — scan registration, the VO depth map — are enqueued on the scan-registration stream) marks the slot reusable.
 // Pageable source memory: hipMemcpyAsync has taken its copy when it returns (the caller may reuse the buffer at once).  Pinned source
 // memory (hipHostMalloc / hipHostRegister) is read by DMA later: it must stay unchanged until the next vloam_sync() (c_api.h).
+static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 0;   // A/B: 1 = copy on the scan-registration stream itself (one buffer, no events)
 static vloam_status stage_begin(vloam_handle* h) {
+  if (g_stage_inline) { h->in_slot = 0; return VLOAM_OK; }
   if (!h->s_copy) {
     HIPCHK(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
     for (int k = 0; k < vloam_handle::kInRing; k++) {
@@ -630,11 +632,12 @@ static vloam_status stage_begin(vloam_handle* h) {
 }
 static vloam_status stage_sweep(vloam_handle* h, int b, const float* xyz_pad4, int n, const float4** d_out) {
   float4* dst = (float4*)((char*)(h->d_in + (size_t)h->in_slot * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
-  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->s_copy));
+  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, g_stage_inline ? h->stream : h->s_copy));
   *d_out = dst;
   return VLOAM_OK;
 }
 static vloam_status stage_end(vloam_handle* h) {
+  if (g_stage_inline) return VLOAM_OK;
   HIPCHK(hipEventRecord(h->ev_in_copied[h->in_slot], h->s_copy));
   HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in_copied[h->in_slot], 0));
   return VLOAM_OK;
@@ -643,6 +646,7 @@ static vloam_status stage_release(vloam_handle* h, vloam_status call_status, hip
   // last_reader: an event the call already recorded behind the slot's last reader (a whole-sweep call: the sweep's ev_sr / ev_vo — with
   // kInRing < kSets it still belongs to that sweep when the slot comes round again); otherwise a marker on the scan-registration stream
   // (also after a refused call: the wait on ev_in_copied was enqueued there, the record behind it is harmless)
+  if (g_stage_inline) { h->in_slot = -1; return call_status; }
   if (h->in_slot >= 0) {
     if (last_reader && call_status == VLOAM_OK) h->in_reader[h->in_slot] = last_reader;
     else { HIPCHK(hipEventRecord(h->ev_in_free[h->in_slot], h->stream)); h->in_reader[h->in_slot] = h->ev_in_free[h->in_slot]; }

@@ -311,8 +311,10 @@ __global__ __launch_bounds__(256) void k_map_ds_bin(const float4* __restrict__ c
                                                     float4* __restrict__ stack0, float4* __restrict__ stack1, StackInfo* fr, size_t ss) {
   VL_SESSION(ss); RB(corner_last); RB(surf_last); RB(S); D0.rebase(so_); D1.rebase(so_); RB(stack0); RB(stack1); RB(fr);
   __shared__ __attribute__((aligned(16))) u64 s_key[2048];
+  __shared__ __attribute__((aligned(16))) u64 s_srt[512];
   __shared__ u64 s_split[kDsMaxBins];
-  const int kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  __shared__ int s_cnt[kDsMaxBins], s_base[kDsMaxBins];
+  const int kind = blockIdx.y, tid = threadIdx.x;
   const DsScratch D = kind ? D1 : D0;
   const float inv = kind ? inv1 : inv0;
   const float4* pts = kind ? surf_last : corner_last;
@@ -334,37 +336,65 @@ __global__ __launch_bounds__(256) void k_map_ds_bin(const float4* __restrict__ c
     const int Sn = ds_num_samples(P);
     for (int j = tid; j < Sn; j += 256) s_key[j] = ds_cell(pts[(int)(((long long)j * n) / Sn)], inv, g);
     __syncthreads();
-    block_bitonic_sort_u64(s_key, Sn, tid, 256);
+    const u64* srt = s_key;
+    if (Sn <= 512) {
+      // few samples: rank by counting (every lane reads every key once, broadcast LDS reads, no dependent exchange stages — a bitonic
+      // network over 512 keys is ~45 dependent stages; this is the prologue of EVERY workgroup of the pass)
+      for (int j = tid; j < Sn; j += 256) {
+        const u64 mine = s_key[j];
+        int rank = 0;
+#pragma unroll 8
+        for (int e = 0; e < Sn; e += 2) {   // (unrolled: eight LDS reads in flight, or every iteration waits out the LDS latency)
+          const ulonglong2 k2 = *(const ulonglong2*)&s_key[e];
+          rank += (k2.x < mine || (k2.x == mine && e < j)) ? 1 : 0;
+          rank += (k2.y < mine || (k2.y == mine && e + 1 < j)) ? 1 : 0;
+        }
+        s_srt[rank] = mine;
+      }
+      __syncthreads();
+      srt = s_srt;
+    } else {
+      block_bitonic_sort_u64(s_key, Sn, tid, 256);
+    }
     for (int j = tid; j < P - 1; j += 256) {
-      const u64 sp = s_key[(int)(((long long)(j + 1) * Sn) / P)];
+      const u64 sp = srt[(int)(((long long)(j + 1) * Sn) / P)];
       s_split[j] = sp;
       if (blockIdx.x == 0) D.splitters[j] = sp;   // the reduce pass's slow path tells the bins of the overflow list by them
     }
     __syncthreads();
   }
   for (int t0 = blockIdx.x * kDsTile; t0 < n; t0 += gridDim.x * kDsTile) {
-    for (int e = 0; e < kDsTile / 256; e++) {
-      const int i = t0 + ((tid >> 6) * (kDsTile / 256) + e) * 64 + lane;   // a wavefront takes 64 CONSECUTIVE points: neighbours in the cloud mostly share a bin
-      const bool act = i < n;
-      u64 cell = 0ull;
-      int bin = -1;
-      if (act) { cell = ds_cell(pts[i], inv, g); bin = P > 1 ? ds_bin_of(s_split, P, cell) : 0; }
-      // one cursor update per distinct bin of the wavefront
-      u64 todo = __ballot(act);
-      int pos = 0;
-      while (todo != 0ull) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader);
-        const u64 mine = __ballot(act && bin == b);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&D.cursor[b], __popcll(mine));
-        base = __shfl(base, leader);
-        if (act && bin == b) pos = base + __popcll(mine & ((1ull << lane) - 1ull));
-        todo &= ~mine;
+    // the tile's points are counted per bin in LDS first: ONE device-scope cursor update per (workgroup, bin) and one memory round trip for
+    // all of them, instead of a dependent atomic round trip per 64 points
+    constexpr int kPer = kDsTile / 256;
+    __syncthreads();
+    for (int b = tid; b < P; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    float4 p[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; e++) { const int i = t0 + e * 256 + tid; p[e] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    u64 cell[kPer];
+    int bin[kPer], pos[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+      const int i = t0 + e * 256 + tid;
+      bin[e] = -1; pos[e] = 0; cell[e] = 0ull;
+      if (i < n) {
+        cell[e] = ds_cell(p[e], inv, g);
+        bin[e] = P > 1 ? ds_bin_of(s_split, P, cell[e]) : 0;
+        pos[e] = atomicAdd(&s_cnt[bin[e]], 1);
       }
-      if (act) {
-        const u64 key = (cell << kDsIdxBits) | (u64)(unsigned)i;
-        if (pos < kDsBinCap) D.region[(size_t)bin * kDsBinCap + pos] = key;
+    }
+    __syncthreads();
+    for (int b = tid; b < P; b += 256) { const int c = s_cnt[b]; s_base[b] = c > 0 ? atomicAdd(&D.cursor[b], c) : 0; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+      const int i = t0 + e * 256 + tid;
+      if (i < n) {
+        const u64 key = (cell[e] << kDsIdxBits) | (u64)(unsigned)i;
+        const int at = s_base[bin[e]] + pos[e];
+        if (at < kDsBinCap) D.region[(size_t)bin[e] * kDsBinCap + at] = key;
         else { const int o = atomicAdd(&D.cursor[kDsMaxBins], 1); D.over[o] = key; }   // (o < n <= max_points: every point is written exactly once)
       }
     }
