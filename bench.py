@@ -27,7 +27,7 @@ import sys
 import time
 
 # the three stage streams of a handle (+ torch's) should not share hardware queues; must be set before the HIP runtime loads
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--map-capacity-log2", type=int, default=0, help="voxel-hash slots per feature kind = 2^n (0: the library's default, 22); A/B runs of the table footprint")
     ap.add_argument("--sustain-seconds", type=float, default=float(os.environ.get("VLOAM_BENCH_SUSTAIN_S", "6")),
                     help="extra leg: stream the headline workload for about this long (sweeps replayed back and forth; 0 = skip)")
+    ap.add_argument("--no-host-input", action="store_true", help="skip the host-input leg (vloam_process_scan from pinned / pageable memory)")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes for the synthetic ray casting (0 = min(cores, 16))")
     args = ap.parse_args()
 
@@ -473,7 +474,7 @@ def main():
     # vloam_main_node.cpp:125-180): vloam_process_scan from (i) pinned and (ii) pageable host memory, a distinct buffer per sweep, next to
     # the same sweeps handed over as device pointers.  The library stages host sweeps through a ring of device buffers on a copy stream.
     host_input = None
-    if extras:
+    if extras and not args.no_host_input:
         n_h = int(min(max(K, 400), 1200))
         order_h, pos, step = [], M0 + W - 1, 1
         for _ in range(n_h):

@@ -8,7 +8,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ["VLOAM_TS_LOG"] = "1"
 import numpy as np
 

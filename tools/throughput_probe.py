@@ -9,7 +9,7 @@ import sys
 import time
 
 # the stage streams of a handle (+ torch's) must not share hardware queues (the runtime's default is 4); before the HIP runtime loads
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

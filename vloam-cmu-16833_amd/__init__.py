@@ -9,7 +9,7 @@ There is no CPU path in this package: importing it requires the built shared lib
 handle requires a HIP device.  (The CPU oracle lives in ``oracle/`` and is test infrastructure only.)
 """
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the stage streams of a handle must not share hardware queues (before the HIP runtime loads)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the stage streams of a handle must not share hardware queues — with each other or with the host's own streams (before the HIP runtime loads)
 import ctypes as C
 import os
 import numpy as np

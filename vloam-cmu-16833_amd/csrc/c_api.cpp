@@ -262,19 +262,21 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       ((cfg->image_width > 0) != (cfg->image_height > 0)) || (cfg->image_width > 0 && (cfg->image_width < 2 * kImgWin || cfg->image_height < 2 * kImgWin))) {
     set_err("image_width x image_height must be 0 x 0 (no image front-end) or between %d x %d and 2^24 pixels", 2 * kImgWin, 2 * kImgWin); return VLOAM_ERR_INVALID;
   }
-  // A handle drives four or five HIP streams that must run side by side (scan registration | scan-feature VoxelGrid | odometry | mapping
-  // [| images]); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two stages sharing a queue serialise —
-  // measured: 214 us per sweep instead of 164.  The variable is read when the HIP runtime initialises, so it belongs to the HOST's
-  // environment (the Python package and bench.py export it before they load the runtime): a library must not setenv()
-  // behind a multi-threaded host's back (not thread-safe against a concurrent getenv, and silently without effect once HIP is up).
+  // A handle drives four to six HIP streams that must run side by side (scan registration | scan-feature VoxelGrid | odometry | mapping
+  // [| images] [| host-input copies]); the runtime maps ALL streams of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two
+  // stages sharing a queue serialise — measured: 214 us per sweep instead of 164 with 4 queues; with 8 queues the same happens as soon as
+  // the host process keeps four streams of its own alive (6 400 -> 4 700 scans/s, 3 800 with five; 16 queues: 6 300 with any number,
+  // profiles/r05_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it belongs to the HOST's environment
+  // (the Python package and bench.py export 16 before they load the runtime): a library must not setenv() behind a
+  // multi-threaded host's back (not thread-safe against a concurrent getenv, and silently without effect once HIP is up).
   // Said once per process instead.
   {
     static bool warned = false;
     const char* q = getenv("GPU_MAX_HW_QUEUES");
-    if (!warned && (!q || atoi(q) < 5)) {
+    if (!warned && (!q || atoi(q) < 8)) {
       warned = true;
       fprintf(stderr, "libvloam_hip: GPU_MAX_HW_QUEUES is %s: the stage streams of a handle will share hardware queues and a sweep takes ~30 %% longer; "
-                      "export GPU_MAX_HW_QUEUES=8 before the process initialises HIP\n", q ? q : "unset (runtime default 4)");
+                      "export GPU_MAX_HW_QUEUES=16 before the process initialises HIP\n", q ? q : "unset (runtime default 4)");
     }
   }
   int ndev = 0;
@@ -302,8 +304,8 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
     {
       // VLOAM_STREAM_PRIO = "sr,lo,map,ds" (0 = default priority, 1 = the device's highest, -1 = its lowest): which stage's workgroups the
       // dispatcher places first when several stages have work pending (batched handles fill the chip; a single sequence does not)
-      int lo_p = 0, hi_p = 0, pr[4] = {0, 0, 0, 0};
-      if (const char* e = getenv("VLOAM_STREAM_PRIO")) sscanf(e, "%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3]);
+      int lo_p = 0, hi_p = 0, pr[5] = {0, 0, 0, 0, 0};   // (a fifth field: the image front-end's stream)
+      if (const char* e = getenv("VLOAM_STREAM_PRIO")) sscanf(e, "%d,%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3], &pr[4]);
       if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess) { lo_p = hi_p = 0; }   // lo_p = numerically greatest = lowest priority
       // VLOAM_RESERVE_CUS = "n[,stride]" (experiment): the scan-registration, odometry and VoxelGrid streams are created with a CU mask that
       // leaves n compute units (every stride-th bit from 0) to the mapping stream alone
@@ -322,11 +324,11 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
         const int p = pr[which] > 0 ? hi_p : (pr[which] < 0 ? lo_p : 0);
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess;
       };
-      if (!mk(&h->stream, 0) || !mk(&h->s_lo, 1) || (cfg->with_mapping && (!mk(&h->s_map, 2) || !mk(&h->s_ds, 3)))) {  // no mapping: no further hardware queues
+      if (!mk(&h->stream, 0) || !mk(&h->s_lo, 1) || (cfg->with_mapping && (!mk(&h->s_map, 2) || !mk(&h->s_ds, 3))) ||   // no mapping: no further hardware queues
+          (cfg->image_width > 0 && !mk(&h->s_img, 4))) {
         set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
       }
     }
-    if (cfg->image_width > 0 && hipStreamCreateWithFlags(&h->s_img, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
     if (sr_init() != hipSuccess) { set_err("sr_init failed (no gfx950 code object for this device?)"); st = VLOAM_ERR_HIP; break; }
     if (cfg->image_width > 0 && img_init() != hipSuccess) { set_err("img_init failed"); st = VLOAM_ERR_HIP; break; }
     auto body = [&]() -> vloam_status {

@@ -19,6 +19,7 @@
 #include <math.h>
 #include "sr_kernels.h"
 #include "bitonic.h"
+#include <cstdlib>
 
 namespace vloam {
 
@@ -83,9 +84,15 @@ __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float 
   return true;
 }
 
+// The OCML bodies of atan2f / atanf are inlined per call site, and how their multiplies and adds pair into fused operations depends on the
+// code around the call: the 256-lane and the 1024-lane form of k_sr_label came out one ulp apart in a point's azimuth (a batched session
+// against the same sequence alone).  One out-of-line body each: every caller, every batch size, the same bits.
+__device__ __noinline__ float sr_atan2f(float y, float x) { return atan2f(y, x); }
+__device__ __noinline__ float sr_atanf(float v) { return atanf(v); }
+
 // SR:192-226.  Returns the ring id or -1 when the point is dropped.
 __device__ __forceinline__ int sr_scan_id(float x, float y, float z, int N_SCANS) {
-  float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
+  float angle = (float)((double)(sr_atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
   int scanID = 0;
   if (N_SCANS == 16) {
     scanID = int((double)((angle + 15) / 2) + 0.5);
@@ -123,20 +130,25 @@ __device__ __forceinline__ float sr_ori_second_half(float ori, float endOri) {
 // kernels (the stages of consecutive sweeps overlap), where a 1024-lane workgroup would have to wait for them to drain.
 constexpr int kFLThreads = 256;
 constexpr int kFLPoints = 4096;   // points a workgroup looks at per trip (sixteen loads in flight per lane: a cloud that opens with a few thousand dropped returns is still one trip)
-// Two workgroups per session: workgroup 0 walks the cloud from the front until it meets a surviving point, workgroup 1 from the back.  On a
-// real sweep that is one trip each (32 KB of the 2 MB cloud: rounds 1 - 4 read all of it for these two indices); a cloud that opens or
-// closes with a long stretch of dropped returns just takes more trips.  slice[0] = (first, -1), slice[1] = (INT_MAX, last).
+// 2 x kFLWalkers workgroups per session: kFLWalkers walk the cloud from the front — walker j looks at trips j, j + kFLWalkers, ... and stops at
+// its first trip with a surviving point — and kFLWalkers from the back.  The first surviving point of the cloud is the smallest of the
+// front walkers' answers (every k_sr_label workgroup folds the records), the last one the largest of the back walkers'.  On a real sweep that
+// is one trip each, 32 KB per walker of the 2 MB cloud (rounds 1 - 4 read all of it for these two indices); a ring-major cloud that closes
+// with ten rings of dropped returns (the synthetic one does: five trips, 15.6 us with ONE walker per end) still is one trip deep.
+// slice[j] = (first, -1) for a front walker, (INT_MAX, last) for a back walker.
+constexpr int kFLWalkers = 8;
 __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float thres, int2* __restrict__ slice, size_t ss) {
   VL_SESSION(ss); RB(slice);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
   __shared__ int s_first, s_last;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool back = blockIdx.x != 0;
+  const bool back = blockIdx.x >= kFLWalkers;
+  const int walker = blockIdx.x - (back ? kFLWalkers : 0);
   if (tid == 0) { s_first = INT_MAX; s_last = -1; }
   __syncthreads();
   const int ntrip = (n + kFLPoints - 1) / kFLPoints;
-  for (int trip = 0; trip < ntrip; trip++) {
+  for (int trip = walker; trip < ntrip; trip += kFLWalkers) {
     const int t0 = (back ? ntrip - 1 - trip : trip) * kFLPoints;
     float4 p[kFLPoints / kFLThreads];
 #pragma unroll
@@ -167,13 +179,17 @@ __global__ __launch_bounds__(kFLThreads) void k_sr_first_last(BatchIn bi, float 
 // ------------------------------------------------------------------------------------------------
 // blk: per-workgroup results for k_sr_scatter — [0, nblk): candidate pivot (SR:246-249) or INT_MAX, [nblk, 2 nblk): points
 // surviving S1.  Plain stores, no counters to re-arm between sweeps.
-constexpr int kLabelThreads = 256;                       // lanes of a label / scatter workgroup ...
-constexpr int kLabelPer = kLabelBlock / kLabelThreads;   // ... each takes this many of the workgroup's kLabelBlock points (chunk e = points e * 256 .. e * 256 + 255)
+// A label / scatter workgroup owns kLabelBlock points and comes in two shapes: kLabelThreads = 256 lanes with four points each (chunk e =
+// points e * 256 .. e * 256 + 255) — a quarter of the wavefronts, what a batch of sessions wants (the chip is short of wave slots there) —
+// and 1024 lanes with one point each for one or two sessions, where the 128 workgroups of a sweep leave the chip mostly empty and four
+// dependent rounds per lane only add latency (B = 1: label 9.3 -> 7.4 us, scatter 12.2 -> 7.0 us).  Same blocks, same results.
+template <int kLabelThreads>
 __global__ __launch_bounds__(kLabelThreads) void k_sr_label(BatchIn bi, float thres, int N_SCANS,
                                                            FrameScalars* S, signed char* __restrict__ sid,
                                                            float* __restrict__ ori_raw, int* __restrict__ blockhist,
                                                            const int2* __restrict__ slice, int nslice, int* __restrict__ blk, size_t ss) {
   VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(slice); RB(blk);
+  constexpr int kLabelPer = kLabelBlock / kLabelThreads;
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
   __shared__ int hist[kMaxRings];
@@ -201,8 +217,8 @@ __global__ __launch_bounds__(kLabelThreads) void k_sr_label(BatchIn bi, float th
     float startOri = 0.f, endOri = 0.f;
     if (s_last >= 0) {
       const float4 pf = in[s_first], pl = in[s_last];
-      startOri = -atan2f(pf.y, pf.x);                                                // SR:166
-      endOri = (float)((double)(-atan2f(pl.y, pl.x)) + 2 * M_PI);                    // SR:167
+      startOri = -sr_atan2f(pf.y, pf.x);                                                // SR:166
+      endOri = (float)((double)(-sr_atan2f(pl.y, pl.x)) + 2 * M_PI);                    // SR:167
       if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);        // SR:169-172
       else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);      // SR:173-176
     }
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(kLabelThreads) void k_sr_label(BatchIn bi, float th
       v1 = sr_survives_s1(p[e].x, p[e].y, p[e].z, thres);
       if (v1) {
         id = sr_scan_id(p[e].x, p[e].y, p[e].z, N_SCANS);
-        float ori = -atan2f(p[e].y, p[e].x);  // SR:234
+        float ori = -sr_atan2f(p[e].y, p[e].x);  // SR:234
         ori_raw[i] = ori;
         if (id >= 0) {
           atomicAdd(&hist[id], 1);
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(kLabelThreads) void k_sr_label(BatchIn bi, float th
 // Stable scatter into the ring-major cloud.  Every workgroup first derives, from the per-WG ring histograms of k_sr_label,
 // the ring offsets (SR:276-281) and its own base inside every ring — 32 KB of L2 reads per WG instead of a separate
 // single-workgroup scan kernel on the critical path.
+template <int kLabelThreads>
 __global__ __launch_bounds__(kLabelThreads) void k_sr_scatter(BatchIn bi, FrameScalars* S,
                                                              const signed char* __restrict__ sid, const float* __restrict__ ori_raw,
                                                              const int* __restrict__ blockhist, int nblk, float4* __restrict__ cloud,
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(kLabelThreads) void k_sr_scatter(BatchIn bi, FrameS
   VL_SESSION(ss); RB(S); RB(sid); RB(ori_raw); RB(blockhist); RB(cloud); RB(blk);
   const float4* __restrict__ in = bi.in[blockIdx.z];
   const int n = bi.n[blockIdx.z];
+  constexpr int kLabelPer = kLabelBlock / kLabelThreads;
   constexpr int kChunks = kLabelBlock / 64, kWaves = kLabelThreads / 64;   // 64-point chunks of the workgroup's points, in input order: chunk c = e * kWaves + wave
   __shared__ int wcnt[kChunks][kMaxRings];
   __shared__ int s_istar, s_nvalid;
@@ -1132,13 +1150,20 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   for (int k = 0; k < se.B; k++) n = bi.n[k] > n ? bi.n[k] : n;   // launch geometry for the largest sweep of the batch (blocks beyond a session's n idle)
   const unsigned Z = (unsigned)se.B;
   const int nblk = (n + kLabelBlock - 1) / kLabelBlock;
-  const int nslice = 2;   // (first, last) from the two ends
-  int2* slice = (int2*)b.blockoff;         // [nslice] <= 4 nblk records of 8 B
-  int* blk = b.blockoff + 16 * nblk;       // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup)
+  const int nslice = 2 * kFLWalkers;   // (first, last) from the two ends, kFLWalkers strided walkers each
+  int2* slice = (int2*)b.blockoff;         // [nslice] records of 8 B
+  int* blk = b.blockoff + 2 * nslice;      // [2][nblk], behind the slice records (blockoff holds 64 ints per label workgroup: 32 + 2 nblk <= 64 nblk)
   VLOAM_LAUNCH(ph, kKSrFirstLast, st, k_sr_first_last, dim3(nslice, 1, Z), dim3(kFLThreads), 0, st, bi, min_range, slice, se.ss);
-  VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label, dim3(nblk, 1, Z), dim3(kLabelThreads), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
-               slice, nslice, blk, se.ss);
-  VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter, dim3(nblk, 1, Z), dim3(kLabelThreads), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  static const int wide_env = getenv("VLOAM_SR_WIDE") ? atoi(getenv("VLOAM_SR_WIDE")) : -1;   // A/B and tests: 1 = always 1024 lanes, 0 = always 256
+  if (wide_env >= 0 ? wide_env != 0 : se.B <= 2) {   // one or two sessions: one point per lane (latency); a batch: four points per lane (wave slots)
+    VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label<1024>, dim3(nblk, 1, Z), dim3(1024), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
+                 slice, nslice, blk, se.ss);
+    VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter<1024>, dim3(nblk, 1, Z), dim3(1024), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  } else {
+    VLOAM_LAUNCH(ph, kKSrLabel, st, k_sr_label<256>, dim3(nblk, 1, Z), dim3(256), 0, st, bi, min_range, N_SCANS, b.S, b.sid, b.ori, b.blockhist,
+                 slice, nslice, blk, se.ss);
+    VLOAM_LAUNCH(ph, kKSrScatter, st, k_sr_scatter<256>, dim3(nblk, 1, Z), dim3(256), 0, st, bi, b.S, b.sid, b.ori, b.blockhist, nblk, b.cloud, blk, se.ss);
+  }
   // Behind the small tier ALWAYS comes the big tier: its full grid while the host has seen long rings (watch word), otherwise ONE catch-all
   // workgroup per session that looks at the ring lengths and works on the (normally zero) rings the small tier had to leave.  Any ring of up
   // to kMaxRingLen points is therefore processed on any sweep, like the reference's 400 000-point scratch (scan_registration.h:90) takes any
