@@ -670,7 +670,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
 #pragma unroll
   for (int i = 0; i < kAcc; i++) sh.red[i * kRedStride + tid] = acc[i];
-  lds_barrier();
+  lds_barrier();   // LDS only: sh.red (every lane's partial sums) -> the 8 * kAcc summing lanes
   if (tid < 8 * kAcc) {
     const int i = tid >> 3, sub = tid & 7;
     const double* col = sh.red + i * kRedStride + sub;
@@ -679,7 +679,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     for (int j = 0; j < kLmThreads / 8; j++) s += col[8 * j];
     sh.part[sub * kAcc + i] = s;
   }
-  lds_barrier();
+  lds_barrier();   // LDS only: sh.part (the strided sub-sums) -> the lanes that fold them / publish the granules
   if (tid < kAcc) {
     double s = 0.0;
 #pragma unroll
@@ -729,7 +729,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       s_out[tid] = tot;
     }
   }
-  lds_barrier();
+  lds_barrier();   // LDS only: s_out (this workgroup's or the exchanged totals) -> every lane of the caller
 }
 
 // packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
@@ -954,7 +954,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
   refresh_normal_equations(sh.acc2[0], true, 0);
   if (tid == 64) sh.gmax_c = grad_max(sh.x, sh.acc2[0]);
   if (tid == 128) sh.xnorm_c = x_norm_of(sh.x);
-  lds_barrier();
+  lds_barrier();   // LDS only: sh.acc2[0], sh.gmax_c, sh.xnorm_c, sh.failed -> every lane
   const bool failed_at_start = NB > 1 && sh.failed;  // (uniform: written before the barrier that ends lm_evaluate)
   if (tid == 0) {
     const double* cur = sh.acc2[0];
@@ -1045,7 +1045,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
       }
       sh.go = go;
     }
-    lds_barrier();
+    lds_barrier();   // LDS only: sh.go, sh.dx / the trial point -> every lane
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
       sh.go2 = stop ? 0 : 1;
       LM_STAMP(7);   // acceptance test
     }
-    lds_barrier();
+    lds_barrier();   // LDS only: sh.go2, sh.gmax_c, sh.xnorm_c, the accepted point -> every lane
     if (accepted) { gmax = sh.gmax_c; x_norm = sh.xnorm_c; }
     cyc_serial += clock64() - t_mark;
     if (sh.go2 == 0) break;
