@@ -72,8 +72,8 @@ def algorithmic_bytes(kernel, c):
         return 2 * 76 * c["K_m"]
     if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
         return 16 * c["N2"] + 16 * c["n_lessFlat"] + 4 * (c["n_sharp"] + c["n_lessSharp"] + c["n_flat"])
-    if kernel == "k_sr_first_last":
-        return 16 * c["N_in"]
+    if kernel == "k_sr_first_last":   # sixteen walkers (eight per end) look at one 4 096-point trip each on an ordinary sweep
+        return 16 * min(c["N_in"], 16 * 4096)
     if kernel == "k_sr_label":
         return 16 * c["N_in"] + 5 * c["N_in"]
     if kernel == "k_sr_scatter":
