@@ -611,13 +611,24 @@ static vloam_status finish_frame(vloam_handle* h) {
   return VLOAM_OK;
 }
 
-// ------------------------------------------------------------------ host sweeps -> the input ring
-// stage_begin picks the ring slot of this call and makes the copy stream wait for the slot's previous readers; stage_sweep enqueues session
-// b's copy and returns the device address; stage_end makes the scan-registration stream wait for the copies; stage_release (after the
-// call's readers — scan registration, the VO depth map — are enqueued on the scan-registration stream) marks the slot reusable.
+// ------------------------------------------------------------------ host sweeps in
+// A host sweep is copied into a device input buffer in front of its scan registration.  Two forms, both behind every host-pointer entry point:
+//   INLINE (default): hipMemcpyAsync on the scan-registration stream itself, one buffer, no events — the stream's order IS the dependency.
+//   RING (VLOAM_STAGE_INLINE=0; what the round-4 review asked for): a copy stream + a ring of kInRing device input buffers, the copy of sweep
+//     k + 1 overlapping scan registration of sweep k.  stage_begin picks the ring slot and makes the copy stream wait for the slot's previous
+//     readers; stage_sweep enqueues session b's copy and returns the device address; stage_end makes the scan-registration stream wait for the
+//     copies; stage_release (after the call's readers — scan registration, the VO depth map — are enqueued on the scan-registration stream) marks
+//     the slot reusable.
+// Measured (tools/host_input_probe.py, one sequence, 64 x 2048, sweeps in pinned memory; device-resident sweeps: 6 100 - 6 400 scans/s): inline
+// 5 360 - 5 430 in every context; ring 2 200 - 2 300 when only host-fed handles live in the process, 4 300 - 5 300 behind handles of other kinds —
+// its two cross-stream waits per sweep and the sixth stream land differently on the hardware queues from process to process
+// (profiles/r05_hw_queues.txt), and nothing is won where it works: the scan-registration stream has the 40 - 87 us to spare (116 of a 157 us
+// period).  A copy KERNEL reading the pinned buffer through its device-side address (49 GB/s, 2.7 us of host time against 24 GB/s and 42 us
+// inside hipMemcpyAsync: tools/microbench/pinned_read.hip) was measured too: every kernel running beside it takes ~45 us longer (system-memory
+// reads ahead of everybody's misses in the L2 queues) — same throughput, not kept.
 // Pageable source memory: hipMemcpyAsync has taken its copy when it returns (the caller may reuse the buffer at once).  Pinned source
 // memory (hipHostMalloc / hipHostRegister) is read by DMA later: it must stay unchanged until the next vloam_sync() (c_api.h).
-static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 0;   // A/B: 1 = copy on the scan-registration stream itself (one buffer, no events)
+static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 1;   // 0 = the ring + copy-stream form
 static vloam_status stage_begin(vloam_handle* h) {
   if (g_stage_inline) { h->in_slot = 0; return VLOAM_OK; }
   if (!h->s_copy) {
