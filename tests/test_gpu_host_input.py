@@ -71,3 +71,17 @@ def test_batched_sessions_from_pinned_and_pageable_sweeps(vl, synth):
         assert np.array_equal(hb.get_map().view(np.uint32), hd.get_map().view(np.uint32)), b
     hb.close()
     hd.close()
+
+
+def test_ring_and_copy_stream_form_gives_the_same_results():
+    """VLOAM_STAGE_INLINE=0 (read when the library loads): the ring of four device input buffers on a copy stream of the handle, kept selectable
+    next to the default (copy on the scan-registration stream).  The two tests above, in a process of their own with the ring form on."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("VLOAM_STAGE_INLINE") == "0":
+        pytest.skip("already inside the ring-form process")
+    env = dict(os.environ, VLOAM_STAGE_INLINE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "pinned", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
