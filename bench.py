@@ -472,7 +472,7 @@ def main():
 
     # ---- extra: HOST input — the path the reference actually has (a host cloud per callback, scan_registration.cpp:131-152,
     # vloam_main_node.cpp:125-180): vloam_process_scan from (i) pinned and (ii) pageable host memory, a distinct buffer per sweep, next to
-    # the same sweeps handed over as device pointers.  The library stages host sweeps through a ring of device buffers on a copy stream.
+    # the same sweeps handed over as device pointers.  The library copies a host sweep into a device input buffer on the scan-registration stream.
     host_input = None
     if extras and not args.no_host_input:
         n_h = int(min(max(K, 400), 1200))
@@ -508,9 +508,9 @@ def main():
         host_input = {"sweeps": n_h, "unit": "scans/s", "device_resident": runs["device"][0], "pinned": runs["pinned"][0], "pageable": runs["pageable"][0],
                       "pinned_over_device_resident": runs["pinned"][0] / runs["device"][0],
                       "same_last_pose": bool(np.array_equal(runs["device"][1], runs["pinned"][1]) and np.array_equal(runs["device"][1], runs["pageable"][1])),
-                      "note": "vloam_process_scan, one 2 MB sweep per call from a buffer of its own; pinned = hipHostMalloc'ed memory read by DMA on the handle's copy "
-                              "stream (ring of 4 device input buffers: the copy of sweep k + 1 overlaps sweep k), pageable = numpy memory (the runtime's "
-                              "staging memcpy runs on the calling thread)"}
+                      "note": "vloam_process_scan, one 2 MB sweep per call from a buffer of its own; pinned = hipHostMalloc'ed memory read by DMA in front of the sweep's "
+                              "scan registration (same stream), pageable = numpy memory (the runtime's staging memcpy runs on the calling thread); "
+                              "tools/host_input_probe.py: the same with a few reused buffers, and the ring + copy-stream form (VLOAM_STAGE_INLINE=0)"}
 
     # ---- extra: configs[3] (synthetic analogue) — the coupled per-frame VLOAM loop, one vloam_process_frame_device per frame:
     # depth-enhanced VO solve -> VO2VeloAndBase -> SR -> LO in combined mode (detach_VO_LO = 0) -> LO -> VO prior -> mapping, no host

@@ -146,12 +146,13 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
  * entry points first enqueue whatever is still owed, so this is invisible except through the raw device pointer below. */
 vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n);
 /* same with a HOST buffer — what the reference's callback hands over (a pcl::PointCloud<pcl::PointXYZ>'s points, scan_registration.cpp:131-152).
- * The sweep is copied into one of four device input buffers on a copy stream of the handle's own, so that the H2D copy of sweep k + 1 overlaps
- * the scan registration of sweep k; the call returns once the copy is enqueued.
+ * The sweep is copied into a device input buffer in front of its scan registration, on the scan-registration stream itself (the stream has the
+ * time: DESIGN.md section 10; VLOAM_STAGE_INLINE=0 selects a ring of four input buffers on a copy stream of the handle's own instead); the call
+ * returns once the copy is enqueued.
  *   pageable memory (malloc, std::vector, a ROS message): the runtime has taken its copy of the sweep when the call returns — the buffer may
  *     be reused at once; the calling thread pays the staging memcpy (~2 MB per sweep);
  *   pinned memory (hipHostMalloc / hipHostRegister): read by DMA AFTER the call returns — leave the buffer unchanged until the next
- *     vloam_sync(); no host-side copy, the fastest way in (bench.py: host_input).
+ *     vloam_sync(); no host-side copy (bench.py: host_input).
  * The same holds for every other entry point that takes a host sweep (vloam_scan_registration, vloam_process_frame*, vloam_batch_process_*). */
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n);
 vloam_status vloam_sync(vloam_handle* h);
