@@ -271,10 +271,9 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   // multi-threaded host's back (not thread-safe against a concurrent getenv, and silently without effect once HIP is up).
   // Said once per process instead.
   {
-    static bool warned = false;
+    static std::atomic<bool> warned{false};   // (handles may be created from several threads)
     const char* q = getenv("GPU_MAX_HW_QUEUES");
-    if (!warned && (!q || atoi(q) < 8)) {
-      warned = true;
+    if ((!q || atoi(q) < 8) && !warned.exchange(true)) {
       fprintf(stderr, "libvloam_hip: GPU_MAX_HW_QUEUES is %s: the stage streams of a handle will share hardware queues and a sweep takes ~30 %% longer; "
                       "export GPU_MAX_HW_QUEUES=16 before the process initialises HIP\n", q ? q : "unset (runtime default 4)");
     }

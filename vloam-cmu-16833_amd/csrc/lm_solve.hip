@@ -1306,9 +1306,9 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F_in, int n_edge_slot
   const FactorTable& F = Fg;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   const bool rowmask = quat && !direct && F.rowmask != nullptr && (F.cap >> 6) <= 2 * kLmThreads;   // the fit kernel left row masks: the solve compacts on its own
-  // Batches keep the cooperative form: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured only 3 % faster at
-  // B = 8 (10 785 vs 10 435 scans/s) and gives up the bit-identity of a batched session with the same sequence run alone (the f64
-  // sums of the normal equations would be added in a different order).
+  // Batches keep the cooperative form because it is faster there: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured
+  // +3 % at B = 8 in round 3 and -10 % in round 4.  (The f64 sums of the normal equations are added in workgroup order:
+  // whatever the count, a batched session equals the same sequence run alone to round-off, not bit for bit — tests/test_gpu_batch.py.)
   static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
   const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1) && !se.no_coop;   // no_coop: a solve of this handle had to degrade once (vloam_sync)
   if (!direct && !rowmask) VLOAM_LAUNCH(ph, kKLmCompact, st, k_lm_compact, dim3(F.cap >> 6, 1, Z), dim3(64), 0, st, F, quat ? 1 : 0, d_enable, se.ss);

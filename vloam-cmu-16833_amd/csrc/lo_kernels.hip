@@ -6,6 +6,9 @@
 // (k_lo_grid_count / scan / scatter); one wavefront per feature scans grid blocks with all 64 lanes and keeps
 // (f32 distance bits << 32 | index or visit order) keys, which reproduces the reference's
 // first-strictly-smaller-wins walks and "lowest index wins" kNN ties exactly.
+// A batched handle splits the association in two launches: k_lo_assoc_fast (a 16-lane group per feature: the common query, settled inside the
+// radius-1 block of the 1 m level or — blocks too full pruned to the cells near the query — on the 5 m level's ring groups) queues what it
+// cannot settle, and k_lo_assoc_dense (this file's wave-per-feature body at a 128-register budget) takes the queue from scratch.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "lo_kernels.h"

@@ -1,14 +1,14 @@
 // laserMapping on gfx950: scan-to-map ICP against a persistent voxel hash.
 // Restates LaserMapping::input / solveMapping, /root/reference/src/lidar_odometry_mapping/src/laser_mapping.cpp:167-708
-// ("LM:<line>").  One sweep = 13 launches + 2 x (compaction + Levenberg–Marquardt), no host synchronisation; the four
+// ("LM:<line>").  One sweep = 11 launches incl. 2 Levenberg–Marquardt solves (which compact on their own), no host synchronisation; the two
 // k_map_ds_* launches only need the sweep's feature clouds and run on a stream of their own.  Every kernel carries the session
 // index of a batched handle in blockIdx.z and rebases its pointer arguments by blockIdx.z * ss (vloam_device.h).
 //   k_map_prepare   1 WG      initial guess (LM:193-194), centre cube + grid roll (LM:207-402), gate (LM:448); stops taking sweeps
 //                             when the voxel table is full
-//   k_map_ds_count  grid      pcl::VoxelGrid of the scan features (LM:432-440), pass 1: hash sweep points to voxels, count
-//   k_map_ds_rank   grid      pass 2: output rank + segment start of every occupied voxel by whole-chip counting
-//   k_map_ds_scatter grid     pass 3: group point indices by voxel
-//   k_map_ds_reduce grid      pass 4: per voxel, input-ordered f32 centroid
+//   k_map_ds_bin    grid      pcl::VoxelGrid of the scan features (LM:432-440) without a global hash, pass 1: PCL's cell index from the cloud's
+//                             bounding box (incl. its index-overflow guard: output = input), sample splitters, (cell << 24 | point) keys binned
+//   k_map_ds_reduce 64 WGs    pass 2: bins drawn by ticket, sorted in LDS, output slots by a decoupled look-back over the bins' cell counts,
+//                             per cell the input-ordered f32 centroid, output in PCL's order (cells ascending)
 //   k_map_assoc     1 wave/pt pointAssociateToMap, exact 5-NN through the block-occupancy index of the voxel hash (one 32-byte
 //                             record per candidate); the second outer round re-ranks the first round's candidates             x2
 //   k_map_fit       1 thread/pt 3x3 eigen / 5x3 least squares, emission of LidarEdgeFactor / LidarPlaneNormFactor (LM:472-581) x2

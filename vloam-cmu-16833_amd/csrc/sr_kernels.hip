@@ -4,14 +4,17 @@
 // (cited per step as "SR:<line>").  Integer / index results are bit-identical to the CPU oracle; f32
 // arithmetic follows the reference's expression order with FMA contraction disabled at compile time.
 //
-// Kernels (one sweep = 5 launches, no host synchronisation):
-//   k_sr_first_last  n/256 WGs   first / last surviving point per slice (folded by every k_sr_label workgroup)  SR:157-176
-//   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262
-//   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266
+// Kernels (one sweep = 6 launches, no host synchronisation):
+//   k_sr_first_last  16 WGs      first / last surviving point: eight strided walkers from each end of the cloud (their records are folded by
+//                                every k_sr_label workgroup)                                                                    SR:157-176
+//   k_sr_label       n/1024 WGs  scanID, raw ori, halfPassed pivot (atomicMin), ring histogram SR:186-262   (1 024 lanes x 1 point for one or two
+//   k_sr_scatter     n/1024 WGs  ring offsets + per-WG bases (SR:276-281), relTime / intensity, stable scatter SR:264-266   sessions, 256 x 4 for a batch)
 //   k_sr_ring        1 WG/ring   LDS-resident ring: curvature, sort-free picks (wavefront arg-max rounds, six sectors
 //                                at once + boundary fixed point), lessFlat + VoxelGrid(0.2) over voxel runs  SR:288-439
-//                                (two capacity tiers: 2 176 points in 78.75 KB of LDS = two rings per CU; 4 096 points only while needed)
-//   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds                             SR:338-344,388,439
+//                                (two capacity tiers: 2 176 points in 78.75 KB of LDS = two rings per CU; the 4 096-point tier follows on every
+//                                sweep — its full grid while long rings are around, one catch-all workgroup otherwise)
+//   k_sr_compact     1 WG/ring   ring/sector-ordered feature clouds (+ per-ring bounding boxes of the less-clouds for the mapping
+//                                stage's VoxelGrid)                                                 SR:338-344,388,439
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <float.h>
