@@ -6,6 +6,8 @@ of intensity is compared with a tolerance (1e-5 absolute on values <= 51); every
 ring ids, compaction order, curvature, per-sector sort order, picks, labels, voxel centroids' xyz —
 must match bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -266,3 +268,52 @@ def test_ring_tiers_follow_the_ring_length(vl, orc, synth):
         h4.process_scan(sweep(4300, 0))
         h4.sync()
     assert e.value.status == vl.ERR_CAPACITY
+
+
+_OPT_OUT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import conftest
+vl = conftest.load_pkg(); synth = conftest.load_synth()
+import orc
+orc.build()
+def sweep(n_az, k):
+    return synth.SynthSequence(n_rings=64, n_azimuth=n_az, n_sweeps=k + 1).sweep(k)
+# ordinary sweeps: same features as the oracle without the catch-all launch
+h = vl.Handle(0, with_mapping=0)
+for k in range(3):
+    c = sweep(2048, k)
+    h.reset_frame(); h.scan_registration(c)
+    o = orc.Oracle(with_mapping=False); assert o.scan_registration(c) == 0
+    for which in (1, 2, 3, 4):
+        d, r = h.features(which), o.cloud(which)
+        assert d.shape == r.shape and np.array_equal(d[:, :3].view(np.uint32), r[:, :3].view(np.uint32)), (k, which)
+    h.laser_odometry()
+h.sync()
+# a ring that outgrows the small tier WITHOUT the watch word's warning is reported, not processed
+h2 = vl.Handle(0, with_mapping=0, max_points=64 * 3072)
+try:
+    h2.process_scan(sweep(3000, 0)); h2.sync()
+    print("NOT-REPORTED")
+except vl.VloamError as e:
+    print("REPORTED" if e.status == vl.ERR_CAPACITY else "OTHER-ERROR %d" % e.status)
+# with the warning (rings growing towards the capacity) the full big tier runs as always
+h3 = vl.Handle(0, with_mapping=0, max_points=64 * 2304)
+for k, n_az in enumerate([2160] * 3 + [2300] * 2):
+    h3.reset_frame(); h3.scan_registration(sweep(n_az, k)); h3.laser_odometry()
+h3.sync()
+print("GROWN-OK")
+"""
+
+
+def test_catch_all_opt_out_reports_instead_of_processing():
+    """VLOAM_SR_CATCHALL=0 (read once per process): no catch-all workgroup behind the small ring tier — for hosts that know their ring lengths
+    (13 - 16 us of single-sweep latency).  Ordinary sweeps give the oracle's features; a ring that jumps past the small tier's capacity without
+    the watch word's warning comes back as VLOAM_ERR_CAPACITY (the rounds 2 - 3 behaviour, now opt-in); rings that GROW towards the capacity
+    still switch the full big tier on."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VLOAM_SR_CATCHALL="0")
+    r = subprocess.run([sys.executable, "-c", _OPT_OUT_SCRIPT, os.path.dirname(os.path.abspath(__file__))], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "REPORTED" in r.stdout.split() and "GROWN-OK" in r.stdout.split(), r.stdout[-1500:]

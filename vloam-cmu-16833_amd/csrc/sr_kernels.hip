@@ -1173,12 +1173,18 @@ hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess
   // ring; the catch-all costs 13 - 16 us of single-sweep latency (a 146 KB LDS request) and 1.4 % of the B = 8 throughput on ordinary sweeps.
   // (Rounds 2 - 3 made it optional and REPORTED a ring that outgrew the small tier without the watch word's warning: a results gap on
   // reachable input.)
+  // VLOAM_SR_CATCHALL=0: a host that KNOWS its rings stay below kRingCapSmall points (any 10 Hz sensor of the reference's three scan_line
+  // settings) may drop the catch-all launch: a ring that outgrows the small tier without the watch word's warning is then REPORTED
+  // (kErrRingTooLong -> VLOAM_ERR_CAPACITY) instead of processed; with the warning the full big tier runs as always.
+  static const int catchall = getenv("VLOAM_SR_CATCHALL") ? atoi(getenv("VLOAM_SR_CATCHALL")) : 1;
+  const bool big_launch = big_tier || catchall != 0;
   VLOAM_LAUNCH(ph, kKSrRing, st, (k_sr_ring<kRingCapSmall, kSectCapSmall, false>), dim3(kMaxRings, 1, Z), dim3(kRingThreads),
                (sr_ring_smem_bytes<kRingCapSmall, kSectCapSmall>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
-               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
+               debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, big_launch ? 1 : 0, se.ss);
   // the full big tier while rings near the small tier's capacity are around, else its one-workgroup catch-all
-  VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(big_tier ? kMaxRings : 1, 1, Z), dim3(kRingThreads),
+  if (big_launch)
+    VLOAM_LAUNCH(ph, kKSrRingBig, st, (k_sr_ring<kMaxRingLen, kSectCap, true>), dim3(big_tier ? kMaxRings : 1, 1, Z), dim3(kRingThreads),
                  (sr_ring_smem_bytes<kMaxRingLen, kSectCap>()), st, b.cloud, b.S, b.sharp_idx, b.less_sharp_idx,
                  b.flat_idx, b.ring_ds, debug ? b.dbg_curv : nullptr, debug ? b.dbg_sort : nullptr, debug ? b.dbg_picked : nullptr,
                  debug ? b.dbg_label : nullptr, stamps ? b.dbg_cyc : nullptr, ring_watch, 1, se.ss);
