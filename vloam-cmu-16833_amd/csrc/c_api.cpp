@@ -255,8 +255,11 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
   if (cfg->max_points < 64 || cfg->max_points > (1 << 24) || cfg->max_frames < 1 || cfg->mapping_skip_frame < 1) {  // 24-bit point tags
     set_err("bad capacity"); return VLOAM_ERR_INVALID;
   }
-  if (!(cfg->mapping_line_resolution >= 0.25f) || !(cfg->mapping_plane_resolution >= 0.25f)) {  // 8-bit voxel index inside a 50 m cube, <= 8 pieces per axis
-    set_err("mapping resolutions below 0.25 m are not supported"); return VLOAM_ERR_INVALID;
+  // laser_mapping.cpp:95-101 takes any leaf; the reference's launch files use 0.2 / 0.4 (VLP-16, HDL-32) and 0.4 / 0.8 (KITTI).  Here the
+  // position of a voxel in the gathered map cloud (the 5-NN tie rank) is a 32-bit mixed-radix number: 75 cubes x radix^3 voxels.
+  for (const float leaf : {cfg->mapping_line_resolution, cfg->mapping_plane_resolution}) {
+    const double nv = leaf > 0.f ? (double)vox_radix(1.0f / leaf) : 1e9;
+    if (!(leaf > 0.f) || 75.0 * nv * nv * nv >= 4294967295.0) { set_err("mapping resolutions below 0.132 m are not supported"); return VLOAM_ERR_INVALID; }
   }
   if (cfg->image_width < 0 || cfg->image_height < 0 || (long long)cfg->image_width * cfg->image_height > (1ll << 24) ||
       ((cfg->image_width > 0) != (cfg->image_height > 0)) || (cfg->image_width > 0 && (cfg->image_width < 2 * kImgWin || cfg->image_height < 2 * kImgWin))) {

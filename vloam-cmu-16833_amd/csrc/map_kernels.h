@@ -20,6 +20,11 @@ constexpr int kStackCapCorner = 8192;   // >= kMaxLessSharp
 constexpr int kStackCapSurf = 16384;    // voxels of one sweep's lessFlat cloud at the plane resolution
 constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
 constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
+// Voxel indices one axis of a 50 m cube can take at a leaf of 1 / inv (+ slack: the first index of a cube is taken one cell early, and the
+// cube test runs in f64 on the point while the voxel index is an f32 product): the radix of k_map_assoc's 32-bit tie rank — the position of
+// a voxel in the reference's gathered map cloud, 75 cubes x radix^3.  vloam_create keeps 75 radix^3 below 2^32 (leaf >= 0.132 m); the
+// voxel key itself has 9 bits per axis (map_kernels.hip).
+__host__ __device__ inline int vox_radix(float inv) { return (int)(50.0f * inv) + 4; }
 
 // One map voxel == one 32-byte record, so that a candidate of the 5-NN search, an insert and a finalize each touch ONE cache line
 // (round 1 kept keys / sums / counts in three arrays: three scattered lines per candidate, 27x the algorithmic traffic).

@@ -53,19 +53,25 @@ __device__ __forceinline__ int cube_hi(double v) { return (int)floor((v + 1e-3 +
 // first global voxel index that can belong to cube A (minus one cell of slack so the local index is never negative)
 __device__ __forceinline__ int cube_voxel_base(int A, float inv) { return (int)floor((50.0 * (double)A - 25.0) * (double)inv) - 1; }
 
-// Voxel key: | seq 8 | cube i + 2048 (12) | cube j + 2048 (12) | cube k + 128 (8) | voxel lx, ly, lz inside the cube (8 each) |.
-// seq = 0: the voxel's record (centroid, or the running sum of a raw voxel); seq = 1..255: one RAW point of a voxel whose cube lies outside
-// the valid 5 x 5 x 3 block (see k_map_finalize) — the reference keeps such points un-merged in their cube until the cube is next
-// re-filtered, and its kd-tree sees them one by one.  Cubes are absolute (no window offset): +-102 km horizontally, +-6.4 km vertically
-// around the start (k_map_insert reports anything beyond).
-constexpr int kCubeOffXY = 2048, kCubeOffZ = 128;
+// Voxel key: | seq 8 (56-63) | - | cube i + 512 (10: 45-54) | cube j + 512 (10: 35-44) | cube k + 128 (8: 27-34) | voxel lx (18-26), ly (9-17),
+// lz (0-8) inside the cube, 9 bits each |.  Nine bits per axis take any leaf down to 50 m / 508 (the reference's launch files use 0.2 / 0.4 and
+// 0.4 / 0.8, laser_mapping.cpp:95-101 takes any value; vloam_create's bound of 0.132 m comes from the 32-bit tie rank of k_map_assoc, not
+// from the key).  seq = 0: the voxel's record (centroid, or the running sum of a raw voxel); seq = 1..255: one RAW point of a voxel whose
+// cube lies outside the valid 5 x 5 x 3 block (see k_map_finalize) — the reference keeps such points un-merged in their cube until the
+// cube is next re-filtered, and its kd-tree sees them one by one.  Cubes are absolute (no window offset): +-25.6 km horizontally,
+// +-6.4 km vertically around the start (k_map_insert reports anything beyond).
+constexpr int kCubeOffXY = 512, kCubeOffZ = 128;
+constexpr int kVoxBits = 9, kVoxMax = (1 << kVoxBits) - 1;
 __device__ __forceinline__ u64 pack_key(int Ai, int Aj, int Ak, int lx, int ly, int lz) {
-  return ((u64)(unsigned)(Ai + kCubeOffXY) << 44) | ((u64)(unsigned)(Aj + kCubeOffXY) << 32) | ((u64)(unsigned)(Ak + kCubeOffZ) << 24) |
-         ((u64)(unsigned)lx << 16) | ((u64)(unsigned)ly << 8) | (u64)(unsigned)lz;
+  return ((u64)(unsigned)(Ai + kCubeOffXY) << 45) | ((u64)(unsigned)(Aj + kCubeOffXY) << 35) | ((u64)(unsigned)(Ak + kCubeOffZ) << 27) |
+         ((u64)(unsigned)lx << (2 * kVoxBits)) | ((u64)(unsigned)ly << kVoxBits) | (u64)(unsigned)lz;
 }
 __device__ __forceinline__ void unpack_cube(u64 k, int* Ai, int* Aj, int* Ak) {
-  *Ai = (int)((k >> 44) & 0xfff) - kCubeOffXY; *Aj = (int)((k >> 32) & 0xfff) - kCubeOffXY; *Ak = (int)((k >> 24) & 0xff) - kCubeOffZ;
+  *Ai = (int)((k >> 45) & 0x3ff) - kCubeOffXY; *Aj = (int)((k >> 35) & 0x3ff) - kCubeOffXY; *Ak = (int)((k >> 27) & 0xff) - kCubeOffZ;
 }
+__device__ __forceinline__ int key_lx(u64 k) { return (int)((k >> (2 * kVoxBits)) & kVoxMax); }
+__device__ __forceinline__ int key_ly(u64 k) { return (int)((k >> kVoxBits) & kVoxMax); }
+__device__ __forceinline__ int key_lz(u64 k) { return (int)(k & kVoxMax); }
 __device__ __forceinline__ bool cube_in_key_range(int Ai, int Aj, int Ak) {
   return Ai >= -kCubeOffXY && Ai < kCubeOffXY && Aj >= -kCubeOffXY && Aj < kCubeOffXY && Ak >= -kCubeOffZ && Ak < kCubeOffZ;
 }
@@ -693,6 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
   const int slot = kind ? kStackCapCorner + i : i;
   const VoxelTable T = kind ? T1 : T0;
   const float inv = kind ? inv1 : inv0;
+  const unsigned nv = (unsigned)vox_radix(inv);
   __shared__ u64 s_cand[QW][CH + 8];        // voxel keys of the pass, flattened per query
   __shared__ u64 s_bestk[QW][8];            // the best five so far: key ...
   __shared__ float4 s_bestp[QW][8];         // ... and centroid
@@ -747,11 +754,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         const int ia = max(lo, base + 1), ib = min(hi, cube_voxel_base(A + 1, inv) + 1);
         if (ia > ib) continue;
         for (int blk = (ia - base) >> 2; blk <= ((ib - base) >> 2); blk++) {
-          if ((unsigned)blk > 63u || n >= 8) { ovf = true; break; }  // not reachable for leaf >= 0.25 m (vloam_create rejects smaller)
+          if ((unsigned)blk > (unsigned)(kVoxMax >> 2) || n >= 8) { ovf = true; break; }  // not reachable for the leaves vloam_create accepts (>= 0.132 m: <= 17 voxels = 6 blocks + a cube face)
           int m4 = 0;
 #pragma unroll
           for (int t = 0; t < 4; t++) { const int iv = base + (blk << 2) + t; if (iv >= ia && iv <= ib) m4 |= 1 << t; }
-          s_piece[qi][gl][n] = ((A + 8192) << 10) | (blk << 4) | m4;
+          s_piece[qi][gl][n] = ((A + 8192) << 11) | (blk << 4) | m4;
           n++;
         }
       }
@@ -811,10 +818,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
               const float d0 = q0 - p.x, d1 = q1 - p.y, d2 = q2 - p.z;
               int Ai, Aj, Ak;
               unpack_cube(key, &Ai, &Aj, &Ak);
-              unsigned tie = ((unsigned)(Ai - ctr0 + 2) << 29) | ((unsigned)(Aj - ctr1 + 2) << 26) | ((unsigned)(Ak - ctr2 + 1) << 24) |
-                             ((unsigned)(key & 0xffu) << 16) | ((unsigned)((key >> 8) & 0xffu) << 8) | (unsigned)((key >> 16) & 0xffu);
+              // position in the gathered cloud as a mixed-radix number: cube (i, j, k loop order of the 5 x 5 x 3 block) then (lz, ly, lx);
+              // every partial result stays below 2^24 until the last step (three full-rate 24-bit multiply-adds)
+              const unsigned cube = (unsigned)((Ai - ctr0 + 2) * 15 + (Aj - ctr1 + 2) * 3 + (Ak - ctr2 + 1));
+              unsigned tie = ((cube * nv + (unsigned)key_lz(key)) * nv + (unsigned)key_ly(key)) * nv + (unsigned)key_lx(key);
               const int seq = key_seq(key);
-              if (seq) tie = (tie & 0xff000000u) | ((tie * 2654435761u + (unsigned)seq * 40503u) & 0x00ffffffu);   // raw points of one voxel: distinct ties inside the cube
+              if (seq) { const unsigned nv3 = nv * nv * nv; tie = cube * nv3 + (tie * 2654435761u + (unsigned)seq * 40503u) % nv3; }   // raw points of one voxel: distinct ties inside the cube
               key_u[u] = ((u64)__float_as_uint(d0 * d0 + d1 * d1 + d2 * d2) << 32) | tie;
               px[u] = p.x; py[u] = p.y; pz[u] = p.z;
             }
@@ -889,9 +898,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
             const int ez = (int)(((float)bb + 0.5f) * __builtin_amdgcn_rcpf((float)n01)), rem = bb - ez * n01;
             const int ey = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)np0)), ex = rem - ey * np0;
             const int w0 = s_piece[qi][0][ex], w1 = s_piece[qi][1][ey], w2 = s_piece[qi][2][ez];
-            pA[k][0] = (w0 >> 10) - 8192; pb[k][0] = (w0 >> 4) & 63; pm[k][0] = w0 & 15;
-            pA[k][1] = (w1 >> 10) - 8192; pb[k][1] = (w1 >> 4) & 63; pm[k][1] = w1 & 15;
-            pA[k][2] = (w2 >> 10) - 8192; pb[k][2] = (w2 >> 4) & 63; pm[k][2] = w2 & 15;
+            pA[k][0] = (w0 >> 11) - 8192; pb[k][0] = (w0 >> 4) & 127; pm[k][0] = w0 & 15;
+            pA[k][1] = (w1 >> 11) - 8192; pb[k][1] = (w1 >> 4) & 127; pm[k][1] = w1 & 15;
+            pA[k][2] = (w2 >> 11) - 8192; pb[k][2] = (w2 >> 4) & 127; pm[k][2] = w2 & 15;
             bkey[k] = pack_key(pA[k][0], pA[k][1], pA[k][2], pb[k][0], pb[k][1], pb[k][2]) | (1ull << 63);
             bs[k] = (unsigned)mix64(bkey[k]) & T.bslots_mask;
           }
@@ -1185,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ s
       if (wi < 0 || wi >= kCubeW || wj < 0 || wj >= kCubeH || wk < 0 || wk >= kCubeD) return -1;  // LM:654-655: outside the grid -> dropped
       const int lx = (int)floorf(p.x * inv) - cube_voxel_base(Ai, inv), ly = (int)floorf(p.y * inv) - cube_voxel_base(Aj, inv),
                 lz = (int)floorf(p.z * inv) - cube_voxel_base(Ak, inv);
-      if ((unsigned)lx > 255u || (unsigned)ly > 255u || (unsigned)lz > 255u || !cube_in_key_range(Ai, Aj, Ak)) { atomicOr(&fr->error, kErrMapFull); return -1; }
+      if ((unsigned)lx > (unsigned)kVoxMax || (unsigned)ly > (unsigned)kVoxMax || (unsigned)lz > (unsigned)kVoxMax || !cube_in_key_range(Ai, Aj, Ak)) { atomicOr(&fr->error, kErrMapFull); return -1; }
       const u64 key = pack_key(Ai, Aj, Ak, lx, ly, lz);
       unsigned s = (unsigned)mix64(key) & T.mask;
       for (int probe = 0; probe < kMaxProbe; probe++, s = (s + 1) & T.mask) {
@@ -1379,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_map_rebuild_insert(VoxelTable T, const 
       rec_store_value(&T.rec[s], make_float4(r.sx, r.sy, r.sz, r.si), r.count, r.pend_cnt);
       int Ai, Aj, Ak;
       unpack_cube(r.key, &Ai, &Aj, &Ak);
-      if (key_seq(r.key) == 0 && !map_publish_block(T, Ai, Aj, Ak, (int)((r.key >> 16) & 0xff), (int)((r.key >> 8) & 0xff), (int)(r.key & 0xff))) atomicOr(&fr->error, kErrMapFull);
+      if (key_seq(r.key) == 0 && !map_publish_block(T, Ai, Aj, Ak, key_lx(r.key), key_ly(r.key), key_lz(r.key))) atomicOr(&fr->error, kErrMapFull);
       if (key_seq(r.key) == 0 && rec_raw(r.count)) {  // raw voxel of a cube outside the valid block: still owed a centroid (see k_map_finalize)
         const int dpos = atomicAdd(&fr->n_deferred[kind], 1);
         if (dpos < deferred_cap) deferred[dpos] = (int)s;
@@ -1575,10 +1584,10 @@ __global__ __launch_bounds__(256) void k_map_export(VoxelTable T, const MapState
     const int i = Ai + cW, j = Aj + cH, k = Ak + cD;
     if (i < 0 || i >= kCubeW || j < 0 || j >= kCubeH || k < 0 || k >= kCubeD) continue;
     const u64 cube = (u64)(i + kCubeW * j + kCubeW * kCubeH * k);
-    const u64 lx = (v.key >> 16) & 0xff, ly = (v.key >> 8) & 0xff, lz = v.key & 0xff;
+    const u64 lx = (u64)key_lx(v.key), ly = (u64)key_ly(v.key), lz = (u64)key_lz(v.key);
     const bool tail = seq != 0 && v.pend_cnt != 0;   // an un-merged arrival: behind the voxel-ordered part, by arrival stamp
     ExportRow r;
-    r.okey = (cube << 50) | ((u64)kind << 49) | ((u64)(tail ? 1 : 0) << 48) | (tail ? (u64)(unsigned)v.pend_cnt : ((lz << 16) | (ly << 8) | lx));
+    r.okey = (cube << 50) | ((u64)kind << 49) | ((u64)(tail ? 1 : 0) << 48) | (tail ? (u64)(unsigned)v.pend_cnt : ((lz << (2 * kVoxBits)) | (ly << kVoxBits) | lx));
     const int n = seq ? 1 : rec_n(v.count);
     const float nn = (float)n;
     r.x = n > 1 ? v.sum.x / nn : v.sum.x; r.y = n > 1 ? v.sum.y / nn : v.sum.y; r.z = n > 1 ? v.sum.z / nn : v.sum.z;
