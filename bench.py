@@ -56,6 +56,17 @@ REFERENCE_TIMERS = {
 }
 
 
+# the per-unit figure behind algorithmic_bytes() for the kernels a roofline object is usually built for
+ALGORITHMIC_UNIT = {
+    "k_lm_solve": "64 B per factor and residual/Jacobian evaluation (SURVEY.md §8d: curr + <= 3 matched points); units per launch = (F E_o + K_m E_m) / 4 of counts_last_sweep",
+    "k_lo_assoc": "16 B per feature + 16 B per point of CornerLast / SurfLast (read once) + 76 B per factor record written",
+    "k_map_assoc": "(16 + 5 x 32 + 20) B per stack point: the point, five 32-byte voxel records, five slot ids",
+    "k_sr_ring": "16 B per point in + 16 B per lessFlat point out + 4 B per pick",
+    "k_map_ds_reduce": "8 B per key + 16 B per point in, 16 B per occupied cell out",
+    "k_map_ds_bin": "16 B per point in + 8 B per sort key out",
+}
+
+
 def algorithmic_bytes(kernel, c):
     """ALGORITHMIC (compulsory) bytes one launch of `kernel` moves, from the measured counts of the run."""
     n_feat = c["n_sharp"] + c["n_flat"]
@@ -64,10 +75,12 @@ def algorithmic_bytes(kernel, c):
     n_less = c["n_lessSharp"] + c["n_lessFlat"]
     if kernel in ("k_lo_assoc", "k_lo_assoc_fast"):  # features + both candidate clouds read once, one 76-byte factor record written per factor
         return 16 * n_feat + 16 * (c["C"] + c["S"]) + 76 * F
-    if kernel == "k_lm_solve":  # every evaluation consumes the factor records (76 B each); average over the solves of a sweep
-        if c["K_m"] > 0:  # 2 odometry + 2 mapping solves per sweep
-            return 76 * (F * c["E_o"] + c["K_m"] * c["E_m"]) / 4.0
-        return 76 * F * max(c["E_o"], 2) / 2.0
+    if kernel == "k_lm_solve":
+        # every residual / Jacobian evaluation reads curr + <= 3 matched points = 64 B per factor; a launch is one solve, the
+        # units of a launch are its factor-evaluations — averaged over the solves of a sweep (2 odometry + 2 mapping): (F E_o + K_m E_m) / 4
+        if c["K_m"] > 0:
+            return 64 * (F * c["E_o"] + c["K_m"] * c["E_m"]) / 4.0
+        return 64 * F * max(c["E_o"], 2) / 2.0
     if kernel == "k_lm_compact":
         return 2 * 76 * c["K_m"]
     if kernel == "k_sr_ring":   # ring-ordered cloud in, per-ring voxel centroids + picks out
@@ -128,6 +141,60 @@ def pmc_traffic(workload, kernel):
     if cnt == 0:
         return None, None
     return tot / cnt, rel
+
+
+def _matching_profile(pattern):
+    """Latest profiles/ table of that name whose header carries the content hash of the kernel sources being timed; (lines, relative path) or (None, why)."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not cands:
+        return None, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    now = pmc_summary.csrc_sha256(ROOT)
+    path = cands[-1]
+    rel = os.path.relpath(path, ROOT)
+    try:
+        lines = open(path).read().split("\n")
+    except OSError:
+        return None, None
+    sha = next((l.split(":", 1)[1].strip() for l in lines if l.startswith("# csrc_sha256:")), None)
+    if sha != now:
+        return None, "%s is STALE (measured on csrc %s, timing csrc %s): not quoted" % (rel, sha or "without a hash", now)
+    return lines, rel
+
+
+def rocprof_avg_us(workload, kernel):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of the same command (all instantiations, weighted
+    by calls) — only when that summary was measured on the kernel sources being timed."""
+    lines, src = _matching_profile("r[0-9][0-9]_%s_kernel_stats.txt" % workload)
+    if lines is None:
+        return None, src
+    tot, calls = 0.0, 0
+    for l in lines:
+        f = l.split()
+        if len(f) >= 5 and not l.startswith("#") and l.split("<")[0].split()[0] == kernel:
+            try:
+                calls += int(f[-4]); tot += float(f[-3])
+            except ValueError:
+                pass
+    return (tot / calls if calls else None), src
+
+
+def sq_wait_pct(kernel):
+    """Share of its wave cycles `kernel` spends waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES, single-sequence run), from the committed SQ-counter
+    table when it was measured on the kernel sources being timed."""
+    lines, src = _matching_profile("r[0-9][0-9]_batch1_sq_counters.txt")
+    if lines is None:
+        return None, src
+    num, den = 0.0, 0.0
+    for l in lines:
+        f = l.split()
+        if len(f) >= 7 and not l.startswith("#") and l.split("<")[0].split()[0] == kernel:
+            try:
+                w = float(f[-5]) * int(f[-6]); num += float(f[-2]) * w; den += w
+            except ValueError:
+                pass
+    return (num / den if den else None), src
 
 
 def sweep_bytes(c, with_mapping):
@@ -664,6 +731,9 @@ def main():
         avg_ms = k_ms / max(k_launches, 1)
         traffic, traffic_src = pmc_traffic(args.workload, kernel)
         achieved = kb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the same figures from the committed profiles of the same command, quoted only when they were measured on the kernel sources being timed
+        rp_us, rp_src = rocprof_avg_us(args.workload, kernel)
+        wait_pct, wait_src = sq_wait_pct(kernel)
         out = {
             "metric": "scans/sec end-to-end odometry on 64x2048 cloud", "value": value, "unit": "scans/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * elapsed / K, "per_rank_ms_per_step": [1e3 * s_ / K for s_ in per_rank_s],
@@ -681,7 +751,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": kb,
+                         "algorithmic_bytes_per_unit": ALGORITHMIC_UNIT.get(kernel),
                          "avg_launch_us": 1e3 * avg_ms, "launches_timed": k_launches,
+                         "avg_launch_us_source": "HIP events around every launch of the kernel on its own stream, untraced replay of the timed sweeps (the bracket adds a few us to a ~30 us kernel; rocprof_* below is the kernel's own duration)",
+                         "rocprof_avg_launch_us": rp_us, "rocprof_source": rp_src,
+                         "frac_rocprof": (kb / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
+                         # what the counters say the kernel draws from HBM: PMC bytes per launch / its duration / peak
+                         "counter_frac": (traffic / ((rp_us or 1e3 * avg_ms) * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "sq_wait_pct": wait_pct, "sq_wait_source": wait_src,
+                         "timed_region_s": elapsed,
                          "sweep_algorithmic_bytes": {"B_SR": b_sr, "B_LO": b_lo, "B_MAP": b_map},
                          "end_to_end_frac": (b_sr + b_lo + b_map) * value / world / 1e9 / HBM_PEAK_GBS},
             "counts_last_sweep": counts,

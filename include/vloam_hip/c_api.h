@@ -87,12 +87,13 @@ vloam_status vloam_destroy(vloam_handle* h);
  * single-sequence handles alive in a process, spread over the XCDs for further ones; one compute unit's worth of registers each) that
  * exchange partial sums INSIDE one launch, so all workgroups of a solve must be
  * resident together; a session of a batch can have one odometry and one mapping solve in flight, i.e. 10 such workgroups.  vloam_create_batch
- * refuses (VLOAM_ERR_CAPACITY) when 10 * n_sessions exceeds the device's compute-unit count (256 on MI355X, so n_sessions <= 16 is
- * always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  The one-XCD
+ * refuses (VLOAM_ERR_CAPACITY) when 10 * n_sessions exceeds the device's compute-unit count (256 on MI355X, so n_sessions <= 24 — the
+ * library's own bound, kMaxBatch — is always accepted there); several batched handles on ONE device share that budget — keep the sum of their sessions within it.  The one-XCD
  * placement of a single sequence's solves holds at most 4 solves per XCD (32 compute units, 8 per solve).  When the workgroups of a solve
  * are NOT resident together after all (another process on the GPU, a CU-masked queue, a partitioned device), the solve does not fail: a
  * workgroup that still waits for its partners after ~0.5 s gives up, the lead workgroup runs the whole solve on its own, vloam_get_health
- * counts it, and from the next vloam_sync on the handle launches one-workgroup solves only (slower per solve, no co-residency needed). */
+ * counts it, and from the next ENQUEUE on (the host polls a host-mapped word, no synchronisation needed) the handle launches one-workgroup
+ * solves only (slower per solve, no co-residency needed). */
 vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessions, vloam_handle** out);
 vloam_status vloam_batch_size(vloam_handle* h, int* n_sessions);
 vloam_status vloam_batch_process_scan_device(vloam_handle* h, const void* const* d_xyz_pad4, const int* n);
@@ -132,6 +133,31 @@ vloam_status vloam_set_lo_prior(vloam_handle* h, const double q_xyzw[4], const d
 /* == LaserOdometry::input + solveLO + output (laser_odometry.cpp:135-146,187-536,610-629).
  * Outputs (any may be NULL): world pose q_w_curr/t_w_curr and the frame-to-frame q_last_curr/t_last_curr. */
 vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]);
+
+/* LaserOdometry::input with clouds that are NOT the ones vloam_scan_registration left on the device — the reference deep-copies whatever it is
+ * handed (laser_odometry.cpp:135-146), so a caller may edit or replace the five clouds between the stages.  Call between
+ * vloam_scan_registration and vloam_laser_odometry; host pointers to packed (x, y, z, intensity) floats, intensity = scan line +
+ * SCAN_PERIOD * relTime as scan registration writes it (scan_registration.cpp:262-264); a NULL cloud keeps the device's.  The clouds replace
+ * the sweep's own: this sweep's odometry, the next sweep's CornerLast / SurfLast (laser_odometry.cpp:506-526) and the mapping stage's input
+ * all see them.  Capacity: 768 / 7 680 / 1 536 points for cornerPointsSharp / LessSharp / surfPointsFlat, max_points for the other two.
+ * Stated limit: the two less-clouds must keep scan registration's ordering (scan lines ascending up to the r / r - 1 jitter of
+ * int(intensity)); the adjacent-line walks of laser_odometry.cpp:294-324,371-428 are evaluated from per-line first / last indices. */
+vloam_status vloam_set_odometry_input(vloam_handle* h, const float* laserCloud, int n_full, const float* cornerPointsSharp, int n_sharp,
+                                      const float* cornerPointsLessSharp, int n_less_sharp, const float* surfPointsFlat, int n_flat,
+                                      const float* surfPointsLessFlat, int n_less_flat);
+
+/* q_w_curr / t_w_curr of the sweep in progress (after vloam_laser_odometry) or of the last finished sweep: what LaserOdometry::output hands to
+ * LaserMapping::input (laser_odometry.cpp:610-616). */
+vloam_status vloam_get_odometry_pose(vloam_handle* h, double q_w[4], double t_w[3]);
+
+/* LaserMapping::input with clouds / an odometry pose that are NOT LaserOdometry::output's (laser_mapping.cpp:167-196 copies what it is handed; on a
+ * sweep skipped by mapping_skip_frame only the pose).  Call between vloam_laser_odometry and vloam_laser_mapping; NULL keeps the device's.  Only
+ * this sweep's mapping (and the /velodyne_cloud_registered product, vloam_get_features(11)) sees them — the odometry keeps its own
+ * CornerLast / SurfLast, like the reference's separate copies.  Stated limit: q_wodom_curr must be a unit quaternion (as any
+ * Eigen::Quaterniond an odometry produces): the solver's closed-form Jacobians are those of a rotation, the reference's autodiff
+ * differentiates Eigen's un-normalised q * v — with |q|^2 = 1 + 5e-6 the map poses part by 1e-9 (measured, tests/test_gpu_stage_inputs.py). */
+vloam_status vloam_set_mapping_input(vloam_handle* h, const float* laserCloudCornerLast, int n_corner, const float* laserCloudSurfLast, int n_surf,
+                                     const float* laserCloudFullRes, int n_full, const double q_wodom_curr[4], const double t_wodom_curr[3]);
 
 /* == LaserMapping::input + solveMapping + the pose of publish() (laser_mapping.cpp:167-196,198-708,718-757).  Outputs the
  * map-frame pose publish() reports: q_w_curr / t_w_curr after a mapped sweep, the high-frequency pose

@@ -67,6 +67,30 @@ class Oracle:
         cloud = np.ascontiguousarray(cloud, dtype=np.float32)
         return self.L.orc_scan_registration(self.h, _p(cloud, F), cloud.shape[0])
 
+    # ---- the façade stage by stage, hand-overs editable in between (lidar_odometry_mapping.cpp:73-154)
+    def stage_sr(self, cloud):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        return self.L.orc_stage_sr(self.h, c.ctypes.data_as(C.c_void_p), c.shape[0])
+
+    def set_sr_cloud(self, which, pts):
+        c = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+        assert self.L.orc_set_sr_cloud(self.h, which, c.ctypes.data_as(C.c_void_p), c.shape[0]) == 0
+
+    def stage_lo(self):
+        return self.L.orc_stage_lo(self.h)
+
+    def stage_map(self, corner=None, surf=None, full=None, q=None, t=None):
+        def arr(a):
+            if a is None:
+                return None, None, 0
+            a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
+            return a, a.ctypes.data_as(C.c_void_p), a.shape[0]
+        keep = [arr(corner), arr(surf), arr(full)]
+        qa = None if q is None else np.ascontiguousarray(q, dtype=np.float64)
+        ta = None if t is None else np.ascontiguousarray(t, dtype=np.float64)
+        return self.L.orc_stage_map(self.h, keep[0][1], keep[0][2], keep[1][1], keep[1][2], keep[2][1], keep[2][2],
+                                    None if qa is None else qa.ctypes.data_as(C.c_void_p), None if ta is None else ta.ctypes.data_as(C.c_void_p))
+
     def set_vo_prior(self, q, t):
         q = np.ascontiguousarray(q, dtype=np.float64)
         t = np.ascontiguousarray(t, dtype=np.float64)

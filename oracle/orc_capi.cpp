@@ -70,6 +70,39 @@ int orc_process(orc_handle* h, const float* xyz_pad4, int n) { return h->p->proc
 int orc_scan_registration(orc_handle* h, const float* xyz_pad4, int n) {
   return scan_registration(xyz_pad4, n, h->p->cfg, &h->p->sr) ? 0 : -1;
 }
+// ---- the façade stage by stage, with the hand-overs in the caller's reach (lidar_odometry_mapping.cpp:73-154 passes clouds and the pose from
+// stage to stage BY VALUE: LaserOdometry::input / LaserMapping::input deep-copy whatever they are handed, laser_odometry.cpp:141-145,
+// laser_mapping.cpp:172-181) — tests of vloam_set_odometry_input / vloam_set_mapping_input edit them in between
+int orc_stage_sr(orc_handle* h, const float* xyz_pad4, int n) {
+  h->p->lm.reset();
+  return scan_registration(xyz_pad4, n, h->p->cfg, &h->p->sr) ? 0 : -1;
+}
+// which: 0 laserCloud, 1 cornerPointsSharp, 2 cornerPointsLessSharp, 3 surfPointsFlat, 4 surfPointsLessFlat (what LaserOdometry::input will copy)
+int orc_set_sr_cloud(orc_handle* h, int which, const float* xyzi, int n) {
+  ScanRegistrationResult& s = h->p->sr;
+  Cloud* c[5] = {&s.laserCloud, &s.cornerPointsSharp, &s.cornerPointsLessSharp, &s.surfPointsFlat, &s.surfPointsLessFlat};
+  if (which < 0 || which > 4 || n < 0) return -1;
+  c[which]->resize((size_t)n);
+  if (n) std::memcpy(c[which]->data(), xyzi, sizeof(PointXYZI) * (size_t)n);
+  return 0;
+}
+int orc_stage_lo(orc_handle* h) { h->p->lo.input(h->p->sr); h->p->lo.solveLO(); return 0; }
+// null cloud / pose = LaserOdometry::output's own
+int orc_stage_map(orc_handle* h, const float* corner, int nc, const float* surf, int ns, const float* full, int nf, const double* q, const double* t) {
+  Pipeline& p = *h->p;
+  if (!p.do_mapping) return -1;
+  Cloud c = p.lo.laserCloudCornerLast, s = p.lo.laserCloudSurfLast, f = p.lo.laserCloudFullRes;
+  if (corner) { c.resize((size_t)nc); if (nc) std::memcpy(c.data(), corner, sizeof(PointXYZI) * (size_t)nc); }
+  if (surf) { s.resize((size_t)ns); if (ns) std::memcpy(s.data(), surf, sizeof(PointXYZI) * (size_t)ns); }
+  if (full) { f.resize((size_t)nf); if (nf) std::memcpy(f.data(), full, sizeof(PointXYZI) * (size_t)nf); }
+  Quat<double> qq = p.lo.q_w_curr;
+  V3<double> tt = p.lo.t_w_curr;
+  if (q) { qq.x = q[0]; qq.y = q[1]; qq.z = q[2]; qq.w = q[3]; }
+  if (t) { tt.x = t[0]; tt.y = t[1]; tt.z = t[2]; }
+  p.lm.input(c, s, f, qq, tt, p.lo.skip_frame);
+  if (!p.lo.skip_frame) p.lm.solveMapping();
+  return 0;
+}
 void orc_set_vo_prior(orc_handle* h, const double* q, const double* t) { h->p->lo.set_vo_prior(q, t); }
 void orc_stage_ms(orc_handle* h, double* ms3) { for (int i = 0; i < 3; i++) ms3[i] = h->p->stage_ms[i]; }
 

@@ -46,10 +46,11 @@ def test_create_validates_and_has_no_cpu_fallback(vl):
         assert st == vl.ERR_NO_DEVICE and b"no CPU fallback" in L.vloam_last_error()
     assert L.vloam_destroy(None) == vl.VLOAM_OK
     assert L.vloam_reset_frame(None) == vl.ERR_INVALID
-    # argument checks that need no device: batch size, mapping leaf (8-bit voxel index inside a 50 m cube)
+    # argument checks that need no device: batch size, mapping leaf (75 x radix^3 voxel positions in a 32-bit tie rank: >= 0.132 m)
     assert L.vloam_create_batch(C.byref(vl.default_config()), 0, 0, C.byref(h)) == vl.ERR_INVALID
     assert L.vloam_create_batch(C.byref(vl.default_config()), 0, 1000, C.byref(h)) == vl.ERR_INVALID and b"n_sessions" in L.vloam_last_error()
-    assert L.vloam_create(C.byref(vl.default_config(mapping_line_resolution=0.2)), 0, C.byref(h)) == vl.ERR_INVALID
+    assert L.vloam_create(C.byref(vl.default_config(mapping_line_resolution=0.13)), 0, C.byref(h)) == vl.ERR_INVALID and b"0.132" in L.vloam_last_error()
+    assert L.vloam_create(C.byref(vl.default_config(mapping_plane_resolution=0.0)), 0, C.byref(h)) == vl.ERR_INVALID
     assert L.vloam_select_session(None, 0) == vl.ERR_INVALID and L.vloam_batch_size(None, None) == vl.ERR_INVALID
     L.vloam_profile_kernel_name.restype = C.c_char_p
     names = [L.vloam_profile_kernel_name(k).decode() for k in range(L.vloam_profile_kernel_count())]

@@ -45,13 +45,14 @@ int main(int argc, char** argv) {
     std::printf("%d %zu %zu %zu %zu %zu %d", k, full.size(), sharp.size(), lessSharp.size(), flat.size(), lessFlat.size(), (int)skip_frame);
     for (int i = 0; i < 4; i++) std::printf(" %.17g", q[i]);
     for (int i = 0; i < 3; i++) std::printf(" %.17g", t[i]);
-    for (int i = 0; i < 4; i++) std::printf(" %.17g", LOAM.laser_mapping.q_w_curr[i]);
-    for (int i = 0; i < 3; i++) std::printf(" %.17g", LOAM.laser_mapping.t_w_curr[i]);
+    // what LaserMapping::publish reports: q_w_curr after a mapped sweep, the high-frequency pose after a skipped one (laser_mapping.cpp:718-757)
+    for (int i = 0; i < 4; i++) std::printf(" %.17g", skip_frame ? LOAM.laser_mapping.q_w_curr_highfreq[i] : LOAM.laser_mapping.q_w_curr[i]);
+    for (int i = 0; i < 3; i++) std::printf(" %.17g", skip_frame ? LOAM.laser_mapping.t_w_curr_highfreq[i] : LOAM.laser_mapping.t_w_curr[i]);
     std::printf("\n");
-    if (k == 1) {   // a substituted cloud must be refused, not silently ignored
+    if (k == 1) {   // a substituted cloud at the wrong moment (the sweep's odometry has run) is an ORDER error, not silence
       vloam::Cloud bogus = sharp; bogus.pop_back();
       bool threw = false;
-      try { LOAM.laser_odometry.input(full, bogus, lessSharp, flat, lessFlat); } catch (const std::invalid_argument&) { threw = true; }
+      try { LOAM.laser_odometry.input(full, bogus, lessSharp, flat, lessFlat); } catch (const std::runtime_error&) { threw = true; }
       if (!threw) return 3;
     }
   }
@@ -189,3 +190,42 @@ def test_cpp_visual_odometry_class_from_images(tmp_path, orc, synth, vl):
             v = np.array([float(x) for x in rows[k][5:11]])
             assert np.linalg.norm(v[:3] - r["angles"]) < 1e-8 and np.linalg.norm(v[3:] - r["t"]) < 1e-8
         prev = images[k]
+
+
+def test_reference_typed_facade_on_the_gpu(tmp_path, orc, sweeps, vl):
+    """tests/cpp/ref_facade_probe.cpp: the façade of lidar_odometry_mapping.cpp:73-154 — pcl::PointCloud<PointType>::Ptr hand-overs,
+    Eigen::Quaterniond / Vector3d poses, `if (!skip_frame) solveMapping(); publish();` — through compat.hpp's templates with the stand-in types of
+    tests/stubs/, on the GPU, against the oracle driven stage by stage; at sweep 3 the caller thins laserCloudCornerLast before
+    LaserMapping::input (uploaded by vloam_set_mapping_input)."""
+    n, shape, skip = 6, (64, 512), 2
+    clouds = [sweeps(shape[0], shape[1], k) for k in range(n)]
+    data = tmp_path / "sweeps.bin"
+    np.stack(clouds).astype(np.float32).tofile(data)
+    exe = tmp_path / "ref_probe"
+    libdir = os.path.join(ROOT, "vloam-cmu-16833_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "ref_facade_probe.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lvloam_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(data), str(n), str(clouds[0].shape[0]), str(skip)]).decode().strip().split("\n")
+    assert len(out) == n + 2, out
+    o = orc.Oracle(with_mapping=True, mapping_skip_frame=skip)
+    for k in range(n):
+        f = out[k].split()
+        assert o.stage_sr(clouds[k]) == 0
+        counts = [o.cloud(w).shape[0] for w in range(5)]
+        o.stage_lo()
+        corner = o.cloud(5)
+        thin = corner[::2] if k == 3 else None
+        assert o.stage_map(corner=thin) == 0
+        assert [int(v) for v in f[1:6]] == counts, "sweep %d feature counts" % k
+        skipped = ((k + 1) % skip) != 0
+        assert int(f[6]) == int(skipped)
+        v = np.array([float(x) for x in f[7:21]])
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert qdist(v[0:4], qw) < 1e-8 and np.linalg.norm(v[4:7] - tw) < 1e-8, "sweep %d odometry pose" % k
+        assert qdist(v[7:11], qm) < 1e-8 and np.linalg.norm(v[11:14] - tm) < 1e-8, "sweep %d mapping pose" % k
+        assert int(f[21]) == (thin.shape[0] if k == 3 else corner.shape[0]) and int(f[22]) == o.cloud(6).shape[0]
+    info = o.map_info()
+    assert int(out[n].split()[1]) == info["total_corner"] + info["total_surf"]
+    assert out[n + 1].split() == ["vo", "1", "0"]

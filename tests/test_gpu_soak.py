@@ -118,3 +118,20 @@ def test_cooperative_solve_degrades_to_one_workgroup(vl, orc, synth, monkeypatch
     check(n - 1)
     assert hs.health()["fallback_solves"] == h1["fallback_solves"] and hb.health()["fallback_solves"] == h2["fallback_solves"]   # one-workgroup launches have no partners to miss
     hs.close(); hb.close()
+    # ... and the switch does not wait for a vloam_sync: a host that streams sweeps sees the solver's host-mapped word before its next enqueue.
+    # 40 sweeps without a sync = 156 solves; the host runs at most 8 sweeps (32 solves) ahead of the device.
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=512, n_sweeps=41, seed_scene=91, seed_traj=8)
+    hn = vl.Handle(0, with_mapping=1)
+    for k in range(40):
+        hn.process_scan(seq.sweep(k))
+    hn.sync()
+    fb = hn.health()["fallback_solves"]
+    assert 0 < fb < 80, fb
+    hn.close()
+    monkeypatch.setenv("VLOAM_LM_SPIN_LIMIT", "0")   # garbage / zero means "default", not "give up at the first poll"
+    hd = vl.Handle(0, with_mapping=1)
+    for k in range(6):
+        hd.process_scan(seq.sweep(k))
+    hd.sync()
+    assert hd.health()["fallback_solves"] == 0
+    hd.close()

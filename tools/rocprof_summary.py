@@ -4,8 +4,12 @@
 Kernels that only run when a handle is created or for host-side bookkeeping (k_lm_sync_probe: the one-off placement probe of the
 solver's sync words, runtime fill / copy kernels, k_map_error_fetch) are listed separately and kept OUT of the percentage column, which
 is the share of the per-sweep kernels only."""
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import csrc_sha256
 
 SETUP = ("k_lm_sync_probe", "__amd_rocclr_", "k_map_error_fetch", "k_map_export", "k_map_register")
 
@@ -23,6 +27,7 @@ def main(db_path, out_path, note=""):
         f.write("# rocprofv3 --kernel-trace --stats  (durations in microseconds; pct = share of the per-sweep kernels' GPU time)\n")
         if note:
             f.write("# %s\n" % note)
+        f.write("# csrc_sha256: %s\n" % csrc_sha256())   # bench.py quotes this table only while it times the same kernel sources
         f.write("%-34s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, t, avg, _ in sweep:
             f.write("%-34s %8d %14.3f %12.3f %8.2f\n" % (short(name), calls, t, avg, 100.0 * t / tot))

@@ -7,7 +7,11 @@ counter collection, so no residency figure is derived from it any more.)
 Usage: sq_summary.py counter_collection.csv [out.txt]"""
 import collections
 import csv
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import csrc_sha256
 
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -15,7 +19,8 @@ for row in csv.DictReader(open(sys.argv[1])):
     name = row["Kernel_Name"].split("(")[0].replace("vloam::", "").replace("void ", "")
     tot[name][row["Counter_Name"]] += float(row["Counter_Value"])
     cnt[name][row["Counter_Name"]] += 1
-lines = ["%-30s %7s %12s %12s %8s %8s %8s" % ("kernel", "calls", "wave_qcyc", "wave_us", "active%", "wait%", "stall%")]
+lines = ["# csrc_sha256: %s" % csrc_sha256(),
+         "%-30s %7s %12s %12s %8s %8s %8s" % ("kernel", "calls", "wave_qcyc", "wave_us", "active%", "wait%", "stall%")]
 rows = []
 for k in tot:
     n = max(cnt[k].get("SQ_WAVE_CYCLES", 1), 1)

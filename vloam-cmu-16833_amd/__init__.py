@@ -144,6 +144,34 @@ class Handle:
         t = np.ascontiguousarray(t, dtype=np.float64)
         self._chk(self.L.vloam_set_lo_prior(self.h, _fp(q), _fp(t)))
 
+    @staticmethod
+    def _cloud_arg(c):
+        if c is None:
+            return None, None, 0
+        a = np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 4)
+        if a.shape[0] == 0:
+            a = np.zeros((1, 4), np.float32)   # a non-null address for an empty substituted cloud
+            return a, _fp(a), 0
+        return a, _fp(a), a.shape[0]
+
+    def set_odometry_input(self, laserCloud=None, cornerPointsSharp=None, cornerPointsLessSharp=None, surfPointsFlat=None, surfPointsLessFlat=None):
+        """LaserOdometry::input with clouds that are not scan registration's (laser_odometry.cpp:135-146); None keeps the device's."""
+        a = [self._cloud_arg(c) for c in (laserCloud, cornerPointsSharp, cornerPointsLessSharp, surfPointsFlat, surfPointsLessFlat)]
+        self._chk(self.L.vloam_set_odometry_input(self.h, a[0][1], a[0][2], a[1][1], a[1][2], a[2][1], a[2][2], a[3][1], a[3][2], a[4][1], a[4][2]))
+
+    def odometry_pose(self):
+        q, t = np.zeros(4), np.zeros(3)
+        self._chk(self.L.vloam_get_odometry_pose(self.h, _fp(q), _fp(t)))
+        return q, t
+
+    def set_mapping_input(self, laserCloudCornerLast=None, laserCloudSurfLast=None, laserCloudFullRes=None, q_wodom_curr=None, t_wodom_curr=None):
+        """LaserMapping::input with clouds / an odometry pose that are not LaserOdometry::output's (laser_mapping.cpp:167-196)."""
+        a = [self._cloud_arg(c) for c in (laserCloudCornerLast, laserCloudSurfLast, laserCloudFullRes)]
+        q = None if q_wodom_curr is None else np.ascontiguousarray(q_wodom_curr, dtype=np.float64)
+        t = None if t_wodom_curr is None else np.ascontiguousarray(t_wodom_curr, dtype=np.float64)
+        self._chk(self.L.vloam_set_mapping_input(self.h, a[0][1], a[0][2], a[1][1], a[1][2], a[2][1], a[2][2], None if q is None else _fp(q),
+                                                 None if t is None else _fp(t)))
+
     def laser_odometry(self):
         qw, tw, ql, tl = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
         self._chk(self.L.vloam_laser_odometry(self.h, _fp(qw), _fp(tw), _fp(ql), _fp(tl)))

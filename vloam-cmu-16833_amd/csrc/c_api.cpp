@@ -32,6 +32,7 @@ static thread_local std::string g_err;
 static const bool g_host_prof = getenv("VLOAM_HOST_PROF") != nullptr;
 namespace vloam { int g_vl_plain_events = getenv("VLOAM_PLAIN_EVENTS") ? atoi(getenv("VLOAM_PLAIN_EVENTS")) : 0; }
 static const int g_enqueue_order = getenv("VLOAM_ENQUEUE_ORDER") ? atoi(getenv("VLOAM_ENQUEUE_ORDER")) : 0;
+static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 1;   // 0 = the ring + copy-stream form
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void set_err(const char* fmt, ...) {
   char buf[512];
@@ -74,6 +75,7 @@ struct vloam_handle {
   double* sync_pool = nullptr;
   bool counted_single = false; // this handle is in g_single_handles
   int* ring_watch = nullptr;   // host-mapped [kMaxBatch]: a ring of that session came near the small ring tier's capacity (k_sr_ring)
+  int* coop_flag = nullptr;    // host-mapped [1]: a cooperative solve of this handle degraded to one workgroup (k_lm_solve) — polled before every enqueue
   long long fallback_solves = 0;   // cooperative solves that degraded to one workgroup, as of the last vloam_sync
   int frame = 0;        // sweeps accepted (scan registration enqueued)
   int lo_done = 0;      // sweeps whose laser odometry has been enqueued (vloam_process_scan defers it, see drain_deferred)
@@ -86,13 +88,18 @@ struct vloam_handle {
   // its buffer, instead of sitting behind it on the scan-registration stream.  ev_in_copied: the copy has landed (the SR stream waits for it);
   // ev_in_free: the last reader of the slot on the SR stream is through (the next copy into the slot waits for it).
   static constexpr int kInRing = 4;
-  float4* d_in = nullptr;         // [kInRing][max_points]
+  float4* d_in = nullptr;         // [1 | kInRing][max_points] (the ring only with VLOAM_STAGE_INLINE=0)
   hipStream_t s_copy = nullptr;   // created by the first host-pointer call
   hipEvent_t ev_in_copied[kInRing] = {}, ev_in_free[kInRing] = {};
   hipEvent_t in_reader[kInRing] = {};   // the event that marks the slot's last reader done: the sweep's own "scan registration finished" / "VO depth map
                                         // built" event when the slot fed a whole-sweep call (no extra marker packet), else ev_in_free[slot]
   int in_next = 0, in_slot = -1;  // next ring slot; the slot being staged by the call in progress
   SRBuffers sr[kSets];  // rotating sets: S, cloud and the feature clouds are per set, the scratch arrays are shared (SR stream only)
+  // clouds / odometry pose the caller handed to LaserMapping::input instead of the odometry's own (vloam_set_mapping_input): the mapping of
+  // that one sweep reads them from here, the odometry keeps its CornerLast / SurfLast (the reference's stages hold separate copies)
+  SRBuffers sub{};             // S, cloud, less_sharp, less_flat only
+  double* sub_row = nullptr;   // [14] trajectory row of the substituted sweep: odometry pose in, map pose out
+  int sub_cloud_frame = -1, sub_pose_frame = -1;
   // laser odometry
   LOState* lo = nullptr;
   FactorTable lo_F{};
@@ -145,7 +152,7 @@ static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
   F->rowmask = nullptr;  // the odometry / VO tables use the per-row counters
   F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated
   F->err = nullptr;    // set once the mapping context (owner of the sticky error word) exists
-  F->fallbacks = nullptr; F->gen = 0; F->spin_limit = 1 << 18;
+  F->fallbacks = nullptr; F->host_degraded = nullptr; F->gen = 0; F->spin_limit = 1 << 18;
   return VLOAM_OK;
 }
 
@@ -158,7 +165,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   const vloam_config* cfg = &h->cfg;
   const int P = cfg->max_points;
   h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
-  TAKE(h->d_in, (size_t)vloam_handle::kInRing * (size_t)P);
+  TAKE(h->d_in, (size_t)(g_stage_inline ? 1 : vloam_handle::kInRing) * (size_t)P);   // the ring of input buffers only where the ring form is selected (the default stages through slot 0)
   SRBuffers& a = h->sr[0];
   TAKE(a.sid, (size_t)P);
   TAKE(a.ori, (size_t)P);
@@ -193,6 +200,11 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
       TAKE(h->grid[k].pts[g], (g & 1) ? (size_t)P : (size_t)kMaxLessSharp);
     }
   }
+  TAKE(h->sub.S, 1);
+  TAKE(h->sub.cloud, (size_t)P);
+  TAKE(h->sub.less_sharp, kMaxLessSharp);
+  TAKE(h->sub.less_flat, (size_t)P);
+  TAKE(h->sub_row, 14);
   TAKE(h->lo, 1);
   vloam_status s = take_factor_table(A, &h->lo_F, kMaxLoFactors);
   if (s != VLOAM_OK) return s;
@@ -382,6 +394,18 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
       HIPCHK(hipMemcpyAsync(h->lo, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
       if (hipHostMalloc((void**)&h->ring_watch, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) { h->ring_watch = nullptr; set_err("hipHostMalloc failed"); return VLOAM_ERR_HIP; }
       for (int b = 0; b < kMaxBatch; b++) h->ring_watch[b] = 0;
+      if (hipHostMalloc((void**)&h->coop_flag, sizeof(int), hipHostMallocMapped) != hipSuccess) { h->coop_flag = nullptr; set_err("hipHostMalloc failed"); return VLOAM_ERR_HIP; }
+      *h->coop_flag = 0;
+      h->lo_F.host_degraded = h->coop_flag; h->map.F[0].host_degraded = h->coop_flag; h->map.F[1].host_degraded = h->coop_flag;
+      {
+        // patience of the workgroups of a cooperative solve (polls before one gives up on its partners, ~0.2 s by default): read ONCE per handle,
+        // here — not on the enqueue path, where a getenv per launch would also race a host thread's setenv.  Tests force the degraded path
+        // with VLOAM_LM_SPIN_LIMIT=1; anything below 1 (a typo, an empty string) would degrade every solve for good and means "default".
+        const char* e = getenv("VLOAM_LM_SPIN_LIMIT");
+        const int v = e ? atoi(e) : 0;
+        const int limit = v >= 1 ? v : (1 << 18);
+        h->lo_F.spin_limit = limit; h->map.F[0].spin_limit = limit; h->map.F[1].spin_limit = limit; h->vo.F.spin_limit = limit;
+      }
       s = map_init(&h->map, h->stream);
       if (s != VLOAM_OK) { set_err("map_init failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
       {
@@ -450,6 +474,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
   for (hipStream_t st : {h->s_copy, h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamDestroy(st);
   map_destroy(&h->map);
   if (h->ring_watch) (void)hipHostFree(h->ring_watch);
+  if (h->coop_flag) (void)hipHostFree(h->coop_flag);
   delete h;
   return VLOAM_OK;
 }
@@ -524,7 +549,15 @@ static vloam_status enqueue_sr(vloam_handle* h, const BatchIn& bi) {
   return VLOAM_OK;
 }
 
+// A cooperative solve that found its partners missing finished on one workgroup and said so in a host-mapped word: from the next enqueue on
+// this handle launches one-workgroup solves (no host synchronisation needed: a host that streams thousands of sweeps between two vloam_sync
+// calls pays the ~0.2 s wait once, not per solve).
+static inline void poll_coop_flag(vloam_handle* h) {
+  if (!h->se.no_coop && h->coop_flag && __atomic_load_n(h->coop_flag, __ATOMIC_RELAXED)) { h->se.no_coop = 1; h->map.se.no_coop = 1; h->vo.se.no_coop = 1; }
+}
+
 static vloam_status enqueue_lo(vloam_handle* h, int frame) {
+  poll_coop_flag(h);
   const int cur = set_of(frame), prev = set_of(frame + vloam_handle::kSets - 1);
   HIPCHK(hipStreamWaitEvent(h->s_lo, h->ev_sr[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[2], h->s_lo));
@@ -561,14 +594,17 @@ static vloam_status enqueue_lo(vloam_handle* h, int frame) {
 }
 
 static vloam_status enqueue_map(vloam_handle* h, int frame) {
+  poll_coop_flag(h);
   const int cur = set_of(frame);
   HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_lo[cur], 0));
   HIPCHK(hipStreamWaitEvent(h->s_map, h->ev_stack[cur], 0));
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[4], h->s_map));
   // LaserOdometry::output: skip_frame = (frameCount % mapping_skip_frame != 0), frameCount already incremented (laser_odometry.cpp:535,618)
   const bool skip = ((frame + 1) % h->cfg.mapping_skip_frame) != 0;
-  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, h->traj + (size_t)frame * 14, skip, cur, &h->prof, h->ev_map[cur]);
+  const bool sub_pose = h->sub_pose_frame == frame;   // LaserMapping::input was handed another odometry pose (vloam_set_mapping_input)
+  vloam_status s = map_enqueue(&h->map, h->cfg, h->s_map, h->sr[cur], h->lo, sub_pose ? h->sub_row : h->traj + (size_t)frame * 14, skip, cur, &h->prof, h->ev_map[cur]);
   if (s != VLOAM_OK) { set_err("map_enqueue failed: %s", hipGetErrorString(hipGetLastError())); return VLOAM_ERR_HIP; }
+  if (sub_pose) HIPCHK(hipMemcpyAsync(h->traj + (size_t)frame * 14 + 7, h->sub_row + 7, 7 * sizeof(double), hipMemcpyDeviceToDevice, h->s_map));   // the map half of the log
   if (h->cfg.timing) HIPCHK(hipEventRecord(h->ev[5], h->s_map));
   return VLOAM_OK;
 }
@@ -630,7 +666,6 @@ static vloam_status finish_frame(vloam_handle* h) {
 // reads ahead of everybody's misses in the L2 queues) — same throughput, not kept.
 // Pageable source memory: hipMemcpyAsync has taken its copy when it returns (the caller may reuse the buffer at once).  Pinned source
 // memory (hipHostMalloc / hipHostRegister) is read by DMA later: it must stay unchanged until the next vloam_sync() (c_api.h).
-static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 1;   // 0 = the ring + copy-stream form
 static vloam_status stage_begin(vloam_handle* h) {
   if (g_stage_inline) { h->in_slot = 0; return VLOAM_OK; }
   if (!h->s_copy) {
@@ -673,7 +708,7 @@ static_assert(vloam_handle::kInRing < vloam_handle::kSets, "a slot's reader even
 #define STAGE_ONE(h, xyz, n, dptr)                                                                              \
   const float4* dptr = nullptr;                                                                                 \
   { vloam_status s_ = stage_begin(h); if (s_ == VLOAM_OK) s_ = stage_sweep(h, 0, xyz, n, &dptr);               \
-    if (s_ == VLOAM_OK) s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+    if (s_ == VLOAM_OK) s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
 
 // ------------------------------------------------------------------ stage-wise API (façade order)
 vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
@@ -712,6 +747,7 @@ vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int ca
   const int cur = set_of(f);
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   SRBuffers bsel = h->sr[cur];
+  if (which == 11 && h->sub_cloud_frame == f) { bsel.cloud = h->sub.cloud; bsel.S = h->sub.S; }   // laserCloudFullRes as handed to LaserMapping::input
   bsel.rebase((size_t)h->sel * h->se.ss);
   FrameScalars S;
   HIPCHK(hipMemcpy(&S, bsel.S, sizeof(S), hipMemcpyDeviceToHost));
@@ -748,6 +784,103 @@ vloam_status vloam_set_lo_prior(vloam_handle* h, const double q[4], const double
   double buf[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
   HIPCHK(hipMemcpyAsync(h->lo->prior_q, buf, sizeof(buf), hipMemcpyHostToDevice, h->s_lo));
   HIPCHK(hipStreamSynchronize(h->s_lo));
+  return VLOAM_OK;
+}
+
+// LaserOdometry::input with clouds that are NOT what scan registration left on the device (the reference deep-copies whatever it is handed,
+// laser_odometry.cpp:141-145).  Between vloam_scan_registration and vloam_laser_odometry; a null cloud keeps the device's.  The clouds go
+// into the sweep's buffer set, and what scan registration had derived from them is rebuilt: counts, the NN grids over the two less-clouds
+// (the NEXT sweep's CornerLast / SurfLast, laser_odometry.cpp:506-526) and the mapping stage's VoxelGrid of them.
+vloam_status vloam_set_odometry_input(vloam_handle* h, const float* laserCloud, int n_full, const float* cornerPointsSharp, int n_sharp,
+                                      const float* cornerPointsLessSharp, int n_less_sharp, const float* surfPointsFlat, int n_flat,
+                                      const float* surfPointsLessFlat, int n_less_flat) {
+  if (!h) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
+  HIPCHK(hipSetDevice(h->device));
+  if (h->stage != 1) { set_err("vloam_set_odometry_input belongs between scan registration and laser odometry"); return VLOAM_ERR_ORDER; }
+  const float* src[5] = {laserCloud, cornerPointsSharp, cornerPointsLessSharp, surfPointsFlat, surfPointsLessFlat};
+  int n[5] = {n_full, n_sharp, n_less_sharp, n_flat, n_less_flat};
+  const int cap[5] = {h->cfg.max_points, kMaxSharp, kMaxLessSharp, kMaxFlat, h->cfg.max_points};
+  for (int k = 0; k < 5; k++) {
+    if (!src[k]) { n[k] = -1; continue; }
+    if (n[k] < 0) { set_err("negative cloud size"); return VLOAM_ERR_INVALID; }
+    if (n[k] > cap[k]) { set_err("substituted cloud %d holds %d points, the buffer takes %d", k, n[k], cap[k]); return VLOAM_ERR_CAPACITY; }
+  }
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  const int cur = set_of(h->frame);
+  const SRBuffers& b = h->sr[cur];
+  float4* dst[5] = {b.cloud, b.sharp, b.less_sharp, b.flat, b.less_flat};
+  for (int k = 0; k < 5; k++) if (src[k] && n[k] > 0) HIPCHK(hipMemcpy(dst[k], src[k], (size_t)n[k] * sizeof(float4), hipMemcpyHostToDevice));
+  sr_adopt_launch(h->stream, b, n[0], n[1], n[2], n[3], n[4]);
+  if (src[2] || src[4]) {
+    lo_grid_build_launch(h->stream, h->se, b.less_sharp, b.less_flat, b.S, h->grid[cur], &h->prof);
+    HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
+    if (h->cfg.with_mapping && ((h->frame + 1) % h->cfg.mapping_skip_frame) == 0) {
+      HIPCHK(hipStreamWaitEvent(h->s_ds, h->ev_sr[cur], 0));
+      if (map_stack_enqueue(&h->map, h->s_ds, b, cur, &h->prof, h->ev_stack[cur]) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }
+    }
+  } else HIPCHK(hipEventRecord(h->ev_sr[cur], h->stream));
+  HIPCHK(hipGetLastError());
+  return VLOAM_OK;
+}
+
+// The laser-odometry pose of the sweep in progress (after vloam_laser_odometry) or of the last finished sweep: q_w_curr / t_w_curr as
+// LaserOdometry::output hands them on (laser_odometry.cpp:610-616).
+vloam_status vloam_get_odometry_pose(vloam_handle* h, double q_w[4], double t_w[3]) {
+  if (!h) return VLOAM_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
+  double row[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (f < h->cfg.max_frames && (h->stage == 2 || h->frame > 0)) HIPCHK(hipMemcpy(row, SEL(h, h->traj) + (size_t)f * 14, sizeof(row), hipMemcpyDeviceToHost));
+  if (q_w) memcpy(q_w, row, sizeof(double) * 4);
+  if (t_w) memcpy(t_w, row + 4, sizeof(double) * 3);
+  return VLOAM_OK;
+}
+
+// LaserMapping::input with clouds / an odometry pose that are NOT LaserOdometry::output's (laser_mapping.cpp:167-196 copies what it is handed;
+// on a skipped sweep only the pose, :172-181).  Between vloam_laser_odometry and vloam_laser_mapping; null = keep the device's.  Only this
+// sweep's mapping sees them: the odometry's CornerLast / SurfLast stay what they were.
+vloam_status vloam_set_mapping_input(vloam_handle* h, const float* laserCloudCornerLast, int n_corner, const float* laserCloudSurfLast, int n_surf,
+                                     const float* laserCloudFullRes, int n_full, const double q_wodom_curr[4], const double t_wodom_curr[3]) {
+  if (!h) return VLOAM_ERR_INVALID;
+  SINGLE_SESSION_ONLY(h);
+  HIPCHK(hipSetDevice(h->device));
+  if (h->stage != 2 || !h->cfg.with_mapping) { set_err("vloam_set_mapping_input belongs between laser odometry and laser mapping of a handle with mapping"); return VLOAM_ERR_ORDER; }
+  if ((laserCloudCornerLast && (n_corner < 0 || n_corner > kMaxLessSharp)) || (laserCloudSurfLast && (n_surf < 0 || n_surf > h->cfg.max_points)) ||
+      (laserCloudFullRes && (n_full < 0 || n_full > h->cfg.max_points))) { set_err("substituted cloud does not fit its buffer"); return VLOAM_ERR_CAPACITY; }
+  if ((q_wodom_curr == nullptr) != (t_wodom_curr == nullptr)) { set_err("the odometry pose is q AND t"); return VLOAM_ERR_INVALID; }
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  const int frame = h->frame, cur = set_of(frame);
+  const bool skip = ((frame + 1) % h->cfg.mapping_skip_frame) != 0;
+  if (q_wodom_curr) {
+    double row[14];
+    HIPCHK(hipMemcpy(row, h->traj + (size_t)frame * 14, sizeof(row), hipMemcpyDeviceToHost));
+    memcpy(row, q_wodom_curr, 4 * sizeof(double)); memcpy(row + 4, t_wodom_curr, 3 * sizeof(double));
+    HIPCHK(hipMemcpy(h->sub_row, row, sizeof(row), hipMemcpyHostToDevice));
+    h->sub_pose_frame = frame;
+  }
+  if (!skip && (laserCloudCornerLast || laserCloudSurfLast || laserCloudFullRes)) {
+    const SRBuffers& b = h->sr[cur];
+    FrameScalars S;
+    HIPCHK(hipMemcpy(&S, b.S, sizeof(S), hipMemcpyDeviceToHost));
+    struct { const float* src; int n; float4* own; int n_own; float4* dst; } c[3] = {
+      {laserCloudCornerLast, n_corner, b.less_sharp, S.n_less_sharp, h->sub.less_sharp}, {laserCloudSurfLast, n_surf, b.less_flat, S.n_less_flat, h->sub.less_flat},
+      {laserCloudFullRes, n_full, b.cloud, S.N2, h->sub.cloud}};
+    int n[3];
+    for (int k = 0; k < 3; k++) {
+      n[k] = c[k].src ? c[k].n : c[k].n_own;
+      if (n[k] > 0) HIPCHK(hipMemcpy(c[k].dst, c[k].src ? (const void*)c[k].src : (const void*)c[k].own, (size_t)n[k] * sizeof(float4),
+                                     c[k].src ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    }
+    HIPCHK(hipMemcpy(h->sub.S, &S, sizeof(S), hipMemcpyHostToDevice));
+    sr_adopt_launch(h->stream, h->sub, n[2], -1, n[0], -1, n[1]);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->sub_cloud_frame = frame;
+    if (laserCloudCornerLast || laserCloudSurfLast)
+      if (map_stack_enqueue(&h->map, h->s_ds, h->sub, cur, &h->prof, h->ev_stack[cur]) != VLOAM_OK) { set_err("map_stack_enqueue failed"); return VLOAM_ERR_HIP; }
+  }
+  HIPCHK(hipGetLastError());
   return VLOAM_OK;
 }
 
@@ -846,10 +979,10 @@ vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_p
   { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
   for (int b = 0; b < h->se.B; b++) {
     vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &bi.in[b]);
-    if (s_ != VLOAM_OK) return s_;
+    if (s_ != VLOAM_OK) return stage_release(h, s_);
     bi.n[b] = n[b];
   }
-  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
   const vloam_status st = process_scan_batch(h, bi);
   return stage_release(h, st, (st == VLOAM_OK && !h->cfg.timing) ? h->ev_sr[set_of(h->frame - 1)] : nullptr);
 }
@@ -990,10 +1123,10 @@ vloam_status vloam_batch_process_frame(vloam_handle* h, const float* const* xyz_
   { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
   for (int b = 0; b < h->se.B; b++) {
     vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &bi.in[b]);
-    if (s_ != VLOAM_OK) return s_;
+    if (s_ != VLOAM_OK) return stage_release(h, s_);
     bi.n[b] = n[b];
   }
-  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
   return stage_release(h, process_frame_common(h, bi, prev_uv, curr_uv, n_match, nullptr, 0, 0, 0));
 }
 
@@ -1060,11 +1193,11 @@ vloam_status vloam_batch_process_frame_image(vloam_handle* h, const float* const
   { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
   for (int b = 0; b < h->se.B; b++) {
     const float4* dst = nullptr;
-    { vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &dst); if (s_ != VLOAM_OK) return s_; }
-    { vloam_status s_ = upload_image(h, gray[b], width, height, stride, b); if (s_ != VLOAM_OK) return s_; }
+    { vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &dst); if (s_ != VLOAM_OK) return stage_release(h, s_); }
+    { vloam_status s_ = upload_image(h, gray[b], width, height, stride, b); if (s_ != VLOAM_OK) return stage_release(h, s_); }
     d_in[b] = dst; d_img[b] = h->img.staging + (size_t)b * h->se.ss;
   }
-  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return s_; }
+  { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
   return stage_release(h, vloam_batch_process_frame_image_device(h, d_in, n, d_img, width, height, width));
 }
 

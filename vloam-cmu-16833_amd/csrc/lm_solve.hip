@@ -988,7 +988,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
         if (it_success && x_cost < minimum_cost) { minimum_cost = x_cost;
 #pragma unroll
           for (int i = 0; i < na; i++) sh.best[i] = sh.x[i]; }
-        if (lead && n_rec < kLmMaxTrace) {
+        if (lead && n_rec < kLmMaxTrace - 1) {   // (row kLmMaxTrace - 1 carries the running in-kernel time below, never an iteration)
           double* row = rec->trace[n_rec];
           row[0] = it_cost; row[1] = it_cost_change; row[2] = gmax; row[3] = it_step_norm; row[4] = it_rho; row[5] = radius;
           row[6] = it_valid; row[7] = it_success;
@@ -1159,6 +1159,8 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(VLOA
       if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
       R = lm_solve_run<QUAT, MODE, 1>(F, edge_rows, rec, max_iters, huber_a, sh, true, row_first, mask_first, tag_base);
       if (tid == 0 && F.fallbacks) atomicAdd(F.fallbacks, 1);
+      // the host learns without a synchronisation (it polls this host-mapped word before every enqueue): no further cooperative launches
+      if (tid == 0 && F.host_degraded) __hip_atomic_store(F.host_degraded, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (MODE != kLmRowMask && lead) {
       for (int r = tid; r < (F.cap >> 6); r += kLmThreads) F.rowcnt[r] = 0;  // every workgroup published its partial sums, i.e. is past its prologue's reads
     }
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(VLOA
     for (int i = 0; i < 7; i++) rec->x_out[i] = i < na ? sh.best[i] : 0.0;
     if (fin_lo) lo_integrate(fin_lo, sh.best, fin_traj);  // LaserOdometry's pose integration rides on its last solve
     rec->final_cost = minimum_cost;
-    rec->n_iterations = n_rec < kLmMaxTrace ? n_rec : kLmMaxTrace;
+    rec->n_iterations = n_rec < kLmMaxTrace - 1 ? n_rec : kLmMaxTrace - 1;
     rec->termination = termination;
     rec->n_evals = n_evals;
     rec->cyc[0] = (double)cyc_fac;  // factor loops only (evaluations minus the block reductions)
@@ -1297,12 +1299,11 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F_in, int n_edge_slot
                const int* d_enable, ProfHook* ph, LOState* fin_lo, double* fin_traj, hipEvent_t done) {
   const int edge_rows = n_edge_slots >> 6;
   const unsigned Z = (unsigned)se.B;
-  // every launch gets a generation of its own (process-wide counter: a sync slot only has to tell its own successive solves apart) and the
-  // patience of its workgroups (VLOAM_LM_SPIN_LIMIT: tests force the degraded path with 1)
+  // every launch gets a generation of its own (process-wide counter: a sync slot only has to tell its own successive solves apart)
   static std::atomic<unsigned> g_gen{1};
   FactorTable Fg = F_in;
   Fg.gen = g_gen.fetch_add(1);
-  { const char* e = getenv("VLOAM_LM_SPIN_LIMIT"); Fg.spin_limit = e ? atoi(e) : (1 << 18); }
+  // (the patience of its workgroups, FactorTable::spin_limit, was fixed when the handle was created: vloam_create reads VLOAM_LM_SPIN_LIMIT once)
   const FactorTable& F = Fg;
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   const bool rowmask = quat && !direct && F.rowmask != nullptr && (F.cap >> 6) <= 2 * kLmThreads;   // the fit kernel left row masks: the solve compacts on its own

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_map_prepare(MapState* ms, MapFrame* fr,
       if (shift[0] | shift[1] | shift[2]) { rolled = 1; ms->cenW = cen[0]; ms->cenH = cen[1]; ms->cenD = cen[2]; }
       // the scan features were voxelised on the scan-registration stream (k_map_ds_*): adopt this sweep's stack
       if (si_err) { atomicOr(&fr->error, si_err); fr_err |= si_err; si->error = 0; }
-      if (fr_err & kErrMapFull) nst[0] = nst[1] = 0;  // the map cannot take this sweep: no association, no insert; the pose stays the odometry guess (vloam_sync reports it)
+      if (fr_err & (kErrMapFull | kErrSolverSync)) nst[0] = nst[1] = 0;  // the map cannot take this sweep (table full), or its stack has holes (a bin of the scan-feature VoxelGrid timed out): no association, no insert; the pose stays the odometry guess (vloam_sync reports it)
       for (int k = 0; k < 2; k++) { fr->n_stack[k] = nst[k]; fr->n_touched[k] = 0; }
       ms->n_corner_stack = nst[0]; ms->n_surf_stack = nst[1];
       for (int k = 0; k < 4; k++) (&fr->n_factors[0][0])[k] = 0;
@@ -446,11 +446,16 @@ __device__ __forceinline__ void ds_reduce_sorted(const u64* key, int m, int bin,
       before += (int)(unsigned)(v & 0xffffffffull);
     }
     for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
-    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&fr->error, kErrSolverSync);   // (never seen: a bounded wait instead of a hang)
-    if (lane == 0) s_cnt[0] = before;
+    // (never seen: a bounded wait instead of a hang.)  The offset would come from a partial sum: this bin stores NOTHING (its centroids would
+    // land on other bins' slots) and the sweep's stack is declared empty, so the mapping of this sweep associates nothing instead of
+    // consuming misplaced centroids; vloam_sync reports the sticky bit
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (any_bad && lane == 0) { atomicOr(&fr->error, kErrSolverSync); }
+    if (lane == 0) s_cnt[0] = any_bad ? -1 : before;
   }
   __syncthreads();
-  before = s_cnt[0];
+  const bool timed_out = s_cnt[0] < 0;
+  before = timed_out ? D.stack_cap : s_cnt[0];   // (every output slot then counts as beyond the stack: nothing is stored)
   // centroids: the thread that owns a head walks the cell (its points in input order: the sort key ends in the point index); cells of more
   // than kDsBigCell points are left to a whole wavefront each
   int r = rank0;
@@ -499,7 +504,7 @@ __device__ __forceinline__ void ds_reduce_sorted(const u64* key, int m, int bin,
   if (bin == P - 1 && tid == 0) {
     // the last bin has seen every other bin's count, i.e. every workgroup of this pass is done with the region counters, the overflow list
     // and the ticket: hand them back clean for the next sweep
-    const int total = before + u;
+    const int total = timed_out ? 0 : before + u;
     fr->n_stack[kind] = min(total, D.stack_cap);
     if (total > D.stack_cap) atomicOr(&fr->error, kErrStackFull);
     D.cursor[kDsMaxBins] = 0; D.cursor[kDsMaxBins + 2] = 0;   // (the ticket counter is reset by the next sweep's binning pass: workgroups still draw from it)
@@ -1442,6 +1447,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;
     F.fallbacks = ok ? &m->frame->fallback_solves : nullptr;
+    F.host_degraded = nullptr;   // (the handle points it at its host-mapped word)
     F.gen = 0; F.spin_limit = 1 << 18;
   }
   ok = ok && A.take(&m->rec, 2) && A.take(&m->nbr, 5 * (size_t)kMapFactorCap);

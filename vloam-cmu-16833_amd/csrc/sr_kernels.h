@@ -40,4 +40,8 @@ hipError_t sr_init();
 hipError_t sr_launch(hipStream_t st, const SRBuffers& b, const BatchIn& bi, Sess se, int N_SCANS, float min_range, int debug_level, ProfHook* ph = nullptr,
                      hipEvent_t done = nullptr, int* ring_watch = nullptr, bool big_tier = true);
 
+// clouds uploaded into a buffer set by the caller (vloam_set_odometry_input / vloam_set_mapping_input): counts (< 0 = keep) and the VoxelGrid boxes
+// of the two less-clouds re-derived from them; single session
+void sr_adopt_launch(hipStream_t st, const SRBuffers& b, int n_full, int n_sharp, int n_less_sharp, int n_flat, int n_less_flat);
+
 }  // namespace vloam

@@ -1130,6 +1130,46 @@ __global__ __launch_bounds__(256) void k_sr_compact(const float4* __restrict__ c
   }
 }
 
+// ---- clouds handed in by the caller instead of produced by the kernels above (LaserOdometry::input / LaserMapping::input deep-copy whatever
+// they are given, laser_odometry.cpp:141-145, laser_mapping.cpp:172-181): the counts and the two VoxelGrid bounding boxes of a buffer set are
+// re-derived from the uploaded clouds.  One workgroup; a count < 0 keeps what the set holds.  (The boxes are only ever min / max-reduced over
+// all 64 slots, so any partition of the points over the slots will do.)
+__global__ __launch_bounds__(256) void k_sr_adopt(FrameScalars* S, const float4* __restrict__ less_sharp, const float4* __restrict__ less_flat, int n_full,
+                                                  int n_sharp, int n_less_sharp, int n_flat, int n_less_flat) {
+  __shared__ float s_box[4][64][6];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    if (n_full >= 0) S->N2 = n_full;
+    if (n_sharp >= 0) S->n_sharp = n_sharp;
+    if (n_flat >= 0) S->n_flat = n_flat;
+    if (n_less_sharp >= 0) S->n_less_sharp = n_less_sharp;
+    if (n_less_flat >= 0) S->n_less_flat = n_less_flat;
+  }
+  for (int kind = 0; kind < 2; kind++) {
+    const int n = kind ? n_less_flat : n_less_sharp;
+    if (n < 0) continue;   // (uniform)
+    const float4* pts = kind ? less_flat : less_sharp;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = tid; i < n; i += 256) {
+      const float4 p = pts[i];
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    for (int a = 0; a < 3; a++) { s_box[w][lane][a] = mn[a]; s_box[w][lane][3 + a] = mx[a]; }
+    __syncthreads();
+    if (tid < 64)
+      for (int a = 0; a < 6; a++) {
+        float v = s_box[0][tid][a];
+        for (int ww = 1; ww < 4; ww++) v = a < 3 ? fminf(v, s_box[ww][tid][a]) : fmaxf(v, s_box[ww][tid][a]);
+        S->less_bbox[kind][tid][a] = v;
+      }
+    __syncthreads();
+  }
+}
+void sr_adopt_launch(hipStream_t st, const SRBuffers& b, int n_full, int n_sharp, int n_less_sharp, int n_flat, int n_less_flat) {
+  VL_RAW_LAUNCH(k_sr_adopt, dim3(1, 1, 1), dim3(256), 0, st, b.S, b.less_sharp, b.less_flat, n_full, n_sharp, n_less_sharp, n_flat, n_less_flat);
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int CAP, int SECT>
 static size_t sr_ring_smem_bytes() {

@@ -131,7 +131,7 @@ enum ErrorBits : int {
   kErrMapDeferred = 8, // raw-point capacity: more than 255 un-merged points in one voxel of a cube outside the valid block, or more than 64 raw voxels around one query
   kErrStackFull = 16,
   kErrVoDegenerate = 64, // the VO solve returned a zero rotation angle: the reference divides by it (visual_odometry.cpp:427-430) -> NaN poses
-  kErrSolverSync = 32,  // a workgroup of a cooperative LM solve gave up waiting at the grid barrier (result of that solve is invalid)
+  kErrSolverSync = 32,  // k_map_ds_reduce: a workgroup of the scan-feature VoxelGrid gave up waiting for the cell counts of the bins in front of it (that sweep's stack is left EMPTY).  (Until round 4 also the cooperative LM solves' timeout: they degrade to one workgroup instead since round 5.)
 };
 
 // Per-frame scalars of scan registration (one per sequence).
@@ -191,6 +191,7 @@ struct FactorTable {
   double* gsync;  // optional [kLmSyncDoubles]: poison word + the tagged partial sums the workgroups of a cooperative solve exchange (null: one workgroup)
   int* err;       // optional sticky error word (ErrorBits) the host polls in vloam_sync
   int* fallbacks; // optional counter: cooperative solves that degraded to one workgroup (k_lm_solve; vloam_get_health)
+  int* host_degraded;  // optional HOST-MAPPED word (not in the arenas, never rebased): set when a cooperative solve degrades; the host polls it before every enqueue
   unsigned gen;   // generation of the launch (lm_launch): the tag of everything the solve's workgroups exchange
   int spin_limit; // polls a workgroup of a cooperative solve waits for its partners before it gives up (lm_launch; VLOAM_LM_SPIN_LIMIT)
   __host__ __device__ void rebase(size_t off) {
