@@ -32,4 +32,8 @@ if os.environ.get("VLOAM_LM_STAMPS_BUILD"):   # library built with -DVLOAM_LM_ST
         row = np.ctypeslib.as_array(rec.trace).reshape(K_LM_MAX_TRACE, 8)[100]
         print("%-12s serial sections (cycles, all iterations): bookkeeping+LDS reads %6.0f  1/radius+diagonal %6.0f  Cholesky %6.0f  model cost+step %6.0f  plus %6.0f | acceptance %6.0f" %
               (name, row[1], row[2], row[3], row[4], row[5], row[7]))
+        print("%-12s first evaluation: cache fill %6.0f cycles" % (name, row[6]))
+        ev = np.ctypeslib.as_array(rec.trace).reshape(K_LM_MAX_TRACE, 8)[101]
+        print("%-12s evaluation phases of thread 0 (cycles, evaluations after the first): factor loops %6.0f  LDS stores %6.0f  barrier %6.0f  column sums %6.0f  barrier %6.0f  fold + publish %6.0f  "
+              "poll %6.0f  fold + barrier %6.0f" % (name, ev[0], ev[1], ev[2], ev[3], ev[4], ev[5], ev[6], ev[7]))
 h.close()

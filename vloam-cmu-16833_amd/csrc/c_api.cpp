@@ -148,6 +148,7 @@ static vloam_status take_factor_table(Arena& A, FactorTable* F, int cap) {
   TAKE(F->ctype, cap);
   TAKE(F->cslot, cap);
   TAKE(F->cpack, 11 * (size_t)cap);
+  TAKE(F->dg, 8 * (size_t)cap);
   TAKE(F->rowcnt, (size_t)cap / 64 + 1);
   F->rowmask = nullptr;  // the odometry / VO tables use the per-row counters
   F->gsync = nullptr;  // placed by lm_sync_calibrate once everything is allocated

@@ -1,18 +1,20 @@
 // Levenberg–Marquardt in one launch: the whole ceres::Solve() of the reference
-// (laser_odometry.cpp:457-463, laser_mapping.cpp:609-617, visual_odometry.cpp:423) runs inside ONE
-// kernel launch.  k_lm_compact (many workgroups) packs the accepted factors in slot order (deterministic) and
-// pre-digests them (edge -> orthonormal pair across the line, plane -> normal + offset); k_lm_solve then keeps them in the
-// registers of 256 lanes, evaluates the residual blocks with closed-form Jacobians in the tangent space of
-// EigenQuaternionParameterization and the Huber corrector, reduces the 6x6 J^T J / J^T r / cost through a fixed-order LDS
-// transpose (bit-reproducible; 64-bit cross-lane shuffles are slower than LDS here), and lane 0 runs the
-// trust-region bookkeeping of Ceres 2.0 (Jacobi scaling, LM diagonal clamp, step acceptance,
-// radius schedule, tolerances) on the 6x6 normal equations.  No host round trips, no float atomics.
-// The scan-to-scan and scan-to-map problems run as FOUR cooperating workgroups (four compute units share the factors, one
-// grid barrier per evaluation, the trust-region bookkeeping replicated in each: see lm_evaluate); the small visual-odometry
-// problem stays on one.
-//
-// Ceres is not vendored by the reference; the algorithm restated here is spelled out in
-// oracle/orc_ceres.cpp (CPU oracle, DENSE_QR on the stacked Jacobian) and SURVEY.md Appendix A.
+// (laser_odometry.cpp:457-463, laser_mapping.cpp:609-617, visual_odometry.cpp:423) runs inside ONE kernel launch.
+//   factors    the kernels that emit a LiDAR factor (k_lo_assoc*, k_map_fit) leave, next to the raw points, the form the evaluation consumes
+//              (FactorTable::dg: edge -> orthonormal pair across the line + offsets, plane -> normal + offset).  Scan-to-scan (kLmDirect): lane t
+//              owns table slots t + 256 m themselves; scan-to-map (kLmRowMask): the solve compacts on its own from the 64-bit accepted-slot masks
+//              k_map_fit leaves per 64-slot row; VO (kLmPacked): k_lm_compact packs the accepted factors in slot order first.
+//   evaluation factors stay in the registers of 256 lanes per workgroup across the evaluations of a solve; residual blocks with closed-form Jacobians
+//              in the tangent space of EigenQuaternionParameterization, Huber as the weight rho' (one rsqrt per block); the 6x6 J^T J / J^T r / cost
+//              reduced through a fixed-order LDS transpose (bit-reproducible).
+//   workgroups a single sequence runs both LiDAR problems as EIGHT cooperating workgroups on ONE XCD (lm_coop_block), a batch as 4 / 6 spread ones;
+//              there is NO grid barrier: the partial sums travel as tagged 8-byte granules {32 payload bits, (launch generation, evaluation)} that
+//              every workgroup polls, each adds them in workgroup order and runs the (cheap) trust-region bookkeeping redundantly.  A workgroup
+//              whose partners never show up gives up after spin_limit polls and the lead workgroup redoes the solve alone (degrade, not fail).
+//   step       lane 0 runs Ceres 2.0's trust-region bookkeeping (Jacobi scaling, LM diagonal clamp, step acceptance, radius schedule,
+//              tolerances) on the 6x6 normal equations; helper lanes on other wavefronts prepare what can be prepared off its dependency chain.
+// No host round trips, no float atomics.  Ceres is not vendored by the reference; the algorithm restated here is spelled out in
+// oracle/orc_ceres.cpp (CPU oracle, DENSE_QR on the stacked Jacobian), tests/ceres_transcription.py and SURVEY.md Appendix A.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <float.h>
@@ -206,26 +208,6 @@ __device__ __forceinline__ void eval_plane(D3 p, D3 n, double d, const double (&
   accumulate_row(acc, J, r0 * sc);
 }
 
-// Line through a, b -> what eval_edge consumes: an orthonormal pair (e1, e2) with e1 x e2 = v = (b - a) / |a - b|
-// (lidarFactor.hpp:37-42 divides by de.norm()), e1 = normalize(v x axis of the smallest |v| component), e2 = v x e1, and the
-// offsets d_i = -(e_i . a).  out = e1, e2, d1, d2.
-__device__ __forceinline__ void edge_frame(double ax, double ay, double az, double bx, double by, double bz, double (&out)[8]) {
-  const double dx = bx - ax, dy = by - ay, dz = bz - az;
-  const double dn = sqrt(dx * dx + dy * dy + dz * dz);
-  const double vx = dx / dn, vy = dy / dn, vz = dz / dn;
-  const double fx = fabs(vx), fy = fabs(vy), fz = fabs(vz);
-  double e1x, e1y, e1z;
-  if (fx <= fy && fx <= fz) { e1x = 0.0; e1y = vz; e1z = -vy; }        // v x (1, 0, 0)
-  else if (fy <= fz) { e1x = -vz; e1y = 0.0; e1z = vx; }              // v x (0, 1, 0)
-  else { e1x = vy; e1y = -vx; e1z = 0.0; }                             // v x (0, 0, 1)
-  const double en = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
-  e1x /= en; e1y /= en; e1z /= en;
-  const double e2x = vy * e1z - vz * e1y, e2y = vz * e1x - vx * e1z, e2z = vx * e1y - vy * e1x;
-  out[0] = e1x; out[1] = e1y; out[2] = e1z; out[3] = e2x; out[4] = e2y; out[5] = e2z;
-  out[6] = -(e1x * ax + e1y * ay + e1z * az);
-  out[7] = -(e2x * ax + e2y * ay + e2z * az);
-}
-
 // ---- packets: NW factors evaluated side by side.  With one wavefront per SIMD nothing hides the ~8-cycle dependent f64
 // latency except independent instructions next to each other, and the compiler keeps source order inside a basic block: every
 // step below is written for all NW factors at once, so the per-factor dependency chains (rotate, residual, Huber weight,
@@ -239,52 +221,69 @@ __device__ __forceinline__ void rotate_pk(const double (&p)[NW][3], const double
 #pragma unroll
   for (int u = 0; u < NW; u++) rp[u][2] = Rm[6] * p[u][0] + Rm[7] * p[u][1] + Rm[8] * p[u][2];
 }
-// one point-to-plane row per factor: c = n . (rp + t) + d, J = sc [-2 (n x rp), n]
+// One point-to-plane row per factor: c = n . (rp + t) + d, J = [-2 (n x rp), n], weighted by w = rho' of the row's residual block:
+// acc += (w J^T c, w J^T J).  Ceres' Corrector (rho'' <= 0 for Huber) scales residual and Jacobian by sqrt(rho') and the normal equations
+// then hold rho' J^T J: the same numbers with ONE dependent rsqrt behind the squared norm instead of sqrt -> rsqrt -> two scalings (the
+// factor loops are a latency chain at one wavefront per SIMD: ~32 cycles per dependent f64 operation, profiles/r04_solver_limits.txt).
 template <int NW>
-__device__ __forceinline__ void row_pk(const double (&rp)[NW][3], const double (&n)[NW][3], const double (&c)[NW], const double (&sc)[NW],
+__device__ __forceinline__ void row_pk(const double (&rp)[NW][3], const double (&n)[NW][3], const double (&c)[NW], const double (&w)[NW],
                                        double (&acc)[kAcc]) {
-  double J[NW][6];
+  double J[NW][6], Jw[NW][6];
 #pragma unroll
   for (int u = 0; u < NW; u++) {
-    const double s2 = -2.0 * sc[u];
-    J[u][0] = s2 * (n[u][1] * rp[u][2] - n[u][2] * rp[u][1]);
-    J[u][1] = s2 * (n[u][2] * rp[u][0] - n[u][0] * rp[u][2]);
-    J[u][2] = s2 * (n[u][0] * rp[u][1] - n[u][1] * rp[u][0]);
-    J[u][3] = n[u][0] * sc[u]; J[u][4] = n[u][1] * sc[u]; J[u][5] = n[u][2] * sc[u];
+    J[u][0] = -2.0 * (n[u][1] * rp[u][2] - n[u][2] * rp[u][1]);
+    J[u][1] = -2.0 * (n[u][2] * rp[u][0] - n[u][0] * rp[u][2]);
+    J[u][2] = -2.0 * (n[u][0] * rp[u][1] - n[u][1] * rp[u][0]);
+    J[u][3] = n[u][0]; J[u][4] = n[u][1]; J[u][5] = n[u][2];
   }
 #pragma unroll
-  for (int u = 0; u < NW; u++) accumulate_row(acc, J[u], c[u] * sc[u]);
-}
-template <int NW>
-__device__ __forceinline__ void huber_pk(const double (&sq)[NW], const double (&rr)[NW], double a, double sqrt_a, double (&sc)[NW], double* cost) {
-  double so[NW];
+  for (int u = 0; u < NW; u++)
 #pragma unroll
-  for (int u = 0; u < NW; u++) so[u] = sqrt_a * rsqrt(fmax(rr[u], DBL_MIN));  // sqrt(a / |r|)
+    for (int a = 0; a < 6; a++) Jw[u][a] = w[u] * J[u][a];
+#pragma unroll
+  for (int u = 0; u < NW; u++) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[1 + a] += Jw[u][a] * c[u];
+    int h = 7;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[h++] += Jw[u][a] * J[u][b];
+  }
+}
+// ceres::HuberLoss(a) on the squared norm sq of a residual block -> w = rho' (1 inside, a / |r| outside) and the block's cost
+// (rho / 2: sq / 2 inside, a |r| - a^2 / 2 outside), with |r| = sq * rsqrt(sq): one transcendental per block
+template <int NW>
+__device__ __forceinline__ void huber_pk(const double (&sq)[NW], double a, double (&w)[NW], double* cost) {
+  double ir[NW];
+#pragma unroll
+  for (int u = 0; u < NW; u++) ir[u] = rsqrt(fmax(sq[u], DBL_MIN));  // 1 / |r|
 #pragma unroll
   for (int u = 0; u < NW; u++) {
     const bool out = sq[u] > a * a;
-    *cost += out ? 0.5 * (2.0 * a * rr[u] - a * a) : 0.5 * sq[u];
-    sc[u] = out ? so[u] : 1.0;
+    const double rr = sq[u] * ir[u];
+    *cost += out ? 0.5 * (2.0 * a * rr - a * a) : 0.5 * sq[u];
+    w[u] = out ? a * ir[u] : 1.0;
   }
 }
 template <int NW>
 __device__ __forceinline__ void eval_plane_pk(const double (&p)[NW][3], const double (&n)[NW][3], const double (&d)[NW], const double (&Rm)[9], D3 t,
-                                              double huber_a, double sqrt_a, double (&acc)[kAcc], double (&r0)[NW]) {
-  double rp[NW][3], sq[NW], rr[NW], sc[NW];
+                                              double huber_a, double (&acc)[kAcc], double (&r0)[NW]) {
+  double rp[NW][3], sq[NW], w[NW];
   rotate_pk<NW>(p, Rm, rp);
 #pragma unroll
   for (int u = 0; u < NW; u++) r0[u] = n[u][0] * (rp[u][0] + t.x) + n[u][1] * (rp[u][1] + t.y) + n[u][2] * (rp[u][2] + t.z) + d[u];
 #pragma unroll
-  for (int u = 0; u < NW; u++) { sq[u] = r0[u] * r0[u]; rr[u] = fabs(r0[u]); }
-  huber_pk<NW>(sq, rr, huber_a, sqrt_a, sc, &acc[0]);
-  row_pk<NW>(rp, n, r0, sc, acc);
+  for (int u = 0; u < NW; u++) sq[u] = r0[u] * r0[u];
+  huber_pk<NW>(sq, huber_a, w, &acc[0]);
+  row_pk<NW>(rp, n, r0, w, acc);
 }
 // edge factors as two rows sharing one weight (see eval_edge)
 template <int NW>
 __device__ __forceinline__ void eval_edge_pk(const double (&p)[NW][3], const double (&e1)[NW][3], const double (&e2)[NW][3], const double (&d1)[NW],
-                                             const double (&d2)[NW], const double (&Rm)[9], D3 t, double huber_a, double sqrt_a,
+                                             const double (&d2)[NW], const double (&Rm)[9], D3 t, double huber_a,
                                              double (&acc)[kAcc], double (&c1)[NW], double (&c2)[NW]) {
-  double rp[NW][3], sq[NW], rr[NW], sc[NW];
+  double rp[NW][3], sq[NW], w[NW];
   rotate_pk<NW>(p, Rm, rp);
 #pragma unroll
   for (int u = 0; u < NW; u++) c1[u] = e1[u][0] * (rp[u][0] + t.x) + e1[u][1] * (rp[u][1] + t.y) + e1[u][2] * (rp[u][2] + t.z) + d1[u];
@@ -292,11 +291,40 @@ __device__ __forceinline__ void eval_edge_pk(const double (&p)[NW][3], const dou
   for (int u = 0; u < NW; u++) c2[u] = e2[u][0] * (rp[u][0] + t.x) + e2[u][1] * (rp[u][1] + t.y) + e2[u][2] * (rp[u][2] + t.z) + d2[u];
 #pragma unroll
   for (int u = 0; u < NW; u++) sq[u] = c1[u] * c1[u] + c2[u] * c2[u];
+  huber_pk<NW>(sq, huber_a, w, &acc[0]);
+  row_pk<NW>(rp, e1, c1, w, acc);
+  row_pk<NW>(rp, e2, c2, w, acc);
+}
+// NE edge factors and NP plane factors SIDE BY SIDE, step by step (the compiler keeps source order inside a basic block): a lane of a
+// cooperative solve typically owns one edge and one or two plane factors, and evaluated one packet after the other their dependency chains
+// (rotate -> residual -> rsqrt -> weight -> rows) simply add up.
+template <int NE, int NP>
+__device__ __forceinline__ void eval_mixed_pk(const double (&pe)[NE][3], const double (&e1)[NE][3], const double (&e2)[NE][3], const double (&d1)[NE],
+                                              const double (&d2)[NE], const double (&pp)[NP][3], const double (&n)[NP][3], const double (&d)[NP],
+                                              const double (&Rm)[9], D3 t, double huber_a, double (&acc)[kAcc], double (&c1)[NE], double (&c2)[NE],
+                                              double (&r0)[NP]) {
+  double rpe[NE][3], rpp[NP][3], sq[NE + NP], w[NE + NP];
+  rotate_pk<NE>(pe, Rm, rpe);
+  rotate_pk<NP>(pp, Rm, rpp);
 #pragma unroll
-  for (int u = 0; u < NW; u++) rr[u] = sqrt(sq[u]);
-  huber_pk<NW>(sq, rr, huber_a, sqrt_a, sc, &acc[0]);
-  row_pk<NW>(rp, e1, c1, sc, acc);
-  row_pk<NW>(rp, e2, c2, sc, acc);
+  for (int u = 0; u < NE; u++) c1[u] = e1[u][0] * (rpe[u][0] + t.x) + e1[u][1] * (rpe[u][1] + t.y) + e1[u][2] * (rpe[u][2] + t.z) + d1[u];
+#pragma unroll
+  for (int u = 0; u < NE; u++) c2[u] = e2[u][0] * (rpe[u][0] + t.x) + e2[u][1] * (rpe[u][1] + t.y) + e2[u][2] * (rpe[u][2] + t.z) + d2[u];
+#pragma unroll
+  for (int u = 0; u < NP; u++) r0[u] = n[u][0] * (rpp[u][0] + t.x) + n[u][1] * (rpp[u][1] + t.y) + n[u][2] * (rpp[u][2] + t.z) + d[u];
+#pragma unroll
+  for (int u = 0; u < NE; u++) sq[u] = c1[u] * c1[u] + c2[u] * c2[u];
+#pragma unroll
+  for (int u = 0; u < NP; u++) sq[NE + u] = r0[u] * r0[u];
+  huber_pk<NE + NP>(sq, huber_a, w, &acc[0]);
+  double we[NE], wp[NP];
+#pragma unroll
+  for (int u = 0; u < NE; u++) we[u] = w[u];
+#pragma unroll
+  for (int u = 0; u < NP; u++) wp[u] = w[NE + u];
+  row_pk<NE>(rpe, e1, c1, we, acc);
+  row_pk<NE>(rpe, e2, c2, we, acc);
+  row_pk<NP>(rpp, n, r0, wp, acc);
 }
 
 // CostFunctor32 / CostFunctor22 on (angle_axis[3], t[3]) — dual numbers == Ceres autodiff
@@ -344,6 +372,7 @@ struct LmShared {
   int curidx;
   double x[8], xc[8];
   double mcc;          // model_cost_change of the pending candidate
+  double inv_mcc, step_norm_c;   // 1 / mcc and |x - xc| of the pending candidate, by a helper lane while the candidate is evaluated
   double gmax_c, xnorm_c;  // gradient max-norm / |x| at the point just evaluated (computed by helper lanes in parallel)
   double scale[6], best[8];  // trust-region state that must survive the evaluations (kept out of registers)
   int scan[kLmThreads], scan2[kLmThreads];
@@ -352,6 +381,10 @@ struct LmShared {
   int n_valid;
   int failed;          // cooperative solve: a workgroup gave up waiting at the grid barrier -> every workgroup abandons the solve
   double x0[8];        // the parameters the solve started from (what an abandoned solve hands back)
+#ifdef VLOAM_LM_STAMPS
+  long long step_cyc[8];  // debug build: thread 0's cycles in the sections of the trust-region step, summed over the iterations
+  long long ev_cyc[8];  // debug build: thread 0's cycles in the phases of lm_evaluate, summed over the evaluations after the first
+#endif
 };
 
 // Factors owned by a lane stay in its registers across the evaluations of a solve (one workgroup = 256 lanes x 512 VGPRs):
@@ -367,6 +400,7 @@ struct LmCache {
   float pp[kCacheP][3];
   double dp[kCacheP][4];  // n, d
   unsigned live_e, live_p;  // direct mode: which of this lane's slots hold a factor
+  int slot_e[kCacheE], slot_p[kCacheP];  // row-mask mode: the table slot of every cached factor (residual hook of the first evaluation)
 };
 
 // ---- factor sources of a solve
@@ -450,7 +484,6 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
   double xl[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) xl[i] = x[i];
-  const double sqrt_a = sqrt(huber_a);
   if (QUAT) {
     // rotation matrix of q = (x, y, z, w) as Eigen's toRotationMatrix() builds it (q is unit up to rounding)
     double Rm[9];
@@ -466,34 +499,63 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     const int n_plane = n_valid - n_edge;
     const double* cp = F.cpack;
     if (first && DIRECT) {
+      // the producer (k_lo_assoc*) left the evaluation's form of every factor next to the raw one (FactorTable::dg, by slot): type, point and
+      // digest are requested together — one memory trip — and dead slots are zeroed by selects (zeros evaluate to an exactly-zero contribution)
       C.live_e = 0u; C.live_p = 0u;
       constexpr int kEdgeSlots = kCacheE * kLmThreads;  // the table's corner part (the plane part follows)
+      const double* dg = F.dg;
+      int ty_e[kCacheE], ty_p[kCacheP];
+      double pe[kCacheE][3], de[kCacheE][8], pp[kCacheP][3], dp[kCacheP][4];
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
-        const int slot_raw = vt + m * VT;
-        const bool in = slot_raw < kEdgeSlots;
-        const int slot = in ? slot_raw : 0;
-        const bool live = in && F.type[slot] == 1;
-        double a[3], b[3], fr[8];
+        ty_e[m] = 0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) { C.pe[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; a[q] = live ? F.A[q * cap + slot] : 0.0; b[q] = live ? F.B[q * cap + slot] : 1.0; }
-        edge_frame(a[0], a[1], a[2], b[0], b[1], b[2], fr);
+        for (int q = 0; q < 3; q++) pe[m][q] = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) C.de[m][q] = live ? fr[q] : 0.0;
+        for (int q = 0; q < 8; q++) de[m][q] = 0.0;
+        if (m * VT < kEdgeSlots) {   // compile-time: with NB workgroups only the first cache slots can hold a table slot at all (no loads for the others)
+          const int slot_raw = vt + m * VT;
+          const int slot = slot_raw < kEdgeSlots ? slot_raw : 0;
+          ty_e[m] = slot_raw < kEdgeSlots ? F.type[slot] : 0;
+#pragma unroll
+          for (int q = 0; q < 3; q++) pe[m][q] = F.p[q * cap + slot];
+#pragma unroll
+          for (int q = 0; q < 8; q++) de[m][q] = dg[q * cap + slot];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheP; m++) {
+        ty_p[m] = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) pp[m][q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dp[m][q] = 0.0;
+        if (m * VT < kCacheP * kLmThreads) {
+          const int slot_raw = kEdgeSlots + vt + m * VT;
+          const int slot = slot_raw < cap ? slot_raw : 0;
+          ty_p[m] = slot_raw < cap ? F.type[slot] : 0;
+#pragma unroll
+          for (int q = 0; q < 3; q++) pp[m][q] = F.p[q * cap + slot];
+#pragma unroll
+          for (int q = 0; q < 4; q++) dp[m][q] = dg[q * cap + slot];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheE; m++) {
+        const bool live = ty_e[m] == 1;
+#pragma unroll
+        for (int q = 0; q < 3; q++) C.pe[m][q] = live ? (float)pe[m][q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) C.de[m][q] = live ? de[m][q] : 0.0;
         if (live) C.live_e |= 1u << m;
       }
 #pragma unroll
       for (int m = 0; m < kCacheP; m++) {
-        const int slot_raw = kEdgeSlots + vt + m * VT;
-        const bool in = slot_raw < cap;
-        const int slot = in ? slot_raw : 0;
-        const bool live = in && F.type[slot] == 2;  // LidarPlaneFactor: (lp - j) . n  ->  n . lp + d, d = -(n . j)
-        double j[3], nn[3];
+        const bool live = ty_p[m] == 2;   // LidarPlaneFactor
 #pragma unroll
-        for (int q = 0; q < 3; q++) { C.pp[m][q] = live ? (float)F.p[q * cap + slot] : 0.f; j[q] = live ? F.A[q * cap + slot] : 0.0; nn[q] = live ? F.B[q * cap + slot] : 0.0; }
+        for (int q = 0; q < 3; q++) C.pp[m][q] = live ? (float)pp[m][q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; q++) C.dp[m][q] = nn[q];
-        C.dp[m][3] = -(nn[0] * j[0] + nn[1] * j[1] + nn[2] * j[2]);
+        for (int q = 0; q < 4; q++) C.dp[m][q] = live ? dp[m][q] : 0.0;
         if (live) C.live_p |= 1u << m;
       }
     }
@@ -525,27 +587,63 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       const u64* rowmask = reinterpret_cast<const u64*>(sh.red + 512);
       const int nrows = cap >> 6;
       double* cpw = F.cpack;
+      // cached factors: compact index -> slot (LDS tables), then point + producer-side digest (FactorTable::dg, k_map_fit) of all of them in
+      // ONE memory trip; the slots stay in registers for the residual hook
+      const double* dg = F.dg;
+      double pe[kCacheE][3], de[kCacheE][8], pp[kCacheP][3], dp[kCacheP][4];
 #pragma unroll
       for (int m = 0; m < kCacheE; m++) {
-        const int k = vt + m * VT;
-        const bool live = k < n_edge;
-        double p[3] = {0, 0, 0}, fr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (live) { const int slot = lm_slot_of(rowoff, rowmask, nrows, k); F.cslot[k] = slot; lm_digest_edge(F, slot, p, fr); }
+        C.slot_e[m] = 0;
 #pragma unroll
-        for (int a = 0; a < 3; a++) C.pe[m][a] = (float)p[a];
+        for (int a = 0; a < 3; a++) pe[m][a] = 0.0;
 #pragma unroll
-        for (int a = 0; a < 8; a++) C.de[m][a] = fr[a];
+        for (int a = 0; a < 8; a++) de[m][a] = 0.0;
+        if (m * VT < n_edge) {   // uniform: cache slots nobody in the solve fills cost no loads (an ordinary sweep fills one edge and two plane slots per lane)
+          const int k = vt + m * VT;
+          const bool live = k < n_edge;
+          const int slot = live ? lm_slot_of(rowoff, rowmask, nrows, k) : 0;
+          C.slot_e[m] = slot;
+          if (live) F.cslot[k] = slot;
+#pragma unroll
+          for (int a = 0; a < 3; a++) pe[m][a] = F.p[a * cap + slot];
+#pragma unroll
+          for (int a = 0; a < 8; a++) de[m][a] = dg[a * cap + slot];
+        }
       }
 #pragma unroll
       for (int m = 0; m < kCacheP; m++) {
-        const int q = vt + m * VT;
-        const bool live = q < n_plane;
-        double p[3] = {0, 0, 0}, nd[4] = {0, 0, 0, 0};
-        if (live) { const int slot = lm_slot_of(rowoff, rowmask, nrows, n_edge + q); F.cslot[n_edge + q] = slot; lm_digest_plane(F, slot, p, nd); }
+        C.slot_p[m] = 0;
 #pragma unroll
-        for (int a = 0; a < 3; a++) C.pp[m][a] = (float)p[a];
+        for (int a = 0; a < 3; a++) pp[m][a] = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; a++) C.dp[m][a] = nd[a];
+        for (int a = 0; a < 4; a++) dp[m][a] = 0.0;
+        if (m * VT < n_plane) {
+          const int q = vt + m * VT;
+          const bool live = q < n_plane;
+          const int slot = live ? lm_slot_of(rowoff, rowmask, nrows, n_edge + q) : 0;
+          C.slot_p[m] = slot;
+          if (live) F.cslot[n_edge + q] = slot;
+#pragma unroll
+          for (int a = 0; a < 3; a++) pp[m][a] = F.p[a * cap + slot];
+#pragma unroll
+          for (int a = 0; a < 4; a++) dp[m][a] = dg[a * cap + slot];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheE; m++) {
+        const bool live = vt + m * VT < n_edge;
+#pragma unroll
+        for (int a = 0; a < 3; a++) C.pe[m][a] = live ? (float)pe[m][a] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; a++) C.de[m][a] = live ? de[m][a] : 0.0;
+      }
+#pragma unroll
+      for (int m = 0; m < kCacheP; m++) {
+        const bool live = vt + m * VT < n_plane;
+#pragma unroll
+        for (int a = 0; a < 3; a++) C.pp[m][a] = live ? (float)pp[m][a] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; a++) C.dp[m][a] = live ? dp[m][a] : 0.0;
       }
       for (int k = kCacheE * VT + vt; k < n_edge; k += VT) {
         double p[3], fr[8];
@@ -567,42 +665,86 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
 #pragma unroll
         for (int a = 0; a < 4; a++) cpw[(3 + a) * cap + n_edge + q] = nd[a];
       }
-      __syncthreads();   // the staged tables make way for the reduction; the cpack / cslot stores above have landed before anything reads them back
+      // the staged tables make way for the reduction.  Only factors BEYOND the register cache are read back from cpack / cslot (and only then do
+      // the stores above have to have landed); on an ordinary sweep there are none and an LDS-only barrier does (a full one waits out a store trip)
+      if (n_edge > kCacheE * VT || n_plane > kCacheP * VT) __syncthreads(); else lds_barrier();
     }
-    auto put_resid = [&](int k, const double* r3) {
-      const int slot = DIRECT ? k : F.cslot[k];
+#ifdef VLOAM_LM_STAMPS
+    if (tid == 0 && first) sh.step_cyc[6] = clock64() - tf0;   // first evaluation: the cache fill (slot search, loads, barrier)
+#endif
+    auto put_resid = [&](int k, const double* r3, int slot_known) {   // slot_known >= 0: the factor's table slot is in a register (row-mask cache)
+      const int slot = DIRECT ? k : (slot_known >= 0 ? slot_known : F.cslot[k]);
       F.resid[slot] = r3[0]; F.resid[cap + slot] = r3[1]; F.resid[2 * cap + slot] = r3[2];
     };
     // ---- edge factors (compact order == slot order: they come first).  Cached slots in packets of kPkE, streamed ones too.
     // (with NB workgroups a lane rarely owns more than one edge factor: packets of one instead of evaluating padding)
     constexpr int kPkE = NB > 1 ? 1 : 3, kPkP = (DIRECT && NB * kLmThreads >= kMaxFlat) ? 1 : 2;   // (scan-to-scan with >= 6 workgroups: a lane owns at most ONE plane slot — a packet of two would evaluate padding; zeros add exactly nothing, so the sums are the same bits)
-    auto edge_packet = [&](const double (&p)[kPkE][3], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], const double (&d1)[kPkE],
-                           const double (&d2)[kPkE], int k0 /* compact index of lane's first factor */, int kstride) {
-      double c1[kPkE], c2[kPkE];
-      eval_edge_pk<kPkE>(p, e1, e2, d1, d2, Rm, tt, huber_a, sqrt_a, acc, c1, c2);
-      if (first)
+    // g: first cache slot of the packet (compile-time at every call site), -1: streamed factors beyond the cache
+    auto edge_resid = [&](const double (&c1)[kPkE], const double (&c2)[kPkE], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], int k0, int kstride, int g) {
 #pragma unroll
-        for (int u = 0; u < kPkE; u++) {
-          const int k = k0 + u * kstride;
-          if (DIRECT ? ((C.live_e >> ((k0 - vt) / VT + u)) & 1u) != 0u : k < n_edge) {  // r = c1 e2 - c2 e1
-            const double r3[3] = {c1[u] * e2[u][0] - c2[u] * e1[u][0], c1[u] * e2[u][1] - c2[u] * e1[u][1], c1[u] * e2[u][2] - c2[u] * e1[u][2]};
-            put_resid(k, r3);
-          }
+      for (int u = 0; u < kPkE; u++) {
+        const int k = k0 + u * kstride;
+        const int known = (MODE == kLmRowMask && g >= 0 && g + u < kCacheE) ? C.slot_e[g + u < kCacheE ? g + u : 0] : -1;
+        if (DIRECT ? ((C.live_e >> ((k0 - vt) / VT + u)) & 1u) != 0u : k < n_edge) {  // r = c1 e2 - c2 e1
+          const double r3[3] = {c1[u] * e2[u][0] - c2[u] * e1[u][0], c1[u] * e2[u][1] - c2[u] * e1[u][1], c1[u] * e2[u][2] - c2[u] * e1[u][2]};
+          put_resid(k, r3, known);
         }
+      }
     };
+    auto plane_resid = [&](const double (&r0)[kPkP], int q0, int qstride, int g) {
+#pragma unroll
+      for (int u = 0; u < kPkP; u++) {
+        const int q = q0 + u * qstride;
+        const int known = (MODE == kLmRowMask && g >= 0 && g + u < kCacheP) ? C.slot_p[g + u < kCacheP ? g + u : 0] : -1;
+        if (DIRECT) { if ((C.live_p >> (q0 / VT + u)) & 1u) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(kCacheE * kLmThreads + q, r3, -1); } }
+        else if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3, known); }
+      }
+    };
+    auto edge_packet = [&](const double (&p)[kPkE][3], const double (&e1)[kPkE][3], const double (&e2)[kPkE][3], const double (&d1)[kPkE],
+                           const double (&d2)[kPkE], int k0 /* compact index of lane's first factor */, int kstride, int g) {
+      double c1[kPkE], c2[kPkE];
+      eval_edge_pk<kPkE>(p, e1, e2, d1, d2, Rm, tt, huber_a, acc, c1, c2);
+      if (first) edge_resid(c1, c2, e1, e2, k0, kstride, g);
+    };
+    auto load_edge_slots = [&](int g, double (&p)[kPkE][3], double (&e1)[kPkE][3], double (&e2)[kPkE][3], double (&d1)[kPkE], double (&d2)[kPkE]) {
+#pragma unroll
+      for (int u = 0; u < kPkE; u++) {
+        const int m = g + u < kCacheE ? g + u : kCacheE - 1;
+        const bool have = g + u < kCacheE;  // compile-time: slots past the cache evaluate zeros
+#pragma unroll
+        for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pe[m][a] : 0.0; e1[u][a] = have ? C.de[m][a] : 0.0; e2[u][a] = have ? C.de[m][3 + a] : 0.0; }
+        d1[u] = have ? C.de[m][6] : 0.0; d2[u] = have ? C.de[m][7] : 0.0;
+      }
+    };
+    auto load_plane_slots = [&](int g, double (&p)[kPkP][3], double (&n)[kPkP][3], double (&d)[kPkP]) {
+#pragma unroll
+      for (int u = 0; u < kPkP; u++) {
+        const int m = g + u < kCacheP ? g + u : kCacheP - 1;
+        const bool have = g + u < kCacheP;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pp[m][a] : 0.0; n[u][a] = have ? C.dp[m][a] : 0.0; }
+        d[u] = have ? C.dp[m][3] : 0.0;
+      }
+    };
+    auto edge_live = [&](int g) { return DIRECT ? __ballot(((C.live_e >> g) & ((1u << kPkE) - 1u)) != 0u) != 0ull : g * VT < n_edge; };
+    auto plane_live = [&](int g) { return DIRECT ? __ballot(((C.live_p >> g) & ((1u << kPkP) - 1u)) != 0u) != 0ull : g * VT < n_plane; };
+    // The FIRST edge packet and the FIRST plane packet of the cache side by side in one basic block (eval_mixed_pk): with NB workgroups that
+    // is all a lane owns on an ordinary sweep, and the two dependency chains overlap instead of following each other.
+    int ge0 = 0, gp0 = 0;
+    if (edge_live(0) && plane_live(0)) {
+      double pe[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE], pp[kPkP][3], n[kPkP][3], d[kPkP], c1[kPkE], c2[kPkE], r0[kPkP];
+      load_edge_slots(0, pe, e1, e2, d1, d2);
+      load_plane_slots(0, pp, n, d);
+      eval_mixed_pk<kPkE, kPkP>(pe, e1, e2, d1, d2, pp, n, d, Rm, tt, huber_a, acc, c1, c2, r0);
+      if (first) { edge_resid(c1, c2, e1, e2, vt, VT, 0); plane_resid(r0, vt, VT, 0); }
+      ge0 = kPkE; gp0 = kPkP;
+    }
 #pragma unroll
     for (int g = 0; g < kCacheE; g += kPkE)
-      if (DIRECT ? __ballot(((C.live_e >> g) & ((1u << kPkE) - 1u)) != 0u) != 0ull : g * VT < n_edge) {
+      if (g >= ge0 && edge_live(g)) {
         double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
-#pragma unroll
-        for (int u = 0; u < kPkE; u++) {
-          const int m = g + u < kCacheE ? g + u : kCacheE - 1;
-          const bool have = g + u < kCacheE;  // compile-time: slots past the cache evaluate zeros
-#pragma unroll
-          for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pe[m][a] : 0.0; e1[u][a] = have ? C.de[m][a] : 0.0; e2[u][a] = have ? C.de[m][3 + a] : 0.0; }
-          d1[u] = have ? C.de[m][6] : 0.0; d2[u] = have ? C.de[m][7] : 0.0;
-        }
-        edge_packet(p, e1, e2, d1, d2, vt + g * VT, VT);
+        load_edge_slots(g, p, e1, e2, d1, d2);
+        edge_packet(p, e1, e2, d1, d2, vt + g * VT, VT, g);
       }
     for (int base = ((kCacheE + kPkE - 1) / kPkE) * kPkE * VT; !DIRECT && base < n_edge; base += kPkE * VT) {  // beyond the cache: streamed
       double p[kPkE][3], e1[kPkE][3], e2[kPkE][3], d1[kPkE], d2[kPkE];
@@ -614,33 +756,20 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + k] : 0.0; e1[u][a] = live ? cp[(3 + a) * cap + k] : 0.0; e2[u][a] = live ? cp[(6 + a) * cap + k] : 0.0; }
         d1[u] = live ? cp[9 * cap + k] : 0.0; d2[u] = live ? cp[10 * cap + k] : 0.0;
       }
-      edge_packet(p, e1, e2, d1, d2, base + vt, VT);
+      edge_packet(p, e1, e2, d1, d2, base + vt, VT, -1);
     }
     // ---- plane factors
-    auto plane_packet = [&](const double (&p)[kPkP][3], const double (&n)[kPkP][3], const double (&d)[kPkP], int q0, int qstride) {
+    auto plane_packet = [&](const double (&p)[kPkP][3], const double (&n)[kPkP][3], const double (&d)[kPkP], int q0, int qstride, int g) {
       double r0[kPkP];
-      eval_plane_pk<kPkP>(p, n, d, Rm, tt, huber_a, sqrt_a, acc, r0);
-      if (first)
-#pragma unroll
-        for (int u = 0; u < kPkP; u++) {
-          const int q = q0 + u * qstride;
-          if (DIRECT) { if ((C.live_p >> (q0 / VT + u)) & 1u) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(kCacheE * kLmThreads + q, r3); } }
-          else if (q < n_plane) { const double r3[3] = {r0[u], 0.0, 0.0}; put_resid(n_edge + q, r3); }
-        }
+      eval_plane_pk<kPkP>(p, n, d, Rm, tt, huber_a, acc, r0);
+      if (first) plane_resid(r0, q0, qstride, g);
     };
 #pragma unroll
     for (int g = 0; g < kCacheP; g += kPkP)
-      if (DIRECT ? __ballot(((C.live_p >> g) & ((1u << kPkP) - 1u)) != 0u) != 0ull : g * VT < n_plane) {
+      if (g >= gp0 && plane_live(g)) {
         double p[kPkP][3], n[kPkP][3], d[kPkP];
-#pragma unroll
-        for (int u = 0; u < kPkP; u++) {
-          const int m = g + u < kCacheP ? g + u : kCacheP - 1;
-          const bool have = g + u < kCacheP;
-#pragma unroll
-          for (int a = 0; a < 3; a++) { p[u][a] = have ? (double)C.pp[m][a] : 0.0; n[u][a] = have ? C.dp[m][a] : 0.0; }
-          d[u] = have ? C.dp[m][3] : 0.0;
-        }
-        plane_packet(p, n, d, vt + g * VT, VT);
+        load_plane_slots(g, p, n, d);
+        plane_packet(p, n, d, vt + g * VT, VT, g);
       }
     for (int base = ((kCacheP + kPkP - 1) / kPkP) * kPkP * VT; !DIRECT && base < n_plane; base += kPkP * VT) {
       double p[kPkP][3], n[kPkP][3], d[kPkP];
@@ -652,7 +781,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         for (int a = 0; a < 3; a++) { p[u][a] = live ? cp[a * cap + n_edge + q] : 0.0; n[u][a] = live ? cp[(3 + a) * cap + n_edge + q] : 0.0; }
         d[u] = live ? cp[6 * cap + n_edge + q] : 0.0;
       }
-      plane_packet(p, n, d, base + vt, VT);
+      plane_packet(p, n, d, base + vt, VT, -1);
     }
   } else {
     for (int k = tid; k < n_valid; k += kLmThreads) {
@@ -666,24 +795,44 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
     }
   }
   *cyc_factors += clock64() - tf0;
+#ifdef VLOAM_LM_STAMPS
+  long long ev_t = clock64();
+#define EV_STAMP(k) do { if (tid == 0 && !first) { const long long now_ = clock64(); sh.ev_cyc[k] += now_ - ev_t; ev_t = now_; } else if (tid == 0) ev_t = clock64(); } while (0)
+  if (tid == 0 && !first) sh.ev_cyc[0] += ev_t - tf0;
+#else
+#define EV_STAMP(k) do { } while (0)
+#endif
   // block reduction without cross-lane shuffles (a chain of ds_bpermute round trips is what dominated this kernel):
   // transpose through LDS, 8 strided sub-sums per value, then 8 -> 1.  Fixed order: bit-reproducible.
 #pragma unroll
   for (int i = 0; i < kAcc; i++) sh.red[i * kRedStride + tid] = acc[i];
+  EV_STAMP(1);
   lds_barrier();   // LDS only: sh.red (every lane's partial sums) -> the 8 * kAcc summing lanes
+  EV_STAMP(2);
   if (tid < 8 * kAcc) {
     const int i = tid >> 3, sub = tid & 7;
     const double* col = sh.red + i * kRedStride + sub;
-    double s = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < kLmThreads / 8; j++) s += col[8 * j];
-    sh.part[sub * kAcc + i] = s;
-  }
-  lds_barrier();   // LDS only: sh.part (the strided sub-sums) -> the lanes that fold them / publish the granules
-  if (tid < kAcc) {
-    double s = 0.0;
+    // 8 independent partial sums (a dependent f64 add costs a lone wavefront ~32 cycles: 32 in a row were a third of the reduction) from
+    // 16-byte LDS reads — lane (value i, sub) takes the lanes {2 sub, 2 sub + 1} + 16 j of the workgroup —, then a fixed tree: the order is
+    // part of the result and the same in every workgroup
+    const double* colp = sh.red + i * kRedStride + 2 * sub;
+    double sx[4] = {0.0, 0.0, 0.0, 0.0}, sy[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int w = 0; w < 8; w++) s += sh.part[w * kAcc + tid];
+    for (int j = 0; j < kLmThreads / 16; j += 4) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) { const double2 v = *reinterpret_cast<const double2*>(colp + 16 * (j + c)); sx[c] += v.x; sy[c] += v.y; }
+    }
+    (void)col;
+    sh.part[sub * kAcc + i] = ((sx[0] + sx[1]) + (sx[2] + sx[3])) + ((sy[0] + sy[1]) + (sy[2] + sy[3]));
+  }
+  EV_STAMP(3);
+  lds_barrier();   // LDS only: sh.part (the strided sub-sums) -> the lanes that fold them / publish the granules
+  EV_STAMP(4);
+  if (tid < kAcc) {
+    double pw[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) pw[w] = sh.part[w * kAcc + tid];
+    const double s = ((pw[0] + pw[1]) + (pw[2] + pw[3])) + ((pw[4] + pw[5]) + (pw[6] + pw[7]));
     if constexpr (NB == 1) s_out[tid] = s;
     else {
       // Exchange of the partial sums between the NB workgroups WITHOUT a barrier: every f64 travels as two naturally aligned 8-byte
@@ -702,6 +851,7 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
       const u64 bits = (u64)__double_as_longlong(s);
       __hip_atomic_store(&gran[blk * 64 + tid], (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&gran[blk * 64 + 32 + tid], (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      EV_STAMP(5);
       u64 lo[NB], hi[NB];
       bool bad = false;
       for (int spins = 0;; spins++) {
@@ -722,14 +872,16 @@ __device__ __forceinline__ void lm_evaluate(const FactorTable& F, int n_edge, in
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      EV_STAMP(6);
       if (bad) sh.failed = 1;  // nobody continues with partial sums that may be incomplete
-      double tot = 0.0;
+      double pv[8];   // workgroup order, folded as a fixed tree (every workgroup adds the same values the same way: bit-identical accumulators)
 #pragma unroll
-      for (int q = 0; q < NB; q++) tot += __longlong_as_double((long long)((hi[q] << 32) | (lo[q] & 0xffffffffull)));
-      s_out[tid] = tot;
+      for (int q = 0; q < 8; q++) pv[q] = q < NB ? __longlong_as_double((long long)((hi[q < NB ? q : 0] << 32) | (lo[q < NB ? q : 0] & 0xffffffffull))) : 0.0;
+      s_out[tid] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
     }
   }
   lds_barrier();   // LDS only: s_out (this workgroup's or the exchanged totals) -> every lane of the caller
+  EV_STAMP(7);
 }
 
 // packed upper triangle accessor; a, b are compile-time constants at every call site after unrolling
@@ -905,7 +1057,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
 #define LM_STAMP(k) do { } while (0)
 #endif
   // ---- trust-region state: registers of thread 0 (statically indexed); other threads only follow sh.go
-  double radius = 1e4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;
+  double radius = 1e4, inv_radius = 1e-4, decrease_factor = 2.0, minimum_cost = DBL_MAX, current_cost = 0, x_cost = 0, x_norm = 0, gmax = 0;   // inv_radius: what the step needs, kept by MULTIPLICATION (the division for `radius` itself — trace, termination test — is off the step's dependency chain)
   int num_invalid = 0, iteration = 0, n_rec = 0, termination = 0, n_evals = 1;
   double it_cost = 0, it_cost_change = 0, it_step_norm = 0, it_rho = 0;
   bool it_valid = true, it_success = true;
@@ -1006,7 +1158,6 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
 #pragma unroll
         for (int a = 0; a < 6; a++) { gs[a] = sh.gs[curidx][a]; dg[a] = sh.diag[curidx][a]; sc6[a] = sh.scale[a]; }
         LM_STAMP(1);   // bookkeeping + trace row + LDS reads issued
-        const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int a = 0; a < 6; a++) { dg[a] = dg[a] * inv_radius; L[LIDX(a, a)] += dg[a]; }
         LM_STAMP(2);   // reciprocal radius, damped diagonal
@@ -1029,6 +1180,7 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
           // ---- HandleInvalidStep
           if (++num_invalid >= 5) { termination = 2; go = 0; break; }
           radius = radius * (1.0 / decrease_factor);   // LevenbergMarquardtStrategy::StepIsInvalid == StepRejected(0.0): divide by decrease_factor, which doubles (oracle/orc_ceres.cpp)
+          inv_radius = inv_radius * decrease_factor;
           decrease_factor *= 2.0;
           it_cost = x_cost; it_cost_change = 0; it_step_norm = 0; it_rho = 0; it_success = false;
           continue;
@@ -1049,6 +1201,13 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
     cyc_serial += clock64() - t_mark;
     if (sh.go == 0) break;
     t_mark = clock64();
+    if (tid == 160) {   // known before the candidate is evaluated, needed right after: off thread 0's chain (a reciprocal and a square root are ~25 dependent operations)
+      double sn = 0;
+#pragma unroll
+      for (int i = 0; i < na; i++) sn += (sh.x[i] - sh.xc[i]) * (sh.x[i] - sh.xc[i]);
+      sh.step_norm_c = sqrt(sn);
+      sh.inv_mcc = 1.0 / sh.mcc;
+    }
     double* cand = sh.acc2[curidx ^ 1];
     lm_evaluate<QUAT, MODE, NB>(F, n_edge, n_valid, sh.xc, huber_a, sh, cand, false, cache, &cyc_fac, eval_idx++, tag_base);
     cyc_eval += clock64() - t_mark;
@@ -1063,21 +1222,17 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
     if (tid == 0) {
       LM_STAMP(6);
       n_evals++;
-      const double model_cost_change = sh.mcc;
       double candidate_cost = cand[0];
       if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
       bool stop = false;
-      { double s = 0;
-#pragma unroll
-        for (int i = 0; i < na; i++) s += (sh.x[i] - sh.xc[i]) * (sh.x[i] - sh.xc[i]);
-        it_step_norm = sqrt(s); }
+      it_step_norm = sh.step_norm_c;
       if (it_step_norm <= 1e-8 * (x_norm + 1e-8)) { termination = 1; stop = true; }  // ParameterToleranceReached
       if (!stop) {
         it_cost_change = x_cost - candidate_cost;
         if (fabs(it_cost_change) <= 1e-6 * x_cost) { termination = 1; stop = true; }  // FunctionToleranceReached
       }
       if (!stop) {
-        it_rho = candidate_cost >= DBL_MAX ? -DBL_MAX : (current_cost - candidate_cost) / model_cost_change;
+        it_rho = candidate_cost >= DBL_MAX ? -DBL_MAX : (current_cost - candidate_cost) * sh.inv_mcc;   // (model_cost_change > 0: a valid step)
         if (it_rho > 1e-3) {  // HandleSuccessfulStep
           accepted = true;
 #pragma unroll
@@ -1085,13 +1240,14 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
           sh.curidx = curidx ^ 1;  // the candidate's accumulators become the current point's
           x_cost = candidate_cost;
           it_cost = x_cost; it_success = true;
-          { const double c = 2.0 * it_rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - c * c * c); }
-          radius = fmin(1e16, radius);
+          { const double c = 2.0 * it_rho - 1.0, f = fmax(1.0 / 3.0, 1.0 - c * c * c); radius = radius / f; inv_radius = inv_radius * f; }
+          if (radius >= 1e16) { radius = 1e16; inv_radius = 1e-16; }
           decrease_factor = 2.0;
           current_cost = candidate_cost;
         } else {              // HandleUnsuccessfulStep
           it_success = false;
           radius = radius * (1.0 / decrease_factor);  // decrease_factor is a power of two: exact, and folded to a multiply
+          inv_radius = inv_radius * decrease_factor;
           decrease_factor *= 2.0;
           it_cost = candidate_cost;
         }
@@ -1106,6 +1262,9 @@ __device__ __forceinline__ LmRun lm_solve_run(FactorTable& F, int edge_rows, LMR
     curidx = sh.curidx;   // accepted (uniform): the candidate's accumulators and its prepared normal equations become the current point's
   }
 
+#ifdef VLOAM_LM_STAMPS
+  if (tid == 0) for (int k = 0; k < 8; k++) if (k != 6) sh.step_cyc[k] = lm_sum[k];   // ([6]: the first evaluation's cache fill, lm_evaluate)
+#endif
   LmRun R;
   R.minimum_cost = minimum_cost; R.termination = termination; R.n_rec = n_rec; R.n_evals = n_evals;
   R.failed = NB > 1 && sh.failed != 0;
@@ -1144,6 +1303,9 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(VLOA
   }
   if (tid < na) { sh.x[tid] = x_first; sh.x0[tid] = x_first; }
   if (tid == 7) { sh.x[7] = 0.0; sh.failed = 0; sh.curidx = 0; }
+#ifdef VLOAM_LM_STAMPS
+  if (tid < 8) sh.ev_cyc[tid] = 0;
+#endif
   const long long t_start = clock64();
   LmRun R = lm_solve_run<QUAT, MODE, NB>(F, edge_rows, rec, max_iters, huber_a, sh, lead, row_first, mask_first, tag_base);
   if constexpr (NB > 1) {
@@ -1183,7 +1345,7 @@ __global__ __launch_bounds__(kLmThreads) __attribute__((amdgpu_waves_per_eu(VLOA
     rec->cyc[3] = (double)(clock64() - t_start);
     rec->trace[kLmMaxTrace - 1][0] += rec->cyc[3]; rec->trace[kLmMaxTrace - 1][1] += 1.0;   // running sum / count over the handle's life (row 103 is never a real iteration: tools read the average in-kernel time of a solve under load from it)
 #ifdef VLOAM_LM_STAMPS
-    for (int k = 0; k < 8; k++) rec->trace[100][k] = (double)lm_sum[k];
+    for (int k = 0; k < 8; k++) { rec->trace[100][k] = (double)sh.step_cyc[k]; rec->trace[101][k] = (double)sh.ev_cyc[k]; }
 #endif
   }
 }

@@ -582,6 +582,8 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
             F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
             F.A[slot] = a.x; F.A[cap + slot] = a.y; F.A[2 * cap + slot] = a.z;
             F.B[slot] = b.x; F.B[cap + slot] = b.y; F.B[2 * cap + slot] = b.z;
+            const double Ad[3] = {(double)a.x, (double)a.y, (double)a.z}, Bd[3] = {(double)b.x, (double)b.y, (double)b.z};
+            factor_digest(F, slot, 1, Ad, Bd);
           }
         }
       } else if (b2 != ~0ull && b3 != ~0ull) {  // LO:419-442
@@ -599,6 +601,8 @@ __device__ __forceinline__ void lo_assoc_body(LO_ASSOC_ARGS, int (*s_inc_all)[51
           F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
           F.A[slot] = pj.x; F.A[cap + slot] = pj.y; F.A[2 * cap + slot] = pj.z;
           F.B[slot] = nx; F.B[cap + slot] = ny; F.B[2 * cap + slot] = nz;
+          const double Ad[3] = {(double)pj.x, (double)pj.y, (double)pj.z}, Bd[3] = {nx, ny, nz};
+          factor_digest(F, slot, 2, Ad, Bd);
         }
       }
     }
@@ -900,6 +904,8 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
           F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
           F.A[slot] = a.x; F.A[cap + slot] = a.y; F.A[2 * cap + slot] = a.z;
           F.B[slot] = b.x; F.B[cap + slot] = b.y; F.B[2 * cap + slot] = b.z;
+          const double Ad[3] = {(double)a.x, (double)a.y, (double)a.z}, Bd[3] = {(double)b.x, (double)b.y, (double)b.z};
+          factor_digest(F, slot, 1, Ad, Bd);
         } else {          // LO:419-442
           ia = idx; ib = decode(b2); ic = decode(b3);
           type = 2;
@@ -913,6 +919,8 @@ __global__ __launch_bounds__(256) void k_lo_assoc_fast(const float4* __restrict_
           F.p[slot] = pf.x; F.p[cap + slot] = pf.y; F.p[2 * cap + slot] = pf.z;
           F.A[slot] = pj.x; F.A[cap + slot] = pj.y; F.A[2 * cap + slot] = pj.z;
           F.B[slot] = nx; F.B[cap + slot] = ny; F.B[2 * cap + slot] = nz;
+          const double Ad[3] = {(double)pj.x, (double)pj.y, (double)pj.z}, Bd[3] = {nx, ny, nz};
+          factor_digest(F, slot, 2, Ad, Bd);
         }
       }
       F.type[slot] = type;

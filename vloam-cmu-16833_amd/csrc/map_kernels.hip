@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(256) void k_map_fit(const float4* __restrict__ stac
       F.p[slot] = pointOri.x; F.p[cap + slot] = pointOri.y; F.p[2 * cap + slot] = pointOri.z;
       F.A[slot] = A3[0]; F.A[cap + slot] = A3[1]; F.A[2 * cap + slot] = A3[2];
       F.B[slot] = B3[0]; F.B[cap + slot] = B3[1]; F.B[2 * cap + slot] = B3[2];
+      factor_digest(F, slot, type, A3, B3);   // the solve's form of the factor, ready when the solve starts (lm_solve.hip)
     }
   }
   F.type[slot] = type;
@@ -1442,7 +1443,7 @@ vloam_status map_layout(MapContext* m, const vloam_config& cfg, Arena& A) {
     FactorTable& F = m->F[k];
     F.cap = kMapFactorCap;
     ok = ok && A.take(&F.type, (size_t)F.cap) && A.take(&F.p, 3 * (size_t)F.cap) && A.take(&F.A, 3 * (size_t)F.cap) && A.take(&F.B, 3 * (size_t)F.cap) &&
-         A.take(&F.resid, 3 * (size_t)F.cap) && A.take(&F.ctype, (size_t)F.cap) && A.take(&F.cslot, (size_t)F.cap) && A.take(&F.cpack, 11 * (size_t)F.cap) &&
+         A.take(&F.resid, 3 * (size_t)F.cap) && A.take(&F.ctype, (size_t)F.cap) && A.take(&F.cslot, (size_t)F.cap) && A.take(&F.cpack, 11 * (size_t)F.cap) && A.take(&F.dg, 8 * (size_t)F.cap) &&
          A.take(&F.rowcnt, (size_t)F.cap / 64 + 1) && A.take(&F.rowmask, (size_t)F.cap / 64 + 2);
     F.gsync = nullptr;  // the handle places the sync words (lm_sync_calibrate)
     F.err = ok ? &m->frame->error : nullptr;

@@ -184,6 +184,9 @@ struct FactorTable {
   int* ctype;     // [cap]    k_lm_solve's compacted copy (accepted factors only, slot order)
   int* cslot;     // [cap]    original slot of every compacted factor
   double* cpack;  // [11][cap] compacted factors: p, then (e1, e2, d1, d2) of an edge / (n, d) of a plane / A, B otherwise
+  double* dg;     // optional [8][cap], by SLOT: what the solve's evaluation consumes of a LiDAR factor — (e1, e2, d1, d2) of an edge, (n, d) of a plane —
+                  // written by the kernel that emits the factor (k_lo_assoc*, k_map_fit: factor_digest below), so that the solve's first evaluation is one
+                  // memory trip instead of type -> raw points -> two square roots and six divisions on the bounding chain
   int* rowcnt;    // [cap / 64] accepted factors per 64-slot row (atomicAdd by the association kernels, zeroed by k_lm_solve)
   unsigned long long* rowmask;  // optional [cap / 64 (+ 2)]: accepted slots of every 64-slot row as a bit mask, rewritten in full by the producer
                                // (k_map_fit) for every solve: the solve then compacts on its own and k_lm_compact is not launched (lm_solve.hip, kLmRowMask)
@@ -195,10 +198,46 @@ struct FactorTable {
   unsigned gen;   // generation of the launch (lm_launch): the tag of everything the solve's workgroups exchange
   int spin_limit; // polls a workgroup of a cooperative solve waits for its partners before it gives up (lm_launch; VLOAM_LM_SPIN_LIMIT)
   __host__ __device__ void rebase(size_t off) {
-    rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off);
+    rbp(type, off); rbp(p, off); rbp(A, off); rbp(B, off); rbp(resid, off); rbp(ctype, off); rbp(cslot, off); rbp(cpack, off); rbp(dg, off);
     rbp(rowcnt, off); rbp(rowmask, off); rbp(gsync, off); rbp(err, off); rbp(fallbacks, off);
   }
 };
+// Line through a, b -> what the solver's edge evaluation consumes: an orthonormal pair (e1, e2) with e1 x e2 = v = (b - a) / |a - b|
+// (lidarFactor.hpp:37-42 divides by de.norm()), e1 = normalize(v x axis of the smallest |v| component), e2 = v x e1, and the
+// offsets d_i = -(e_i . a).  out = e1, e2, d1, d2.  (r = ((lp - a) x (lp - b)) / |a - b| = c1 e2 - c2 e1 with c_i = e_i . lp + d_i: lm_solve.hip.)
+__device__ __forceinline__ void edge_frame(double ax, double ay, double az, double bx, double by, double bz, double (&out)[8]) {
+  const double dx = bx - ax, dy = by - ay, dz = bz - az;
+  const double dn = sqrt(dx * dx + dy * dy + dz * dz);
+  const double vx = dx / dn, vy = dy / dn, vz = dz / dn;
+  const double fx = fabs(vx), fy = fabs(vy), fz = fabs(vz);
+  double e1x, e1y, e1z;
+  if (fx <= fy && fx <= fz) { e1x = 0.0; e1y = vz; e1z = -vy; }        // v x (1, 0, 0)
+  else if (fy <= fz) { e1x = -vz; e1y = 0.0; e1z = vx; }              // v x (0, 1, 0)
+  else { e1x = vy; e1y = -vx; e1z = 0.0; }                             // v x (0, 0, 1)
+  const double en = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+  e1x /= en; e1y /= en; e1z /= en;
+  const double e2x = vy * e1z - vz * e1y, e2y = vz * e1x - vx * e1z, e2z = vx * e1y - vy * e1x;
+  out[0] = e1x; out[1] = e1y; out[2] = e1z; out[3] = e2x; out[4] = e2y; out[5] = e2z;
+  out[6] = -(e1x * ax + e1y * ay + e1z * az);
+  out[7] = -(e2x * ax + e2y * ay + e2z * az);
+}
+// The digest of the factor just written to slot `slot` of F (type 1: A = last_point_a, B = last_point_b; type 2: A = last_point_j, B = ljm_norm;
+// type 3: A = plane_unit_norm, B.x = negative_OA_dot_norm) -> F.dg.  One lane.
+__device__ __forceinline__ void factor_digest(const FactorTable& F, int slot, int type, const double (&A)[3], const double (&B)[3]) {
+  if (!F.dg) return;
+  const int cap = F.cap;
+  if (type == 1) {
+    double fr[8];
+    edge_frame(A[0], A[1], A[2], B[0], B[1], B[2], fr);
+#pragma unroll
+    for (int q = 0; q < 8; q++) F.dg[q * cap + slot] = fr[q];
+  } else if (type == 2) {   // (lp - j) . n  ->  n . lp + d with d = -(n . j)
+    F.dg[slot] = B[0]; F.dg[cap + slot] = B[1]; F.dg[2 * cap + slot] = B[2]; F.dg[3 * cap + slot] = -(B[0] * A[0] + B[1] * A[1] + B[2] * A[2]);
+  } else if (type == 3) {   // n . lp + negative_OA_dot_norm
+    F.dg[slot] = A[0]; F.dg[cap + slot] = A[1]; F.dg[2 * cap + slot] = A[2]; F.dg[3 * cap + slot] = B[0];
+  }
+}
+
 constexpr int kLmMaxBlocks = 8;                          // workgroups a cooperative solve may use
 constexpr int kLmSyncDoubles = 8 + 2 * kLmMaxBlocks * 64;  // generation, poison word (+ spare) | [parity][workgroup][2][32] tagged 8-byte granules of the partial accumulators
 

@@ -289,6 +289,8 @@ vloam_status vo_layout(VOContext* v, const vloam_config& cfg, Arena& A) {
        A.take(&v->F.cslot, kVoMaxMatches) && A.take(&v->F.cpack, 11 * kVoMaxMatches) &&
        A.take(&v->F.rowcnt, kVoMaxMatches / 64 + 1);
   v->F.gsync = nullptr;
+  v->F.dg = nullptr;   // (the VO factors are evaluated from their raw form)
+  v->F.host_degraded = nullptr;
   v->F.err = nullptr;
   ok = ok && A.take(&v->rec, 1) && A.take(&v->x, 8) && A.take(&v->match_dbg, 7 * kVoMaxMatches) && A.take(&v->counters, 4);
   v->max_points = cfg.max_points;
