@@ -688,6 +688,20 @@ def main():
             hf.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
         itab = hf.profile_table()
         hf.close()
+        # the same front-end in the reference's DEFAULT configuration (optical_flow_match = false: ORB descriptors + brute-force Hamming matches),
+        # a seeded stand-in for OpenCV's sampling pattern
+        ho = vl.Handle(local_rank, with_mapping=0, image_width=IW, image_height=IH)
+        ho.vo_set_orb_pattern(synth.orb_test_pattern())
+        for j in range(2 * ni):
+            ho.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
+        ho.sync()
+        o0 = time.perf_counter()
+        for j in range(reps):
+            ho.vo_process_image_device(d_img.data_ptr() + (j % ni) * IW * IH, IW, IH)
+        ho.sync()
+        o1 = time.perf_counter()
+        orb_matches = int(ho.vo_flow_matches()[0].shape[0])
+        ho.close()
         # CPU restatement beside it (part of the cpu_baseline leg; oracle: cv::goodFeaturesToTrack + cv::calcOpticalFlowPyrLK restated, one thread)
         cpu_img_ms = None
         if not args.no_cpu_baseline:
@@ -709,7 +723,9 @@ def main():
                                                             "frac": IW * IH * (1 + 1.33 + 4 * 1.33) / ((a1 - a0) / reps) / 1e9 / HBM_PEAK_GBS,
                                                             "bytes": "the image once, its 8-bit pyramid (x1.33) and the int16 Scharr pairs of every level (4 B x 1.33) once"},
                                                "cpu_oracle_ms_per_image": cpu_img_ms},
-                     "note": "images are synthetic renders of the LiDAR scene (synth.render_image); ORB + brute-force matching (optical_flow_match = false) is not provided"}
+                     "orb_brute_force_front_end_alone": {"value": reps / (o1 - o0), "unit": "images/s", "us_per_image": 1e6 * (o1 - o0) / reps, "matches_last": orb_matches,
+                                                         "what": "optical_flow_match = false (vloam_main.launch:10): Shi-Tomasi corners + ORB descriptors + BF Hamming 2-NN with the 0.8 ratio test; sampling pattern = synth.orb_test_pattern() (OpenCV's table is library data the caller hands in)"},
+                     "note": "images are synthetic renders of the LiDAR scene (synth.render_image); the coupled legs run the optical-flow configuration"}
         if img_batched:
             img_stage["batched"] = img_batched
 

@@ -217,6 +217,19 @@ vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, doub
 /* last frame: VO estimate (angles_0to1, t_0to1), counter32 / counter22, and velo_last_VOT_velo_curr derived from it (any may be NULL) */
 vloam_status vloam_get_vo_result(vloam_handle* h, double angle_axis[3], double t[3], int counters32_22[2], double prior_q[4], double prior_t[3]);
 
+/* The ORB + brute-force configuration of VisualOdometry::processImage — optical_flow_match = false, the reference's LAUNCH DEFAULT
+ * (vloam_main/launch/vloam_main.launch:10; visual_odometry.cpp:106-116): ImageUtil::descKeypoints = cv::ORB::create()->compute on the Shi-Tomasi
+ * corners (image_util.cpp:162-212: border filter at 31 px, 7 x 7 Gaussian blur, the 256 steered binary tests — the provided keypoints carry
+ * angle -1, which OpenCV uses as -1 degree), then ImageUtil::matchDescriptors with BF / NORM_HAMMING / 2-NN + ratio 0.8 (:214-296).
+ * OpenCV's sampling pattern (modules/features2d/src/orb.cpp: bit_pattern_31_, 256 tests x (x0, y0, x1, y1)) is learned DATA of the library that
+ * is not in the reference tree: the caller hands it in.  pattern_256x4 != NULL switches the handle's image front-end (all sessions) to this
+ * configuration, NULL back to optical flow; not in the middle of a sequence.  vloam_vo_process_image*, vloam_process_frame_image* and the
+ * batched forms then work as before; vloam_vo_get_flow_matches returns the descriptor matches' pixel pairs, vloam_vo_get_flow nothing. */
+vloam_status vloam_vo_set_orb_pattern(vloam_handle* h, const signed char* pattern_256x4);
+/* the keypoints of the latest image that survive ORB's border filter (what DMatch indices refer to: descKeypoints edits the caller's vector)
+ * and their 32-byte descriptors */
+vloam_status vloam_vo_get_descriptors(vloam_handle* h, float* xy, unsigned char* desc32, int cap, int* n);
+
 /* ---- Image front-end of the visual odometry, optical-flow configuration (vloam_main.launch: optical_flow_match = true); needs
  * cfg.image_width / image_height > 0.  Replaces, on the device:
  *   ImageUtil::detKeypoints (ShiTomasi)   src/visual_odometry/src/image_util.cpp:13-36    cv::goodFeaturesToTrack(img, 1024, 0.03, 7.5, 5)

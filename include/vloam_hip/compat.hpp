@@ -328,7 +328,7 @@ struct Transform {
   }
 };
 
-// visual_odometry.h:36-96 in its optical-flow configuration.  processImage takes the 8-bit grey image as a pointer (cv::Mat::data /
+// visual_odometry.h:36-96, optical-flow configuration or (setOrbPattern) the ORB + brute-force one.  processImage takes the 8-bit grey image as a pointer (cv::Mat::data /
 // cols / rows / step) or any matrix class with those members (cv::Mat).  The session needs cfg.image_width / image_height.
 // The reference reads its initial guess from the vloam_tf blackboard (cam0_curr_LOT_cam0_prev, visual_odometry.cpp:258-281): here the
 // caller leaves it in angles_0to1 / t_0to1 before solveNlsAll (zeros = reset_VO_to_identity), which also returns the estimate there and —
@@ -354,6 +354,9 @@ class VisualOdometry {
   template <class Mat> auto processImage(const Mat& img00) -> decltype(img00.data, img00.cols, img00.rows, void()) {   // visual_odometry.h:44: const cv::Mat&
     processImage(img00.data, img00.cols, img00.rows, static_cast<int>(img00.step));
   }
+  // optical_flow_match = false (the launch default, vloam_main.launch:10; read at visual_odometry.cpp:50-52): ORB descriptors + brute-force matches
+  // instead of optical flow.  OpenCV's sampling table (orb.cpp: bit_pattern_31_, 256 x (x0, y0, x1, y1)) is library data the caller hands in.
+  void setOrbPattern(const signed char* bit_pattern_31_256x4) { check(vloam_vo_set_orb_pattern(s_->get(), bit_pattern_31_256x4)); }
   void setUpPointCloud(const vloam_calib& calib) { check(vloam_vo_set_calib(s_->get(), &calib)); }   // visual_odometry.cpp:134-155
   void processPointCloud(const Cloud& cloud) {                                                        // visual_odometry.cpp:157-186
     check(vloam_vo_process_point_cloud(s_->get(), cloud.empty() ? nullptr : &cloud[0].x, static_cast<int>(cloud.size())));

@@ -308,6 +308,37 @@ def clahe(img, clip_limit=2.0, tiles=8):
     return out
 
 
+def gaussian_blur(img):
+    """cv::GaussianBlur(img, (7, 7), 2, 2, BORDER_REFLECT_101) in OpenCV's fixed-point form (orc_img.h)."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    L.orc_gaussian_blur(_p(img, U8), img.shape[1], img.shape[0], _p(out, U8))
+    return out
+
+
+def orb_descriptors(img, kps, pattern):
+    """image_util.cpp:162-212 with ORB on goodFeaturesToTrack keypoints: (kept indices into kps, descriptors [m, 32] u8)."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    k = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 2)
+    pat = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
+    cap = max(k.shape[0], 1)
+    kept = np.zeros(cap, dtype=np.int32)
+    desc = np.zeros((cap, 32), dtype=np.uint8)
+    n = L.orc_orb_descriptors(_p(img, U8), img.shape[1], img.shape[0], _p(k, F), k.shape[0], pat.ctypes.data_as(C.c_void_p), _p(kept, I), _p(desc, U8), cap)
+    return kept[:n], desc[:n]
+
+
+def orb_matches(kps_prev, kept_prev, desc_prev, kps_curr, kept_curr, desc_curr):
+    """visual_odometry.cpp:113-116,296-303 without optical flow: matchDescriptors(prev, curr) (BF, Hamming, 2-NN + ratio 0.8) -> the match loop's
+    integer pixel pairs (prev_uv, curr_uv): keypoints[1 - i][queryIdx].pt / keypoints[i][trainIdx].pt truncated to int."""
+    q, t = bf_match_hamming(desc_prev, desc_curr, knn=True)
+    kp = np.asarray(kps_prev, np.float32)[np.asarray(kept_prev)]
+    kc = np.asarray(kps_curr, np.float32)[np.asarray(kept_curr)]
+    return kp[q].astype(np.int32), kc[t].astype(np.int32)
+
+
 def bf_match_hamming(desc0, desc1, knn=True):
     """image_util.cpp:221-296 (BF, NORM_HAMMING): (queryIdx, trainIdx) int32 arrays; knn: 2-NN + ratio 0.8, else NN + cross check."""
     L = lib()

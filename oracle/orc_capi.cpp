@@ -368,6 +368,19 @@ int orc_bf_match_hamming(const unsigned char* d0, int n0, const unsigned char* d
   return (int)m.size();
 }
 
+int orc_gaussian_blur(const unsigned char* img, int w, int h, unsigned char* out) { gaussian_blur_7x7_s2(img, w, h, out); return 0; }
+// kept_idx [cap], desc [cap][32]; returns the number of keypoints that survive the border filter
+int orc_orb_descriptors(const unsigned char* img, int w, int h, const float* kps_xy, int n, const signed char* pattern, int* kept_idx, unsigned char* desc, int cap) {
+  std::vector<ImgCorner> kps((size_t)n);
+  for (int i = 0; i < n; i++) { kps[(size_t)i].x = kps_xy[2 * i]; kps[(size_t)i].y = kps_xy[2 * i + 1]; }
+  std::vector<int> kept;
+  std::vector<uint8_t> d;
+  orb_descriptors(img, w, h, kps, pattern, &kept, &d);
+  const int m = (int)kept.size() < cap ? (int)kept.size() : cap;
+  for (int i = 0; i < m; i++) kept_idx[i] = kept[(size_t)i];
+  if (m > 0) std::memcpy(desc, d.data(), (size_t)m * 32);
+  return (int)kept.size();
+}
 int orc_clahe(const unsigned char* img, int w, int h, double clip_limit, int tiles, unsigned char* out) {
   clahe_apply(img, w, h, clip_limit, tiles, out);
   return 0;

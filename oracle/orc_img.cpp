@@ -325,6 +325,55 @@ static inline int hamming(const uint8_t* a, const uint8_t* b, int bytes) {
   return d;
 }
 
+// ---------------------------------------------------------------- ORB descriptors on provided keypoints (see orc_img.h)
+void gaussian_blur_7x7_s2(const uint8_t* img, int w, int h, uint8_t* out) {
+  static const int K[7] = {18, 34, 48, 56, 48, 34, 18};   // Q8, sums to 256
+  std::vector<uint16_t> row((size_t)w * h);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int s = 0;
+      for (int k = -3; k <= 3; k++) s += K[k + 3] * (int)img[(size_t)y * w + reflect101(x + k, w)];
+      row[(size_t)y * w + x] = (uint16_t)s;   // <= 255 * 256
+    }
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      uint32_t s = 0;
+      for (int k = -3; k <= 3; k++) s += (uint32_t)K[k + 3] * (uint32_t)row[(size_t)reflect101(y + k, h) * w + x];
+      out[(size_t)y * w + x] = (uint8_t)((s + (1u << 15)) >> 16);
+    }
+}
+static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }   // cvRound: round half to even (default rounding mode)
+void orb_descriptors(const uint8_t* img, int w, int h, const std::vector<ImgCorner>& kps, const int8_t* pattern, std::vector<int>* kept,
+                     std::vector<uint8_t>* desc) {
+  kept->clear(); desc->clear();
+  const int edge = 31;
+  std::vector<uint8_t> blur((size_t)w * h);
+  gaussian_blur_7x7_s2(img, w, h, blur.data());
+  const float angle = -1.0f * (float)(3.14159265358979323846 / 180.0);   // kpt.angle (-1) * (float)(CV_PI / 180.f)
+  const float a = (float)std::cos(angle), b = (float)std::sin(angle);
+  int ox[512], oy[512];
+  for (int i = 0; i < 512; i++) {
+    const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+    ox[i] = cv_round_f(px * a - py * b);
+    oy[i] = cv_round_f(px * b + py * a);
+  }
+  for (int i = 0; i < (int)kps.size(); i++) {
+    const float x = kps[i].x, y = kps[i].y;
+    if (!(x >= (float)edge && x < (float)(w - edge) && y >= (float)edge && y < (float)(h - edge))) continue;   // Rect(edge, edge, w - 2 edge, h - 2 edge).contains(pt)
+    kept->push_back(i);
+    const int cx = cv_round_f(x), cy = cv_round_f(y);
+    for (int j = 0; j < 32; j++) {
+      int val = 0;
+      for (int bit = 0; bit < 8; bit++) {
+        const int t = 8 * j + bit;
+        const int v0 = blur[(size_t)(cy + oy[2 * t]) * w + (cx + ox[2 * t])], v1 = blur[(size_t)(cy + oy[2 * t + 1]) * w + (cx + ox[2 * t + 1])];
+        val |= (v0 < v1) << bit;
+      }
+      desc->push_back((uint8_t)val);
+    }
+  }
+}
+
 std::vector<std::pair<int, int>> bf_match_hamming(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, int bytes, bool knn) {
   std::vector<std::pair<int, int>> out;
   if (knn) {

@@ -21,9 +21,10 @@
 //     f32 running sums (boxFilter's RowSum / ColumnSum), identical on every machine;
 //   * Lucas-Kanade: the 2x2 gradient matrix and the mismatch vector are sums of integer products (OpenCV's fixed-point
 //     window, W_BITS = 14); they are summed exactly and rounded to f32 once (OpenCV: f32 accumulation, order build-dependent).
-// Of the ORB descriptor / brute-force Hamming configuration (optical_flow_match = false) the MATCHER is restated (bf_match_hamming,
-// image_util.cpp:221-296); the ORB descriptor itself needs OpenCV's learned 256-pair sampling table (orb.cpp, bit_pattern_31_), which
-// cannot be restated without the library: descriptors are an input there.
+// The ORB + brute-force configuration (optical_flow_match = false, the launch file's default: vloam_main.launch:10) is restated too:
+// orb_descriptors below (ImageUtil::descKeypoints = cv::ORB::create()->compute on the Shi-Tomasi corners, image_util.cpp:162-212) and
+// bf_match_hamming (image_util.cpp:221-296).  ONE input stays outside: OpenCV's learned sampling table (orb.cpp, bit_pattern_31_: 256 x 4
+// integers) is data of the library, not an algorithm — it is handed in by the caller (vloam_vo_set_orb_pattern; tests use a seeded one).
 #pragma once
 #include <cstdint>
 #include <utility>
@@ -64,6 +65,26 @@ void clahe_apply(const uint8_t* img, int w, int h, double clip_limit, int tiles,
 // cv::batchDistance keeps the K smallest distances per query, admitting a train descriptor only on a strictly smaller distance: equal
 // distances resolve to the lower train index (and, for the cross check, to the lower query index).  Returns (queryIdx, trainIdx) pairs
 // in query order.  desc: n x bytes, row major.
+// cv::GaussianBlur(img, Size(7, 7), 2, 2, BORDER_REFLECT_101) on an 8-bit image — what ORB_Impl::detectAndCompute applies to every pyramid
+// level before the descriptors (orb.cpp).  OpenCV >= 4.1 runs 8-bit images through its bit-exact fixed-point path (smooth.dispatch.cpp):
+// the kernel in Q8 by error diffusion from the taps outward-in, the centre taking what is left of 256 — {18, 34, 48, 56, 48, 34, 18} for
+// sigma 2 (restated from the published source as recalled; PARITY UNPINNED) —, a horizontal pass in Q8.8 (exact: the weights sum to 1), a
+// vertical pass in Q16.16, and one rounding (+ 2^15) >> 16.  All integers: no build dependence.
+void gaussian_blur_7x7_s2(const uint8_t* img, int w, int h, uint8_t* out);
+
+// ImageUtil::descKeypoints with DescriptorType::ORB (image_util.cpp:178-180,203: cv::ORB::create()->compute(img, keypoints, descriptors)) on
+// keypoints that come from goodFeaturesToTrack (octave 0, angle -1 — image_util.cpp:30-34 sets only pt and size):
+//   * KeyPointsFilter::runByImageBorder(keypoints, size, edgeThreshold = 31): keypoints outside [31, w - 31) x [31, h - 31) are REMOVED from the
+//     caller's vector (descKeypoints takes it by reference: the match indices refer to the filtered list), order kept;
+//   * every keypoint has octave 0 -> one pyramid level, the image itself, blurred as above;
+//   * the orientation is NOT recomputed for provided keypoints: computeOrbDescriptors steers the pattern by kpt.angle = -1 DEGREE for every
+//     keypoint (a = cos, b = sin of -pi / 180 in f32; x' = cvRound(x a - y b), y' = cvRound(x b + y a));
+//   * WTA_K = 2: bit k of the 256 = blurred[p0_k] < blurred[p1_k], 32 bytes, bit i of byte j = test 8 j + i.
+// pattern: [256][4] = (x0, y0, x1, y1) of test k (OpenCV: bit_pattern_31_).  kept (out): indices into kps of the keypoints that survive the
+// border filter; desc (out): 32 bytes each.
+void orb_descriptors(const uint8_t* img, int w, int h, const std::vector<ImgCorner>& kps, const int8_t* pattern, std::vector<int>* kept,
+                     std::vector<uint8_t>* desc);
+
 std::vector<std::pair<int, int>> bf_match_hamming(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, int bytes, bool knn);
 
 }  // namespace orc

@@ -158,14 +158,29 @@ class VloamOracle:
         return rc
 
     def process_image(self, cloud, gray):
-        """One callback() from raw inputs with optical_flow_match = true: VisualOdometry::processImage (visual_odometry.cpp:91-132) —
-        corners of the new image, tracked from the previous image into the new one — then the match loop's integer pairs."""
+        """One callback() from raw inputs: VisualOdometry::processImage (visual_odometry.cpp:91-132) — corners of the new image, then either
+        (optical_flow_match = true) tracked from the previous image into the new one, or (self.orb_pattern set: optical_flow_match = false)
+        described by ORB and matched by brute force against the previous image's — then the match loop's integer pairs."""
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         if getattr(self, "CLAHE", False):                                  # visual_odometry.cpp:97-98
             gray = orc.clahe(gray)
         corners = orc.good_features(gray)                                  # image_util.cpp:13-36
         prev_uv = curr_uv = None
         self.flow = None
+        pattern = getattr(self, "orb_pattern", None)
+        if pattern is not None:
+            # optical_flow_match = false (the launch default, vloam_main.launch:10): descKeypoints edits the keypoint vector (border filter),
+            # matchDescriptors(previous, this), and the match loop reads the FILTERED keypoints through the DMatch indices (visual_odometry.cpp:106-116,296-303)
+            kept, desc = orc.orb_descriptors(gray, corners, pattern)
+            self.orb = (corners[kept], desc)
+            if self.count > 0:
+                pk, pd = self.prev_orb
+                q, t = orc.bf_match_hamming(pd, desc, knn=True)
+                prev_uv, curr_uv = pk[q].astype(np.int32), corners[kept][t].astype(np.int32)
+            self.prev_orb = self.orb
+            self.prev_image = gray
+            self.keypoints = corners
+            return self.process(cloud, prev_uv, curr_uv)
         if self.count > 0:
             tracked, status = orc.pyr_lk(self.prev_image, gray, corners)   # image_util.cpp:351-372 (prev image, new image, NEW corners)
             prev_uv, curr_uv = orc.flow_matches(corners, tracked, status)   # visual_odometry.cpp:296-308

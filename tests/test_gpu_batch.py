@@ -145,10 +145,11 @@ def test_batched_coupled_frames_equal_single_session_runs(vl, synth):
     hb.close()
 
 
-def test_batched_frames_from_raw_images_equal_single_session_runs(vl, synth):
-    """vloam_batch_process_frame_image: every session gets its own sweep AND its own grey image (corners + pyramidal LK on the device feed
-    the session's VO solve).  Each session must equal the same inputs through vloam_process_frame_image on a handle of its own:
-    trajectory, VO trajectory, key points, tracked matches."""
+@pytest.mark.parametrize("orb", [False, True], ids=["optical_flow", "orb_brute_force"])
+def test_batched_frames_from_raw_images_equal_single_session_runs(vl, synth, orb):
+    """vloam_batch_process_frame_image: every session gets its own sweep AND its own grey image (corners + pyramidal LK — or, with an ORB pattern
+    set, ORB descriptors + brute-force matches — on the device feed the session's VO solve).  Each session must equal the same inputs through
+    vloam_process_frame_image on a handle of its own: trajectory, VO trajectory, key points, matches."""
     B, n, W, H = 3, 4, 1242, 375
     cam_T_velo, rect0_T_cam, P = synth.kitti_like_calib()
     base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
@@ -160,6 +161,8 @@ def test_batched_frames_from_raw_images_equal_single_session_runs(vl, synth):
     def setup(h):
         h.vo_set_calib(cam_T_velo, rect0_T_cam, P)
         h.set_extrinsics(base_T_cam0, velo_T_cam0)
+        if orb:
+            h.vo_set_orb_pattern(synth.orb_test_pattern())
         return h
 
     hb = setup(vl.Handle(0, n_sessions=B, with_mapping=1, detach_VO_LO=0, image_width=W, image_height=H))
@@ -176,7 +179,10 @@ def test_batched_frames_from_raw_images_equal_single_session_runs(vl, synth):
         assert same_poses(hb.vo_trajectory(), hs.vo_trajectory()), "session %d VO trajectory" % b
         assert np.array_equal(hb.vo_keypoints(), hs.vo_keypoints()) and hs.vo_keypoints().shape[0] > 50, "session %d key points" % b
         mb, ms = hb.vo_flow_matches(), hs.vo_flow_matches()
-        assert np.array_equal(mb[0], ms[0]) and np.array_equal(mb[1], ms[1]) and ms[0].shape[0] > 20, "session %d tracked matches" % b
+        assert np.array_equal(mb[0], ms[0]) and np.array_equal(mb[1], ms[1]) and ms[0].shape[0] > 20, "session %d matches" % b
+        if orb:
+            db, ds = hb.vo_descriptors(), hs.vo_descriptors()
+            assert np.array_equal(db[0], ds[0]) and np.array_equal(db[1], ds[1]), "session %d descriptors" % b
         hs.close()
     # distinct sessions really had distinct images
     hb.select(0); k0 = hb.vo_keypoints()

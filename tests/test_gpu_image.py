@@ -187,3 +187,76 @@ def test_clahe_parity(vl, orc, synth, w, h, seed):
     a, b, s = hd.vo_flow()
     assert np.array_equal(a, c1) and np.array_equal(b, out) and np.array_equal(s, st)
     hd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,seed", [(320, 96, 1), (641, 203, 2), (1242, 375, 3)])
+def test_orb_configuration_parity(vl, orc, synth, w, h, seed):
+    """optical_flow_match = false — the reference's launch default (vloam_main.launch:10): ORB descriptors on the Shi-Tomasi corners
+    (image_util.cpp:162-212) + brute-force Hamming 2-NN with the 0.8 ratio test (:214-296), the sampling pattern handed in by the caller.
+    Blurred image, border-filtered keypoints and their order, all 256 bits of every descriptor, the matches and the match loop's integer
+    pixel pairs: bit for bit against the oracle."""
+    pat = synth.orb_test_pattern()
+    prev, nxt, _ = synth.synth_image_pair(w, h, seed=seed, shift=(2.0, -1.0), rot=0.002, scale=1.001)
+    hd = vl.Handle(0, with_mapping=0, image_width=w, image_height=h)
+    hd.vo_set_orb_pattern(pat)
+    ref = []
+    for k, img in enumerate((prev, nxt)):
+        hd.vo_process_image(img)
+        corners = orc.good_features(img)
+        assert np.array_equal(hd.vo_keypoints(), corners)
+        kept, desc = orc.orb_descriptors(img, corners, pat)
+        xy, d = hd.vo_descriptors()
+        assert np.array_equal(xy, corners[kept]) and kept.size < corners.shape[0], "border filter, order kept"
+        assert np.array_equal(d, desc), "descriptor bits"
+        ref.append((corners, kept, desc))
+        pu, cu = hd.vo_flow_matches()
+        if k == 0:
+            assert pu.shape[0] == 0
+        else:
+            pu_o, cu_o = orc.orb_matches(ref[0][0], ref[0][1], ref[0][2], corners, kept, desc)
+            assert np.array_equal(pu, pu_o) and np.array_equal(cu, cu_o) and pu.shape[0] > 10
+            assert np.median(np.abs((cu - pu)[:, 0] - 2)) <= 1 and np.median(np.abs((cu - pu)[:, 1] + 1)) <= 1, "the matches follow the 2 px / -1 px shift"
+    with pytest.raises(vl.VloamError) as e:
+        hd.vo_set_orb_pattern(None)          # not in the middle of a sequence
+    assert e.value.status == vl.ERR_ORDER
+    hd.close()
+    bad = pat.copy()
+    bad[7] = [40, 0, 1, 1]                   # a test point outside the 31-pixel border the keypoints keep
+    hb = vl.Handle(0, with_mapping=0, image_width=w, image_height=h)
+    with pytest.raises(vl.VloamError) as e:
+        hb.vo_set_orb_pattern(bad)
+    assert e.value.status == vl.ERR_INVALID
+    hb.close()
+
+
+@pytest.mark.gpu
+def test_coupled_frame_loop_with_orb_matches(vl, synth):
+    """configs[3] in the reference's DEFAULT image configuration, from raw inputs: sweep + grey image per frame, corners -> ORB -> brute-force
+    matches -> depth-enhanced VO -> VO prior -> scan registration / odometry / mapping, all on the device, against the coupled-loop oracle."""
+    from test_gpu_laser_odometry import qdist
+    from test_gpu_vloam import make
+    nframes, W, H = 6, 1242, 375
+    pat = synth.orb_test_pattern()
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=1024, n_sweeps=nframes + 1)
+    h, o = make(vl, synth, detach=False, with_mapping=1, image_width=W, image_height=H)
+    h.vo_set_orb_pattern(pat)
+    o.orb_pattern = pat
+    for k in range(nframes):
+        cloud, img = seq.sweep(k), synth.render_image(seq, k, W, H)
+        h.process_frame_image(cloud, img)
+        assert o.process_image(cloud, img) == 0
+        xy, d = h.vo_descriptors()
+        assert np.array_equal(xy, o.orb[0]) and np.array_equal(d, o.orb[1])
+        if k > 0:
+            r, v = h.vo_result(), o.vo_result
+            assert (r["counter32"], r["counter22"]) == (v["counter32"], v["counter22"]) and r["counter32"] + r["counter22"] > 50
+            tol = 2e-7 if k == 1 else 1e-8
+            assert np.linalg.norm(r["angles"] - v["angles"]) < tol and np.linalg.norm(r["t"] - v["t"]) < tol, "VO estimate, frame %d" % k
+        tol = 1e-6 if k == 1 else 1e-8 * (k + 1)
+        tj = h.trajectory()[k]
+        qw, tw, _, _ = o.lidar.lo_pose()
+        qm, tm = o.lidar.map_published_pose()
+        assert qdist(tj[0:4], qw) < tol and np.linalg.norm(tj[4:7] - tw) < tol, "LO world pose, frame %d" % k
+        assert qdist(tj[7:11], qm) < tol and np.linalg.norm(tj[11:14] - tm) < tol, "map pose, frame %d" % k
+    h.close()

@@ -315,3 +315,79 @@ def test_clahe_vs_numpy_transcription(orc, synth):
         assert out.std() > img.std()                      # it does equalise
     flat = np.full((64, 64), 100, dtype=np.uint8)
     assert np.array_equal(orc.clahe(flat), _np_clahe(flat))
+
+
+def numpy_gaussian_blur(img):
+    """cv::GaussianBlur(img, (7, 7), 2, 2, BORDER_REFLECT_101) in OpenCV's fixed-point form, array-formulated (independent of oracle/orc_img.cpp):
+    the Q8 kernel from the error-diffusion rule (softdouble arithmetic == IEEE f64 here), separable integer passes, one rounding."""
+    x = np.arange(-3, 4, dtype=np.float64)
+    g = np.exp(-(x * x) / (2.0 * 2.0 * 2.0))
+    g /= g.sum()
+    q, err = np.zeros(7, np.int64), 0.0
+    for i in range(3):                       # getGaussianKernelFixedPoint_ED: outer taps first, the rounding error carried inward
+        adj = g[i] * 256.0 + err
+        v = int(np.rint(adj))
+        err = adj - v
+        q[i] = q[6 - i] = v
+    q[3] = 256 - 2 * int(q[:3].sum())       # the centre takes what is left of 1.0
+    assert list(q) == [18, 34, 48, 56, 48, 34, 18]
+    a = img.astype(np.int64)
+    h, w = a.shape
+    p = np.pad(a, ((0, 0), (3, 3)), mode="reflect")
+    rows = sum(q[k] * p[:, k:k + w] for k in range(7))
+    p = np.pad(rows, ((3, 3), (0, 0)), mode="reflect")
+    out = sum(q[k] * p[k:k + h, :] for k in range(7))
+    return ((out + (1 << 15)) >> 16).astype(np.uint8)
+
+
+def numpy_orb(img, kps, pattern):
+    """ORB::compute on provided goodFeaturesToTrack keypoints (octave 0, angle -1), array-formulated: border filter, blur, steered tests."""
+    h, w = img.shape
+    kps = np.asarray(kps, np.float32).reshape(-1, 2)
+    keep = (kps[:, 0] >= 31) & (kps[:, 0] < w - 31) & (kps[:, 1] >= 31) & (kps[:, 1] < h - 31)
+    kept = np.nonzero(keep)[0]
+    blur = numpy_gaussian_blur(img)
+    ang = np.float32(-1.0) * np.float32(np.pi / 180.0)
+    a, b = np.float32(np.cos(np.float64(ang))), np.float32(np.sin(np.float64(ang)))
+    pts = np.asarray(pattern, np.int8).reshape(512, 2).astype(np.float32)
+    ox = np.rint(pts[:, 0] * a - pts[:, 1] * b).astype(np.int64)
+    oy = np.rint(pts[:, 0] * b + pts[:, 1] * a).astype(np.int64)
+    cx = np.rint(kps[kept, 0]).astype(np.int64)[:, None]
+    cy = np.rint(kps[kept, 1]).astype(np.int64)[:, None]
+    v = blur[cy + oy[None, :], cx + ox[None, :]]            # [kept, 512]
+    bits = (v[:, 0::2] < v[:, 1::2]).astype(np.uint8)      # [kept, 256]
+    desc = np.packbits(bits.reshape(-1, 32, 8), axis=2, bitorder="little").reshape(-1, 32)
+    return kept, desc
+
+
+def test_orb_descriptors_vs_numpy_transcription_and_properties(orc, synth):
+    """The ORB + brute-force configuration (optical_flow_match = false, the launch default): blur, border filter and the 256 steered tests of the
+    C++ restatement against an array-formulated numpy transcription, bit for bit; and what the construction promises — keypoints within 31 px of
+    the border are dropped (order kept), a featureless image gives the all-zero descriptor, every keypoint of an image matches ITSELF at distance 0
+    against the same image and survives the ratio test, a 1-pixel-shifted copy of a smooth texture still matches most keypoints to their shifted
+    selves."""
+    pat = synth.orb_test_pattern()
+    assert pat.shape == (256, 4) and np.abs(pat).max() <= 13
+    prev, nxt, _ = synth.synth_image_pair(320, 160, seed=4)
+    blur = orc.gaussian_blur(nxt)
+    assert np.array_equal(blur, numpy_gaussian_blur(nxt))
+    flat = np.full((64, 96), 77, np.uint8)
+    assert np.array_equal(orc.gaussian_blur(flat), flat), "the Q8 kernel sums to exactly 256"
+    kps = orc.good_features(nxt)
+    extra = np.array([[5.0, 80.0], [300.0, 80.0], [160.0, 3.0], [31.0, 31.0], [288.0, 128.0], [289.0, 128.0], [30.75, 64.0]], np.float32)   # border cases of Rect::contains
+    kps = np.concatenate([kps, extra])
+    kept, desc = orc.orb_descriptors(nxt, kps, pat)
+    nk, nd = numpy_orb(nxt, kps, pat)
+    assert np.array_equal(kept, nk) and np.array_equal(desc, nd) and kept.size > 20
+    n0 = kps.shape[0] - extra.shape[0]
+    assert [int(k - n0) for k in kept if k >= n0] == [3, 4], "x in [31, w - 31): (31, 31) and (288, 128) stay, (289, .), (30.75, .) go"
+    _, dflat = orc.orb_descriptors(flat, np.array([[48.0, 32.0]], np.float32), pat)
+    assert dflat.shape == (1, 32) and not dflat.any()
+    q, t = orc.bf_match_hamming(desc, desc, knn=True)
+    uniq = np.array([np.count_nonzero((desc == d).all(axis=1)) == 1 for d in desc])
+    assert np.array_equal(q[np.isin(q, np.nonzero(uniq)[0])], t[np.isin(q, np.nonzero(uniq)[0])]) and q.size >= 0.8 * uniq.sum()
+    shifted = np.roll(nxt, 1, axis=1)
+    k2 = orc.good_features(shifted)
+    kept2, desc2 = orc.orb_descriptors(shifted, k2, pat)
+    pu, cu = orc.orb_matches(kps, kept, desc, k2, kept2, desc2)
+    assert pu.shape[0] > 10 and np.mean((cu[:, 0] - pu[:, 0] == 1) & (cu[:, 1] == pu[:, 1])) > 0.8

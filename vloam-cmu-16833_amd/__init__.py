@@ -382,6 +382,23 @@ class Handle:
         self._chk(self.L.vloam_vo_get_flow_matches(self.h, _fp(a), _fp(b), K_IMG_MAX_CORNERS, C.byref(n)))
         return a[:n.value], b[:n.value]
 
+    def vo_set_orb_pattern(self, pattern):
+        """ORB + brute-force configuration (optical_flow_match = false): OpenCV's bit_pattern_31_ as int8 [256, 4]; None = optical flow."""
+        if pattern is None:
+            self._chk(self.L.vloam_vo_set_orb_pattern(self.h, None))
+            return
+        p = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
+        self._chk(self.L.vloam_vo_set_orb_pattern(self.h, _fp(p)))
+
+    def vo_descriptors(self):
+        """(keypoints [n, 2] f32 after ORB's border filter, descriptors [n, 32] u8) of the latest image."""
+        n = C.c_int(0)
+        self._chk(self.L.vloam_vo_get_descriptors(self.h, None, None, 0, C.byref(n)))
+        xy = np.zeros((max(n.value, 1), 2), np.float32)
+        d = np.zeros((max(n.value, 1), 32), np.uint8)
+        self._chk(self.L.vloam_vo_get_descriptors(self.h, _fp(xy), _fp(d), n.value, C.byref(n)))
+        return xy[:n.value], d[:n.value]
+
     def vo_match_descriptors(self, desc_prev, desc_curr, knn=True):
         """ImageUtil::matchDescriptors (BF, NORM_HAMMING): (queryIdx, trainIdx) int32 arrays in query order."""
         a = np.ascontiguousarray(desc_prev, dtype=np.uint8)

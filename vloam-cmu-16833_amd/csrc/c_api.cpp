@@ -1288,8 +1288,75 @@ vloam_status vloam_vo_get_flow(vloam_handle* h, float* prev_xy, float* curr_xy, 
   return VLOAM_OK;
 }
 
+// ORB + brute-force configuration: the keypoints that survive ORB's border filter (what match indices refer to) and their descriptors
+static vloam_status orb_results(vloam_handle* h, int which /* 0: the latest image, 1: the one before */, std::vector<float2>* kp, std::vector<unsigned char>* desc) {
+  if (h->img.max_w == 0 || h->img.count < 0) { set_err("no image processed yet"); return VLOAM_ERR_ORDER; }
+  if (!h->img.orb) { set_err("the handle runs the optical-flow configuration (no ORB pattern set: vloam_vo_set_orb_pattern)"); return VLOAM_ERR_ORDER; }
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  const ImgContext img = h->img.rebased((size_t)h->sel * h->se.ss);
+  const int slot = (h->img.count + (which ? 1 : 0)) % 2;
+  int n = 0;
+  if (!(which && h->img.count == 0)) HIPCHK(hipMemcpy(&n, img.n_okp[slot], sizeof(int), hipMemcpyDeviceToHost));
+  kp->resize((size_t)n);
+  if (n) HIPCHK(hipMemcpy(kp->data(), img.okp[slot], sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
+  if (desc) {
+    std::vector<unsigned> rows((size_t)n * (kImgMaxDescBytes / 4));
+    if (n) HIPCHK(hipMemcpy(rows.data(), img.desc[slot], rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    desc->resize((size_t)n * 32);
+    for (int k = 0; k < n; k++) memcpy(desc->data() + (size_t)k * 32, rows.data() + (size_t)k * (kImgMaxDescBytes / 4), 32);
+  }
+  return VLOAM_OK;
+}
+
+vloam_status vloam_vo_set_orb_pattern(vloam_handle* h, const signed char* pattern_256x4) {
+  if (!h) return VLOAM_ERR_INVALID;
+  if (h->img.max_w == 0) { set_err("the handle was created without an image front-end (cfg.image_width / image_height)"); return VLOAM_ERR_ORDER; }
+  HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
+  if (h->img.count >= 0 && (pattern_256x4 != nullptr) != h->img.orb) { set_err("the image configuration cannot change in the middle of a sequence"); return VLOAM_ERR_ORDER; }
+  const vloam_status s = img_set_orb_pattern(&h->img, h->stream, pattern_256x4, h->se.B, h->se.ss);
+  if (s == VLOAM_ERR_INVALID) set_err("ORB pattern: a steered offset leaves the 31-pixel border the keypoints keep (|x|, |y| <= 30)");
+  return s;
+}
+
+vloam_status vloam_vo_get_descriptors(vloam_handle* h, float* xy, unsigned char* desc32, int cap, int* n) {
+  if (!h || !n || cap < 0) return VLOAM_ERR_INVALID;
+  std::vector<float2> kp;
+  std::vector<unsigned char> d;
+  vloam_status s = orb_results(h, 0, &kp, &d);
+  if (s != VLOAM_OK) return s;
+  *n = (int)kp.size();
+  const int m = *n < cap ? *n : cap;
+  for (int k = 0; xy && k < m; k++) { xy[2 * k] = kp[(size_t)k].x; xy[2 * k + 1] = kp[(size_t)k].y; }
+  if (desc32 && m > 0) memcpy(desc32, d.data(), (size_t)m * 32);
+  return VLOAM_OK;
+}
+
 vloam_status vloam_vo_get_flow_matches(vloam_handle* h, int* prev_uv, int* curr_uv, int cap, int* n) {
   if (!h || !n || cap < 0 || (cap > 0 && (!prev_uv || !curr_uv))) return VLOAM_ERR_INVALID;
+  if (h->img.max_w != 0 && h->img.orb) {
+    // ORB + brute force: matchDescriptors(previous, latest) + the match loop's reads (visual_odometry.cpp:113-116,296-303), from what the device left
+    std::vector<float2> kc, kp;
+    vloam_status s = orb_results(h, 0, &kc, nullptr);
+    if (s == VLOAM_OK) s = orb_results(h, 1, &kp, nullptr);
+    if (s != VLOAM_OK) return s;
+    *n = 0;
+    if (h->img.count == 0 || kp.empty() || kc.size() < 2) return VLOAM_OK;
+    const ImgContext img = h->img.rebased((size_t)h->sel * h->se.ss);
+    std::vector<uint2> best(kp.size());
+    HIPCHK(hipMemcpy(best.data(), img.best2[0], sizeof(uint2) * best.size(), hipMemcpyDeviceToHost));
+    int m = 0;
+    for (size_t q = 0; q < kp.size(); q++) {
+      const uint2 b = best[q];
+      if (b.y == 0xffffffffu || !((double)(float)(b.x >> 16) < 0.8 * (double)(float)(b.y >> 16))) continue;
+      const float2 a = kp[q], c = kc[(size_t)(b.x & 0xffffu)];
+      if (m < cap) { prev_uv[2 * m] = (int)a.x; prev_uv[2 * m + 1] = (int)a.y; curr_uv[2 * m] = (int)c.x; curr_uv[2 * m + 1] = (int)c.y; }
+      m++;
+    }
+    *n = m;
+    return VLOAM_OK;
+  }
   std::vector<float2> c, t;
   std::vector<unsigned char> st;
   int nc = 0, m = 0;

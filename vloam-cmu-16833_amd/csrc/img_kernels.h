@@ -58,6 +58,12 @@ struct ImgContext {
   bool clahe = false;          // cfg.CLAHE
   unsigned char* clahe_img = nullptr;   // [max_w * max_h] equalised image
   unsigned char* clahe_lut = nullptr;   // [tiles^2][256]
+  // ---- ORB + brute-force configuration (optical_flow_match = false): active once the caller has handed in OpenCV's sampling pattern
+  bool orb = false;
+  short2* orb_off = nullptr;   // [512] the pattern steered by the provided keypoints' angle (-1 degree) and rounded: pixel offsets of tests' two points
+  unsigned char* blur = nullptr;   // [max_w * max_h] GaussianBlur(7 x 7, sigma 2) of the current image
+  float2* okp[2] = {nullptr, nullptr};   // [kImgMaxCorners] per image: the corners that survive ORB's border filter, order kept (what the match indices refer to)
+  int* n_okp[2] = {nullptr, nullptr};
   unsigned* desc[2] = {nullptr, nullptr};   // [kImgMaxDesc][kImgMaxDescBytes / 4] descriptors of the two images (brute-force matcher)
   uint2* best2[2] = {nullptr, nullptr};     // [kImgMaxDesc] per descriptor: the two smallest (distance << 16 | index) keys against the other set
 
@@ -69,10 +75,10 @@ struct ImgContext {
     auto mv = [off](auto*& p) { if (p) p = (typename std::remove_reference<decltype(p)>::type)((char*)p + off); };
     for (int k = 0; k < 2; k++) {
       for (int l = 0; l < kImgLevels; l++) { mv(c.pyr[k].img[l]); mv(c.pyr[k].deriv[l]); }
-      mv(c.corners[k]); mv(c.n_corners[k]); mv(c.desc[k]); mv(c.best2[k]);
+      mv(c.corners[k]); mv(c.n_corners[k]); mv(c.desc[k]); mv(c.best2[k]); mv(c.okp[k]); mv(c.n_okp[k]);
     }
     mv(c.sobel); mv(c.eig); mv(c.maxbits); mv(c.cmap); mv(c.clist); mv(c.n_cand); mv(c.nbr); mv(c.nbr_cnt); mv(c.acc); mv(c.tracked); mv(c.status);
-    mv(c.error); mv(c.staging); mv(c.clahe_img); mv(c.clahe_lut);
+    mv(c.error); mv(c.staging); mv(c.clahe_img); mv(c.clahe_lut); mv(c.orb_off); mv(c.blur);
     return c;
   }
   // img_process advanced a rebased copy: take over its host-side state (image size / count, pyramid level dimensions), not its pointers
@@ -96,6 +102,10 @@ vloam_status img_check(const ImgContext* c, int width, int height, int stride); 
 vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_gray, int width, int height, int stride, int* prev_uv, int* curr_uv,
                          ProfHook* ph);
 vloam_status img_debug_get(ImgContext* c, int item, void* buf, long long cap, long long* n);
+// ImageUtil::descKeypoints with ORB (image_util.cpp:162-212) needs OpenCV's learned sampling pattern (orb.cpp: bit_pattern_31_, 256 tests x (x0, y0,
+// x1, y1)): third-party DATA that is not in the reference tree.  Handing it in switches the handle's image front-end to the ORB + brute-force
+// configuration (optical_flow_match = false); null switches back to optical flow.  n_sessions: every session's arena gets the steered offsets.
+vloam_status img_set_orb_pattern(ImgContext* c, hipStream_t st, const signed char* pattern_256x4, int n_sessions, size_t ss);
 // ImageUtil::matchDescriptors, MatcherType::BF + NORM_HAMMING (image_util.cpp:221-296): descriptors in HOST memory (n x bytes), matches
 // (queryIdx into desc0, trainIdx into desc1) in query order; knn: 2-NN + ratio 0.8 (SelectType::KNN), else NN with cross check.
 vloam_status img_match_descriptors(ImgContext* c, hipStream_t st, const unsigned char* desc0, int n0, const unsigned char* desc1, int n1, int bytes, bool knn,

@@ -629,16 +629,16 @@ __global__ __launch_bounds__(256) void k_img_lk(ImgPyrDev P, ImgPyrDev N, const 
 // Brute-force Hamming matcher (cv::BFMatcher(NORM_HAMMING)::knnMatch with k = 2): one wavefront per query descriptor; every lane walks
 // the train descriptors with stride 64 and keeps its two smallest keys (distance << 16 | train index): unique, and ordered the way
 // cv::batchDistance resolves ties (strictly smaller distance wins, i.e. the lower index among equals).
-__global__ __launch_bounds__(256) void k_img_bf_knn(const unsigned* __restrict__ q_desc, int nq, const unsigned* __restrict__ t_desc, int nt, int words,
-                                                    uint2* __restrict__ best2) {
+__device__ __forceinline__ void bf_knn_body(const unsigned* __restrict__ q_desc, int nq, const unsigned* __restrict__ t_desc, int nt, int words, int stride_words,
+                                            uint2* __restrict__ best2) {
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   unsigned qw[kImgMaxDescBytes / 4];
 #pragma unroll
-  for (int w = 0; w < kImgMaxDescBytes / 4; w++) qw[w] = w < words ? q_desc[(size_t)q * words + w] : 0u;
+  for (int w = 0; w < kImgMaxDescBytes / 4; w++) qw[w] = w < words ? q_desc[(size_t)q * stride_words + w] : 0u;
   unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
   for (int t = lane; t < nt; t += 64) {
-    const unsigned* td = t_desc + (size_t)t * words;
+    const unsigned* td = t_desc + (size_t)t * stride_words;
     int d = 0;
 #pragma unroll
     for (int w = 0; w < kImgMaxDescBytes / 4; w++) if (w < words) d += __popc(qw[w] ^ td[w]);
@@ -650,6 +650,106 @@ __global__ __launch_bounds__(256) void k_img_bf_knn(const unsigned* __restrict__
   unsigned c1 = (k0 == g0 && g0 != 0xffffffffu) ? k1 : k0;   // the winner's lane offers its runner-up
   for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(c1, s); c1 = o < c1 ? o : c1; }
   if (lane == 0) best2[q] = make_uint2(g0, c1);
+}
+__global__ __launch_bounds__(256) void k_img_bf_knn(const unsigned* __restrict__ q_desc, int nq, const unsigned* __restrict__ t_desc, int nt, int words,
+                                                    uint2* __restrict__ best2) {
+  bf_knn_body(q_desc, nq, t_desc, nt, words, words, best2);
+}
+
+// ---- ORB + brute-force configuration of processImage (optical_flow_match = false: vloam_main.launch:10, visual_odometry.cpp:106-116)
+// cv::GaussianBlur(level, Size(7, 7), 2, 2, BORDER_REFLECT_101) as OpenCV's bit-exact fixed-point path computes it for 8-bit images
+// (oracle/orc_img.h: Q8 kernel {18, 34, 48, 56, 48, 34, 18}, exact horizontal pass, vertical pass rounded once): integers only.
+__constant__ int kGaussQ8[7] = {18, 34, 48, 56, 48, 34, 18};
+__global__ __launch_bounds__(256) void k_img_gauss_h(const unsigned char* __restrict__ img, int w, int h, int stride, unsigned short* __restrict__ row) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= w * h) return;
+  const int y = p / w, x = p - y * w;
+  const unsigned char* src = img + (size_t)y * stride;
+  int s = 0;
+#pragma unroll
+  for (int k = -3; k <= 3; k++) s += kGaussQ8[k + 3] * (int)src[reflect101_near(x + k, w)];
+  row[p] = (unsigned short)s;
+}
+__global__ __launch_bounds__(256) void k_img_gauss_v(const unsigned short* __restrict__ row, int w, int h, unsigned char* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= w * h) return;
+  const int y = p / w, x = p - y * w;
+  unsigned s = 0;
+#pragma unroll
+  for (int k = -3; k <= 3; k++) s += (unsigned)kGaussQ8[k + 3] * (unsigned)row[(size_t)reflect101_near(y + k, h) * w + x];
+  out[p] = (unsigned char)((s + (1u << 15)) >> 16);
+}
+// KeyPointsFilter::runByImageBorder(edgeThreshold 31) + computeOrbDescriptors on the surviving corners, order kept (image_util.cpp:203 hands the
+// keypoint vector in by reference: the matcher's indices refer to the FILTERED list).  One workgroup: the filter is a 1 024-wide ordered
+// compaction; a thread then computes one 32-bit word (32 tests, 64 pixel reads of the blurred image) of one descriptor at a time.
+__global__ __launch_bounds__(1024) void k_img_orb(const float2* __restrict__ corners, const int* __restrict__ n_corners, const unsigned char* __restrict__ blur,
+                                                  int w, int h, const short2* __restrict__ off, float2* __restrict__ okp, int* __restrict__ n_okp,
+                                                  unsigned* __restrict__ desc) {
+  __shared__ int s_wave[16], s_total;
+  __shared__ short2 s_off[512];
+  __shared__ int s_cx[kImgMaxCorners], s_cy[kImgMaxCorners];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 512) s_off[tid] = off[tid];
+  const int n = min(*n_corners, kImgMaxCorners);
+  float2 pt = make_float2(0.f, 0.f);
+  bool keep = false;
+  if (tid < n) {
+    pt = corners[tid];
+    const float edge = 31.f;   // cv::ORB::create(): edgeThreshold 31
+    keep = pt.x >= edge && pt.x < (float)(w - 31) && pt.y >= edge && pt.y < (float)(h - 31);
+  }
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) s_wave[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0;
+  for (int q = 0; q < wave; q++) base += s_wave[q];
+  if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_total = t; *n_okp = t; }
+  if (keep) {
+    const int o = base + __popcll(m & ((1ull << lane) - 1ull));
+    okp[o] = pt;
+    s_cx[o] = (int)rintf(pt.x); s_cy[o] = (int)rintf(pt.y);   // cvRound(kpt.pt * scale), scale = 1
+  }
+  __syncthreads();
+  const int total = s_total;
+  for (int e = tid; e < total * 8; e += 1024) {
+    const int kp = e >> 3, word = e & 7;
+    const unsigned char* c = blur + (size_t)s_cy[kp] * w + s_cx[kp];
+    unsigned val = 0;
+#pragma unroll 8
+    for (int bit = 0; bit < 32; bit++) {
+      const int t = 32 * word + bit;
+      const short2 o0 = s_off[2 * t], o1 = s_off[2 * t + 1];
+      const int v0 = c[o0.y * w + o0.x], v1 = c[o1.y * w + o1.x];
+      val |= (unsigned)(v0 < v1) << bit;   // byte j of the descriptor = tests 8 j .. 8 j + 7, LSB first: word = four bytes, little endian
+    }
+    desc[(size_t)kp * (kImgMaxDescBytes / 4) + word] = val;
+  }
+}
+// matchDescriptors(descriptors[1 - i], descriptors[i]) with BF / NORM_HAMMING / KNN (image_util.cpp:221-296): the previous image's descriptors
+// are the queries; counts come from the device (no host round trip in the frame loop)
+__global__ __launch_bounds__(256) void k_img_bf_knn_dev(const unsigned* __restrict__ q_desc, const int* __restrict__ nq, const unsigned* __restrict__ t_desc,
+                                                        const int* __restrict__ nt, uint2* __restrict__ best2) {
+  bf_knn_body(q_desc, *nq, t_desc, *nt, 8, kImgMaxDescBytes / 4, best2);
+}
+// ... the ratio test (knn_match[0].distance < 0.8 * knn_match[1].distance, float distances, double product) and the match loop's reads
+// (visual_odometry.cpp:296-303: keypoints[1 - i][queryIdx].pt / keypoints[i][trainIdx].pt truncated to int) into the frame's match slots,
+// query order; a slot without a match is marked like an untracked corner
+__global__ void k_img_orb_matches(const uint2* __restrict__ best2, const int* __restrict__ nq, const int* __restrict__ nt, const float2* __restrict__ kp_prev,
+                                  const float2* __restrict__ kp_curr, int* __restrict__ prev_uv, int* __restrict__ curr_uv) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= kImgMaxCorners) return;
+  bool ok = false;
+  int t = 0;
+  if (q < *nq && *nt >= 2) {   // (a single train descriptor: the reference would read knn_match[1] out of range)
+    const uint2 b = best2[q];
+    ok = b.y != 0xffffffffu && (double)(float)(b.x >> 16) < 0.8 * (double)(float)(b.y >> 16);
+    t = (int)(b.x & 0xffffu);
+  }
+  if (prev_uv) {
+    const float2 a = ok ? kp_prev[q] : make_float2(0.f, 0.f), c = ok ? kp_curr[t] : make_float2(0.f, 0.f);
+    prev_uv[2 * q] = ok ? (int)a.x : INT_MIN; prev_uv[2 * q + 1] = ok ? (int)a.y : 0;
+    curr_uv[2 * q] = ok ? (int)c.x : INT_MIN; curr_uv[2 * q + 1] = ok ? (int)c.y : 0;
+  }
 }
 
 __global__ void k_img_no_matches(int* prev_uv, int* curr_uv) {
@@ -692,6 +792,8 @@ vloam_status img_layout(ImgContext* c, const vloam_config& cfg, Arena& A) {
   c->clahe = cfg.CLAHE != 0;
   ok = ok && A.take(&c->clahe_img, npx) && A.take(&c->clahe_lut, (size_t)kImgClaheTiles * kImgClaheTiles * 256);
   for (int k = 0; k < 2; k++) ok = ok && A.take(&c->desc[k], (size_t)kImgMaxDesc * (kImgMaxDescBytes / 4)) && A.take(&c->best2[k], kImgMaxDesc);
+  ok = ok && A.take(&c->orb_off, 512) && A.take(&c->blur, npx);
+  for (int k = 0; k < 2; k++) ok = ok && A.take(&c->okp[k], kImgMaxCorners) && A.take(&c->n_okp[k], 1);
   return ok ? VLOAM_OK : VLOAM_ERR_CAPACITY;
 }
 
@@ -737,6 +839,22 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
                (float)(min_distance * min_distance), (int)min_distance, c->nbr, c->nbr_cnt, c->error);
   VLOAM_LAUNCH(ph, kKImgSelect, st, k_img_select, dim3(1), dim3(kSelThreads), sizeof(u64) * kImgAccCap, st, c->eig, width, c->clist, c->n_cand, c->nbr,
                c->nbr_cnt, c->acc, kImgMaxCorners, c->corners[cur], c->n_corners[cur], c->error);
+  if (c->orb) {
+    // visual_odometry.cpp:106-116 with optical_flow_match = false: descKeypoints on this image's corners, then — from the second image on —
+    // matchDescriptors(previous, this).  No pyramid, no flow.
+    unsigned short* rows = reinterpret_cast<unsigned short*>(c->sobel);   // (the Sobel pairs have been consumed by k_img_eig: same stream)
+    VL_RAW_LAUNCH(k_img_gauss_h, dim3(gpx), dim3(256), 0, st, d_gray, width, height, stride, rows);
+    VL_RAW_LAUNCH(k_img_gauss_v, dim3(gpx), dim3(256), 0, st, rows, width, height, c->blur);
+    VL_RAW_LAUNCH(k_img_orb, dim3(1), dim3(1024), 0, st, c->corners[cur], c->n_corners[cur], c->blur, width, height, c->orb_off, c->okp[cur], c->n_okp[cur], c->desc[cur]);
+    if (c->count > 0) {
+      VL_RAW_LAUNCH(k_img_bf_knn_dev, dim3(kImgMaxCorners / 4), dim3(256), 0, st, c->desc[1 - cur], c->n_okp[1 - cur], c->desc[cur], c->n_okp[cur], c->best2[0]);
+      VL_RAW_LAUNCH(k_img_orb_matches, dim3(kImgMaxCorners / 256), dim3(256), 0, st, c->best2[0], c->n_okp[1 - cur], c->n_okp[cur], c->okp[1 - cur], c->okp[cur],
+                    prev_uv, curr_uv);
+    } else if (prev_uv) {
+      VL_RAW_LAUNCH(k_img_no_matches, dim3(kImgMaxCorners / 256), dim3(256), 0, st, prev_uv, curr_uv);
+    }
+    return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
+  }
   for (int l = 1; l < P.levels; l++)
     VLOAM_LAUNCH(ph, kKImgPyrDown, st, k_img_pyrdown, dim3((P.w[l] * P.h[l] + 255) / 256), dim3(256), 0, st, P.img[l - 1], P.w[l - 1], P.h[l - 1], P.img[l],
                  P.w[l], P.h[l]);
@@ -753,6 +871,30 @@ vloam_status img_process(ImgContext* c, hipStream_t st, const unsigned char* d_g
   return hipGetLastError() == hipSuccess ? VLOAM_OK : VLOAM_ERR_HIP;
 }
 
+
+vloam_status img_set_orb_pattern(ImgContext* c, hipStream_t st, const signed char* pattern, int n_sessions, size_t ss) {
+  if (c->max_w == 0) return VLOAM_ERR_ORDER;
+  if (!pattern) { c->orb = false; return VLOAM_OK; }
+  // computeOrbDescriptors (orb.cpp) for a keypoint with angle = -1 (goodFeaturesToTrack keypoints carry no orientation, image_util.cpp:30-34):
+  //   float angle = kpt.angle; angle *= (float)(CV_PI / 180.f); float a = (float)cos(angle), b = (float)sin(angle);
+  //   x = pattern[idx].x * a - pattern[idx].y * b;  y = pattern[idx].x * b + pattern[idx].y * a;  ix = cvRound(x), iy = cvRound(y)
+  // — the same for every keypoint, so the steered offsets are computed once, here (f32 products and sums, no contraction: csrc/Makefile)
+  float angle = -1.0f;
+  angle *= (float)(3.14159265358979323846 / 180.0);
+  const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+  short2 off[512];
+  for (int i = 0; i < 512; i++) {
+    const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+    const float x = px * a - py * b, y = px * b + py * a;
+    off[i] = make_short2((short)lrintf(x), (short)lrintf(y));
+    if (abs((int)off[i].x) > 30 || abs((int)off[i].y) > 30) return VLOAM_ERR_INVALID;   // must stay inside the 31-pixel border the keypoints keep
+  }
+  for (int b_ = 0; b_ < n_sessions; b_++)
+    if (hipMemcpyAsync((char*)c->orb_off + (size_t)b_ * ss, off, sizeof(off), hipMemcpyHostToDevice, st) != hipSuccess) return VLOAM_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return VLOAM_ERR_HIP;
+  c->orb = true;
+  return VLOAM_OK;
+}
 
 vloam_status img_match_descriptors(ImgContext* c, hipStream_t st, const unsigned char* desc0, int n0, const unsigned char* desc1, int n1, int bytes, bool knn,
                                    int* query_idx, int* train_idx, int cap, int* n_matches) {

@@ -456,3 +456,18 @@ def synth_image_pair(w=1242, h=375, seed=7, shift=(3.6, -1.3), rot=0.004, scale=
     Binv = np.linalg.inv(B)
     flow = lambda p: (np.asarray(p, dtype=np.float64) + m - tb) @ Binv.T   # noqa: E731
     return prev, nxt, flow
+
+
+def orb_test_pattern(seed=31):
+    """A seeded stand-in for OpenCV's learned ORB sampling table (orb.cpp: bit_pattern_31_ — library data that is not in the reference tree, handed
+    in by the caller: vloam_vo_set_orb_pattern): int8 [256, 4] = (x0, y0, x1, y1) per test, Gaussian around the patch centre like the original's
+    distribution, inside the 31 x 31 patch, the two points of a test distinct."""
+    rng = np.random.default_rng(seed)
+    pat = np.zeros((256, 4), np.int8)
+    for k in range(256):
+        while True:
+            v = np.clip(np.rint(rng.normal(0.0, 5.5, 4)), -13, 13).astype(np.int8)
+            if (v[0], v[1]) != (v[2], v[3]):
+                pat[k] = v
+                break
+    return pat
