@@ -232,6 +232,25 @@ static std::atomic<int> g_single_handles{0};   // single-sequence handles alive 
 template <class T>
 static inline T* SEL(const vloam_handle* h, T* p) { return p ? (T*)((char*)p + (size_t)h->sel * h->se.ss) : p; }
 
+// A/B path (VLOAM_STAGE_KERNEL=1, off by default): a sweep in PINNED host memory fetched by a copy kernel through the buffer's device-side
+// address instead of hipMemcpyAsync.  The DMA path moves 2 MB in 87 us on the stream and costs 42 us inside the call; a kernel reads it at
+// the link's rate (43 us, 2.7 us of host time: profiles/r05_pinned_read.txt).  Round 5 tried that with 32 workgroups x 16 loads in flight per
+// lane and every kernel beside it ran ~45 us longer; round 6 tried the opposite — FEW workgroups with few loads in flight, on the idea that the
+// link's bandwidth-delay product (~100 KB) does not need 2 MB of queued reads: 2 / 4 / 8 workgroups are latency-bound (0.34 / 0.56 / 0.73 x the
+// device-resident rate), 16 - 32 reach 0.83 - 0.85 x, the DMA copy 0.88 x, on the copy stream + ring 0.37 - 0.75 x
+// (profiles/r06_host_input.txt).  The 2 MB have to cross the link in front of the sweep's scan registration either way; the DMA copy stays.
+template <int ILP>
+__global__ __launch_bounds__(256) void k_stage_copy(const float4* __restrict__ src, float4* __restrict__ dst, int n) {
+  const int stride = gridDim.x * 256;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += stride * ILP) {
+    float4 v[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) { const int i = i0 + u * stride; if (i < n) v[u] = src[i]; }
+#pragma unroll
+    for (int u = 0; u < ILP; u++) { const int i = i0 + u * stride; if (i < n) dst[i] = v[u]; }
+  }
+}
+
 extern "C" {
 
 void vloam_default_config(vloam_config* c) {
@@ -681,9 +700,28 @@ static vloam_status stage_begin(vloam_handle* h) {
   if (h->in_reader[h->in_slot]) HIPCHK(hipStreamWaitEvent(h->s_copy, h->in_reader[h->in_slot], 0));
   return VLOAM_OK;
 }
+static const int g_stage_kernel = getenv("VLOAM_STAGE_KERNEL") ? atoi(getenv("VLOAM_STAGE_KERNEL")) : 0;
+static const int g_stage_wgs = getenv("VLOAM_STAGE_WGS") ? atoi(getenv("VLOAM_STAGE_WGS")) : 16;
+static const int g_stage_ilp = getenv("VLOAM_STAGE_ILP") ? atoi(getenv("VLOAM_STAGE_ILP")) : 4;
 static vloam_status stage_sweep(vloam_handle* h, int b, const float* xyz_pad4, int n, const float4** d_out) {
   float4* dst = (float4*)((char*)(h->d_in + (size_t)h->in_slot * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
-  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, g_stage_inline ? h->stream : h->s_copy));
+  hipStream_t st = g_stage_inline ? h->stream : h->s_copy;
+  if (g_stage_kernel) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, xyz_pad4) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+      const float4* src = (const float4*)attr.devicePointer;
+      const int wgs = g_stage_wgs < 1 ? 1 : (g_stage_wgs > 256 ? 256 : g_stage_wgs);
+      if (g_stage_ilp >= 16) VL_RAW_LAUNCH(k_stage_copy<16>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
+      else if (g_stage_ilp >= 8) VL_RAW_LAUNCH(k_stage_copy<8>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
+      else if (g_stage_ilp >= 4) VL_RAW_LAUNCH(k_stage_copy<4>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
+      else VL_RAW_LAUNCH(k_stage_copy<2>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
+      HIPCHK(hipGetLastError());
+      *d_out = dst;
+      return VLOAM_OK;
+    }
+    (void)hipGetLastError();   // a pageable pointer: hipPointerGetAttributes says so through an error code
+  }
+  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
   *d_out = dst;
   return VLOAM_OK;
 }
