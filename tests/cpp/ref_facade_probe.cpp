@@ -133,6 +133,11 @@ int main(int argc, char** argv) {
     if (std::fread(point_cloud_pcl.points.data(), sizeof(pcl::PointXYZ), (size_t)n_pts, f) != (size_t)n_pts) return 2;
     LOAM.reset();
     LOAM.scanRegistrationIO(point_cloud_pcl);   // vloam_main_node.cpp:166-168
+    if (k == 2) {   // a caller that edits a hand-over: every third surfPointsLessFlat point dropped before LaserOdometry::input (uploaded: vloam_set_odometry_input)
+      pcl::PointCloud<PointType>::Ptr thin = boost::make_shared<pcl::PointCloud<PointType>>();
+      for (size_t i = 0; i < LOAM.surfPointsLessFlat->points.size(); i++) if (i % 3 != 1) thin->points.push_back(LOAM.surfPointsLessFlat->points[i]);
+      LOAM.surfPointsLessFlat = thin;
+    }
     LOAM.laserOdometryIO();
     if (k == 3) {   // a caller that edits a hand-over: every second corner point dropped before LaserMapping::input
       pcl::PointCloud<PointType>::Ptr thin = boost::make_shared<pcl::PointCloud<PointType>>();

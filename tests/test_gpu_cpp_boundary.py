@@ -195,8 +195,8 @@ def test_cpp_visual_odometry_class_from_images(tmp_path, orc, synth, vl):
 def test_reference_typed_facade_on_the_gpu(tmp_path, orc, sweeps, vl):
     """tests/cpp/ref_facade_probe.cpp: the façade of lidar_odometry_mapping.cpp:73-154 — pcl::PointCloud<PointType>::Ptr hand-overs,
     Eigen::Quaterniond / Vector3d poses, `if (!skip_frame) solveMapping(); publish();` — through compat.hpp's templates with the stand-in types of
-    tests/stubs/, on the GPU, against the oracle driven stage by stage; at sweep 3 the caller thins laserCloudCornerLast before
-    LaserMapping::input (uploaded by vloam_set_mapping_input)."""
+    tests/stubs/, on the GPU, against the oracle driven stage by stage; at sweep 2 the caller thins surfPointsLessFlat before LaserOdometry::input (uploaded by
+    vloam_set_odometry_input), at sweep 3 laserCloudCornerLast before LaserMapping::input (vloam_set_mapping_input)."""
     n, shape, skip = 6, (64, 512), 2
     clouds = [sweeps(shape[0], shape[1], k) for k in range(n)]
     data = tmp_path / "sweeps.bin"
@@ -212,6 +212,9 @@ def test_reference_typed_facade_on_the_gpu(tmp_path, orc, sweeps, vl):
     for k in range(n):
         f = out[k].split()
         assert o.stage_sr(clouds[k]) == 0
+        if k == 2:   # the probe thins surfPointsLessFlat before LaserOdometry::input at sweep 2
+            lf = o.cloud(4)
+            o.set_sr_cloud(4, lf[np.arange(lf.shape[0]) % 3 != 1])
         counts = [o.cloud(w).shape[0] for w in range(5)]
         o.stage_lo()
         corner = o.cloud(5)
