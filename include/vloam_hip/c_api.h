@@ -141,7 +141,8 @@ vloam_status vloam_laser_odometry(vloam_handle* h, double q_w[4], double t_w[3],
  * the sweep's own: this sweep's odometry, the next sweep's CornerLast / SurfLast (laser_odometry.cpp:506-526) and the mapping stage's input
  * all see them.  Capacity: 768 / 7 680 / 1 536 points for cornerPointsSharp / LessSharp / surfPointsFlat, max_points for the other two.
  * Stated limit: the two less-clouds must keep scan registration's ordering (scan lines ascending up to the r / r - 1 jitter of
- * int(intensity)); the adjacent-line walks of laser_odometry.cpp:294-324,371-428 are evaluated from per-line first / last indices. */
+ * int(intensity)); the adjacent-line walks of laser_odometry.cpp:294-324,371-428 are evaluated from per-line first / last indices.
+ * Both stage-input calls are for single-sequence handles driven stage by stage (VLOAM_ERR_INVALID on n_sessions > 1: a batch is enqueued whole). */
 vloam_status vloam_set_odometry_input(vloam_handle* h, const float* laserCloud, int n_full, const float* cornerPointsSharp, int n_sharp,
                                       const float* cornerPointsLessSharp, int n_less_sharp, const float* surfPointsFlat, int n_flat,
                                       const float* surfPointsLessFlat, int n_less_flat);
@@ -173,7 +174,7 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
 vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n);
 /* same with a HOST buffer — what the reference's callback hands over (a pcl::PointCloud<pcl::PointXYZ>'s points, scan_registration.cpp:131-152).
  * The sweep is copied into a device input buffer in front of its scan registration, on the scan-registration stream itself (the stream has the
- * time: DESIGN.md section 10; VLOAM_STAGE_INLINE=0 selects a ring of four input buffers on a copy stream of the handle's own instead); the call
+ * time: DESIGN.md section 5, profiles/r06_host_input.txt; VLOAM_STAGE_INLINE=0 selects a ring of four input buffers on a copy stream of the handle's own instead); the call
  * returns once the copy is enqueued.
  *   pageable memory (malloc, std::vector, a ROS message): the runtime has taken its copy of the sweep when the call returns — the buffer may
  *     be reused at once; the calling thread pays the staging memcpy (~2 MB per sweep);

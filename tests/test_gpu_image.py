@@ -211,6 +211,7 @@ def test_orb_configuration_parity(vl, orc, synth, w, h, seed):
         assert np.array_equal(d, desc), "descriptor bits"
         ref.append((corners, kept, desc))
         pu, cu = hd.vo_flow_matches()
+        assert hd.vo_flow()[0].shape[0] == 0, "nothing is tracked in the ORB configuration (calcOpticalFlowPyrLK is not called, visual_odometry.cpp:105-116)"
         if k == 0:
             assert pu.shape[0] == 0
         else:

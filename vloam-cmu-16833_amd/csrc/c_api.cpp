@@ -1288,7 +1288,7 @@ static vloam_status img_results(vloam_handle* h, std::vector<float2>* corners, s
   HIPCHK(hipMemcpy(n_corners, img.n_corners[cur], sizeof(int), hipMemcpyDeviceToHost));
   corners->resize((size_t)*n_corners + 1);
   if (*n_corners) HIPCHK(hipMemcpy(corners->data(), img.corners[cur], sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));
-  *have_flow = h->img.count > 0;
+  *have_flow = h->img.count > 0 && !h->img.orb;   // ORB + brute-force tracks nothing: matches come from vloam_vo_get_flow_matches
   if (tracked && *have_flow && *n_corners) {
     tracked->resize((size_t)*n_corners); status->resize((size_t)*n_corners);
     HIPCHK(hipMemcpy(tracked->data(), img.tracked, sizeof(float2) * (size_t)*n_corners, hipMemcpyDeviceToHost));

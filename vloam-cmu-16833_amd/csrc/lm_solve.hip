@@ -1470,7 +1470,7 @@ void lm_launch(hipStream_t st, Sess se, const FactorTable& F_in, int n_edge_slot
   const bool direct = quat && F.cap == kLmThreads * (kCacheE + kCacheP) && n_edge_slots == kLmThreads * kCacheE;  // the odometry table
   const bool rowmask = quat && !direct && F.rowmask != nullptr && (F.cap >> 6) <= 2 * kLmThreads;   // the fit kernel left row masks: the solve compacts on its own
   // Batches keep the cooperative form because it is faster there: one workgroup per session and solve (VLOAM_BATCH_SINGLE_WG=1) measured
-  // +3 % at B = 8 in round 3 and -10 % in round 4.  (The f64 sums of the normal equations are added in workgroup order:
+  // +3 % at B = 8 in round 3 and -10 % in round 4 (DESIGN_HISTORY.md).  (The f64 sums of the normal equations are added in workgroup order:
   // whatever the count, a batched session equals the same sequence run alone to round-off, not bit for bit — tests/test_gpu_batch.py.)
   static const int single_wg = getenv("VLOAM_BATCH_SINGLE_WG") ? atoi(getenv("VLOAM_BATCH_SINGLE_WG")) : 0;
   const bool coop = F.gsync != nullptr && !(single_wg && se.B > 1) && !se.no_coop;   // no_coop: a solve of this handle had to degrade once (vloam_sync)
