@@ -575,9 +575,11 @@ def main():
         host_input = {"sweeps": n_h, "unit": "scans/s", "device_resident": runs["device"][0], "pinned": runs["pinned"][0], "pageable": runs["pageable"][0],
                       "pinned_over_device_resident": runs["pinned"][0] / runs["device"][0],
                       "same_last_pose": bool(np.array_equal(runs["device"][1], runs["pinned"][1]) and np.array_equal(runs["device"][1], runs["pageable"][1])),
-                      "note": "vloam_process_scan, one 2 MB sweep per call from a buffer of its own; pinned = hipHostMalloc'ed memory read by DMA in front of the sweep's "
-                              "scan registration (same stream), pageable = numpy memory (the runtime's staging memcpy runs on the calling thread); "
-                              "tools/host_input_probe.py: the same with a few reused buffers, and the ring + copy-stream form (VLOAM_STAGE_INLINE=0)"}
+                      "pageable_over_device_resident": runs["pageable"][0] / runs["device"][0],
+                      "note": "vloam_process_scan, one 2 MB sweep per call from a buffer of its own; copied on the handle's copy stream into a ring of device "
+                              "input buffers while the previous sweep's scan registration runs, the sweep enqueued by the next call (c_api.h); pinned = "
+                              "hipHostMalloc'ed memory read by DMA, pageable = numpy memory (the runtime's staging memcpy runs on the calling thread); "
+                              "tools/host_input_probe.py: the same with a few reused buffers, and the inline form (VLOAM_STAGE_INLINE=1)"}
 
     # ---- extra: configs[3] (synthetic analogue) — the coupled per-frame VLOAM loop, one vloam_process_frame_device per frame:
     # depth-enhanced VO solve -> VO2VeloAndBase -> SR -> LO in combined mode (detach_VO_LO = 0) -> LO -> VO prior -> mapping, no host

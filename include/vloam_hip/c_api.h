@@ -173,14 +173,19 @@ vloam_status vloam_laser_mapping(vloam_handle* h, double q_map[4], double t_map[
  * entry points first enqueue whatever is still owed, so this is invisible except through the raw device pointer below. */
 vloam_status vloam_process_scan_device(vloam_handle* h, const void* d_xyz_pad4, int n);
 /* same with a HOST buffer — what the reference's callback hands over (a pcl::PointCloud<pcl::PointXYZ>'s points, scan_registration.cpp:131-152).
- * The sweep is copied into a device input buffer in front of its scan registration, on the scan-registration stream itself (the stream has the
- * time: DESIGN.md section 5, profiles/r06_host_input.txt; VLOAM_STAGE_INLINE=0 selects a ring of four input buffers on a copy stream of the handle's own instead); the call
- * returns once the copy is enqueued.
+ * The sweep is copied into one of four device input buffers on a copy stream of the handle; the call returns once the copy is enqueued, and the
+ * sweep itself — like its odometry and mapping — is ENQUEUED BY THE NEXT CALL on the handle, whatever that call is (another sweep of any kind, a
+ * stage-wise call, a getter, vloam_sync): by then the copy has landed, so the 2 MB cross the host link beside the previous sweep's scan
+ * registration and no stream waits for another (0.96 - 0.98 x the device-resident rate; profiles/r06_host_input.txt).  The sweep counts
+ * (vloam_frame_count, trajectory rows) from the moment it is handed over.  What can be refused is refused by THIS call (null / empty / oversized
+ * cloud, a full trajectory log); an enqueue failure of the deferred sweep (VLOAM_ERR_HIP) is reported by the call that enqueues it.
  *   pageable memory (malloc, std::vector, a ROS message): the runtime has taken its copy of the sweep when the call returns — the buffer may
  *     be reused at once; the calling thread pays the staging memcpy (~2 MB per sweep);
  *   pinned memory (hipHostMalloc / hipHostRegister): read by DMA AFTER the call returns — leave the buffer unchanged until the next
  *     vloam_sync(); no host-side copy (bench.py: host_input).
- * The same holds for every other entry point that takes a host sweep (vloam_scan_registration, vloam_process_frame*, vloam_batch_process_*). */
+ * vloam_batch_process_scan works the same way.  Every other entry point that takes a host sweep (vloam_scan_registration, vloam_process_frame*,
+ * vloam_vo_process_point_cloud) copies it on the scan-registration stream in front of its first reader, nothing deferred (the memory rules are
+ * the same); VLOAM_STAGE_INLINE=1 in the environment selects that form for the two whole-sweep calls as well. */
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n);
 vloam_status vloam_sync(vloam_handle* h);
 

@@ -22,11 +22,11 @@ for W in map lo; do
 done
 # multi-session scaling: B distinct sequences per launch chain (the sweeps are synthesised once and cached for the profiler passes below)
 timeout 600 python tools/batch_scaling.py --configs 1x1,1x2,1x4,1x8,1x12,1x16,1x24 --table --cache /tmp/sw24.npy > $OUT/batch_scaling.txt 2>&1; grep "H x B" $OUT/batch_scaling.txt
-# host sweeps in: the default (copy on the scan-registration stream) against the ring + copy-stream form, mixed and host-fed-only processes
-( echo "# tools/host_input_probe.py (3 passes each; device / pinned / pageable handles alternate)"; timeout 200 python tools/host_input_probe.py --reps 3 --cache /tmp/hi40.npy 2>&1 | tail -3
-  echo "# VLOAM_STAGE_INLINE=0 (ring of four input buffers + copy stream)"; VLOAM_STAGE_INLINE=0 timeout 200 python tools/host_input_probe.py --reps 3 --cache /tmp/hi40.npy 2>&1 | tail -3
+# host sweeps in: the default (deferred ring on the copy stream) against the inline form (copy on the scan-registration stream), mixed and host-fed-only processes
+( echo "# tools/host_input_probe.py (3 passes each; device / pinned / pageable handles alternate), default: deferred ring + copy stream"; timeout 200 python tools/host_input_probe.py --reps 3 --cache /tmp/hi40.npy 2>&1 | tail -3
+  echo "# VLOAM_STAGE_INLINE=1 (copy on the scan-registration stream in front of the sweep)"; VLOAM_STAGE_INLINE=1 timeout 200 python tools/host_input_probe.py --reps 3 --cache /tmp/hi40.npy 2>&1 | tail -3
   echo "# --only pinned"; timeout 200 python tools/host_input_probe.py --reps 3 --only pinned --cache /tmp/hi40.npy 2>&1 | tail -1
-  echo "# --only pinned, VLOAM_STAGE_INLINE=0"; VLOAM_STAGE_INLINE=0 timeout 200 python tools/host_input_probe.py --reps 3 --only pinned --cache /tmp/hi40.npy 2>&1 | tail -1
+  echo "# --only pinned, VLOAM_STAGE_INLINE=1"; VLOAM_STAGE_INLINE=1 timeout 200 python tools/host_input_probe.py --reps 3 --only pinned --cache /tmp/hi40.npy 2>&1 | tail -1
   echo "# --only pageable"; timeout 200 python tools/host_input_probe.py --reps 3 --only pageable --cache /tmp/hi40.npy 2>&1 | tail -1 ) > $OUT/host_input.txt 2>&1; cat $OUT/host_input.txt
 # batched: kernel stats of B = 8
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_b8 -- python $GRAFT_REPO_ROOT/tools/batch_scaling.py --configs 1x8 --procs 1 --cache /tmp/sw24.npy > $OUT/prof_b8.log 2>&1)

@@ -32,7 +32,7 @@ static thread_local std::string g_err;
 static const bool g_host_prof = getenv("VLOAM_HOST_PROF") != nullptr;
 namespace vloam { int g_vl_plain_events = getenv("VLOAM_PLAIN_EVENTS") ? atoi(getenv("VLOAM_PLAIN_EVENTS")) : 0; }
 static const int g_enqueue_order = getenv("VLOAM_ENQUEUE_ORDER") ? atoi(getenv("VLOAM_ENQUEUE_ORDER")) : 0;
-static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 1;   // 0 = the ring + copy-stream form
+static const int g_stage_inline = getenv("VLOAM_STAGE_INLINE") ? atoi(getenv("VLOAM_STAGE_INLINE")) : 0;   // 1: vloam_process_scan / vloam_batch_process_scan stage inline too (no deferred ring)
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void set_err(const char* fmt, ...) {
   char buf[512];
@@ -83,17 +83,20 @@ struct vloam_handle {
   int stage = 0;        // façade order inside a sweep: 0 idle, 1 after SR, 2 after LO
   int nblk_max = 0;
   // scan registration
-  // Host sweeps (vloam_process_scan and the other host-pointer entry points) are staged through a ring of kInRing device input buffers per
-  // session on a copy stream of their own: the H2D copy of sweep k + 1 runs (on a DMA engine) while sweep k's scan registration still reads
-  // its buffer, instead of sitting behind it on the scan-registration stream.  ev_in_copied: the copy has landed (the SR stream waits for it);
-  // ev_in_free: the last reader of the slot on the SR stream is through (the next copy into the slot waits for it).
+  // Host sweeps.  vloam_process_scan / vloam_batch_process_scan (the asynchronous whole-sweep calls): a copy stream + a ring of kInRing device
+  // input buffers, and the sweep itself is ENQUEUED BY THE NEXT CALL (like its odometry and mapping: drain_deferred) — by then its copy has
+  // landed, so nothing on the device ever waits for the host link and no stream waits for another: the copy of sweep k + 1 runs beside the scan
+  // registration of sweep k.  ev_in_copied: the copy into the slot has landed (checked by the HOST); in_reader: the event behind the slot's last
+  // reader (the sweep's own "scan registration finished" event; checked by the HOST before the slot is copied into again, three calls later).
+  // Every other host-pointer entry point (stage-wise calls, frames) stages INLINE: hipMemcpyAsync on the scan-registration stream into a
+  // buffer of its own (slot kInRing), the stream's order being the dependency.
   static constexpr int kInRing = 4;
-  float4* d_in = nullptr;         // [1 | kInRing][max_points] (the ring only with VLOAM_STAGE_INLINE=0)
-  hipStream_t s_copy = nullptr;   // created by the first host-pointer call
-  hipEvent_t ev_in_copied[kInRing] = {}, ev_in_free[kInRing] = {};
-  hipEvent_t in_reader[kInRing] = {};   // the event that marks the slot's last reader done: the sweep's own "scan registration finished" / "VO depth map
-                                        // built" event when the slot fed a whole-sweep call (no extra marker packet), else ev_in_free[slot]
-  int in_next = 0, in_slot = -1;  // next ring slot; the slot being staged by the call in progress
+  float4* d_in = nullptr;         // [kInRing + 1][max_points]
+  hipStream_t s_copy = nullptr;   // created by the first deferred host sweep
+  hipEvent_t ev_in_copied[kInRing] = {};
+  hipEvent_t in_reader[kInRing] = {};
+  int in_next = 0;                // next ring slot
+  struct { bool valid = false; BatchIn bi; int slot = -1; } pend;   // the host sweep whose copy is in flight: enqueued by the next call / any drain
   SRBuffers sr[kSets];  // rotating sets: S, cloud and the feature clouds are per set, the scratch arrays are shared (SR stream only)
   // clouds / odometry pose the caller handed to LaserMapping::input instead of the odometry's own (vloam_set_mapping_input): the mapping of
   // that one sweep reads them from here, the odometry keeps its CornerLast / SurfLast (the reference's stages hold separate copies)
@@ -166,7 +169,7 @@ static vloam_status handle_layout(vloam_handle* h, Arena& A) {
   const vloam_config* cfg = &h->cfg;
   const int P = cfg->max_points;
   h->nblk_max = (P + kLabelBlock - 1) / kLabelBlock;
-  TAKE(h->d_in, (size_t)(g_stage_inline ? 1 : vloam_handle::kInRing) * (size_t)P);   // the ring of input buffers only where the ring form is selected (the default stages through slot 0)
+  TAKE(h->d_in, (size_t)(vloam_handle::kInRing + 1) * (size_t)P);   // the ring of the deferred host sweeps + the inline staging buffer
   SRBuffers& a = h->sr[0];
   TAKE(a.sid, (size_t)P);
   TAKE(a.ori, (size_t)P);
@@ -231,25 +234,6 @@ static std::atomic<int> g_single_handles{0};   // single-sequence handles alive 
 // session-relative pointer for the host-side getters
 template <class T>
 static inline T* SEL(const vloam_handle* h, T* p) { return p ? (T*)((char*)p + (size_t)h->sel * h->se.ss) : p; }
-
-// A/B path (VLOAM_STAGE_KERNEL=1, off by default): a sweep in PINNED host memory fetched by a copy kernel through the buffer's device-side
-// address instead of hipMemcpyAsync.  The DMA path moves 2 MB in 87 us on the stream and costs 42 us inside the call; a kernel reads it at
-// the link's rate (43 us, 2.7 us of host time: profiles/r05_pinned_read.txt).  Round 5 tried that with 32 workgroups x 16 loads in flight per
-// lane and every kernel beside it ran ~45 us longer; round 6 tried the opposite — FEW workgroups with few loads in flight, on the idea that the
-// link's bandwidth-delay product (~100 KB) does not need 2 MB of queued reads: 2 / 4 / 8 workgroups are latency-bound (0.34 / 0.56 / 0.73 x the
-// device-resident rate), 16 - 32 reach 0.83 - 0.85 x, the DMA copy 0.88 x, on the copy stream + ring 0.37 - 0.75 x
-// (profiles/r06_host_input.txt).  The 2 MB have to cross the link in front of the sweep's scan registration either way; the DMA copy stays.
-template <int ILP>
-__global__ __launch_bounds__(256) void k_stage_copy(const float4* __restrict__ src, float4* __restrict__ dst, int n) {
-  const int stride = gridDim.x * 256;
-  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += stride * ILP) {
-    float4 v[ILP];
-#pragma unroll
-    for (int u = 0; u < ILP; u++) { const int i = i0 + u * stride; if (i < n) v[u] = src[i]; }
-#pragma unroll
-    for (int u = 0; u < ILP; u++) { const int i = i0 + u * stride; if (i < n) dst[i] = v[u]; }
-  }
-}
 
 extern "C" {
 
@@ -358,6 +342,19 @@ vloam_status vloam_create_batch(const vloam_config* cfg, int device, int n_sessi
         const int p = pr[which] > 0 ? hi_p : (pr[which] < 0 ? lo_p : 0);
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess;
       };
+      // The copy stream of the deferred host-sweep ring comes FIRST and is used once before any other stream of the handle has work: measured
+      // (tools/host_input_probe.py, extring / extring_late) a copy stream that gets its hardware queue after the compute streams runs host-fed
+      // sequences at 3 900 - 4 600 scans/s, one that got it before them at 5 650.
+      if (!g_stage_inline && !cfg->timing) {
+        if (hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break; }
+        static int warm_src = 0;
+        int* warm_dst = nullptr;
+        if (hipMalloc(&warm_dst, sizeof(int)) == hipSuccess) {
+          (void)hipMemcpyAsync(warm_dst, &warm_src, sizeof(int), hipMemcpyHostToDevice, h->s_copy);
+          (void)hipStreamSynchronize(h->s_copy);
+          (void)hipFree(warm_dst);
+        }
+      }
       if (!mk(&h->stream, 0) || !mk(&h->s_lo, 1) || (cfg->with_mapping && (!mk(&h->s_map, 2) || !mk(&h->s_ds, 3))) ||   // no mapping: no further hardware queues
           (cfg->image_width > 0 && !mk(&h->s_img, 4))) {
         set_err("hipStreamCreate failed"); st = VLOAM_ERR_HIP; break;
@@ -486,7 +483,7 @@ vloam_status vloam_destroy(vloam_handle* h) {
   (void)hipSetDevice(h->device);
   for (hipStream_t st : {h->s_copy, h->stream, h->s_lo, h->s_map, h->s_ds, h->s_img}) if (st) (void)hipStreamSynchronize(st);
   if (h->arena) (void)hipFree(h->arena);
-  for (int k = 0; k < vloam_handle::kInRing; k++) for (hipEvent_t e : {h->ev_in_copied[k], h->ev_in_free[k]}) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < vloam_handle::kInRing; k++) if (h->ev_in_copied[k]) (void)hipEventDestroy(h->ev_in_copied[k]);
   for (int k = 0; k < 6; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < vloam_handle::kSets; k++)
     for (hipEvent_t e : {h->ev_sr[k], h->ev_lo[k], h->ev_map[k], h->ev_stack[k], h->ev_vo[k], h->ev_img[k]}) if (e) (void)hipEventDestroy(e);
@@ -508,6 +505,7 @@ vloam_status vloam_reset_frame(vloam_handle* h) {
 // ------------------------------------------------------------------ stage enqueue helpers
 static inline int set_of(int frame) { return frame % vloam_handle::kSets; }
 static vloam_status drain_deferred(vloam_handle* h, int lag_lo, int lag_map);
+static vloam_status flush_pending(vloam_handle* h);
 static vloam_status sync_all(vloam_handle* h) {
   { vloam_status s_ = drain_deferred(h, 0, 0); if (s_ != VLOAM_OK) return s_; }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -633,6 +631,7 @@ static vloam_status enqueue_map(vloam_handle* h, int frame) {
 // producing stage has normally finished, hipStreamWaitEvent on a completed event inserts nothing, and the ~11 us cross-stream
 // barrier packet disappears from the stream that bounds the throughput.  Everything that reads results drains first (sync_all).
 static vloam_status drain_deferred(vloam_handle* h, int lag_lo, int lag_map) {
+  if (lag_lo == 0 && lag_map == 0) { vloam_status s0 = flush_pending(h); if (s0 != VLOAM_OK) return s0; }   // a full drain: the host sweep still in flight first
   while (h->lo_done < h->frame - lag_lo) {
     const double t0 = g_host_prof ? now_s() : 0.0;
     vloam_status s = enqueue_lo(h, h->lo_done);
@@ -670,84 +669,66 @@ static vloam_status finish_frame(vloam_handle* h) {
 }
 
 // ------------------------------------------------------------------ host sweeps in
-// A host sweep is copied into a device input buffer in front of its scan registration.  Two forms, both behind every host-pointer entry point:
-//   INLINE (default): hipMemcpyAsync on the scan-registration stream itself, one buffer, no events — the stream's order IS the dependency.
-//   RING (VLOAM_STAGE_INLINE=0; what the round-4 review asked for): a copy stream + a ring of kInRing device input buffers, the copy of sweep
-//     k + 1 overlapping scan registration of sweep k.  stage_begin picks the ring slot and makes the copy stream wait for the slot's previous
-//     readers; stage_sweep enqueues session b's copy and returns the device address; stage_end makes the scan-registration stream wait for the
-//     copies; stage_release (after the call's readers — scan registration, the VO depth map — are enqueued on the scan-registration stream) marks
-//     the slot reusable.
-// Measured (tools/host_input_probe.py, one sequence, 64 x 2048, sweeps in pinned memory; device-resident sweeps: 6 100 - 6 400 scans/s): inline
-// 5 360 - 5 430 in every context; ring 2 200 - 2 300 when only host-fed handles live in the process, 4 300 - 5 300 behind handles of other kinds —
-// its two cross-stream waits per sweep and the sixth stream land differently on the hardware queues from process to process
-// (profiles/r05_hw_queues.txt), and nothing is won where it works: the scan-registration stream has the 40 - 87 us to spare (116 of a 157 us
-// period).  A copy KERNEL reading the pinned buffer through its device-side address (49 GB/s, 2.7 us of host time against 24 GB/s and 42 us
-// inside hipMemcpyAsync: tools/microbench/pinned_read.hip) was measured too: every kernel running beside it takes ~45 us longer (system-memory
-// reads ahead of everybody's misses in the L2 queues) — same throughput, not kept.
+// Two forms (vloam_handle: "Host sweeps").
+//   INLINE: hipMemcpyAsync on the scan-registration stream itself into the inline buffer, no events — the stream's order IS the dependency.
+//     Every host-pointer entry point except the two below; with VLOAM_STAGE_INLINE=1 those two as well.  The 2 MB cross the link IN FRONT of the
+//     sweep's scan registration (24 GB/s inside hipMemcpyAsync: ~87 us on a stream with ~30 us to spare per period): 0.88 - 0.92 x the
+//     device-resident rate.
+//   DEFERRED RING (vloam_process_scan, vloam_batch_process_scan): copy on a stream of its own into ring slot k % kInRing, the sweep enqueued
+//     by the NEXT call once the HOST has seen the copy's event — no stream ever waits for another one, the copy of sweep k + 1 runs beside
+//     the scan registration of sweep k: 0.95 - 0.98 x (tools/host_input_probe.py).  Rounds 4 - 5 had a ring WITHOUT the deferral (two live
+//     cross-stream waits per sweep): 2 200 - 4 400 scans/s depending on what else the process had created (profiles/r05_host_input.txt); a copy
+//     KERNEL reading the pinned buffer (49 GB/s) slows every kernel beside it by ~45 us (profiles/r06_host_input.txt).  Both are gone.
 // Pageable source memory: hipMemcpyAsync has taken its copy when it returns (the caller may reuse the buffer at once).  Pinned source
 // memory (hipHostMalloc / hipHostRegister) is read by DMA later: it must stay unchanged until the next vloam_sync() (c_api.h).
-static vloam_status stage_begin(vloam_handle* h) {
-  if (g_stage_inline) { h->in_slot = 0; return VLOAM_OK; }
-  if (!h->s_copy) {
-    HIPCHK(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
-    for (int k = 0; k < vloam_handle::kInRing; k++) {
-      HIPCHK(hipEventCreateWithFlags(&h->ev_in_copied[k], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&h->ev_in_free[k], hipEventDisableTiming));
-    }
-  }
-  h->in_slot = h->in_next % vloam_handle::kInRing;
-  h->in_next++;
-  if (h->in_reader[h->in_slot]) HIPCHK(hipStreamWaitEvent(h->s_copy, h->in_reader[h->in_slot], 0));
-  return VLOAM_OK;
-}
-static const int g_stage_kernel = getenv("VLOAM_STAGE_KERNEL") ? atoi(getenv("VLOAM_STAGE_KERNEL")) : 0;
-static const int g_stage_wgs = getenv("VLOAM_STAGE_WGS") ? atoi(getenv("VLOAM_STAGE_WGS")) : 16;
-static const int g_stage_ilp = getenv("VLOAM_STAGE_ILP") ? atoi(getenv("VLOAM_STAGE_ILP")) : 4;
 static vloam_status stage_sweep(vloam_handle* h, int b, const float* xyz_pad4, int n, const float4** d_out) {
-  float4* dst = (float4*)((char*)(h->d_in + (size_t)h->in_slot * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
-  hipStream_t st = g_stage_inline ? h->stream : h->s_copy;
-  if (g_stage_kernel) {
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, xyz_pad4) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
-      const float4* src = (const float4*)attr.devicePointer;
-      const int wgs = g_stage_wgs < 1 ? 1 : (g_stage_wgs > 256 ? 256 : g_stage_wgs);
-      if (g_stage_ilp >= 16) VL_RAW_LAUNCH(k_stage_copy<16>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
-      else if (g_stage_ilp >= 8) VL_RAW_LAUNCH(k_stage_copy<8>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
-      else if (g_stage_ilp >= 4) VL_RAW_LAUNCH(k_stage_copy<4>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
-      else VL_RAW_LAUNCH(k_stage_copy<2>, dim3(wgs), dim3(256), 0, st, src, dst, n);   // (kernels of this library see the logical grid: vloam_device.h)
-      HIPCHK(hipGetLastError());
-      *d_out = dst;
-      return VLOAM_OK;
-    }
-    (void)hipGetLastError();   // a pageable pointer: hipPointerGetAttributes says so through an error code
-  }
-  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
+  float4* dst = (float4*)((char*)(h->d_in + (size_t)vloam_handle::kInRing * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
+  HIPCHK(hipMemcpyAsync(dst, xyz_pad4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   *d_out = dst;
   return VLOAM_OK;
 }
-static vloam_status stage_end(vloam_handle* h) {
-  if (g_stage_inline) return VLOAM_OK;
-  HIPCHK(hipEventRecord(h->ev_in_copied[h->in_slot], h->s_copy));
-  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in_copied[h->in_slot], 0));
-  return VLOAM_OK;
+static vloam_status process_scan_batch(vloam_handle* h, const BatchIn& bi);
+// the host sweep whose copy is in flight: enqueue it (every drain, every new sweep of whatever kind, vloam_sync)
+static vloam_status flush_pending(vloam_handle* h) {
+  if (!h->pend.valid) return VLOAM_OK;
+  h->pend.valid = false;
+  const int slot = h->pend.slot;
+  HIPCHK(hipEventSynchronize(h->ev_in_copied[slot]));   // host side; the copy was enqueued a whole call ago
+  const vloam_status st = process_scan_batch(h, h->pend.bi);
+  // the slot's last reader is this sweep's scan registration (its event belongs to the sweep until the buffer set comes round again: kInRing < kSets)
+  h->in_reader[slot] = st == VLOAM_OK ? h->ev_sr[set_of(h->frame - 1)] : nullptr;
+  if (st != VLOAM_OK) HIPCHK(hipStreamSynchronize(h->stream));   // a refused sweep: whatever was enqueued before the refusal may still read the slot
+  return st;
 }
-static vloam_status stage_release(vloam_handle* h, vloam_status call_status, hipEvent_t last_reader = nullptr) {
-  // last_reader: an event the call already recorded behind the slot's last reader (a whole-sweep call: the sweep's ev_sr / ev_vo — with
-  // kInRing < kSets it still belongs to that sweep when the slot comes round again); otherwise a marker on the scan-registration stream
-  // (also after a refused call: the wait on ev_in_copied was enqueued there, the record behind it is harmless)
-  if (g_stage_inline) { h->in_slot = -1; return call_status; }
-  if (h->in_slot >= 0) {
-    if (last_reader && call_status == VLOAM_OK) h->in_reader[h->in_slot] = last_reader;
-    else { HIPCHK(hipEventRecord(h->ev_in_free[h->in_slot], h->stream)); h->in_reader[h->in_slot] = h->ev_in_free[h->in_slot]; }
-    h->in_slot = -1;
+static vloam_status host_scan_deferred(vloam_handle* h, const float* const* xyz_pad4, const int* n) {
+  if (h->frame + (h->pend.valid ? 1 : 0) >= h->cfg.max_frames) { set_err("trajectory log full (max_frames=%d)", h->cfg.max_frames); return VLOAM_ERR_CAPACITY; }
+  if (!h->s_copy) HIPCHK(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));   // (normally created first of all streams: vloam_create)
+  if (!h->ev_in_copied[0]) for (int k = 0; k < vloam_handle::kInRing; k++) HIPCHK(hipEventCreateWithFlags(&h->ev_in_copied[k], hipEventDisableTiming));
+  const int slot = h->in_next % vloam_handle::kInRing;
+  h->in_next++;
+  // host side.  The slot's reader was enqueued kInRing - 1 calls ago; it can still be running while the host sprints ahead at the start of a
+  // burst (measured: without this wait the last pose of a 300-sweep run changes from run to run)
+  if (h->in_reader[slot]) HIPCHK(hipEventSynchronize(h->in_reader[slot]));
+  BatchIn bi;
+  memset(&bi, 0, sizeof(bi));
+  for (int b = 0; b < h->se.B; b++) {
+    float4* dst = (float4*)((char*)(h->d_in + (size_t)slot * (size_t)h->cfg.max_points) + (size_t)b * h->se.ss);
+    HIPCHK(hipMemcpyAsync(dst, xyz_pad4[b], (size_t)n[b] * sizeof(float4), hipMemcpyHostToDevice, h->s_copy));
+    bi.in[b] = dst; bi.n[b] = n[b];
   }
-  return call_status;
+  HIPCHK(hipEventRecord(h->ev_in_copied[slot], h->s_copy));
+  const vloam_status st = flush_pending(h);   // the sweep before this one
+  h->pend.bi = bi; h->pend.slot = slot; h->pend.valid = true;
+  return st;
 }
 static_assert(vloam_handle::kInRing < vloam_handle::kSets, "a slot's reader event (per buffer set) must not be re-recorded before the slot is reused");
+// the inline form's brackets around a call's copies: whatever host sweep is still pending goes first (it is older than this call's sweep)
+static inline vloam_status stage_begin(vloam_handle* h) { return flush_pending(h); }
+static inline vloam_status stage_end(vloam_handle*) { return VLOAM_OK; }
+static inline vloam_status stage_release(vloam_handle*, vloam_status call_status) { return call_status; }
 #define STAGE_ONE(h, xyz, n, dptr)                                                                              \
   const float4* dptr = nullptr;                                                                                 \
-  { vloam_status s_ = stage_begin(h); if (s_ == VLOAM_OK) s_ = stage_sweep(h, 0, xyz, n, &dptr);               \
-    if (s_ == VLOAM_OK) s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
+  { vloam_status s_ = flush_pending(h); if (s_ == VLOAM_OK) s_ = stage_sweep(h, 0, xyz, n, &dptr); if (s_ != VLOAM_OK) return s_; }
 
 // ------------------------------------------------------------------ stage-wise API (façade order)
 vloam_status vloam_scan_registration_device(vloam_handle* h, const void* d_xyz_pad4, int n) {
@@ -781,10 +762,10 @@ static vloam_status read_sr_error(vloam_handle* h, int cur) {
 vloam_status vloam_get_features(vloam_handle* h, int which, float* xyzi4, int cap, int* n) {
   if (!h || !n) return VLOAM_ERR_INVALID;
   HIPCHK(hipSetDevice(h->device));
+  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }   // (first: a host sweep still in flight is enqueued by this and counts)
   // after finish_frame() the sweep just processed is frame-1
   const int f = (h->stage == 0 && h->frame > 0) ? h->frame - 1 : h->frame;
   const int cur = set_of(f);
-  { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   SRBuffers bsel = h->sr[cur];
   if (which == 11 && h->sub_cloud_frame == f) { bsel.cloud = h->sub.cloud; bsel.S = h->sub.S; }   // laserCloudFullRes as handed to LaserMapping::input
   bsel.rebase((size_t)h->sel * h->se.ss);
@@ -968,6 +949,7 @@ static constexpr int kLagLO = 1, kLagMap = 2;
 static_assert(kLagLO <= vloam_handle::kSets - 2 && kLagMap <= vloam_handle::kSets - 1, "deferred stages must be enqueued before enqueue_sr waits for them");
 static vloam_status process_scan_batch(vloam_handle* h, const BatchIn& bi) {
   HIPCHK(hipSetDevice(h->device));
+  { vloam_status s0 = flush_pending(h); if (s0 != VLOAM_OK) return s0; }   // (a device-pointer sweep behind a host sweep: the older one first)
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
   if (g_enqueue_order == 1 && !h->cfg.timing) {   // A/B: the deferred odometry / mapping of earlier sweeps first, then this sweep's scan registration
     vloam_status s0 = drain_deferred(h, kLagLO - 1, kLagMap - 1);
@@ -1015,6 +997,7 @@ vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_p
     if (n[b] > h->cfg.max_points) { set_err("cloud of %d points exceeds max_points=%d", n[b], h->cfg.max_points); return VLOAM_ERR_CAPACITY; }
     if (n[b] <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
   }
+  if (!g_stage_inline && !h->cfg.timing) return host_scan_deferred(h, xyz_pad4, n);
   { vloam_status s_ = stage_begin(h); if (s_ != VLOAM_OK) return s_; }
   for (int b = 0; b < h->se.B; b++) {
     vloam_status s_ = stage_sweep(h, b, xyz_pad4[b], n[b], &bi.in[b]);
@@ -1022,8 +1005,7 @@ vloam_status vloam_batch_process_scan(vloam_handle* h, const float* const* xyz_p
     bi.n[b] = n[b];
   }
   { vloam_status s_ = stage_end(h); if (s_ != VLOAM_OK) return stage_release(h, s_); }
-  const vloam_status st = process_scan_batch(h, bi);
-  return stage_release(h, st, (st == VLOAM_OK && !h->cfg.timing) ? h->ev_sr[set_of(h->frame - 1)] : nullptr);
+  return stage_release(h, process_scan_batch(h, bi));
 }
 
 vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
@@ -1032,9 +1014,9 @@ vloam_status vloam_process_scan(vloam_handle* h, const float* xyz_pad4, int n) {
   if (n <= 0) { set_err("empty cloud"); return VLOAM_ERR_EMPTY; }
   SINGLE_SESSION_ONLY(h);
   HIPCHK(hipSetDevice(h->device));
+  if (!g_stage_inline && !h->cfg.timing) return host_scan_deferred(h, &xyz_pad4, &n);
   STAGE_ONE(h, xyz_pad4, n, d);
-  const vloam_status st = vloam_process_scan_device(h, d, n);
-  return stage_release(h, st, (st == VLOAM_OK && !h->cfg.timing) ? h->ev_sr[set_of(h->frame - 1)] : nullptr);
+  return vloam_process_scan_device(h, d, n);
 }
 
 // ------------------------------------------------------------------ coupled VLOAM frame (configs[3])
@@ -1091,6 +1073,7 @@ static vloam_status process_frame_common(vloam_handle* h, const BatchIn& bi, con
     return VLOAM_ERR_INVALID;
   }
   HIPCHK(hipSetDevice(h->device));
+  { vloam_status s0 = flush_pending(h); if (s0 != VLOAM_OK) return s0; }   // a host sweep of vloam_process_scan still in flight: the older one first
   if (h->stage == 2) { vloam_status s0 = finish_frame(h); if (s0 != VLOAM_OK) return s0; }
   vloam_status s = enqueue_sr(h, bi);
   if (s != VLOAM_OK) return s;
@@ -1415,7 +1398,7 @@ vloam_status vloam_vo_get_flow_matches(vloam_handle* h, int* prev_uv, int* curr_
 
 // world_VOT_base_last of frames first..first+count-1 as {q xyzw, t} (what VO2Cam0StartFrame turns into VO rows, vloam_tf.cpp:77-101)
 vloam_status vloam_get_vo_trajectory(vloam_handle* h, int first, int count, double* poses7) {
-  if (!h || !poses7 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
+  if (!h || !poses7 || first < 0 || count < 0 || first + count > h->frame + (h->pend.valid ? 1 : 0)) return VLOAM_ERR_INVALID;   // (a host sweep in flight is enqueued by the sync below)
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   if (count) HIPCHK(hipMemcpy(poses7, SEL(h, h->vo_traj) + (size_t)first * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
@@ -1478,7 +1461,7 @@ vloam_status vloam_sync(vloam_handle* h) {
 }
 
 vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double* poses14) {
-  if (!h || !poses14 || first < 0 || count < 0 || first + count > h->frame) return VLOAM_ERR_INVALID;
+  if (!h || !poses14 || first < 0 || count < 0 || first + count > h->frame + (h->pend.valid ? 1 : 0)) return VLOAM_ERR_INVALID;   // (a host sweep in flight is enqueued by the sync below)
   HIPCHK(hipSetDevice(h->device));
   { vloam_status s_ = sync_all(h); if (s_ != VLOAM_OK) return s_; }
   if (count) HIPCHK(hipMemcpy(poses14, SEL(h, h->traj) + (size_t)first * 14, sizeof(double) * 14 * (size_t)count, hipMemcpyDeviceToHost));
@@ -1486,7 +1469,7 @@ vloam_status vloam_get_trajectory(vloam_handle* h, int first, int count, double*
 }
 vloam_status vloam_frame_count(vloam_handle* h, int* frames) {
   if (!h || !frames) return VLOAM_ERR_INVALID;
-  *frames = h->frame;
+  *frames = h->frame + (h->pend.valid ? 1 : 0);   // sweeps handed over (the last host sweep may still be in flight: deferred ring)
   return VLOAM_OK;
 }
 vloam_status vloam_trajectory_device_ptr(vloam_handle* h, void** d_ptr, long long* bytes) {
