@@ -687,7 +687,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (dbg_cyc) tp[0] = clock64();
   constexpr int Q = 64 / G, QW = 4 * Q;     // queries per wavefront / per workgroup
-  constexpr int U = G == 16 ? 4 : 2, CH = U * G;   // candidates per lane and pass / per query and pass (64 / 64 / 128: the typical query has ~30)
+  constexpr int U = G == 16 ? 4 : 2, CH = U * G;   // candidates per lane and pass / per query and pass (64 / 64 / 128: the typical query has ~30; four per lane in the
+  // 32-lane form — one pass for the ~100 candidates of a corner query in a dense map — measured: 96 VGPRs with 13 spills, 23.3 instead of 20.3 us)
   // KB: blocks per lane and trip
   static_assert(CH <= kCandCache, "the second round's candidate cache holds kCandCache entries per slot");   // (rows of CH entries: a query's candidates sit in 1 - 2 KB, not in a 4 KB page of their own)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), qi = wave * Q + lane / G;
@@ -715,21 +716,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
   __shared__ int s_rawn[QW][kRawCap];
   __shared__ int s_nraw[QW];
   float4 pointOri = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) pointOri = kind ? stack1[i] : stack0[i];
+  // second outer round: the box of the first round and this lane's entries of its candidate cache are requested WITH the point and the pose —
+  // their addresses depend on the slot only, and behind the pose they would be two more dependent memory trips (box, then entries) on the
+  // chain that bounds the sweep period; entries fetched for nothing (the box moved: ~15 % of the queries) cost 32 bytes per lane
+  // (single-sequence forms only: the 16-lane groups of a batch hold four entries per lane and are bound by registers and wave slots, not by this chain)
+  constexpr bool PRE = G >= 32;
+  int4 box0 = make_int4(0, 0, 0, 0), box1 = make_int4(0, 0, -1, 0);
+  constexpr int UP = PRE ? 2 : 1;   // entries per lane requested up front (the first 2 G candidates: the typical query's whole list)
+  float4 cc_pre[UP];
+#pragma unroll
+  for (int u = 0; u < UP; u++) cc_pre[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+  if (live) {
+    pointOri = kind ? stack1[i] : stack0[i];
+    if (outer > 0) {
+      box0 = cbox[2 * slot]; box1 = cbox[2 * slot + 1];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int u = 0; u < UP; u++) cc_pre[u] = ccand[(size_t)slot * kCandCache + gl + u * G];
+      }
+    }
+  }
   const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
   const float q0 = sel.x, q1 = sel.y, q2 = sel.z;
   const int cen0 = ms->cenW, cen1 = ms->cenH, cen2 = ms->cenD;
   const int ctr0 = ms->centerCube[0] - cen0, ctr1 = ms->centerCube[1] - cen1, ctr2 = ms->centerCube[2] - cen2;  // absolute centre cube
   // voxel-index box that can hold a point within 1 m (pointSearchSqDis[4] < 1.0 gates everything, LM:479 / LM:547)
-  const int blo0 = (int)floorf((q0 - 1.001f) * inv), bhi0 = (int)floorf((q0 + 1.001f) * inv);
-  const int blo1 = (int)floorf((q1 - 1.001f) * inv), bhi1 = (int)floorf((q1 + 1.001f) * inv);
-  const int blo2 = (int)floorf((q2 - 1.001f) * inv), bhi2 = (int)floorf((q2 + 1.001f) * inv);
+  // The FIRST round searches 5 cm more than the 1.001 m it needs: the second round's query — the same point under a pose that moved by
+  // millimetres to centimetres — then still finds its box INSIDE the cached one and re-ranks the cached candidates (a superset of its own:
+  // the five nearest within 1 m are the same).  With the exact box 15 % of the second round's queries saw a voxel boundary move and
+  // searched again, and the launch lasted as long as the slowest of them.
+  const float mg = outer == 0 ? 1.051f : 1.001f;
+  int blo0 = (int)floorf((q0 - mg) * inv), bhi0 = (int)floorf((q0 + mg) * inv);
+  int blo1 = (int)floorf((q1 - mg) * inv), bhi1 = (int)floorf((q1 + mg) * inv);
+  int blo2 = (int)floorf((q2 - mg) * inv), bhi2 = (int)floorf((q2 + mg) * inv);
   // second outer round: same box as the first round => same candidates, re-ranked from the cache without a hash probe
   bool from_cache = false;
   int total = 0;
   if (outer > 0 && live) {
-    const int4 b0 = cbox[2 * slot], b1 = cbox[2 * slot + 1];
-    from_cache = b1.z >= 0 && b1.z <= CH && b0.x == blo0 && b0.y == bhi0 && b0.z == blo1 && b0.w == bhi1 && b1.x == blo2 && b1.y == bhi2;
+    const int4 b0 = box0, b1 = box1;
+    from_cache = b1.z >= 0 && b1.z <= kCandCache && b0.x <= blo0 && b0.y >= bhi0 && b0.z <= blo1 && b0.w >= bhi1 && b1.x <= blo2 && b1.y >= bhi2;
     if (from_cache) total = b1.z;
   }
   const bool search = live && !from_cache;
@@ -839,7 +864,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
           rv[h] = rec_load(&T.rec[sl[h]]);
         }
         if (cache_pass)   // leave the candidate for the second round
-          ccand[(size_t)slot * CH + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
+          ccand[(size_t)slot * kCandCache + c0 + gl + u * G] = make_float4(px[u], py[u], pz[u], __uint_as_float(key_u[u] == ~0ull ? 0xffffffffu : (unsigned)key_u[u]));
       }
     }
   };
@@ -953,20 +978,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
       sw_lds_sync();
       ncand = gen ? min(total - c0, CH) : 0;
       if (dbg_cyc && c0 == 0) tp[3] = clock64() + (ncand & 0);
-      cache_pass = outer == 0 && c0 == 0 && total <= CH;
+      cache_pass = outer == 0 && total <= kCandCache;   // (lists of up to kCandCache candidates: every pass leaves its part)
       probe_pair(std::integral_constant<int, 0>{});
       if constexpr (U > 2) { if (__ballot(2 * G < ncand) != 0ull) probe_pair(std::integral_constant<int, 2>{}); }
       cache_pass = false;
     }
-    if (c0 == 0 && __ballot(from_cache) != 0ull) {
-      // all of a lane's cache entries in flight together, complete 16-byte entries (a load that is conditional on the entry's own tie
-      // field turns into two dependent trips per entry)
+    if (__ballot(from_cache && act) != 0ull) {
+      // the entries came in with the point (top of the kernel): complete 16-byte entries, valid up to the round-1 candidate count
       float4 cc[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int w = gl + u * G;
+        const int w = c0 + gl + u * G;
         cc[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-        if (from_cache && w < total) cc[u] = ccand[(size_t)slot * CH + w];
+        if (PRE && c0 == 0 && u < UP) { if (from_cache && w < total) cc[u] = cc_pre[u < UP ? u : 0]; }
+        else { if (from_cache && act && w < total) cc[u] = ccand[(size_t)slot * kCandCache + w]; }   // all of a lane's entries in flight together
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -1012,7 +1037,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
   }
   if (outer == 0 && search && gl == 0) {
     cbox[2 * slot] = make_int4(blo0, bhi0, blo1, bhi1);
-    cbox[2 * slot + 1] = make_int4(blo2, bhi2, (total <= CH && !overflow && s_nraw[qi] == 0) ? total : -1, 0);
+    cbox[2 * slot + 1] = make_int4(blo2, bhi2, (total <= kCandCache && !overflow && s_nraw[qi] == 0) ? total : -1, total);   // (.w: the count itself, tools/assoc_phases.py)
   }
   // hand the five neighbours to k_map_fit (one THREAD per query there: the 3x3 eigen / 5x3 least-squares fits are heavy in registers
   // and pure per-query math) — as points, so that the fit does not have to go back to the table
@@ -1708,6 +1733,7 @@ vloam_status map_debug_get(MapContext* m0, int item, void* buf, long long cap, l
     return VLOAM_OK;
   }
   if (item == 72) return copy_dev(m->ts_log, sizeof(long long) * 2048, buf, cap, n);   // VLOAM_TS_LOG=1: [sweep % 1024][prepare start, finalize start], 100 MHz ticks
+  if (item == 73) return copy_dev(m->cbox, sizeof(int4) * 2 * (size_t)kMapFactorCap, buf, cap, n);   // per stack slot: the first round's search box + its candidate count (-1: not cached)
   if (item == 71) return copy_dev(m->assoc_cyc, sizeof(long long) * 16, buf, cap, n);   // k_map_assoc phase cycles (debug handles): [outer][6 phases, spare, wavefronts]
   if (item == 69) {  // table health: {keys, purged, block keys, spare} x {corner, surf}, rebuilds, largest candidate list
     int out[12] = {0};
