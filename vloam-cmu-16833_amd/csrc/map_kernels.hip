@@ -716,25 +716,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
   __shared__ int s_rawn[QW][kRawCap];
   __shared__ int s_nraw[QW];
   float4 pointOri = make_float4(0.f, 0.f, 0.f, 0.f);
-  // second outer round: the box of the first round and this lane's entries of its candidate cache are requested WITH the point and the pose —
-  // their addresses depend on the slot only, and behind the pose they would be two more dependent memory trips (box, then entries) on the
-  // chain that bounds the sweep period; entries fetched for nothing (the box moved: ~15 % of the queries) cost 32 bytes per lane
-  // (single-sequence forms only: the 16-lane groups of a batch hold four entries per lane and are bound by registers and wave slots, not by this chain)
-  constexpr bool PRE = G >= 32;
+  // second outer round: the box of the first round is requested WITH the point and the pose (its address depends on the slot only).  The
+  // cache entries are not: fetching the first 2 G of them up front as well was measured (A/B builds) — no change in the launch's duration
+  // (10.1 us either way), 4 MB more traffic per sweep for entries beyond the lists' ends.
   int4 box0 = make_int4(0, 0, 0, 0), box1 = make_int4(0, 0, -1, 0);
-  constexpr int UP = PRE ? 2 : 1;   // entries per lane requested up front (the first 2 G candidates: the typical query's whole list)
-  float4 cc_pre[UP];
-#pragma unroll
-  for (int u = 0; u < UP; u++) cc_pre[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
   if (live) {
     pointOri = kind ? stack1[i] : stack0[i];
-    if (outer > 0) {
-      box0 = cbox[2 * slot]; box1 = cbox[2 * slot + 1];
-      if constexpr (PRE) {
-#pragma unroll
-        for (int u = 0; u < UP; u++) cc_pre[u] = ccand[(size_t)slot * kCandCache + gl + u * G];
-      }
-    }
+    if (outer > 0) { box0 = cbox[2 * slot]; box1 = cbox[2 * slot + 1]; }
   }
   const float4 sel = associate_to_map(pointOri, ms->parameters, ms->parameters + 4);  // LM:476 / LM:542
   const float q0 = sel.x, q1 = sel.y, q2 = sel.z;
@@ -984,14 +972,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
       cache_pass = false;
     }
     if (__ballot(from_cache && act) != 0ull) {
-      // the entries came in with the point (top of the kernel): complete 16-byte entries, valid up to the round-1 candidate count
+      // all of a lane's cache entries of the pass in flight together, complete 16-byte entries (a load that is conditional on the entry's own
+      // tie field turns into two dependent trips per entry)
       float4 cc[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int w = c0 + gl + u * G;
         cc[u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-        if (PRE && c0 == 0 && u < UP) { if (from_cache && w < total) cc[u] = cc_pre[u < UP ? u : 0]; }
-        else { if (from_cache && act && w < total) cc[u] = ccand[(size_t)slot * kCandCache + w]; }   // all of a lane's entries in flight together
+        if (from_cache && act && w < total) cc[u] = ccand[(size_t)slot * kCandCache + w];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
