@@ -1,0 +1,171 @@
+"""-m gpu: scanRegistration (and two sweeps of scan-to-scan odometry behind it) on RANDOM range images vs the CPU oracle.
+
+The scene generator of synth.py draws streets: long planes, few range jumps, full rings.  These clouds are not scenes: every ring is a
+random piecewise-smooth range profile with steps, spikes, dropouts (NaN / inf / zero), returns inside minimum_range, exact repeats of the
+previous return (equal curvatures), RAGGED rings (a random subset of the columns per ring, down to rings too short for a sector) and a
+random number of columns — the edge cases of scan_registration.cpp:157-449 in combinations no street produces.  Same bars as
+test_gpu_scan_registration.py: everything integer / xyz bit for bit.
+
+The clouds that MOVE (odometry / whole-pipeline cases) keep to <= 2 048 columns: a rigid motion shifts near returns into the neighbouring
+scan line, a ring then holds the returns of two lasers, and 2 x 2 048 is the ring capacity of the device (4 096 points, DESIGN.md section 8;
+beyond it the ABI reports VLOAM_ERR_CAPACITY where the reference runs on — a hunting run with 3 299 columns met exactly that).
+
+Elevations stay within 0.03 deg of the beam table: the reference maps the f32 elevation to a scan line by truncation
+(scan_registration.cpp:195-226), so a return an ulp from a bin edge may legitimately land on either side (atanf of glibc vs OCML).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_scan_registration import check_cloud, unwrap_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def random_cloud(synth, rings, n_az, seed, keep_lo=0.55):
+    rng = np.random.default_rng(seed)
+    el0 = synth.beam_elevations_deg(rings)
+    az0 = -2 * np.pi * np.arange(n_az) / n_az
+    cols = []
+    for r in range(rings):
+        # piecewise-smooth profile: a few sinusoids + steps at random columns + centimetre noise
+        a = np.arange(n_az) / n_az
+        rad = rng.uniform(6.0, 40.0) + sum(rng.uniform(0.2, 3.0) * np.sin(2 * np.pi * rng.integers(1, 9) * a + rng.uniform(0, 6.28)) for _ in range(3))
+        for _ in range(rng.integers(0, 24)):
+            j = rng.integers(0, n_az)
+            rad[j:] += rng.uniform(-4.0, 4.0)
+        rad = np.abs(rad) + 0.3 + 0.01 * rng.standard_normal(n_az)
+        spikes = rng.random(n_az) < 0.01
+        rad[spikes] *= rng.uniform(0.3, 2.5, int(spikes.sum()))
+        close = rng.random(n_az) < 0.02
+        rad[close] = rng.uniform(0.05, 5.5, int(close.sum()))          # around minimum_range (5 m) and far inside it
+        el = np.deg2rad(el0[r] + rng.uniform(-0.03, 0.03, n_az))
+        az = az0 + rng.uniform(-0.2, 0.2, n_az) * (2 * np.pi / n_az)
+        p = np.zeros((n_az, 4), dtype=np.float32)
+        p[:, 0] = (rad * np.cos(el) * np.cos(az)).astype(np.float32)
+        p[:, 1] = (rad * np.cos(el) * np.sin(az)).astype(np.float32)
+        p[:, 2] = (rad * np.sin(el)).astype(np.float32)
+        rep = np.nonzero(rng.random(n_az) < 0.01)[0]
+        rep = rep[rep > 0]
+        p[rep, :3] = p[rep - 1, :3]                                      # the same return twice: zero differences, equal curvatures
+        bad = rng.random(n_az)
+        p[bad < 0.02, :3] = np.nan
+        p[(bad >= 0.02) & (bad < 0.025), 0] = np.inf
+        p[(bad >= 0.025) & (bad < 0.03), :3] = 0.0
+        # ragged: this ring keeps a random share of its columns; a few rings keep almost nothing (too short for a sector)
+        share = rng.uniform(keep_lo, 1.0) if rng.random() > 0.08 else rng.uniform(0.0, 0.01)
+        keep = rng.random(n_az) < share
+        p[:, 3] = np.arange(n_az)   # column, for the firing order below (overwritten)
+        cols.append(p[keep])
+    allp = np.concatenate(cols)
+    order = np.argsort(allp[:, 3], kind="stable")   # firing order: every laser of a column, then the next column
+    out = allp[order].copy()
+    out[:, 3] = 0.0
+    return out
+
+
+CASES = [(64, 2048, 101), (64, 1777, 102), (64, 600, 103), (64, 3100, 104), (32, 1500, 105), (16, 2048, 106), (16, 257, 107), (64, 2048, 108)]
+# VLOAM_FUZZ_EXTRA=N: N more cases per test with seeds / shapes drawn from N itself (hunting runs; the committed cases are the ones above)
+_EXTRA = int(os.environ.get("VLOAM_FUZZ_EXTRA", "0"))
+_xr = np.random.default_rng(_EXTRA)
+EXTRA = [(int(_xr.choice([16, 32, 64, 64, 64])), int(_xr.integers(200, 3300)), 1000 + i) for i in range(_EXTRA)]
+
+
+@pytest.mark.parametrize("rings,n_az,seed", CASES + EXTRA)
+def test_scan_registration_on_random_range_images(vl, orc, synth, rings, n_az, seed):
+    cloud = random_cloud(synth, rings, n_az, seed)
+    h = vl.Handle(0, scan_line=rings, debug=1, with_mapping=0, max_points=max(cloud.shape[0], 1024))
+    h.reset_frame()
+    h.scan_registration(cloud)
+    o = orc.Oracle(scan_line=rings, with_mapping=False)
+    assert o.scan_registration(cloud) == 0
+    d, sc = h.sr_debug(), o.sr_scalars()
+    assert d["n_after_s1"] == sc["n_after_s1"]
+    flips = check_cloud(h.features(0), o.cloud(0), "laserCloud", unwrap_bounds(sc["startOri"], sc["endOri"]))
+    assert np.array_equal(d["scanStartInd"][:rings], o.sr_ints(3)) and np.array_equal(d["scanEndInd"][:rings], o.sr_ints(4))
+    start, end = o.sr_ints(3), o.sr_ints(4)
+    cur_o, lab_o, pick_o = o.sr_curvature(), o.sr_ints(2), o.sr_ints(1)
+    short = 0
+    for r in range(rings):
+        if end[r] - start[r] < 6:
+            short += 1
+            continue
+        s, e = start[r], end[r]
+        assert np.array_equal(d["curvature"][s:e].view(np.uint32), cur_o[s:e].view(np.uint32)), "curvature ring %d" % r
+        assert np.array_equal(d["label"][s:e], lab_o[s:e]), "labels ring %d" % r
+        assert np.array_equal(d["picked"][s - 5:e + 6], pick_o[s - 5:e + 6]), "picked ring %d" % r
+    assert np.array_equal(d["sharpInd"], o.sr_ints(5))
+    assert np.array_equal(d["lessSharpInd"], o.sr_ints(6))
+    assert np.array_equal(d["flatInd"], o.sr_ints(7))
+    for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+        check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
+    assert o.cloud(1).shape[0] > 0 and o.cloud(3).shape[0] > 0, "the case must produce features"
+
+
+@pytest.mark.parametrize("rings,n_az,seed", [(64, 2048, 201), (16, 1800, 202)] + [(r, min(max(a, 900), 2040), sd + 5000) for r, a, sd in EXTRA[::3]])
+def test_odometry_between_two_random_range_images(vl, orc, synth, rings, n_az, seed):
+    """Two random clouds, the second one the first one moved by a small rigid motion (so that correspondences exist): correspondence
+    triples exact, trust-region trace equal, pose to 1e-8 — on feature sets (ragged rings, sparse sectors) a street never has."""
+    from test_gpu_laser_odometry import POSE_TOL, compare_outer, qdist
+    a = random_cloud(synth, rings, n_az, seed, keep_lo=0.8)
+    ang = 0.01
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float64)
+    b = a.copy()
+    fin = np.isfinite(a[:, :3]).all(axis=1)
+    b[fin, :3] = (a[fin, :3].astype(np.float64) @ R.T + np.array([0.25, -0.05, 0.01])).astype(np.float32)
+    h = vl.Handle(0, scan_line=rings, debug=1, with_mapping=0, max_points=max(a.shape[0], 1024))
+    o = orc.Oracle(scan_line=rings, with_mapping=False)
+    for k, c in enumerate([a, b, a]):
+        h.reset_frame()
+        h.scan_registration(c)
+        qw, tw, ql, tl = h.laser_odometry()
+        assert o.process(c) == 0
+        oqw, otw, oql, otl = o.lo_pose()
+        if k > 0:
+            assert o.lo_num_outer() == 2
+            n_corr = 0
+            for outer in range(2):
+                d = h.lo_debug(outer)
+                compare_outer(d, o, outer)
+                n_corr += d["corner"].shape[0] + d["plane"].shape[0]
+            assert n_corr > 200, "the pair must produce correspondences (%d)" % n_corr
+        assert qdist(ql, oql) < POSE_TOL and np.linalg.norm(tl - otl) < POSE_TOL, "frame %d f2f pose" % k
+        assert qdist(qw, oqw) < POSE_TOL * (k + 1) and np.linalg.norm(tw - otw) < POSE_TOL * (k + 1), "frame %d world pose" % k
+
+
+@pytest.mark.parametrize("rings,n_az,seed,n", [(64, 1500, 301, 14), (16, 2048, 302, 20)] + [(r, min(max(a, 900), 2040), sd + 9000, 12) for r, a, sd in EXTRA[::5]])
+def test_whole_pipeline_on_a_moving_random_range_image(vl, orc, synth, rings, n_az, seed, n):
+    """One random range image seen from a sensor that yaws and creeps forward, fresh centimetre noise and dropouts per sweep: scan
+    registration -> odometry -> scan-to-map on cluttered geometry (kNN sets full of near-ties, many rejected line / plane fits, voxels
+    with one point).  Every pose and the whole map against the oracle, as in test_gpu_soak.py."""
+    from test_gpu_laser_mapping import lexsort_rows, oracle_map_points, qdist
+    base = random_cloud(synth, rings, n_az, seed, keep_lo=0.85)
+    fin = np.isfinite(base[:, :3]).all(axis=1)
+    rng = np.random.default_rng(seed + 1)
+    clouds = []
+    for k in range(n):
+        ang, t = -0.004 * k, np.array([-0.12 * k, 0.01 * k, 0.0])
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float64)
+        c = base.copy()
+        p = base[fin, :3].astype(np.float64) @ R.T + t
+        c[fin, :3] = (p * (1.0 + 0.0005 * rng.standard_normal((p.shape[0], 1)))).astype(np.float32)   # range noise along the ray
+        c[rng.random(c.shape[0]) < 0.01, :3] = np.nan
+        clouds.append(c)
+    h = vl.Handle(0, scan_line=rings, with_mapping=1, max_points=max(base.shape[0], 1024))
+    for c in clouds:
+        h.process_scan(c)
+    h.sync()
+    tj = h.trajectory()
+    o = orc.Oracle(scan_line=rings, with_mapping=True)
+    for k, c in enumerate(clouds):
+        assert o.process(c) == 0
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert qdist(tj[k, 0:4], qw) < 1e-7 and np.linalg.norm(tj[k, 4:7] - tw) < 1e-7, "LO pose, sweep %d" % k
+        assert qdist(tj[k, 7:11], qm) < 1e-7 and np.linalg.norm(tj[k, 11:14] - tm) < 1e-7, "map pose, sweep %d" % k
+    for kind in (0, 1):
+        cnt, pts = h.map_dump(kind)
+        ref = oracle_map_points(o, kind)
+        assert pts.shape == ref.shape and pts.shape[0] > 1000
+        assert np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32)), "map kind %d" % kind
