@@ -72,7 +72,7 @@ def test_laser_mapping_parity(vl, orc, sweeps, shape, nframes):
         for which in (7, 8):
             dv, rf = h.features(which), o.cloud(which)
             assert dv.shape == rf.shape, (which, dv.shape, rf.shape)
-            assert np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d" % which
+            assert np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32)), "stack %d" % which
         st = h.map_state()
         assert st["deferred"] == 0
         if k == 0:
@@ -93,7 +93,7 @@ def test_laser_mapping_parity(vl, orc, sweeps, shape, nframes):
             assert np.all(cnt == 1)
             assert pts.shape == ref.shape, "map kind %d: %s vs %s" % (kind, pts.shape, ref.shape)
             a, b = lexsort_rows(pts), lexsort_rows(ref)
-            assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+            assert np.array_equal(a[:, :4].view(np.uint32), b[:, :4].view(np.uint32)), "map kind %d centroids" % kind
     # full-resolution cloud registered in the map frame (LaserMapping::publish, laser_mapping.cpp:795-799)
     # f32(q * p + t) with poses that agree to ~1e-10: the same float, or its neighbour when the f64 value sits on a rounding boundary
     reg_d, reg_o = h.features(11), o.cloud(11)
@@ -115,8 +115,8 @@ def oracle_published_map(o):
 
 
 def same_cloud(a, b):
-    """xyz bit for bit in the same order; intensity (ring + 0.1 relTime, through atan2f: OCML vs glibc) to 1e-5."""
-    return np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)) and np.max(np.abs(a[:, 3] - b[:, 3]), initial=0) < 1e-5
+    """x, y, z and intensity bit for bit in the same order."""
+    return a.shape == b.shape and np.array_equal(a[:, :4].view(np.uint32), b[:, :4].view(np.uint32))
 
 
 def same_cloud_to_rounding(a, b):
@@ -127,7 +127,7 @@ def same_cloud_to_rounding(a, b):
     if a.shape != b.shape:
         return False
     ulp = np.abs(a[:, :3].view(np.int32).astype(np.int64) - b[:, :3].view(np.int32).astype(np.int64))
-    return int(ulp.max(initial=0)) <= 1 and float(np.mean(ulp == 0)) > 0.999 and np.max(np.abs(a[:, 3] - b[:, 3]), initial=0) < 1e-5
+    return int(ulp.max(initial=0)) <= 1 and float(np.mean(ulp == 0)) > 0.999 and np.array_equal(a[:, 3].view(np.uint32), b[:, 3].view(np.uint32))
 
 
 def test_public_map_export(vl, orc, sweeps):
@@ -254,7 +254,7 @@ def test_pipelined_burst_matches_oracle(vl, orc, sweeps, skip):
         ref = oracle_map_points(o, kind)
         assert pts.shape == ref.shape
         a, b = lexsort_rows(pts), lexsort_rows(ref)
-        assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+        assert np.array_equal(a[:, :4].view(np.uint32), b[:, :4].view(np.uint32)), "map kind %d centroids" % kind
 
 
 @pytest.mark.gpu
@@ -325,7 +325,7 @@ def test_long_run_with_grid_roll(vl, orc, synth):
         ref = oracle_map_points(o, kind)
         assert pts.shape == ref.shape
         a, b = lexsort_rows(pts), lexsort_rows(ref)
-        assert np.array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32)), "map kind %d centroids" % kind
+        assert np.array_equal(a[:, :4].view(np.uint32), b[:, :4].view(np.uint32)), "map kind %d centroids" % kind
 
 
 def test_full_size_steady_state_run(vl, orc, synth):
@@ -447,7 +447,7 @@ def test_dense_scan_voxels_take_the_wavefront_rank_path(vl, orc, sweeps):
         big = max(big, int(np.unique(keys, axis=0, return_counts=True)[1].max()))
         for which in (7, 8):
             dv, rf = h.features(which), o.cloud(which)
-            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32)), "stack %d, sweep %d" % (which, k)
         oq, ot, _, _ = o.map_pose()
         assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, k
     assert big > 256, big   # the case is what it claims to be
@@ -475,7 +475,7 @@ def test_scan_voxel_bins_overflow(vl, orc, sweeps):
         big = max(big, int(np.unique(keys, axis=0, return_counts=True)[1].max()))
         for which in (7, 8):
             dv, rf = h.features(which), o.cloud(which)
-            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32)), "stack %d, sweep %d" % (which, k)
         oq, ot, _, _ = o.map_pose()
         assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, k
     assert big > 4096, big   # more points in one cell than a bin's region holds

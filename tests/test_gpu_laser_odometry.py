@@ -67,7 +67,7 @@ def test_laser_odometry_parity(vl, orc, sweeps, shape, nframes):
         # laserCloudCornerLast / laserCloudSurfLast handed to mapping (laser_odometry.cpp:610-629)
         for which in (5, 6):
             dv, rf = h.features(which), o.cloud(which)
-            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32))
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32))
 
 
 def test_async_path_matches_stagewise(vl, sweeps):

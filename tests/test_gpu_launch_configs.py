@@ -73,11 +73,11 @@ def assert_map(h, o, what):
         ref = oracle_map_points(o, kind)
         assert pts.shape == ref.shape, (what, kind, pts.shape, ref.shape)
         assert ref.shape[0] > 500, "the %s map should not be trivial" % what
-        assert np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32)), "%s: map kind %d" % (what, kind)
+        assert np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32)), "%s: map kind %d" % (what, kind)
     # /laser_cloud_map in the reference's publishing order (laser_mapping.cpp:778-793)
     pub = h.get_map()
     ref = np.concatenate([np.concatenate([o.map_cube(0, c), o.map_cube(1, c)]) for c in range(21 * 21 * 11)])
-    assert pub.shape == ref.shape and np.array_equal(pub[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)), "%s: /laser_cloud_map order" % what
+    assert pub.shape == ref.shape and np.array_equal(pub[:, :4].view(np.uint32), ref[:, :4].view(np.uint32)), "%s: /laser_cloud_map order" % what
 
 
 @pytest.mark.parametrize("name,speed", [("VLP_16", 1.5), ("HDL_32", 4.0)])
@@ -116,7 +116,7 @@ def test_launch_file_configuration_stagewise_with_factor_sets(vl, orc, synth, na
         assert o.process(c) == 0
         for which in (7, 8):
             dv, rf = h.features(which), o.cloud(which)
-            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32)), "stack %d, sweep %d" % (which, k)
         if k > 0:
             assert o.map_num_outer() == 2
             for outer in range(2):

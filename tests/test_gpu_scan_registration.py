@@ -1,10 +1,10 @@
-"""-m gpu: scanRegistration through the C ABI vs the CPU oracle (bit-exact integer / xyz work).
+"""-m gpu: scanRegistration through the C ABI vs the CPU oracle — bit for bit, ALL FOUR floats of every point.
 
-Reference: src/lidar_odometry_mapping/src/scan_registration.cpp:131-449.  Intensity carries
-relTime = f(atan2f) whose libm/OCML implementations differ in the last ulp, so the fractional part
-of intensity is compared with a tolerance (1e-5 absolute on values <= 51); everything else —
-ring ids, compaction order, curvature, per-sector sort order, picks, labels, voxel centroids' xyz —
-must match bit for bit.
+Reference: src/lidar_odometry_mapping/src/scan_registration.cpp:131-449.  Ring ids, compaction order, curvature, per-sector sort order,
+picks, labels, voxel centroids AND intensity (= scan line + 0.1 relTime, relTime through atan2f and the reference's +-pi unwrap tests,
+:234-265) must be identical.  Until round 6 the intensity's fraction carried a tolerance: the device called OCML's atan2f / atanf, the
+reference's platform glibc's (1 - 2 ulp apart); the device now computes both the way glibc does (csrc/fdlibm_f32.h, tests/test_fdlibm_f32.py),
+startOri / endOri included.
 """
 import os
 
@@ -12,9 +12,6 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-INT_TOL = 1e-5
-
 
 def run_both(vl, orc, cloud, scan_line=64, minimum_range=5.0):
     h = vl.Handle(0, scan_line=scan_line, minimum_range=minimum_range, debug=1, with_mapping=0)
@@ -26,28 +23,14 @@ def run_both(vl, orc, cloud, scan_line=64, minimum_range=5.0):
 
 
 def check_cloud(dev, ref, what, ori_bounds=None, max_flips=0):
-    """xyz and ring id bit-exact; relTime fraction within INT_TOL except at the reference's unwrap boundaries.
-
-    relTime goes through atan2f and the +-2*pi unwrap tests of scan_registration.cpp:237-261: one ulp of
-    libm-vs-OCML difference right at such a boundary moves relTime by a full turn (0.1 in intensity).
-    Nothing downstream reads the fraction (DISTORTION == false).  Returns the number of flipped points.
-    """
+    """x, y, z and intensity bit-exact.  (ori_bounds / max_flips: the tolerance arguments of rounds 1 - 5, kept so that callers read the
+    same; no flip of relTime at an unwrap boundary is accepted any more.)  Returns 0."""
     assert dev.shape == ref.shape, "%s: %s vs %s" % (what, dev.shape, ref.shape)
     assert np.array_equal(dev[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)), "%s xyz not bit-identical" % what
     assert np.array_equal(dev[:, 3].astype(np.int32), ref[:, 3].astype(np.int32)), "%s ring id differs" % what
-    dlt = np.abs(dev[:, 3] - ref[:, 3])
-    assert np.max(dlt, initial=0) <= 0.11, "%s intensity" % what
-    bad = dlt > INT_TOL
-    if ori_bounds is not None:  # full-resolution cloud: every flip must sit on an unwrap boundary
-        ori = -np.arctan2(ref[:, 1].astype(np.float64), ref[:, 0].astype(np.float64))
-        dmin = np.full(ori.shape, np.inf)
-        for b in ori_bounds:
-            w = np.abs((ori - b + np.pi) % (2 * np.pi) - np.pi)
-            dmin = np.minimum(dmin, w)
-        assert np.all(dmin[bad] < 5e-6), "%s: relTime differs away from an unwrap boundary" % what
-    else:                       # voxel means / picks: at most as many as the full cloud had
-        assert np.count_nonzero(bad) <= max_flips, "%s intensity fraction" % what
-    return int(np.count_nonzero(bad))
+    same = dev[:, 3].view(np.uint32) == ref[:, 3].view(np.uint32)
+    assert np.all(same), "%s: intensity differs in %d of %d points (max %.3g)" % (what, np.count_nonzero(~same), same.size, np.max(np.abs(dev[:, 3] - ref[:, 3])))
+    return 0
 
 
 def unwrap_bounds(startOri, endOri):
@@ -65,8 +48,9 @@ def test_scan_registration_parity(vl, orc, sweeps, shape, k):
     assert d["n_after_s1"] == sc["n_after_s1"]
     full_d, full_o = h.features(0), o.cloud(0)
     flips = check_cloud(full_d, full_o, "laserCloud", unwrap_bounds(sc["startOri"], sc["endOri"]))
-    # startOri / endOri come straight out of atan2f (OCML vs glibc: <= 1-2 ulp apart)
-    assert abs(float(d["startOri"]) - float(sc["startOri"])) < 1e-6 and abs(float(d["endOri"]) - float(sc["endOri"])) < 1e-6
+    # startOri / endOri come straight out of atan2f: the same bits
+    assert np.float32(d["startOri"]).view(np.uint32) == np.float32(sc["startOri"]).view(np.uint32)
+    assert np.float32(d["endOri"]).view(np.uint32) == np.float32(sc["endOri"]).view(np.uint32)
     assert d["N2"] == full_o.shape[0]
     assert np.array_equal(d["scanStartInd"][:shape[0]], o.sr_ints(3))
     assert np.array_equal(d["scanEndInd"][:shape[0]], o.sr_ints(4))

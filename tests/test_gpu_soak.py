@@ -38,7 +38,7 @@ def test_pipeline_soak(vl, orc, synth, c):
         cnt, pts = h.map_dump(kind)
         ref = oracle_map_points(o, kind)
         assert pts.shape == ref.shape
-        assert np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32)), "map kind %d" % kind
+        assert np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32)), "map kind %d" % kind
 
 
 def test_concurrent_sessions_are_bit_reproducible(vl, synth):

@@ -22,6 +22,7 @@
 #include <math.h>
 #include "sr_kernels.h"
 #include "bitonic.h"
+#include "fdlibm_f32.h"
 #include <cstdlib>
 
 namespace vloam {
@@ -87,11 +88,11 @@ __device__ __forceinline__ bool sr_survives_s1(float x, float y, float z, float 
   return true;
 }
 
-// The OCML bodies of atan2f / atanf are inlined per call site, and how their multiplies and adds pair into fused operations depends on the
-// code around the call: the 256-lane and the 1024-lane form of k_sr_label came out one ulp apart in a point's azimuth (a batched session
-// against the same sequence alone).  One out-of-line body each: every caller, every batch size, the same bits.
-__device__ __noinline__ float sr_atan2f(float y, float x) { return atan2f(y, x); }
-__device__ __noinline__ float sr_atanf(float v) { return atanf(v); }
+// atan2f / atanf exactly as glibc (fdlibm float) computes them on the reference's platform — fdlibm_f32.h; OCML's bodies differ from them in the
+// last bit on ~10 % of the arguments, which moves returns that sit on a scan-line bin edge or on an unwrap threshold.  One out-of-line body
+// each: every caller, every batch size, the same instruction sequence.
+__device__ __noinline__ float sr_atan2f(float y, float x) { return fd_atan2f(y, x); }
+__device__ __noinline__ float sr_atanf(float v) { return fd_atanf(v); }
 
 // SR:192-226.  Returns the ring id or -1 when the point is dropped.
 __device__ __forceinline__ int sr_scan_id(float x, float y, float z, int N_SCANS) {
