@@ -21,7 +21,8 @@ constexpr int kImgMaxLevel = 2;        // image_util.cpp:364  maxLevel
 constexpr int kImgLkIters = 10;        // image_util.cpp:362  TermCriteria count
 constexpr int kImgLevels = kImgMaxLevel + 1;
 constexpr int kImgCandCap = 65536;     // local maxima above the quality threshold (one status byte each in the selection kernel's LDS)
-constexpr int kImgNbrCap = 64;         // stronger candidates within minDistance of a candidate (3x3 local maxima are >= 2 px apart)
+constexpr int kImgNbrCap = 176;        // stronger candidates within minDistance of a candidate = EVERY pixel offset inside the 7.5 px circle (OpenCV's local-maximum
+                                       // test is val == dilate(val): on a plateau of the eigenvalue map adjacent pixels are all candidates; rounds 2 - 5 held 64)
 constexpr int kImgAccCap = 16384;      // corners before the maxCorners cut (a 1242 x 375 image holds < 10 600 at minDistance 7.5)
 constexpr int kImgMaxRadius = 8;       // floor(minDistance) the neighbourhood scan supports
 constexpr int kImgClaheTiles = 8;       // cv::createCLAHE default tileGridSize (8, 8); clipLimit 2.0 (visual_odometry.cpp:31)

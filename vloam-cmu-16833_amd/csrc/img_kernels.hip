@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void k_img_neighbours(const float* __restrict_
 
 constexpr int kSelThreads = 1024;
 static_assert(kImgCandCap <= 65536, "candidate indices travel as 16-bit values in k_img_select");
+static_assert(kImgNbrCap % 4 == 0 && kImgNbrCap <= 255, "neighbour rows are read as int4, their lengths stored in a byte");
 __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restrict__ eig, int w, const int* __restrict__ clist,
                                                             const int* __restrict__ n_cand, const int* __restrict__ nbr,
                                                             const unsigned char* __restrict__ nbr_cnt, u64* acc, int max_corners,
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kSelThreads) void k_img_select(const float* __restr
     for (int k = 0; k < kFastN / 2; k++) f_pk[m][k] = 0u;
     if (c < n) {
       const int cnt = nbr_cnt[c];
-      const int4* row = reinterpret_cast<const int4*>(nbr + (size_t)c * kImgNbrCap);   // 256-byte rows
+      const int4* row = reinterpret_cast<const int4*>(nbr + (size_t)c * kImgNbrCap);   // rows of kImgNbrCap ints, 16-byte aligned
       int4 v[kFastN / 4];
 #pragma unroll
       for (int k = 0; k < kFastN / 4; k++) v[k] = row[k];   // entries past cnt are stale or zero candidate indices: never looked at
