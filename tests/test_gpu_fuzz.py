@@ -342,3 +342,107 @@ def test_image_front_end_on_random_images(vl, orc, synth, w, h, kind, seed):
             pu_o, cu_o = orc.orb_matches(ref[0][0], ref[0][1], ref[0][2], corners, kept, desc)
             assert np.array_equal(pu, pu_o) and np.array_equal(cu, cu_o), "ORB matches"
     hd.close()
+
+
+def moving_clouds(synth, rings, n_az, seed, n, step=0.12):
+    """The whole-pipeline input above as a function: one random range image seen from a sensor that yaws and creeps forward."""
+    base = random_cloud(synth, rings, n_az, seed, keep_lo=0.85)
+    fin = np.isfinite(base[:, :3]).all(axis=1)
+    rng = np.random.default_rng(seed + 1)
+    clouds, poses = [], []
+    for k in range(n):
+        ang, t = -0.004 * k, np.array([-step * k, 0.01 * k, 0.0])
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float64)
+        c = base.copy()
+        p = base[fin, :3].astype(np.float64) @ R.T + t
+        c[fin, :3] = (p * (1.0 + 0.0005 * rng.standard_normal((p.shape[0], 1)))).astype(np.float32)
+        c[rng.random(c.shape[0]) < 0.01, :3] = np.nan
+        clouds.append(c)
+        poses.append((R, t))
+    return base, fin, clouds, poses
+
+
+@pytest.mark.parametrize("sizes,seed", [([(64, 1200), (64, 700), (64, 2040)], 601), ([(16, 1800), (16, 900)], 602)]
+                         + [([(r, min(max(a, 600), 2040)), (r, 800), (r, 1500)], sd + 21000) for r, a, sd in EXTRA[::6]])
+def test_batched_sessions_on_random_range_images(vl, orc, synth, sizes, seed):
+    """B sessions of one batched handle, each with its own moving random range image of its own size: trajectories and maps equal the
+    same sequences run alone (integer / f32 work bit for bit, f64 poses to round-off), the last poses equal the oracle's."""
+    from test_gpu_batch import same_map, same_poses
+    n = 10
+    rings = sizes[0][0]
+    seqs = [moving_clouds(synth, r, a, seed + 10 * i, n)[2] for i, (r, a) in enumerate(sizes)]
+    mp = max(max(c.shape[0] for c in s) for s in seqs)
+    hb = vl.Handle(0, n_sessions=len(sizes), scan_line=rings, with_mapping=1, max_points=max(mp, 1024))
+    for k in range(n):
+        hb.batch_process_scan([s[k] for s in seqs])
+    hb.sync()
+    for b, s in enumerate(seqs):
+        hs = vl.Handle(0, scan_line=rings, with_mapping=1, max_points=max(mp, 1024))
+        for c in s:
+            hs.process_scan(c)
+        hs.sync()
+        hb.select(b)
+        tb, ts = hb.trajectory(), hs.trajectory()
+        assert same_poses(tb, ts), "session %d trajectory" % b
+        assert same_map(hb.get_map(), hs.get_map()), "session %d map" % b
+        o = orc.Oracle(scan_line=rings, with_mapping=True)
+        for c in s:
+            assert o.process(c) == 0
+        qw, tw, _, _ = o.lo_pose()
+        qm, tm = o.map_published_pose()
+        assert same_poses(tb[-1:, :7], np.concatenate([qw, tw])[None, :], 1e-7) and same_poses(tb[-1:, 7:], np.concatenate([qm, tm])[None, :], 1e-7), b
+
+
+@pytest.mark.parametrize("n_az,seed,detach", [(1500, 701, False), (2040, 702, True)] + [(min(max(a, 900), 2040), sd + 25000, bool(sd % 2)) for r, a, sd in EXTRA[::6]])
+def test_coupled_frames_on_random_inputs(vl, synth, n_az, seed, detach):
+    """The coupled VO + LiDAR frame loop (vloam_main_node.cpp:125-180) on a moving random range image, a perturbed calibration and matches
+    with 25 % outliers: VO estimate, the VO -> LO prior, LO / map / VO world poses of every frame against orc_vloam.VloamOracle."""
+    import orc_vloam
+    from test_gpu_laser_odometry import qdist
+    rng = np.random.default_rng(seed)
+    cam_T_velo, rect0_T_cam, P = _perturbed_calib(synth, rng)
+    base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
+    velo_T_cam0 = np.linalg.inv(cam_T_velo.astype(np.float64))
+    n = 8
+    base, fin, clouds, poses = moving_clouds(synth, 64, n_az, seed, n, step=0.3)
+    K, T = P[:, :3].astype(np.float64), cam_T_velo.astype(np.float64)
+
+    def pixels(k):
+        R, t = poses[k]
+        pc = (base[fin, :3].astype(np.float64) @ R.T + t) @ T[:3, :3].T + T[:3, 3]
+        uv = pc @ K.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return uv[:, :2] / uv[:, 2:3], pc[:, 2]
+    h = vl.Handle(0, detach_VO_LO=int(detach), with_mapping=1, max_points=max(base.shape[0], 1024))
+    h.vo_set_calib(cam_T_velo, rect0_T_cam, P)
+    h.set_extrinsics(base_T_cam0, velo_T_cam0)
+    o = orc_vloam.VloamOracle(cam_T_velo, rect0_T_cam, P, base_T_cam0, velo_T_cam0, detach_VO_LO=detach, with_mapping=True)
+    for k in range(n):
+        m = (None, None)
+        if k > 0:
+            (u0, z0), (u1, z1) = pixels(k - 1), pixels(k)
+            ok = (z0 > 0.5) & (z1 > 0.5) & (u0[:, 0] >= 0) & (u0[:, 0] < 1242) & (u0[:, 1] >= 0) & (u0[:, 1] < 375) & (u1[:, 0] >= 0) & (u1[:, 0] < 1242) & (u1[:, 1] >= 0) & (u1[:, 1] < 375)
+            idx = rng.choice(np.nonzero(ok)[0], size=min(900, int(ok.sum())), replace=False)
+            pu = np.concatenate([u0[idx].astype(np.float32).astype(np.int32), np.stack([rng.integers(0, 1242, 300), rng.integers(0, 375, 300)], axis=1).astype(np.int32)])
+            cu = np.concatenate([u1[idx].astype(np.float32).astype(np.int32), np.stack([rng.integers(0, 1242, 300), rng.integers(0, 375, 300)], axis=1).astype(np.int32)])
+            m = (np.ascontiguousarray(pu), np.ascontiguousarray(cu))
+        h.process_frame(clouds[k], m[0], m[1])
+        assert o.process(clouds[k], m[0], m[1]) == 0
+        r = h.vo_result()
+        if k > 0:
+            v = o.vo_result
+            assert (r["counter32"], r["counter22"]) == (v["counter32"], v["counter22"]) and r["counter32"] > 100
+            tol = 1e-6 if k == 1 else 1e-7   # frame 1: the VO starts from 2 acos(1 - ulp) (tests/test_oracle_vloam.py)
+            assert np.linalg.norm(r["angles"] - v["angles"]) < tol and np.linalg.norm(r["t"] - v["t"]) < tol, "VO estimate, frame %d" % k
+            oq, ot = o.lo_prior()
+            assert qdist(r["prior_q"], oq) < tol and np.linalg.norm(r["prior_t"] - ot) < tol, "VO -> LO prior, frame %d" % k
+        tol = 1e-6 if k <= 1 else 1e-7 * (k + 1)
+        tj = h.trajectory()[k]
+        qw, tw, _, _ = o.lidar.lo_pose()
+        qm, tm = o.lidar.map_published_pose()
+        assert qdist(tj[0:4], qw) < tol and np.linalg.norm(tj[4:7] - tw) < tol, "LO world pose, frame %d" % k
+        assert qdist(tj[7:11], qm) < tol and np.linalg.norm(tj[11:14] - tm) < tol, "map pose, frame %d" % k
+        vq, vt = o.vo_world_pose()
+        vj = h.vo_trajectory()[k]
+        assert qdist(vj[0:4], vq) < tol and np.linalg.norm(vj[4:7] - vt) < tol, "world_VOT_base_last, frame %d" % k
+    h.sync()
