@@ -141,20 +141,33 @@ VLP = dict(minimum_range=0.3, mapping_line_resolution=0.2, mapping_plane_resolut
 KITTI = dict(minimum_range=5.0, mapping_line_resolution=0.4, mapping_plane_resolution=0.8)  # loam_velodyne_HDL_64.launch:3-13
 
 
-@pytest.mark.parametrize("rings,n_az,seed,n,cfg", [(64, 1500, 301, 14, KITTI), (16, 2048, 302, 20, KITTI), (16, 1800, 303, 16, VLP), (32, 2040, 304, 12, VLP)]
-                         + [(r, min(max(a, 900), 2040), sd + 9000, 12, VLP if (r < 64 and sd % 2) else KITTI) for r, a, sd in EXTRA[::2]],
-                         ids=lambda v: ("leaf%g" % v["mapping_line_resolution"]) if isinstance(v, dict) else str(v))
+def _random_cfg(sd, rings):
+    """hunting runs: leaf sizes down to the ABI's bound (0.132 m), any minimum range, mapping_skip_frame 1 - 3, faster / slower sensors —
+    inside the device's stated capacities, which a first hunting run with finer surf leaves / longer steps hit and
+    REPORTED (VLOAM_ERR_CAPACITY, 21 of 125 cases: 16 x more than 16 384 surf voxels of a 64-line sweep below a ~0.45 m leaf, 5 x a ring with
+    the returns of three lasers after 1 m+ steps), never mis-computed"""
+    g = np.random.default_rng(sd)
+    return dict(minimum_range=float(g.uniform(0.2, 6.0)), mapping_line_resolution=float(g.uniform(0.14, 0.9)),
+                mapping_plane_resolution=float(g.uniform(0.5 if rings == 64 else 0.2, 1.6)), mapping_skip_frame=int(g.integers(1, 4)), _step=float(g.uniform(0.02, 0.6)))
+
+
+@pytest.mark.parametrize("rings,n_az,seed,n,cfg", [(64, 1500, 301, 14, KITTI), (16, 2048, 302, 20, KITTI), (16, 1800, 303, 16, VLP), (32, 2040, 304, 12, VLP),
+                                                   (64, 1300, 305, 12, dict(minimum_range=2.5, mapping_line_resolution=0.15, mapping_plane_resolution=1.3, mapping_skip_frame=2, _step=0.9))]
+                         + [(r, min(max(a, 900), 2040), sd + 9000, 12, _random_cfg(sd, r)) for r, a, sd in EXTRA[::2]],
+                         ids=lambda v: ("leaf%.2f" % v["mapping_line_resolution"]) if isinstance(v, dict) else str(v))
 def test_whole_pipeline_on_a_moving_random_range_image(vl, orc, synth, rings, n_az, seed, n, cfg):
     """One random range image seen from a sensor that yaws and creeps forward, fresh centimetre noise and dropouts per sweep: scan
     registration -> odometry -> scan-to-map on cluttered geometry (kNN sets full of near-ties, many rejected line / plane fits, voxels
     with one point).  Every pose and the whole map against the oracle, as in test_gpu_soak.py."""
     from test_gpu_laser_mapping import lexsort_rows, oracle_map_points, qdist
+    cfg = dict(cfg)
+    step, skip = cfg.pop("_step", 0.12), cfg.setdefault("mapping_skip_frame", 1)
     base = random_cloud(synth, rings, n_az, seed, keep_lo=0.85)
     fin = np.isfinite(base[:, :3]).all(axis=1)
     rng = np.random.default_rng(seed + 1)
     clouds = []
     for k in range(n):
-        ang, t = -0.004 * k, np.array([-0.12 * k, 0.01 * k, 0.0])
+        ang, t = -0.004 * k, np.array([-step * k, 0.01 * k, 0.0])
         R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float64)
         c = base.copy()
         p = base[fin, :3].astype(np.float64) @ R.T + t
@@ -162,12 +175,17 @@ def test_whole_pipeline_on_a_moving_random_range_image(vl, orc, synth, rings, n_
         c[rng.random(c.shape[0]) < 0.01, :3] = np.nan
         clouds.append(c)
     h = vl.Handle(0, scan_line=rings, with_mapping=1, max_points=max(base.shape[0], 1024), **cfg)
-    for c in clouds:
-        h.process_scan(c)
-    h.sync()
+    try:
+        for c in clouds:
+            h.process_scan(c)
+        h.sync()
+    except vl.VloamError as e:
+        if seed >= 9000 and e.status == vl.ERR_CAPACITY:   # hunting cases only: a stated capacity, reported (see _random_cfg)
+            pytest.skip(str(e))
+        raise
     tj = h.trajectory()
     o = orc.Oracle(scan_line=rings, with_mapping=True, minimum_range=cfg["minimum_range"], line_res=cfg["mapping_line_resolution"],
-                   plane_res=cfg["mapping_plane_resolution"])
+                   plane_res=cfg["mapping_plane_resolution"], mapping_skip_frame=skip)
     for k, c in enumerate(clouds):
         assert o.process(c) == 0
         qw, tw, _, _ = o.lo_pose()
@@ -177,7 +195,7 @@ def test_whole_pipeline_on_a_moving_random_range_image(vl, orc, synth, rings, n_
     for kind in (0, 1):
         cnt, pts = h.map_dump(kind)
         ref = oracle_map_points(o, kind)
-        assert pts.shape == ref.shape and pts.shape[0] > 1000
+        assert pts.shape == ref.shape and pts.shape[0] > 100
         assert np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32)), "map kind %d" % kind
 
 
