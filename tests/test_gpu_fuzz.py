@@ -197,6 +197,9 @@ def test_whole_pipeline_on_a_moving_random_range_image(vl, orc, synth, rings, n_
         ref = oracle_map_points(o, kind)
         assert pts.shape == ref.shape and pts.shape[0] > 100
         assert np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32)), "map kind %d" % kind
+    # /laser_cloud_map (vloam_get_map): the same points in the reference's publishing ORDER (cube by cube, corner then surf, VoxelGrid order inside)
+    from test_gpu_laser_mapping import oracle_published_map, same_cloud
+    assert same_cloud(h.get_map(), oracle_published_map(o)), "/laser_cloud_map order"
 
 
 def _perturbed_calib(synth, rng):
@@ -464,3 +467,25 @@ def test_coupled_frames_on_random_inputs(vl, synth, n_az, seed, detach):
         vj = h.vo_trajectory()[k]
         assert qdist(vj[0:4], vq) < tol and np.linalg.norm(vj[4:7] - vt) < tol, "world_VOT_base_last, frame %d" % k
     h.sync()
+
+
+@pytest.mark.parametrize("rings", [16, 32, 64])
+def test_returns_at_the_origin_with_minimum_range_zero(vl, orc, synth, rings):
+    """minimum_range 0 keeps a return at the origin itself (x^2 + y^2 + z^2 < 0 is false, scan_registration.cpp:100-129); its elevation is
+    atan(0 / 0) = NaN and `int(NaN)` — undefined in C++, INT_MIN on the reference's x86-64 — makes `scanID < 0` drop it in every branch of
+    :195-226.  The GPU's float -> int conversion gives 0 for NaN (scan line 0, or 32 on a 64-line sensor): the device tests for NaN first.
+    Returns ON the z axis (z / 0 = +-inf, elevation +-90 deg) are dropped by the range tests on both sides."""
+    cloud = random_cloud(synth, rings, 700, 800 + rings)
+    rng = np.random.default_rng(rings)
+    at = rng.choice(cloud.shape[0], 60, replace=False)
+    cloud[at[:40], :3] = 0.0
+    cloud[at[40:50], :3] = [0.0, 0.0, 3.0]
+    cloud[at[50:], :3] = [0.0, 0.0, -2.0]
+    h = vl.Handle(0, scan_line=rings, debug=1, with_mapping=0, minimum_range=0.0, max_points=max(cloud.shape[0], 1024))
+    h.reset_frame()
+    h.scan_registration(cloud)
+    o = orc.Oracle(scan_line=rings, with_mapping=False, minimum_range=0.0)
+    assert o.scan_registration(cloud) == 0
+    assert h.sr_debug()["n_after_s1"] == o.sr_scalars()["n_after_s1"]
+    for which, name in [(0, "laserCloud"), (1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
+        check_cloud(h.features(which), o.cloud(which), name)

@@ -97,6 +97,9 @@ __device__ __noinline__ float sr_atanf(float v) { return fd_atanf(v); }
 // SR:192-226.  Returns the ring id or -1 when the point is dropped.
 __device__ __forceinline__ int sr_scan_id(float x, float y, float z, int N_SCANS) {
   float angle = (float)((double)(sr_atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
+  // a return at the origin itself (0 / 0; it survives S1 only with minimum_range <= 0): int(NaN) is INT_MIN on the reference's x86-64
+  // (cvttsd2si), i.e. "scanID < 0" in every branch below — dropped; the GPU's conversion would give 0, i.e. scan line 0 / 32
+  if (angle != angle) return -1;
   int scanID = 0;
   if (N_SCANS == 16) {
     scanID = int((double)((angle + 15) / 2) + 0.5);
