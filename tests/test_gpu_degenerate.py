@@ -74,7 +74,7 @@ def test_degenerate_session_inside_a_batch(vl, orc, synth, case, with_mapping):
     """(a), (b) as session 2 of a batch of four: the cooperative solves of all sessions share their launches, one of them with an empty
     (or nearly empty) factor table.  Every session — the degenerate one and its three neighbours — against its own oracle run."""
     n = 7
-    # (with mapping: 256 columns — the far sweep puts every point into a voxel of its own, and 64 x 512 would exceed the 16 384 surf voxels
+    # (with mapping: 256 columns — the far sweep puts every point into a voxel of its own, and 64 x 512 would exceed the surf voxels
     # a sweep may bring, a stated capacity of the handle; the far sweep's map solve then runs without a single factor as well)
     deg = dc.lo_sequence(synth, n=n, shape=(64, 256) if with_mapping else (64, 512), far_at=(3,) if case == "zero" else (),
                          wedge_at=() if case == "zero" else (3,))

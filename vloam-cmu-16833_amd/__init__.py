@@ -25,7 +25,7 @@ K_MAX_SHARP, K_MAX_LESS_SHARP, K_MAX_FLAT = 768, 7680, 1536
 K_MAX_LO_FACTORS = K_MAX_SHARP + K_MAX_FLAT
 K_IMG_MAX_CORNERS = 1024   # image_util.cpp:23 maxCorners
 K_LM_MAX_TRACE = 104
-K_STACK_CAP_CORNER, K_STACK_CAP_SURF = 8192, 16384
+K_STACK_CAP_CORNER, K_STACK_CAP_SURF = 8192, 24576
 K_MAP_FACTOR_CAP = K_STACK_CAP_CORNER + K_STACK_CAP_SURF
 
 

@@ -17,7 +17,7 @@ namespace vloam {
 
 constexpr int kCubeW = 21, kCubeH = 21, kCubeD = 11, kCubeNum = kCubeW * kCubeH * kCubeD;  // laser_mapping.h:110-117
 constexpr int kStackCapCorner = 8192;   // >= kMaxLessSharp
-constexpr int kStackCapSurf = 16384;    // voxels of one sweep's lessFlat cloud at the plane resolution
+constexpr int kStackCapSurf = 24576;    // voxels of one sweep's lessFlat cloud at the plane resolution (with the corner stack: 32 768 slots = the 512 mask rows of a solve)
 constexpr int kMapFactorCap = kStackCapCorner + kStackCapSurf;
 constexpr int kPendCap = 16;            // stack points that may land in one map voxel in one sweep
 // Voxel indices one axis of a 50 m cube can take at a leaf of 1 / inv (+ slack: the first index of a cube is taken one cell early, and the
