@@ -27,3 +27,33 @@ def test_restated_atanf_atan2f_equal_the_c_library(tmp_path):
     rows = dict((ln.split()[0], [int(v) for v in ln.split()[1:]]) for ln in r.stdout.strip().splitlines()[-2:])
     assert rows["atanf"][0] > (1 << 25) and rows["atanf"][1] == 0
     assert rows["atan2f"][0] > (1 << 25) and rows["atan2f"][1] == 0
+
+
+def test_numpy_statement_equals_the_c_library():
+    """tests/fdlibm_np.py (used by the literal Python transcription of scan registration) against the C library through ctypes."""
+    import ctypes
+    import ctypes.util
+
+    import numpy as np
+
+    import fdlibm_np as fd
+    libc = platform.libc_ver()
+    if libc[0] == "glibc" and tuple(int(v) for v in libc[1].split(".")[:2]) >= (2, 41):
+        pytest.skip("glibc %s: correctly-rounded atanf / atan2f" % libc[1])
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.atanf.restype = ctypes.c_float
+    libm.atanf.argtypes = [ctypes.c_float]
+    libm.atan2f.restype = ctypes.c_float
+    libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.integers(0, 2 ** 32, 8000, dtype=np.uint64).astype(np.uint32).view(np.float32), rng.uniform(-0.6, 0.6, 8000).astype(np.float32),
+                         np.array([0.4375, 0.6875, 1.1875, 2.4375, 0.0, -0.0, 1, -1, np.inf, -np.inf, 33554432.0], np.float32)])
+    with np.errstate(all="ignore"):
+        for x in xs:
+            a, b = np.float32(libm.atanf(float(x))), np.float32(fd.atanf(x))
+            assert (np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32), float(x)
+        for y, x in zip(rng.uniform(-120, 120, 8000).astype(np.float32), rng.uniform(-120, 120, 8000).astype(np.float32)):
+            assert np.float32(libm.atan2f(float(y), float(x))).view(np.uint32) == np.float32(fd.atan2f(y, x)).view(np.uint32), (float(y), float(x))
+        for y in (0.0, -0.0, 1.0, -1.0, np.inf, -np.inf):
+            for x in (0.0, -0.0, 1.0, -1.0, np.inf, -np.inf):
+                assert np.float32(libm.atan2f(y, x)).view(np.uint32) == np.float32(fd.atan2f(y, x)).view(np.uint32), (y, x)
