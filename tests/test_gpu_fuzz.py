@@ -1,4 +1,7 @@
-"""-m gpu: scanRegistration (and two sweeps of scan-to-scan odometry behind it) on RANDOM range images vs the CPU oracle.
+"""-m gpu: every stage of the path on RANDOM inputs vs the CPU oracle — scan registration, scan-to-scan odometry, the whole pipeline (the three launch
+configurations and random ones), batched sessions, the VO residual stack, the coupled VO + LiDAR frame loop, both image configurations.
+VLOAM_FUZZ_EXTRA=N adds N random shapes / seeds / configurations per test (hunting runs; profiles/r06_fuzz_hunt.txt keeps their record);
+without it the committed cases run in a few seconds each.
 
 The scene generator of synth.py draws streets: long planes, few range jumps, full rings.  These clouds are not scenes: every ring is a
 random piecewise-smooth range profile with steps, spikes, dropouts (NaN / inf / zero), returns inside minimum_range, exact repeats of the
