@@ -63,3 +63,17 @@ def tie_clouds():
             if i < 9 and 1 <= j <= 7:
                 qs.append([20.125 + 0.875 * i + 0.4375, -3.5 + 0.875 * j, -1.5, 0.0])
     return tuple(np.array(a, np.float32) for a in (sc, ss, qc, qs))
+
+
+def six_way_walk(step=55.0):
+    """Offsets (metres, one per sweep) added to the odometry translation handed to LaserMapping::input so that the 21 x 21 x 11 cube window
+    (50 m cubes, centre index kept inside [3, size - 3), laser_mapping.cpp:218-402) rolls along every axis in BOTH directions: out to -440 m in
+    x, +165 m / -165 m in z, -440 m / +440 m in y, then back across the origin to +440 m in x.  Consecutive sweeps stay within sensor range of
+    each other, so the valid 5 x 5 x 3 block around a new position holds earlier sweeps' points and the scan-to-map gate opens along the way."""
+    way = [(0, 0, 0), (-440, 0, 0), (-440, 0, 165), (-440, 0, -165), (-440, -440, -165), (-440, 440, 0), (440, 440, 0)]
+    out = [np.zeros(3)]
+    for a, b in zip(way[:-1], way[1:]):
+        a, b = np.array(a, float), np.array(b, float)
+        n = int(np.ceil(np.linalg.norm(b - a) / step))
+        out += [a + (b - a) * (i / n) for i in range(1, n + 1)]
+    return out

@@ -159,7 +159,7 @@ def test_exact_knn_ties_empty_and_single_cell_clouds_in_the_map(vl, orc, synth):
     run_map_ties(o, seq, oracle=True)
     assert o.map_num_outer() == 2
     for which in (7, 8):
-        assert np.array_equal(h.features(which)[:, :3].view(np.uint32), o.cloud(which)[:, :3].view(np.uint32))
+        assert np.array_equal(h.features(which)[:, :4].view(np.uint32), o.cloud(which)[:, :4].view(np.uint32))
     for outer in range(2):
         compare_map_round(h, o, outer)     # factor sets, the lines / planes fitted through the five TIED-BROKEN neighbours, traces, poses
     oq, ot, _, _ = o.map_pose()
@@ -167,13 +167,13 @@ def test_exact_knn_ties_empty_and_single_cell_clouds_in_the_map(vl, orc, synth):
     qm, tm = run_map_empty_and_single_cell(h, seq)
     run_map_empty_and_single_cell(o, seq, oracle=True)
     assert h.features(7).shape[0] == 0 and h.features(8).shape[0] == 1
-    assert np.array_equal(h.features(8)[:, :3].view(np.uint32), o.cloud(8)[:, :3].view(np.uint32)), "the single cell's f32 centroid, input order"
+    assert np.array_equal(h.features(8)[:, :4].view(np.uint32), o.cloud(8)[:, :4].view(np.uint32)), "the single cell's f32 centroid, input order"
     oq, ot, _, _ = o.map_pose()
     assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL
     for kind in (0, 1):
         _, pts = h.map_dump(kind)
         ref = oracle_map_points(o, kind)
-        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32))
+        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32))
     h.sync()
     h.close()
 

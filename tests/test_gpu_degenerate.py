@@ -131,12 +131,12 @@ def test_small_map_gate_after_frame_zero(vl, orc, synth):
         assert qdist(st["q_wmap_wodom"], oqm) < POSE_TOL and np.linalg.norm(st["t_wmap_wodom"] - otm) < POSE_TOL
         for which in (7, 8):
             dv, rf = h.features(which), o.cloud(which)
-            assert dv.shape == rf.shape and np.array_equal(dv[:, :3].view(np.uint32), rf[:, :3].view(np.uint32)), "stack %d" % which
+            assert dv.shape == rf.shape and np.array_equal(dv[:, :4].view(np.uint32), rf[:, :4].view(np.uint32)), "stack %d" % which
         for kind in (0, 1):
             cnt, pts = h.map_dump(kind)
             ref = oracle_map_points(o, kind)
             assert pts.shape == ref.shape, "frame %d map kind %d: %s vs %s" % (k, kind, pts.shape, ref.shape)
-            assert np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32)), "frame %d map kind %d" % (k, kind)
+            assert np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32)), "frame %d map kind %d" % (k, kind)
     assert [g[0] for g in gate[:4]] == [0, 0, 0, 1] and 0 < gate[1][2] <= 50 and 0 < gate[2][2] <= 50, gate
     h.sync()
     h.close()
@@ -164,7 +164,7 @@ def test_small_map_session_inside_a_batch(vl, orc, synth):
     for kind in (0, 1):
         _, pts = hb.map_dump(kind)
         ref = oracle_map_points(oracles[1], kind)
-        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32))
+        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32))
     hb.close()
 
 

@@ -170,7 +170,7 @@ def test_equal_curvatures_are_picked_in_the_canonical_order(vl, orc, synth):
         for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
             dev, ref = h.features(which), o.cloud(which)
             assert dev.shape == ref.shape, name
-            assert np.array_equal(dev[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)), "%s: picks among equal curvatures differ (debug=%d)" % (name, debug)
+            assert np.array_equal(dev[:, :4].view(np.uint32), ref[:, :4].view(np.uint32)), "%s: picks among equal curvatures differ (debug=%d)" % (name, debug)
         if debug:
             d = h.sr_debug()
             assert np.array_equal(d["sharpInd"], o.sr_ints(5)) and np.array_equal(d["lessSharpInd"], o.sr_ints(6)) and np.array_equal(d["flatInd"], o.sr_ints(7))
@@ -271,7 +271,7 @@ for k in range(3):
     o = orc.Oracle(with_mapping=False); assert o.scan_registration(c) == 0
     for which in (1, 2, 3, 4):
         d, r = h.features(which), o.cloud(which)
-        assert d.shape == r.shape and np.array_equal(d[:, :3].view(np.uint32), r[:, :3].view(np.uint32)), (k, which)
+        assert d.shape == r.shape and np.array_equal(d[:, :4].view(np.uint32), r[:, :4].view(np.uint32)), (k, which)
     h.laser_odometry()
 h.sync()
 # a ring that outgrows the small tier WITHOUT the watch word's warning is reported, not processed

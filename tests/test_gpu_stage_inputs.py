@@ -42,8 +42,8 @@ def test_edited_clouds_between_scan_registration_and_odometry(vl, orc, sweeps):
         h.scan_registration(cloud)
         assert o.stage_sr(cloud) == 0
         five = [h.features(w) for w in range(5)]
-        for w in range(5):   # (intensity = scan line + 0.1 relTime goes through atan2f: OCML vs glibc, 1e-5)
-            assert np.array_equal(five[w][:, :3].view(np.uint32), o.cloud(w)[:, :3].view(np.uint32)) and np.max(np.abs(five[w][:, 3] - o.cloud(w)[:, 3]), initial=0) < 1e-5
+        for w in range(5):   # all four floats (intensity = scan line + 0.1 relTime goes through atan2f: the device computes it the way glibc does)
+            assert np.array_equal(np.ascontiguousarray(five[w][:, :4]).view(np.uint32), np.ascontiguousarray(o.cloud(w)[:, :4]).view(np.uint32))
         ed = edited(five, k)
         if any(e is not None for e in ed):
             n_edits += 1
@@ -63,18 +63,18 @@ def test_edited_clouds_between_scan_registration_and_odometry(vl, orc, sweeps):
                 assert np.array_equal(d["corner"], oc) and np.array_equal(d["plane"], op), "correspondences, sweep %d round %d" % (k, outer)
         # LaserOdometry::output hands the (edited) less-clouds on as CornerLast / SurfLast
         for which in (5, 6):
-            assert np.array_equal(h.features(which)[:, :3].view(np.uint32), o.cloud(which)[:, :3].view(np.uint32))
+            assert np.array_equal(h.features(which)[:, :4].view(np.uint32), o.cloud(which)[:, :4].view(np.uint32))
         qm, tm = h.laser_mapping()
         assert o.stage_map() == 0
         for which in (7, 8):
-            assert np.array_equal(h.features(which)[:, :3].view(np.uint32), o.cloud(which)[:, :3].view(np.uint32)), "stack %d, sweep %d" % (which, k)
+            assert np.array_equal(h.features(which)[:, :4].view(np.uint32), o.cloud(which)[:, :4].view(np.uint32)), "stack %d, sweep %d" % (which, k)
         oq, ot, _, _ = o.map_pose()
         assert qdist(qm, oq) < POSE_TOL and np.linalg.norm(tm - ot) < POSE_TOL, "map pose, sweep %d" % k
     assert n_edits >= 5
     for kind in (0, 1):
         _, pts = h.map_dump(kind)
         ref = oracle_map_points(o, kind)
-        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32))
+        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32))
     h.close()
 
 
@@ -128,7 +128,7 @@ def test_edited_inputs_between_odometry_and_mapping(vl, orc, sweeps, skip):
     for kind in (0, 1):
         _, pts = h.map_dump(kind)
         ref = oracle_map_points(o, kind)
-        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :3].view(np.uint32), lexsort_rows(ref)[:, :3].view(np.uint32))
+        assert pts.shape == ref.shape and np.array_equal(lexsort_rows(pts)[:, :4].view(np.uint32), lexsort_rows(ref)[:, :4].view(np.uint32))
     h.close()
 
 

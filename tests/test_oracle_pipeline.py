@@ -682,23 +682,21 @@ def test_vo_bucket_fold_and_query_depth_vs_literal_python(orc, synth):
     assert checked > 300 and v.query_depth(0, -500.0, -500.0) == -1.0
 
 
-def test_map_window_roll_vs_literal_python_replay(orc, synth):
-    """Replay of the whole map bookkeeping in Python across a 500 m drive (the 21 x 21 x 11 cube window has to roll):
-    centre cube from the initial guess with the `< 0` correction (laser_mapping.cpp:207-216), the six literal shift loops that
-    move the cube grid and clear the slab that wraps (:218-402), the 5 x 5 x 3 valid block in its loop order (:404-420),
-    insertion by truncated cube index (:639-683) and the re-VoxelGrid of the valid cubes (:689-702).  Poses and feature clouds
-    are taken from the oracle, the VoxelGrid primitive from orc.voxel_grid (pinned bit-exact elsewhere).  After EVERY sweep
-    the window position, the valid list, every cube this replay holds and the point totals must equal the oracle's."""
+def replay_map_window(orc, o, n, drive):
+    """Replay of the whole map bookkeeping in Python: centre cube from the initial guess with the `< 0` correction
+    (laser_mapping.cpp:207-216), the six literal shift loops that move the cube grid and clear the slab that wraps (:218-402), the
+    5 x 5 x 3 valid block in its loop order (:404-420), insertion by truncated cube index (:639-683) and the re-VoxelGrid of the valid
+    cubes (:689-702).  `drive(k)` runs sweep k through the oracle `o` and returns the odometry translation LaserMapping::input was
+    handed; poses and feature clouds are taken from the oracle, the VoxelGrid primitive from orc.voxel_grid (pinned bit-exact elsewhere).
+    After EVERY sweep the window position, the valid list, every cube this replay holds and the point totals must equal the oracle's.
+    Returns the number of one-cube shifts per (axis, direction)."""
     f32 = np.float32
     W, H, D = 21, 21, 11
-    n = 175
-    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n, speed=30.0)
-    o = orc.Oracle(with_mapping=True)
     grid = [dict(), dict()]  # (i, j, k) -> (N, 4) f32, corner / surf
     cen = [10, 10, 5]        # laser_mapping.h:76-78
     q_mo, t_mo = np.array([0, 0, 0, 1.0]), np.zeros(3)
     leaf = (0.4, 0.8)
-    rolled = 0
+    rolled = {(a, up): 0 for a in range(3) for up in (True, False)}
 
     def qmul(a, b):
         ax, ay, az, aw = a; bx, by, bz, bw = b
@@ -726,15 +724,14 @@ def test_map_window_roll_vs_literal_python_replay(orc, synth):
             g.clear(); g.update(new)
 
     for k in range(n):
-        assert o.process(seq.sweep(k)) == 0
-        qw, tw, _, _ = o.lo_pose()
+        tw = drive(k)
         t_guess = qrot(q_mo, tw) + t_mo
         cc = [cube_of(float(t_guess[a]), cen[a]) for a in range(3)]
         for a, size in enumerate((W, H, D)):
             while cc[a] < 3:
-                shift(a, True); cc[a] += 1; cen[a] += 1; rolled += 1
+                shift(a, True); cc[a] += 1; cen[a] += 1; rolled[(a, True)] += 1
             while cc[a] >= size - 3:
-                shift(a, False); cc[a] -= 1; cen[a] -= 1; rolled += 1
+                shift(a, False); cc[a] -= 1; cen[a] -= 1; rolled[(a, False)] += 1
         valid = [i + W * j + W * H * kk for i in range(cc[0] - 2, cc[0] + 3) for j in range(cc[1] - 2, cc[1] + 3)
                  for kk in range(cc[2] - 1, cc[2] + 2) if 0 <= i < W and 0 <= j < H and 0 <= kk < D]
         info = o.map_info()
@@ -765,7 +762,40 @@ def test_map_window_roll_vs_literal_python_replay(orc, synth):
                 assert got.shape == pts.shape and np.array_equal(got.view(np.uint32), pts.view(np.uint32)), (k, which, key)
                 total += pts.shape[0]
             assert total == (info["total_corner"], info["total_surf"])[which], (k, which)
-    assert rolled >= 1, "the drive was too short to roll the window"
+    return rolled
+
+
+def test_map_window_roll_vs_literal_python_replay(orc, synth):
+    """The replay across a 500 m drive (the 21 x 21 x 11 cube window has to roll)."""
+    n = 175
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=n, speed=30.0)
+    o = orc.Oracle(with_mapping=True)
+
+    def drive(k):
+        assert o.process(seq.sweep(k)) == 0
+        return o.lo_pose()[1]
+    rolled = replay_map_window(orc, o, n, drive)
+    assert sum(rolled.values()) >= 1, "the drive was too short to roll the window"
+
+
+def test_map_window_rolls_in_all_six_directions_vs_literal_python_replay(orc, synth):
+    """A street drive only ever rolls the window one way along x (and perhaps y).  Here LaserMapping::input is handed the odometry pose plus
+    the offsets of branch_cases.six_way_walk (the reference takes whatever pose its caller hands it, laser_mapping.cpp:167-196): 55 m per
+    sweep out to -440 m in x, up and down 165 m in z, both ways in y and back across the origin to +440 m — each of the six `while` loops
+    (:218-402) runs at least once, cubes leave the window at both ends of every axis and come back empty."""
+    import branch_cases
+    walk = branch_cases.six_way_walk()
+    seq = synth.SynthSequence(n_rings=64, n_azimuth=256, n_sweeps=len(walk))
+    o = orc.Oracle(with_mapping=True)
+
+    def drive(k):
+        assert o.stage_sr(seq.sweep(k)) == 0
+        o.stage_lo()
+        qw, tw, _, _ = o.lo_pose()
+        assert o.stage_map(q=qw, t=tw + walk[k]) == 0
+        return tw + walk[k]
+    rolled = replay_map_window(orc, o, len(walk), drive)
+    assert all(v >= 1 for v in rolled.values()), rolled
 
 
 def test_vo_objective_and_minimum_vs_numpy(orc, synth):
