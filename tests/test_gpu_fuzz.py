@@ -32,7 +32,15 @@ pytestmark = pytest.mark.gpu
 def random_cloud(synth, rings, n_az, seed, keep_lo=0.55):
     rng = np.random.default_rng(seed)
     el0 = synth.beam_elevations_deg(rings)
-    az0 = -2 * np.pi * np.arange(n_az) / n_az
+    # seeds below 900 (the first committed cases): the sweep starts at azimuth 0 and covers one turn, like the synthetic sequences.  From 900 on
+    # the first column points anywhere (startOri anywhere in (-pi, pi]: both `endOri` corrections and every unwrap branch of
+    # scan_registration.cpp:176-265 are taken) and the columns cover 0.93 - 1.04 of a turn (a tenth of the cases: 0.3 - 0.9)
+    yaw0, turn = 0.0, 1.0
+    if seed >= 900:
+        g = np.random.default_rng(seed + 77)
+        yaw0 = g.uniform(-np.pi, np.pi)
+        turn = g.uniform(0.93, 1.04) if g.random() > 0.1 else g.uniform(0.3, 0.9)
+    az0 = yaw0 - 2 * np.pi * turn * np.arange(n_az) / n_az
     cols = []
     for r in range(rings):
         # piecewise-smooth profile: a few sinusoids + steps at random columns + centimetre noise
@@ -71,7 +79,8 @@ def random_cloud(synth, rings, n_az, seed, keep_lo=0.55):
     return out
 
 
-CASES = [(64, 2048, 101), (64, 1777, 102), (64, 600, 103), (64, 3100, 104), (32, 1500, 105), (16, 2048, 106), (16, 257, 107), (64, 2048, 108)]
+CASES = [(64, 2048, 101), (64, 1777, 102), (64, 600, 103), (64, 3100, 104), (32, 1500, 105), (16, 2048, 106), (16, 257, 107), (64, 2048, 108),
+         (64, 2048, 927), (64, 1900, 997), (16, 1800, 908), (32, 2000, 945), (64, 1500, 940), (64, 2048, 936), (64, 1700, 988), (16, 2048, 953)]   # start azimuth anywhere, 0.3 - 1.04 turns
 # VLOAM_FUZZ_EXTRA=N: N more cases per test with seeds / shapes drawn from N itself (hunting runs; the committed cases are the ones above)
 _EXTRA = int(os.environ.get("VLOAM_FUZZ_EXTRA", "0"))
 _BASE = int(os.environ.get("VLOAM_FUZZ_SEED_BASE", "1000"))   # first seed of the extra cases: another base = another set of inputs (>= 1000: the committed seeds lie below)
@@ -110,7 +119,7 @@ def test_scan_registration_on_random_range_images(vl, orc, synth, rings, n_az, s
     assert o.cloud(1).shape[0] > 0 and o.cloud(3).shape[0] > 0, "the case must produce features"
 
 
-@pytest.mark.parametrize("rings,n_az,seed", [(64, 2048, 201), (16, 1800, 202)] + [(r, min(max(a, 900), 2040), sd + 5000) for r, a, sd in EXTRA[::3]])
+@pytest.mark.parametrize("rings,n_az,seed", [(64, 2048, 201), (16, 1800, 202), (64, 2048, 945), (32, 1800, 961)] + [(r, min(max(a, 900), 2040), sd + 5000) for r, a, sd in EXTRA[::3]])
 def test_odometry_between_two_random_range_images(vl, orc, synth, rings, n_az, seed):
     """Two random clouds, the second one the first one moved by a small rigid motion (so that correspondences exist): correspondence
     triples exact, trust-region trace equal, pose to 1e-8 — on feature sets (ragged rings, sparse sectors) a street never has."""
@@ -173,6 +182,7 @@ def _motion(seed, step, k):
 
 
 @pytest.mark.parametrize("rings,n_az,seed,n,cfg", [(64, 1500, 301, 14, KITTI), (16, 2048, 302, 20, KITTI), (16, 1800, 303, 16, VLP), (32, 2040, 304, 12, VLP),
+                                                   (64, 1500, 927, 10, KITTI), (16, 1800, 983, 12, VLP),   # sweeps that start at azimuth -pi / +3.04 (0.855 of a turn)
                                                    (64, 1500, 306, 10, VLP),   # a 64-line sensor with the 16 / 32-line launch values: 17 000 - 21 000 surf voxels per sweep (the stack held 16 384 until round 6)
                                                    (64, 1300, 305, 12, dict(minimum_range=2.5, mapping_line_resolution=0.15, mapping_plane_resolution=1.3, mapping_skip_frame=2, _step=0.9))]
                          + [(r, min(max(a, 900), 2040), sd + 9000, 12, _random_cfg(sd, r)) for r, a, sd in EXTRA[::2]],

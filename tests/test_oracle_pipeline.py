@@ -377,14 +377,15 @@ def test_feature_picks_vs_literal_python_loops(orc, sweeps, rings, az):
     assert np.array_equal(full[np.array(flat)].view(np.uint32), o.cloud(3).view(np.uint32))
 
 
-@pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512), (64, -1), (16, -2)])
+@pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512), (64, -1), (16, -2), (64, -27), (32, -97), (16, -8), (64, -83)])
 def test_ring_labelling_vs_literal_python_loop(orc, sweeps, rings, az):
     """Second, independent transcription of scan_registration.cpp:157-281 in plain Python: NaN / minimum-range removal, the
     vertical-angle -> scan line tables of the three sensor models, the sequential half-sweep unwrap state machine
     (halfPassed), relTime, ring-major concatenation and scanStartInd / scanEndInd.  Ring ids, the order of the points and ALL
     FOUR floats must match the oracle exactly: the transcription calls a numpy statement of glibc's (fdlibm's) float atan / atan2
     (tests/fdlibm_np.py; np.arctan2 is another algorithm, 1 - 2 ulp away, which rounds 1 - 5 covered with a tolerance).  az < 0: a random range
-    image of tests/test_gpu_fuzz.py, moved rigidly — returns anywhere inside the elevation bins and on both sides of the unwrap thresholds."""
+    image of tests/test_gpu_fuzz.py (seed 900 - az), moved rigidly — returns anywhere inside the elevation bins and on both sides of the unwrap thresholds;
+    from seed 900 on the sweep starts at any azimuth (927: -pi, 997: +pi with 4 % overlap, 908 / 983: half / 0.86 of a turn)."""
     from fdlibm_np import atan2f, atanf
     f32, pi = np.float32, np.pi
     if az > 0:
