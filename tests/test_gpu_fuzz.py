@@ -29,7 +29,7 @@ from test_gpu_scan_registration import check_cloud, unwrap_bounds
 pytestmark = pytest.mark.gpu
 
 
-def random_cloud(synth, rings, n_az, seed, keep_lo=0.55):
+def random_cloud(synth, rings, n_az, seed, keep_lo=0.55, min_turn=0.0):
     rng = np.random.default_rng(seed)
     el0 = synth.beam_elevations_deg(rings)
     # seeds below 900 (the first committed cases): the sweep starts at azimuth 0 and covers one turn, like the synthetic sequences.  From 900 on
@@ -40,6 +40,7 @@ def random_cloud(synth, rings, n_az, seed, keep_lo=0.55):
         g = np.random.default_rng(seed + 77)
         yaw0 = g.uniform(-np.pi, np.pi)
         turn = g.uniform(0.93, 1.04) if g.random() > 0.1 else g.uniform(0.3, 0.9)
+        turn = max(turn, min_turn)   # (the camera tests need returns in front of the camera whatever the start azimuth: min_turn = 1)
     az0 = yaw0 - 2 * np.pi * turn * np.arange(n_az) / n_az
     cols = []
     for r in range(rings):
@@ -261,7 +262,7 @@ def test_vo_stack_on_random_range_images_and_matches(vl, orc, synth, n_az, seed)
     buckets hold one point, 30 % outliers.  Bucket maps, per-match depths and observations bit for bit, the solve to 1e-8."""
     rng = np.random.default_rng(seed)
     cam_T_velo, rect0_T_cam, P = _perturbed_calib(synth, rng)
-    a = random_cloud(synth, 64, n_az, seed, keep_lo=0.8)
+    a = random_cloud(synth, 64, n_az, seed, keep_lo=0.8, min_turn=1.0)
     ang, tr = rng.uniform(-0.02, 0.02), np.array([rng.uniform(0.2, 1.0), rng.uniform(-0.1, 0.1), rng.uniform(-0.03, 0.03)])
     R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float64)
     fin = np.isfinite(a[:, :3]).all(axis=1)
@@ -402,9 +403,9 @@ def test_image_front_end_on_random_images(vl, orc, synth, w, h, kind, seed):
     hd.close()
 
 
-def moving_clouds(synth, rings, n_az, seed, n, step=0.12):
+def moving_clouds(synth, rings, n_az, seed, n, step=0.12, min_turn=0.0):
     """The whole-pipeline input above as a function: one random range image seen from a sensor that yaws and creeps forward."""
-    base = random_cloud(synth, rings, n_az, seed, keep_lo=0.85)
+    base = random_cloud(synth, rings, n_az, seed, keep_lo=0.85, min_turn=min_turn)
     fin = np.isfinite(base[:, :3]).all(axis=1)
     rng = np.random.default_rng(seed + 1)
     clouds, poses = [], []
@@ -461,7 +462,7 @@ def test_coupled_frames_on_random_inputs(vl, synth, n_az, seed, detach):
     base_T_cam0, velo_T_cam0 = synth.kitti_like_extrinsics()
     velo_T_cam0 = np.linalg.inv(cam_T_velo.astype(np.float64))
     n = 8
-    base, fin, clouds, poses = moving_clouds(synth, 64, n_az, seed, n, step=0.3)
+    base, fin, clouds, poses = moving_clouds(synth, 64, n_az, seed, n, step=0.3, min_turn=1.0)
     K, T = P[:, :3].astype(np.float64), cam_T_velo.astype(np.float64)
 
     def pixels(k):

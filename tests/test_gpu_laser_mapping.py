@@ -130,6 +130,20 @@ def same_cloud_to_rounding(a, b):
     return int(ulp.max(initial=0)) <= 1 and float(np.mean(ulp == 0)) > 0.999 and np.array_equal(a[:, 3].view(np.uint32), b[:, 3].view(np.uint32))
 
 
+def same_cloud_to_pose_rounding(a, b, tol=1e-8):
+    """Far from the start (hundreds of metres) or after large rotations: same points in the same order, intensities bit for bit, every
+    coordinate the oracle's float, its neighbour, or — for coordinates near zero, whose ulp is smaller than the poses' round-off — within
+    `tol` (the pose bar); > 99.9 % of the coordinates the same float.  Returns (ok, number of coordinates not bit-equal, max ulp distance)."""
+    if a.shape != b.shape:
+        return False, -1, -1
+    g, w = np.ascontiguousarray(a[:, :4]), np.ascontiguousarray(b[:, :4])
+    ulp = np.abs(g[:, :3].view(np.int32).astype(np.int64) - w[:, :3].view(np.int32).astype(np.int64))
+    absd = np.abs(g[:, :3].astype(np.float64) - w[:, :3].astype(np.float64))
+    ok = (np.array_equal(g[:, 3].view(np.uint32), w[:, 3].view(np.uint32)) and not ((ulp > 1) & (absd > tol)).any()
+          and float(np.mean(ulp == 0)) > 0.999)
+    return ok, int(np.count_nonzero(ulp)), int(ulp.max(initial=0))
+
+
 def test_public_map_export(vl, orc, sweeps):
     """vloam_get_map == /laser_cloud_map: same points in the same order (cube by cube, corner then surf, VoxelGrid order inside)."""
     h = vl.Handle(0, with_mapping=1)

@@ -64,7 +64,7 @@ def quat_to_rot(q):
 
 class SynthSequence:
     def __init__(self, n_rings=64, n_azimuth=2048, n_sweeps=200, seed_scene=1234, seed_traj=42, seed_noise=5678,
-                 noise_sigma=0.02, speed=10.0, dt=0.1):
+                 noise_sigma=0.02, speed=10.0, dt=0.1, pitch_amp=0.01, roll_amp=0.01, heave_amp=0.05):
         self.n_rings, self.n_azimuth, self.n_sweeps = n_rings, n_azimuth, n_sweeps
         self.seed_noise, self.noise_sigma = seed_noise, noise_sigma
         el = np.deg2rad(beam_elevations_deg(n_rings))
@@ -86,9 +86,9 @@ class SynthSequence:
         yaw = np.concatenate([[0.0], np.cumsum(yaw_rate[:-1] * dt)])
         x = np.concatenate([[0.0], np.cumsum(v[:-1] * np.cos(yaw[:-1]) * dt)])
         y = np.concatenate([[0.0], np.cumsum(v[:-1] * np.sin(yaw[:-1]) * dt)])
-        z = 0.05 * np.sin(2 * np.pi * t / 5.0 + ph[2])
-        pitch = 0.01 * np.sin(2 * np.pi * t / 3.7 + ph[3])
-        roll = 0.01 * np.sin(2 * np.pi * t / 4.3 + ph[4])
+        z = heave_amp * np.sin(2 * np.pi * t / 5.0 + ph[2])        # (defaults: the benchmark sequence; larger amplitudes: steep / banked test drives)
+        pitch = pitch_amp * np.sin(2 * np.pi * t / 3.7 + ph[3])
+        roll = roll_amp * np.sin(2 * np.pi * t / 4.3 + ph[4])
         self.R = [_rot_zyx(yaw[i], pitch[i], roll[i]) for i in range(n_sweeps)]
         self.t = np.stack([x, y, z], -1)
         # ---- scene placed along the path corridor
