@@ -1,7 +1,8 @@
 """-m gpu: every stage of the path on RANDOM inputs vs the CPU oracle — scan registration, scan-to-scan odometry, the whole pipeline (the three launch
 configurations and random ones), batched sessions, the VO residual stack, the coupled VO + LiDAR frame loop, both image configurations.
-VLOAM_FUZZ_EXTRA=N adds N random shapes / seeds / configurations per test (hunting runs; profiles/r06_fuzz_hunt.txt keeps their record);
-without it the committed cases run in a few seconds each.
+VLOAM_FUZZ_EXTRA=N adds N random shapes / seeds / configurations per test, VLOAM_FUZZ_SEED_BASE=S starts their seeds at S (hunting runs;
+profiles/r06_fuzz_hunt.txt keeps their record); without them the committed cases run in a few seconds each.  From seed 900 on a sweep starts at
+any azimuth and covers 0.3 - 1.04 of a turn; hunting cases with an odd seed move in 3-D (any heading, a little pitch / roll).
 
 The scene generator of synth.py draws streets: long planes, few range jumps, full rings.  These clouds are not scenes: every ring is a
 random piecewise-smooth range profile with steps, spikes, dropouts (NaN / inf / zero), returns inside minimum_range, exact repeats of the
