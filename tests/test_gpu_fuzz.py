@@ -77,12 +77,22 @@ def random_cloud(synth, rings, n_az, seed, keep_lo=0.55, min_turn=0.0):
     allp = np.concatenate(cols)
     order = np.argsort(allp[:, 3], kind="stable")   # firing order: every laser of a column, then the next column
     out = allp[order].copy()
+    if seed >= 1000 and np.random.default_rng(seed + 78).random() < 0.35:
+        # an occluded wedge (the vehicle's own body, a truck alongside): 20 - 120 degrees of azimuth without a single return on any ring
+        g = np.random.default_rng(seed + 79)
+        a0, wd = g.uniform(-np.pi, np.pi), np.deg2rad(g.uniform(20.0, 120.0))
+        col_az = yaw0 - 2 * np.pi * turn * out[:, 3].astype(np.float64) / n_az
+        out = out[np.mod(col_az - a0, 2 * np.pi) > wd].copy()
     out[:, 3] = 0.0
+    if seed >= 1000:   # the fourth float of an input point is padding (the reference's input is pcl::PointXYZ): whatever it holds must not matter
+        g = np.random.default_rng(seed + 80)
+        junk = g.choice(np.array([np.nan, np.inf, -np.inf, 1e30, -7.5, 0.0], np.float32), out.shape[0])
+        out[:, 3] = junk
     return out
 
 
 CASES = [(64, 2048, 101), (64, 1777, 102), (64, 600, 103), (64, 3100, 104), (32, 1500, 105), (16, 2048, 106), (16, 257, 107), (64, 2048, 108),
-         (64, 2048, 927), (64, 1900, 997), (16, 1800, 908), (32, 2000, 945), (64, 1500, 940), (64, 2048, 936), (64, 1700, 988), (16, 2048, 953)]   # start azimuth anywhere, 0.3 - 1.04 turns
+         (64, 2000, 1013), (16, 1900, 1014), (64, 2048, 1011), (32, 1800, 1003), (64, 2048, 927), (64, 1900, 997), (16, 1800, 908), (32, 2000, 945), (64, 1500, 940), (64, 2048, 936), (64, 1700, 988), (16, 2048, 953)]   # start azimuth anywhere, 0.3 - 1.04 turns; from 1000 on: junk in the padding float, 1011 / 1013 / 1014: an occluded wedge
 # VLOAM_FUZZ_EXTRA=N: N more cases per test with seeds / shapes drawn from N itself (hunting runs; the committed cases are the ones above)
 _EXTRA = int(os.environ.get("VLOAM_FUZZ_EXTRA", "0"))
 _BASE = int(os.environ.get("VLOAM_FUZZ_SEED_BASE", "1000"))   # first seed of the extra cases: another base = another set of inputs (>= 1000: the committed seeds lie below)
@@ -118,7 +128,8 @@ def test_scan_registration_on_random_range_images(vl, orc, synth, rings, n_az, s
     assert np.array_equal(d["flatInd"], o.sr_ints(7))
     for which, name in [(1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
         check_cloud(h.features(which), o.cloud(which), name, max_flips=flips)
-    assert o.cloud(1).shape[0] > 0 and o.cloud(3).shape[0] > 0, "the case must produce features"
+    if seed < 2000:   # (committed cases; a hunting case of 200 columns over a third of a turn may have no flat feature at all — compared above like any other)
+        assert o.cloud(1).shape[0] > 0 and o.cloud(3).shape[0] > 0, "the case must produce features"
 
 
 @pytest.mark.parametrize("rings,n_az,seed", [(64, 2048, 201), (16, 1800, 202), (64, 2048, 945), (32, 1800, 961)] + [(r, min(max(a, 900), 2040), sd + 5000) for r, a, sd in EXTRA[::3]])
@@ -184,7 +195,7 @@ def _motion(seed, step, k):
 
 
 @pytest.mark.parametrize("rings,n_az,seed,n,cfg", [(64, 1500, 301, 14, KITTI), (16, 2048, 302, 20, KITTI), (16, 1800, 303, 16, VLP), (32, 2040, 304, 12, VLP),
-                                                   (64, 1500, 927, 10, KITTI), (16, 1800, 983, 12, VLP),   # sweeps that start at azimuth -pi / +3.04 (0.855 of a turn)
+                                                   (64, 1500, 927, 10, KITTI), (16, 1800, 983, 12, VLP), (64, 1500, 1021, 10, KITTI),   # sweeps that start at azimuth -pi / +3.04 (0.855 of a turn)
                                                    (64, 1500, 306, 10, VLP),   # a 64-line sensor with the 16 / 32-line launch values: 17 000 - 21 000 surf voxels per sweep (the stack held 16 384 until round 6)
                                                    (64, 1300, 305, 12, dict(minimum_range=2.5, mapping_line_resolution=0.15, mapping_plane_resolution=1.3, mapping_skip_frame=2, _step=0.9))]
                          + [(r, min(max(a, 900), 2040), sd + 9000, 12, _random_cfg(sd, r)) for r, a, sd in EXTRA[::2]],
@@ -304,7 +315,7 @@ def test_vo_stack_on_random_range_images_and_matches(vl, orc, synth, n_az, seed)
         for q in range(3):
             assert np.array_equal(dm[q].view(np.uint32), om[q].view(np.uint32)), "bucket array %d map %d" % (q, which)
     assert (c32, c22) == (r["counter32"], r["counter22"])
-    assert c32 > 100, "the case must produce depth-enhanced matches (%d)" % c32
+    assert c32 > 100 or seed >= 9000, "the case must produce depth-enhanced matches (%d)" % c32   # (hunting cases: an occluded wedge may cover the camera's view; compared all the same)
     md = r["match_debug"]
     assert np.array_equal(d["match_rows"][:, 0], md[:, 0])
     assert np.array_equal(d["match_rows"][:, 1].astype(np.float32).view(np.uint32), md[:, 1].astype(np.float32).view(np.uint32))
@@ -502,7 +513,7 @@ def test_coupled_frames_on_random_inputs(vl, synth, n_az, seed, detach):
         r = h.vo_result()
         if k > 0:
             v = o.vo_result
-            assert (r["counter32"], r["counter22"]) == (v["counter32"], v["counter22"]) and r["counter32"] > 100
+            assert (r["counter32"], r["counter22"]) == (v["counter32"], v["counter22"]) and (r["counter32"] > 100 or seed >= 9000)
             tol = 1e-6 if k == 1 else 1e-7   # frame 1: the VO starts from 2 acos(1 - ulp) (tests/test_oracle_vloam.py)
             assert np.linalg.norm(r["angles"] - v["angles"]) < tol and np.linalg.norm(r["t"] - v["t"]) < tol, "VO estimate, frame %d" % k
             oq, ot = o.lo_prior()
@@ -539,3 +550,27 @@ def test_returns_at_the_origin_with_minimum_range_zero(vl, orc, synth, rings):
     assert h.sr_debug()["n_after_s1"] == o.sr_scalars()["n_after_s1"]
     for which, name in [(0, "laserCloud"), (1, "sharp"), (2, "lessSharp"), (3, "flat"), (4, "lessFlat")]:
         check_cloud(h.features(which), o.cloud(which), name)
+
+
+def test_padding_float_of_the_input_is_ignored(vl, sweeps):
+    """The ABI takes packed float4 points (x, y, z, pad); the reference's input is pcl::PointXYZ (vloam_main_node.cpp:148), there is no fourth
+    value.  The same sweeps with zeros and with NaN / inf / large numbers in the padding float: every cloud, pose and the map bit for bit."""
+    rng = np.random.default_rng(5)
+    runs = []
+    for junk in (False, True):
+        h = vl.Handle(0, with_mapping=1)
+        feats = []
+        for k in range(4):
+            c = sweeps(64, 512, k).copy()
+            c[:, 3] = rng.choice(np.array([np.nan, np.inf, -np.inf, 1e30, -7.5, 3.0], np.float32), c.shape[0]) if junk else 0.0
+            h.process_scan(c)
+            h.sync()
+            feats.append([h.features(w).copy() for w in range(5)])
+        runs.append((feats, h.trajectory().copy(), h.get_map().copy()))
+        h.close()
+    (fa, ta, ma), (fb, tb, mb) = runs
+    for k in range(4):
+        for w in range(5):
+            assert fa[k][w].shape == fb[k][w].shape and np.array_equal(fa[k][w].view(np.uint32), fb[k][w].view(np.uint32)), (k, w)
+    assert np.array_equal(ta.view(np.uint64), tb.view(np.uint64))
+    assert ma.shape == mb.shape and ma.shape[0] > 1000 and np.array_equal(ma.view(np.uint32), mb.view(np.uint32))

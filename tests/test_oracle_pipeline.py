@@ -377,7 +377,7 @@ def test_feature_picks_vs_literal_python_loops(orc, sweeps, rings, az):
     assert np.array_equal(full[np.array(flat)].view(np.uint32), o.cloud(3).view(np.uint32))
 
 
-@pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512), (64, -1), (16, -2), (64, -27), (32, -97), (16, -8), (64, -83)])
+@pytest.mark.parametrize("rings,az", [(64, 512), (16, 512), (32, 512), (64, -1), (16, -2), (64, -27), (32, -97), (16, -8), (64, -83), (64, -111), (16, -114)])
 def test_ring_labelling_vs_literal_python_loop(orc, sweeps, rings, az):
     """Second, independent transcription of scan_registration.cpp:157-281 in plain Python: NaN / minimum-range removal, the
     vertical-angle -> scan line tables of the three sensor models, the sequential half-sweep unwrap state machine
